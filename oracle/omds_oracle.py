@@ -1,0 +1,384 @@
+"""CPU ORACLE for the MPPI rollout + DS-modulation hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain numpy (float32) restatement of the reference algorithm, in the same
+*unfused* op sequence as the reference (materialised [N*O, n+4] network input, dense layers,
+sort / top-k, forward+backward on N*k rows, per-sample modulation, Euler step, cost, weighted
+update).  It is the checker the HIP path is compared against; it is never the product path:
+only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it (the package ``optimalmodulationds_amd`` never does, and fails loudly without its HIP
+library).
+
+Parity pinning: the reference ships NO tests, golden vectors or known-answer fixtures for this
+path, so this oracle is pinned against outputs of the reference itself,
+captured in this build container by ``tools/make_golden.py`` (which imports the reference from
+/root/reference) and committed as ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks
+every fixture (<= 1e-5 rel on trajectories / velocities, exact on indices).
+
+Each function cites the reference file:line it follows (paths relative to
+``/root/reference/python_scripts``; ``FN`` = ``ds_mppi/functions``, ``ML`` = ``mlp_learn/sdf``).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+F32 = np.float32
+FLT_MAX = np.finfo(np.float32).max
+
+
+# ---------------------------------------------------------------------------------------------
+# distance network: NeRF-encoded MLP, forward and vjp of the arg-min output
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class Mlp:
+    """Weights ``W[i]`` are [out, in] like torch ``nn.Linear`` (ML/network_macros_mod.py:69-93)."""
+    W: list
+    b: list
+    act: str = "relu"
+
+    @property
+    def out_channels(self):
+        return self.W[-1].shape[0]
+
+    @staticmethod
+    def from_npz(path):
+        z = np.load(path)
+        n = len([k for k in z.files if k.startswith("W")])
+        act = str(z["act"]) if "act" in z.files else "relu"
+        return Mlp([z[f"W{i}"].astype(F32) for i in range(n)], [z[f"b{i}"].astype(F32) for i in range(n)], act)
+
+
+def _act(z, act):
+    return np.maximum(z, F32(0)) if act == "relu" else np.tanh(z)
+
+
+def _dact(z, h, act):
+    """Derivative of the activation given pre-activation z and output h."""
+    return (z > 0).astype(F32) if act == "relu" else (F32(1) - h * h).astype(F32)
+
+
+def positional_encoding(x):
+    """x -> [x, sin x, cos x]  (ML/network_macros_mod.py:139-140)."""
+    return np.concatenate((x, np.sin(x), np.cos(x)), axis=-1).astype(F32)
+
+
+def mlp_forward(m: Mlp, x):
+    """MLPRegression.forward with skips=[] (ML/network_macros_mod.py:137-146)."""
+    h = positional_encoding(np.asarray(x, dtype=F32))
+    for i in range(len(m.W) - 1):
+        h = _act(h @ m.W[i].T + m.b[i], m.act)
+    return (h @ m.W[-1].T + m.b[-1]).astype(F32)
+
+
+def mlp_vjp_argmin(m: Mlp, x):
+    """functorch_vjp (ML/robot_sdf.py:153-158): forward, minIdx = argmin over ALL raw outputs,
+    gradient of y[b, minIdx[b]] w.r.t. the n+3 inputs, as an analytic backward (masks + PE chain
+    rule) instead of autograd."""
+    x = np.asarray(x, dtype=F32)
+    d = x.shape[1]
+    feats = positional_encoding(x)
+    hs, zs = [feats], []
+    for i in range(len(m.W) - 1):
+        z = hs[-1] @ m.W[i].T + m.b[i]
+        zs.append(z)
+        hs.append(_act(z, m.act))
+    y = (hs[-1] @ m.W[-1].T + m.b[-1]).astype(F32)
+    min_idx = np.argmin(y, axis=1)
+    g = m.W[-1][min_idx]                                     # dy/dh_last  [B, width]
+    for i in range(len(m.W) - 2, -1, -1):
+        g = (g * _dact(zs[i], hs[i + 1], m.act)) @ m.W[i]    # -> grad wrt layer i input
+    grad = g[:, :d] + g[:, d:2 * d] * np.cos(x) - g[:, 2 * d:] * np.sin(x)
+    return y, grad.astype(F32), min_idx
+
+
+# ---------------------------------------------------------------------------------------------
+# distance + joint-space gradient over rollouts x obstacles
+# ---------------------------------------------------------------------------------------------
+def build_nn_input(q, obs):
+    """Obstacle-major Cartesian product, row o*N + t = [q_t, obs_o(x,y,z,r)]  (FN/MPPI.py:93-95)."""
+    q = np.asarray(q, dtype=F32)
+    obs = np.asarray(obs, dtype=F32)
+    return np.hstack((np.tile(q, (obs.shape[0], 1)), np.repeat(obs, q.shape[0], axis=0))).astype(F32)
+
+
+def pass1_mindist(m: Mlp, q, obs, ignored_links):
+    """First forward pass and per-(rollout, obstacle) min link distance  (FN/MPPI.py:233-243)."""
+    n_in = q.shape[0]
+    nn_input = build_nn_input(q, obs)
+    nn_dist = mlp_forward(m, nn_input[:, :-1])
+    if m.out_channels == 9:
+        nn_dist = nn_dist / F32(100)
+    nn_dist = nn_dist - nn_input[:, -1:]
+    if len(ignored_links):
+        nn_dist[:, list(ignored_links)] = F32(1e6)
+    mindist = nn_dist.min(axis=1)
+    return nn_input, mindist.reshape(obs.shape[0], n_in).T.copy()
+
+
+def distance_repulsion_nn(m: Mlp, q, obs, k, ignored_links):
+    """MPPI.distance_repulsion_nn (FN/MPPI.py:227-282): returns (distance [N], nn_grad [N, n]) and
+    the intermediates (min-distance matrix, sorted obstacle indices)."""
+    q = np.asarray(q, dtype=F32)
+    n_in, n_dof = q.shape
+    nn_input, mind = pass1_mindist(m, q, obs, ignored_links)
+    sort_idx = np.argsort(mind, axis=1, kind="stable")[:, :k]                 # :245-247
+    rows = (np.arange(n_in)[:, None] + sort_idx * n_in).reshape(-1)           # :251
+    nn_in2 = nn_input[rows]
+    y, grad, min_idx = mlp_vjp_argmin(m, nn_in2[:, :-1])                      # :259
+    if m.out_channels == 9:
+        y = y / F32(100)
+    y = y - nn_in2[:, -1:]
+    d = y[np.arange(y.shape[0]), min_idx].reshape(n_in, k)                    # :270-272
+    g = grad[:, :n_dof].reshape(n_in, k, n_dof)
+    e = np.exp((F32(-10) * d) - (F32(-10) * d).max(axis=1, keepdims=True))    # softmax(-10 d)  :277
+    w = (e / e.sum(axis=1, keepdims=True)).astype(F32)
+    nn_grad = (g * w[:, :, None]).sum(axis=1).astype(F32)                     # :278
+    return d[:, 0].copy(), nn_grad, mind, sort_idx
+
+
+# ---------------------------------------------------------------------------------------------
+# nominal DS, sigmoid, RBF policy
+# ---------------------------------------------------------------------------------------------
+def lin_ds_velocity(x, q_goal, lin_thr=0.015):
+    """LinDS.get_velocity (FN/LinDS.py:11-21)."""
+    x_dif = (x - q_goal).astype(F32)
+    dst = np.sqrt((x_dif * x_dif).sum(axis=-1))
+    y = (-x_dif).astype(F32)
+    far = dst > F32(lin_thr)
+    if far.any():
+        y[far] = y[far] / dst[far][:, None]
+    return y
+
+
+def generalized_sigmoid(x, y_min, y_max, x0, x1, k):
+    """FN/MPPI.py:352-353."""
+    with np.errstate(over="ignore"):
+        return (F32(y_min) + F32(y_max - y_min) / (F32(1) + np.exp(F32(k) * (-x + F32((x0 + x1) / 2))))).astype(F32)
+
+
+def eval_rbf(q, mu, sigma, p=2):
+    """FN/policy.py:186-199: phi[t, kappa] = exp(-sigma * ||q - mu||_p^2)."""
+    diff = np.abs(q[:, None, :] - mu)
+    if p == 2:
+        nrm = np.sqrt((diff * diff).sum(axis=2))
+    else:
+        nrm = (diff ** F32(p)).sum(axis=2) ** F32(1.0 / p)
+    return np.exp(-sigma * nrm * nrm).astype(F32)
+
+
+def nan_to_num(x):
+    return np.nan_to_num(x, nan=0.0, posinf=FLT_MAX, neginf=-FLT_MAX).astype(F32)
+
+
+def qr_basis(nn_grad):
+    """E = qr([g, e_2 .. e_n]).Q with column 0 overwritten by +g/||g||  (FN/MPPI.py:122-127)."""
+    N, n = nn_grad.shape
+    E = np.empty((N, n, n), dtype=F32)
+    for t in range(N):
+        A = np.eye(n, dtype=F32)
+        A[:, 0] = nn_grad[t]
+        Q, _ = np.linalg.qr(A)
+        E[t] = Q
+    E[:, :, 0] = nn_grad / np.sqrt((nn_grad * nn_grad).sum(axis=1))[:, None]
+    return E
+
+
+# ---------------------------------------------------------------------------------------------
+# the rollout loop
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class Params:
+    """Hard-coded constants of FN/MPPI.py:132-155,193-216 and LinDS, as parameters."""
+    dst_thr: float = 0.5
+    lin_thr: float = 0.015
+    p: int = 2
+    lvel: tuple = (0.0, 1.0, -1.0, 0.0, 10.0)          # :132
+    ln: tuple = (0.0, 1.0, 0.0, 0.1, 100.0)            # :149-153
+    ltau: tuple = (5.0, 1.0, 0.0, 0.1, 100.0)          # :155
+    goal_act_cut: float = 0.5                          # :194
+    norm_clamp: float = 0.5                            # :212
+    coll_slow: float = 0.1                             # :215
+    coll_repulse: float = 0.1                          # :216
+    softmax_k: float = -10.0                           # :277
+    want_basis: bool = False
+
+
+@dataclass
+class RolloutOut:
+    all_traj: np.ndarray
+    closest_dist_all: np.ndarray
+    kernel_val_all: np.ndarray
+    dot_products: np.ndarray
+    kernel_activations: np.ndarray
+    qdot: np.ndarray
+    norm_basis_n: np.ndarray
+    norm_basis: np.ndarray | None = None
+    extras: dict = field(default_factory=dict)
+
+
+def propagate(m: Mlp, q_cur, qf, obs, *, N, H, dt, k, ignored_links, mu_tmp, sigma_tmp, alpha_tmp,
+              prm: Params = Params()):
+    """MPPI.propagate (FN/MPPI.py:97-224).  ``mu_tmp [N,K,n]``, ``sigma_tmp [N,K]``,
+    ``alpha_tmp [N,K,n]`` are the sampled policy tensors (first K kernels)."""
+    q_cur = np.asarray(q_cur, dtype=F32)
+    qf = np.asarray(qf, dtype=F32)
+    n = q_cur.shape[-1]
+    K = mu_tmp.shape[1]
+    dt = F32(dt)
+    all_traj = np.zeros((N, H, n), dtype=F32)
+    dist_all = np.full((N, H), 100, dtype=F32)
+    kval_all = np.zeros((N, H, K), dtype=F32)
+    dots = np.zeros((N, H), dtype=F32)
+    acts = np.zeros((N, H), dtype=F32)
+    nb_n = np.zeros((N, H, n), dtype=F32)
+    nb = np.zeros((N, H, n, n), dtype=F32) if prm.want_basis else None
+    qdot = np.zeros((N, n), dtype=F32)
+    all_traj[:, 0, :] = q_cur
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+        for i in range(1, H + 1):
+            q_prev = all_traj[:, i - 1, :]
+            v = lin_ds_velocity(q_prev, qf, prm.lin_thr)                              # :106
+            vnorm = np.sqrt((v * v).sum(axis=1)).reshape(-1, 1)
+            vhat = v / vnorm
+            distance, g_raw, _, _ = distance_repulsion_nn(m, q_prev, obs, k, ignored_links)   # :113
+            distance = (distance - F32(prm.dst_thr)).astype(F32)                       # :117
+            dist_all[:, i - 1] = distance
+            ghat = (g_raw / np.sqrt((g_raw * g_raw).sum(axis=1))[:, None]).astype(F32)  # :126
+            nb_n[:, i - 1] = ghat
+            if nb is not None:
+                nb[:, i - 1] = qr_basis(g_raw)
+            dot = (ghat * vhat).sum(axis=-1)                                           # :129
+            dots[:, i - 1] = dot
+            l_vel = generalized_sigmoid(dot, *prm.lvel)                                # :132
+            l_n = generalized_sigmoid(distance, *prm.ln)
+            l_nv = l_vel * F32(1) + (F32(1) - l_vel) * l_n                              # :154
+            l_tau = generalized_sigmoid(distance, *prm.ltau)
+            # policy (:165-186)
+            if K > 0:
+                phi = eval_rbf(q_prev, mu_tmp, sigma_tmp, prm.p)
+                kval_all[:, i - 1, :] = phi
+                pol = (alpha_tmp * phi[:, :, None]).sum(axis=1).astype(F32)
+            else:
+                pol = v * F32(0)
+            ca = (F32(1) - l_n)[:, None]
+            va = (F32(1) - l_vel)[:, None]
+            ga = (np.sqrt(np.abs(q_prev - qf)).sum(axis=1) ** 2).clip(0, 1)[:, None].astype(F32)  # norm(p=0.5)
+            ga[ga < F32(prm.goal_act_cut)] = 0
+            act = ca * va * ga
+            acts[:, i - 1] = act[:, 0]
+            v_tot = v + act * pol * vnorm                                              # :197-206
+            # M v with M = E diag(l_nv, l_tau, ...) E^T  ==  l_tau v + (l_nv - l_tau)(g.v) g   (:161,209)
+            u = l_tau[:, None] * v_tot + ((l_nv - l_tau) * (ghat * v_tot).sum(axis=1))[:, None] * ghat
+            s = np.sqrt((u * u).sum(axis=1)).reshape(-1, 1)
+            s[s <= F32(prm.norm_clamp)] = 1                                            # :212
+            u = nan_to_num(u / s)
+            coll = distance < 0
+            u[coll] *= F32(prm.coll_slow)                                              # :215
+            rep = ghat * vnorm * F32(prm.coll_repulse)
+            u[coll] += rep[coll]                                                       # :217
+            u = u.astype(F32)
+            if i < H:
+                all_traj[:, i, :] = all_traj[:, i - 1, :] + dt * u
+            if i == 1:
+                qdot = u.copy()
+    return RolloutOut(all_traj, dist_all, kval_all, dots, acts, qdot, nb_n, nb)
+
+
+# ---------------------------------------------------------------------------------------------
+# cost (FN/cost.py) and forward kinematics (FN/fk_num.py)
+# ---------------------------------------------------------------------------------------------
+def dh_transform(q, d, theta, a, alpha):
+    """Modified-DH link transform (FN/fk_num.py:7-27)."""
+    sa, ca = np.sin(F32(alpha)), np.cos(F32(alpha))
+    sq, cq = np.sin(F32(q + theta)), np.cos(F32(q + theta))
+    return np.array([[cq, -sq, 0.0, a],
+                     [sq * ca, cq * ca, -sa, -d * sa],
+                     [sq * sa, cq * sa, ca, d * ca],
+                     [0.0, 0.0, 0.0, 1.0]], dtype=F32)
+
+
+def link_endpoints(q, dh_params):
+    """Last sample point of every link: frame_{i+1} applied to [a_{i+1}, 0, 0]
+    (FN/fk_num.py:30-75 with n_pts=2, the [:, :, -1, :] slice of FN/cost.py:28)."""
+    n = len(q)
+    T = np.eye(4, dtype=F32)
+    pts = np.zeros((n, 3), dtype=F32)
+    for i in range(n):
+        d, theta, a, alpha = dh_params[i]
+        T = (T @ dh_transform(q[i], d, theta, a, alpha)).astype(F32)
+        p1 = np.array([dh_params[i + 1, 2], 0, 0], dtype=F32)
+        pts[i] = T[:3, :3] @ p1 + T[:3, 3]
+    return pts
+
+
+def evaluate_costs(all_traj, closest_dist_all, qf, dh_params, q_min, q_max):
+    """Cost.evaluate_costs (FN/cost.py:13-46)."""
+    q_end = all_traj[:, -1, :]
+    goal = F32(10) * np.sqrt(((q_end - qf) ** 2).sum(axis=1))
+    coll = F32(100) * (closest_dist_all < 0).sum(axis=1)
+    viol = ((all_traj < q_min).sum(axis=1) + (all_traj > q_max).sum(axis=1)).sum(axis=1)
+    jl = F32(100) * (viol > 0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dist = np.sqrt(((all_traj[:, 0, :] - q_end) ** 2).sum(axis=1))
+        stag = F32(10) * goal * nan_to_num(F32(1) / dist)
+    goal_fk = link_endpoints(qf, dh_params)
+    fk = np.zeros(all_traj.shape[0], dtype=F32)
+    for t in range(all_traj.shape[0]):
+        diff = link_endpoints(q_end[t], dh_params) - goal_fk
+        fk[t] = np.sqrt((diff * diff).sum(axis=1)).sum()
+    fk = F32(10) * fk
+    total = goal + coll + jl + stag + fk
+    return total.astype(F32), dict(goal=goal.astype(F32), coll=coll, jl=jl, stag=stag, fk=fk.astype(F32))
+
+
+# ---------------------------------------------------------------------------------------------
+# MPPI weights and policy update (FN/MPPI.py:319-345, FN/policy.py:88-113)
+# ---------------------------------------------------------------------------------------------
+def mppi_weights(cost):
+    beta = cost.mean(dtype=F32) / F32(50)
+    w = np.exp(F32(-1) / beta * cost).astype(F32)
+    return (w / w.sum(dtype=F32)).astype(F32)
+
+
+def shift_policy_means(cost, kernel_val_all, kernel_activations, mu_c, sigma_c, alpha_c,
+                       mu_tmp, sigma_tmp, alpha_tmp, ker_thr, rate):
+    """Returns new (mu_c, sigma_c, alpha_c), update mask, weights.  K = mu_c.shape[0]."""
+    w = mppi_weights(cost)
+    K = mu_c.shape[0]
+    if K == 0:
+        return mu_c, sigma_c, alpha_c, np.zeros(0, dtype=bool), w
+    with np.errstate(invalid="ignore"):
+        prod = kernel_val_all * kernel_activations[:, :, None]
+        mx = np.where(np.isnan(prod).any(axis=1), np.nan, np.nanmax(np.where(np.isnan(prod), -np.inf, prod), axis=1))
+        mask = mx.mean(axis=0) > F32(ker_thr)                                   # FN/MPPI.py:336-339
+        mask_base = kernel_val_all[0].mean(axis=0) > F32(ker_thr)               # :341
+    mask = mask & mask_base
+    upd = np.where(mask, F32(rate), F32(0)).astype(F32)
+    mu_sum = (w[:, None, None] * mu_tmp).sum(axis=0)
+    sg_sum = (w[:, None] * sigma_tmp).sum(axis=0)
+    al_sum = (w[:, None, None] * alpha_tmp).sum(axis=0)
+    mu_new = (F32(1) - upd[:, None]) * mu_c + upd[:, None] * mu_sum
+    sg_new = (F32(1) - upd) * sigma_c + upd * sg_sum
+    al_new = (F32(1) - upd[:, None]) * alpha_c + upd[:, None] * al_sum
+    return mu_new.astype(F32), sg_new.astype(F32), al_new.astype(F32), mask, w
+
+
+def get_qdot(cost, qdot, mode="best"):
+    """MPPI.get_qdot (FN/MPPI.py:319-329)."""
+    if mode == "best":
+        return qdot[int(np.argmin(cost))]
+    w = mppi_weights(cost)
+    return (w[:, None] * qdot).sum(axis=0).astype(F32)
+
+
+def check_traj_for_kernels(all_traj, dist_all, dots_all, mu_c, sigma_c, thr_dist, thr_kernel, thr_dot, p=2):
+    """TensorPolicyMPPI.check_traj_for_kernels (FN/policy.py:153-175): candidate kernel centres."""
+    sel = (dist_all < thr_dist) & (dots_all < thr_dot)
+    cand = all_traj[sel].reshape(-1, all_traj.shape[-1])
+    if mu_c.shape[0] > 0 and cand.shape[0] > 0:
+        diff = np.abs(cand[:, None, :] - mu_c)
+        nrm = np.sqrt((diff * diff).sum(axis=-1)) if p == 2 else (diff ** p).sum(axis=-1) ** (1.0 / p)
+        rbf = np.exp(-sigma_c * nrm * nrm)
+        cand = cand[rbf.max(axis=-1) < thr_kernel]
+    return cand
