@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Benchmark of the MPPI rollout + DS-modulation hot path on MI355X.
+
+One "step" = one planner iteration of the reference (frankaPlanner.py:132-145):
+sample_policy + propagate (H network evaluations over N x O pairs + modulation + Euler steps)
++ get_cost + shift_policy_means.  metric = modulated rollout-steps/s = N * H * steps / time,
+the inverse of the reference's "Time per rollout step" (scripts/standalonePlanar2d.py:217).
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 10 --warmup 2
+
+Weak scaling: every rank (one process per GPU) owns --rollouts rollouts; the only exchange is
+the cost-weighted update (two tiny all-reduces + one all-gather over RCCL, dist.py).
+Prints ONE JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (weights, n_dof, C, scene, N, H, dt, k, dst_thr, ker_thr, alpha_s, sigma_nom, ignored)
+    "franka_shelf_1024x32": dict(kind="franka", N=1024, H=32, dt=0.5, k=5, dst_thr=0.01, ker_thr=0.1, alpha_s=3.0,
+                                 sigma=1.0, ignored=[0, 1, 2]),
+    "franka_shelf_4096x32": dict(kind="franka", N=4096, H=32, dt=0.5, k=5, dst_thr=0.01, ker_thr=0.1, alpha_s=3.0,
+                                 sigma=1.0, ignored=[0, 1, 2]),
+    "planar7_1024x32": dict(kind="planar7", N=1024, H=32, dt=0.3, k=1, dst_thr=0.25, ker_thr=1e-3, alpha_s=0.75,
+                            sigma=0.5, ignored=[]),
+}
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 FLOP/clk
+
+
+def setup(wl, rank):
+    from optimalmodulationds_amd import scenes
+    w = WORKLOADS[wl]
+    z = np.load(os.path.join(ROOT, "tests", "golden", "weights", w["kind"] + ".npz"))
+    nl = len([k for k in z.files if k.startswith("W")])
+    W = [z[f"W{i}"] for i in range(nl)]
+    b = [z[f"b{i}"] for i in range(nl)]
+    if w["kind"] == "franka":
+        obs, q0, qf, dh = scenes.shelf_scene(), scenes.FRANKA_Q0, scenes.FRANKA_QF, scenes.franka_dh_params()
+        from optimalmodulationds_amd.cost import FRANKA_Q_MAX, FRANKA_Q_MIN
+        qmin, qmax = np.array(FRANKA_Q_MIN, np.float32), np.array(FRANKA_Q_MAX, np.float32)
+    else:
+        obs = scenes.planar7_scene()
+        q0 = np.zeros(7, np.float32); q0[0] = np.pi / 2
+        qf = np.zeros(7, np.float32); qf[0] = -np.pi / 2
+        dh = scenes.planar_dh_params(7, 1.0)
+        from optimalmodulationds_amd.cost import FRANKA_Q_MAX, FRANKA_Q_MIN
+        qmin, qmax = np.array(FRANKA_Q_MIN, np.float32), np.array(FRANKA_Q_MAX, np.float32)
+    return w, W, b, obs, q0, qf, dh, qmin, qmax
+
+
+def flops_per_row(W):
+    """Algorithmic FLOPs of one network forward: 2 * sum(in*out) over the Linear layers."""
+    return 2 * sum(int(w.shape[0]) * int(w.shape[1]) for w in W)
+
+
+def cpu_baseline(w, W, b, obs, q0, qf, K, seed):
+    """The numpy oracle (a port of the reference's unfused op sequence) timed on a bounded sample of
+    the same workload on this box's host cores."""
+    from oracle import omds_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    m = orc.Mlp([x.astype(np.float32) for x in W], [x.astype(np.float32) for x in b])
+    Ns, Hs = 128, 4
+    rng = np.random.RandomState(seed)
+    n = q0.shape[0]
+    mu = (q0 + (qf - q0) * rng.rand(Ns, K, 1) + 0.1 * rng.standard_normal((Ns, K, n))).astype(np.float32)
+    sg = np.full((Ns, K), w["sigma"], np.float32)
+    al = (w["alpha_s"] * rng.standard_normal((Ns, K, n))).astype(np.float32)
+    prm = orc.Params(dst_thr=w["dst_thr"])
+    t0 = time.time()
+    reps = 0
+    while True:
+        orc.propagate(m, q0, qf, obs, N=Ns, H=Hs, dt=w["dt"], k=w["k"], ignored_links=w["ignored"], mu_tmp=mu,
+                      sigma_tmp=sg, alpha_tmp=al, prm=prm)
+        reps += 1
+        if time.time() - t0 > 10.0 or reps >= 20:
+            break
+    el = time.time() - t0
+    return {"value": Ns * Hs * reps / el, "unit": "rollout-steps/s", "cores": int(threads), "kind": "port",
+            "sample": f"numpy oracle propagate, {Ns} rollouts x {Hs} steps x {obs.shape[0]} obstacles, {reps} reps in {el:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="franka_shelf_1024x32", choices=sorted(WORKLOADS))
+    ap.add_argument("--kernels", type=int, default=10, help="active RBF navigation kernels K")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from optimalmodulationds_amd.dist import sharded_update
+    from optimalmodulationds_amd.engine import Engine
+
+    w, W, b, obs, q0, qf, dh, qmin, qmax = setup(args.workload, rank)
+    N, H, n, K = w["N"], w["H"], q0.shape[0], args.kernels
+    eng = Engine(n, N, H, w["k"], max_obs=max(64, obs.shape[0]), device=local_rank)
+    eng.set_mlp(W, b)
+    eng.set_obstacles(obs)
+    p = eng.params
+    p.dt, p.dst_thr = w["dt"], w["dst_thr"]
+    p.ignored_links = sum(1 << l for l in w["ignored"])
+    eng.push_params()
+    eng.set_ds(qf)
+    eng.set_cost(dh, qmin, qmax)
+    # policy means: K kernel centres near the q0 -> qf segment (SURVEY 8d "policy state for timing")
+    rng = np.random.RandomState(1234)
+    s = (np.arange(K) + 0.5) / max(K, 1)
+    mu_c = (q0 + s[:, None] * (qf - q0) + 0.15 * rng.standard_normal((K, n))).astype(np.float32)
+    sg_c = np.full(K, w["sigma"], np.float32)
+    al_c = rng.standard_normal((K, n)).astype(np.float32)
+    q_cur = q0.copy()
+
+    def iteration(it):
+        nonlocal mu_c, sg_c, al_c, q_cur
+        eng.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, w["alpha_s"], K, seed=1234 * 1000003 + it, rollout_offset=rank * N)
+        eng.propagate(q_cur)
+        eng.cost(fetch=False)
+        mu_c, sg_c, al_c, mask, qd_w, qd_best = sharded_update(eng.cost_sum, eng.local_sums, K, n, H, 0.1, w["ker_thr"],
+                                                               mu_c, sg_c, al_c)
+        q_cur = (q_cur + 0.1 * w["dt"] * qd_best).astype(np.float32)   # drift along the best rollout: non-degenerate states
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(args.warmup):
+        iteration(it)
+    eng.prof_enable(True)
+    eng.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        iteration(args.warmup + it)
+    eng.lib.omds_sync(eng.h)
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    p1_ms, p1_launches, p1_rows = eng.prof_read()
+
+    if rank == 0:
+        f_row = flops_per_row(W)
+        ach = (p1_rows * f_row) / (p1_ms * 1e-3) / 1e12 if p1_ms > 0 else 0.0
+        out = {
+            "metric": "modulated rollout-steps/sec", "value": world * N * H * args.steps / el,
+            "unit": "rollout-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "rollouts_per_gpu": N, "horizon": H, "obstacles": int(obs.shape[0]),
+                       "n_closest": w["k"], "active_kernels": K, "network": "x".join(str(x.shape[1]) for x in W) + f"x{W[-1].shape[0]} relu (shipped reference weights)",
+                       "parallelism": f"rollout-sharded x{world}"},
+            "roofline": {"bound": "mfma", "kernel": "k_pass1", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "launches": int(p1_launches), "avg_launch_ms": p1_ms / max(p1_launches, 1),
+                         "flops_per_launch": f_row * p1_rows / max(p1_launches, 1)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(w, W, b, obs, q0, qf, K, 7)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

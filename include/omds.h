@@ -1,0 +1,174 @@
+/*
+ * omds.h -- C-ABI of the MI355X-native MPPI rollout + DS-modulation hot path.
+ *
+ * The reference (epfl-lasa/OptimalModulationDS) is pure Python on PyTorch-CPU and has NO
+ * FFI / plugin boundary of its own; its "interface" for this path is the Python class API of
+ * python_scripts/ds_mppi/functions/{MPPI,policy,cost,LinDS}.py and
+ * python_scripts/mlp_learn/sdf/robot_sdf.py.  Each entry point below names the reference
+ * method(s) it replaces (file:line relative to python_scripts/).  A maintainer binds these with
+ * ctypes; optimalmodulationds_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - every function returns an omds_status (0 = OK); omds_last_error() gives the message;
+ *     nothing aborts the process and there is no CPU fallback: without a usable HIP device
+ *     omds_create() fails with OMDS_ERR_HIP.
+ *   - all host arrays are C-contiguous fp32 / int32 in the reference's axis order; the caller
+ *     owns host buffers, the library owns device buffers for the life of the context.
+ *   - one context per device; calls on a context are not re-entrant; every call enqueues on the
+ *     context's HIP stream and synchronises before returning unless stated otherwise.
+ */
+#ifndef OMDS_H
+#define OMDS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMDS_API __attribute__((visibility("default")))
+
+typedef struct omds_ctx omds_ctx;
+
+typedef enum {
+    OMDS_OK = 0,
+    OMDS_ERR_INVALID_ARG = 1,
+    OMDS_ERR_HIP = 2,
+    OMDS_ERR_RCCL = 3,
+    OMDS_ERR_NOT_INITIALISED = 4,
+    OMDS_ERR_UNSUPPORTED = 5
+} omds_status;
+
+#define OMDS_MAX_DOF 7
+#define OMDS_ACT_RELU 0
+#define OMDS_ACT_TANH 1
+
+/* MPPI.__init__ arguments (ds_mppi/functions/MPPI.py:22-66). */
+typedef struct {
+    int32_t n_dof;         /* n: joints (<= OMDS_MAX_DOF)                                   */
+    int32_t n_traj;        /* N: rollouts held by THIS context (the shard, in multi-GPU)   */
+    int32_t horizon;       /* H: dt_H                                                      */
+    int32_t n_kernel_max;  /* TensorPolicyMPPI.N_KERNEL_MAX (policy.py:18), 50             */
+    int32_t max_obs;       /* capacity of the obstacle buffer                              */
+    int32_t n_closest;     /* k: n_closest_obs                                             */
+    int32_t device;        /* HIP device ordinal                                           */
+    int32_t flags;         /* reserved, 0                                                  */
+} omds_config;
+
+/* The constants the reference hard-codes inside propagate() (MPPI.py:117-217,277) and
+ * LinDS (LinDS.py:9), as parameters; omds_default_params() fills the reference values.   */
+typedef struct {
+    float dt;              /* integration step of the rollouts (MPPI.py:221)               */
+    float dst_thr;         /* subtracted from the network distance (MPPI.py:117)           */
+    float lin_thr;         /* LinDS.lin_thr (LinDS.py:9)                                   */
+    float lvel[5];         /* generalized_sigmoid (y_min,y_max,x0,x1,k) of l_vel  (:132)   */
+    float ln[5];           /* ... of l_n   (:143-153)                                      */
+    float ltau[5];         /* ... of l_tau (:155)                                          */
+    float goal_act_cut;    /* goal activation hard cut, 0.5 (:194)                         */
+    float norm_clamp;      /* velocities with norm <= this are not normalised, 0.5 (:212)  */
+    float coll_slow;       /* in-collision slow-down factor 0.1 (:215)                     */
+    float coll_repulse;    /* in-collision repulsion gain 0.1 (:216)                       */
+    float softmax_k;       /* -10: weights of the k closest gradients (:277)               */
+    float rbf_p;           /* Policy.p, RBF norm order (policy.py:41), 2                   */
+    uint32_t ignored_links;/* bit c set: link c is masked in pass 1 (MPPI.py:241)          */
+} omds_params;
+
+OMDS_API void omds_default_params(omds_params* p);
+
+/* MPPI.__init__ tensor allocation (MPPI.py:37-66); no warm-up propagates are run. */
+OMDS_API int omds_create(const omds_config* cfg, omds_ctx** out);
+OMDS_API void omds_destroy(omds_ctx* ctx);
+/* Message of the last failure on ctx (ctx == NULL: last omds_create failure of this thread). */
+OMDS_API const char* omds_last_error(const omds_ctx* ctx);
+
+/* RobotSdfCollisionNet.load_weights + model preparation (robot_sdf.py:31-51,
+ * frankaPlanner.py:43-51).  n_linear Linear layers; dims[n_linear+1] = {3(n+3), hidden...,
+ * C}; W[i] is [dims[i+1], dims[i]] row-major like torch, b[i] is [dims[i+1]].  act =
+ * OMDS_ACT_*; out_div = 100 when C == 9 (cm -> m, MPPI.py:236-237) else 1.                */
+OMDS_API int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* const* W,
+                          const float* const* b, int act, float out_div);
+
+/* MPPI.update_obstacles (MPPI.py:347-350): xyzr is [O,4] spheres (x,y,z,r). */
+OMDS_API int omds_set_obstacles(omds_ctx* ctx, const float* xyzr, int n_obs);
+/* LinDS(q_goal) / MPPI.reset_DS / switch_DS_idx (LinDS.py:7-10, MPPI.py:76-84). */
+OMDS_API int omds_set_ds(omds_ctx* ctx, const float* q_goal);
+OMDS_API int omds_set_params(omds_ctx* ctx, const omds_params* p);
+/* Cost(q_f, dh_params) + the q_min/q_max attributes (cost.py:5-12): dh_params [n+1,4]
+ * rows (d, theta, a, alpha); q_min/q_max [n].                                             */
+OMDS_API int omds_set_cost(omds_ctx* ctx, const float* dh_params, const float* q_min, const float* q_max);
+
+/* TensorPolicyMPPI.sample_policy (policy.py:51-74) with injected samples (parity runs):
+ * mu [N,K,n], sigma [N,K], alpha [N,K,n] = the first K kernels of mu_tmp/sigma_tmp/alpha_tmp. */
+OMDS_API int omds_set_policy_samples(omds_ctx* ctx, const float* mu, const float* sigma, const float* alpha,
+                                     int n_kernels);
+/* TensorPolicyMPPI.sample_policy on the device (Philox4x32-10 + Box-Muller): theta_tmp =
+ * N(0, theta_s) + theta_c; mean arrays are [K,n], [K], [K,n].  rollout_offset = global index
+ * of this shard's rollout 0 (the global rollout 0 gets alpha_tmp = alpha_c, policy.py:74). */
+OMDS_API int omds_sample_policy(omds_ctx* ctx, const float* mu_c, const float* sigma_c, const float* alpha_c,
+                                float mu_s, float sigma_s, float alpha_s, int n_kernels, uint64_t seed,
+                                int64_t rollout_offset);
+/* Read back the sampled tensors in the reference layout (first K kernels). NULL = skip. */
+OMDS_API int omds_get_policy_samples(omds_ctx* ctx, float* mu, float* sigma, float* alpha);
+
+/* MPPI.propagate (MPPI.py:97-224).  q_cur is [n] (broadcast to all rollouts, per_rollout = 0)
+ * or [N,n] (per-rollout start states, per_rollout = 1: used for teacher-forced parity tests). */
+OMDS_API int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout);
+/* The 5-tuple returned by propagate() plus its side outputs, reference layouts:
+ * all_traj [N,H,n], closest_dist_all [N,H], kernel_val_all [N,H,K], dot_products [N,H],
+ * kernel_activations [N,H], qdot [N,n], normal [N,H,n] (= norm_basis[..., 0]).  NULL = skip. */
+OMDS_API int omds_get_rollouts(omds_ctx* ctx, float* all_traj, float* closest_dist_all, float* kernel_val_all,
+                               float* dot_products, float* kernel_activations, float* qdot, float* normal);
+
+/* MPPI.distance_repulsion_nn on an arbitrary batch (MPPI.py:227-282): q [B,n], B <= N.
+ * Outputs (NULL = skip): distance [B], nn_grad [B,n], mindist [B,O] (pass-1 matrix),
+ * closest_idx [B,k] (ascending distance).  Also serves update_kernel_normal_bases (:284-304). */
+OMDS_API int omds_dist_grad(omds_ctx* ctx, const float* q, int batch, float* distance, float* nn_grad,
+                            float* mindist, int32_t* closest_idx);
+/* MLPRegression.forward on raw rows (network_macros_mod.py:137-146) and the vjp of the
+ * arg-min output (robot_sdf.py:153-158): x [B,n+3]; y [B,C], grad [B,n+3], min_idx [B]. B <= N*k. */
+OMDS_API int omds_mlp_forward_vjp(omds_ctx* ctx, const float* x, int batch, float* y, float* grad,
+                                  int32_t* min_idx);
+
+/* MPPI.get_cost -> Cost.evaluate_costs (MPPI.py:315-317, cost.py:13-22). cost_out [N] or NULL. */
+OMDS_API int omds_cost(omds_ctx* ctx, float* cost_out);
+/* MPPI.shift_policy_means + TensorPolicyMPPI.update_policy (MPPI.py:331-345,
+ * policy.py:88-113), single-shard form.  mu_c/sigma_c/alpha_c: in/out host means of the first K
+ * kernels; mask_out [K] (1 = updated); weights_out [N] (normalised MPPI weights) or NULL.   */
+OMDS_API int omds_weighted_update(omds_ctx* ctx, float rate, float ker_thr, float* mu_c, float* sigma_c,
+                                  float* alpha_c, int32_t* mask_out, float* weights_out);
+/* MPPI.get_qdot (MPPI.py:319-329): mode 0 = 'best', 1 = 'weighted'; out [n]. */
+OMDS_API int omds_get_qdot(omds_ctx* ctx, int mode, float* out);
+
+/* Multi-GPU (new work): rollouts shard across one process per GPU; the only exchange
+ * is the cost-weighted update.  The library produces this shard's partial sums in two phases
+ * and the host side (optimalmodulationds_amd/dist.py) all-reduces them with torch.distributed
+ * (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests):
+ *   omds_cost_sum    -> out2 = [sum_t cost, N_local]                 (all-reduce SUM, 8 bytes)
+ *   omds_local_sums  -> packed buffer of omds_red_count() floats for the GLOBAL beta:
+ *        [0] sum w' | sum w' mu (K*n) | sum w' sigma (K) | sum w' alpha (K*n) |
+ *        sum_t max_h(phi*act) (K) | sum_h phi of GLOBAL rollout 0 (K; include_rollout0 != 0
+ *        only on the shard that owns it) | sum w' qdot (n)            (all-reduce SUM)
+ *        | min cost of the shard, qdot of its arg-min (1+n)          (all-gather, MINLOC)
+ *   omds_apply_update: pure host arithmetic on the reduced buffer (masks MPPI.py:336-342 +
+ *        TensorPolicyMPPI.update_policy policy.py:88-113); needs no context / no GPU.      */
+OMDS_API int omds_cost_sum(omds_ctx* ctx, float* out2);
+OMDS_API int omds_red_count(const omds_ctx* ctx);
+OMDS_API int omds_local_sums(omds_ctx* ctx, float sum_cost, float n_total, int include_rollout0, float* red_out);
+OMDS_API int omds_apply_update(int n_kernels, int n_dof, int horizon, const float* red, float n_total, float rate,
+                               float ker_thr, float* mu_c, float* sigma_c, float* alpha_c, int32_t* mask_out);
+
+/* Measurement: when enabled, every launch of the dominant kernel (mlp_pass1) is bracketed by
+ * HIP events on the context stream; omds_prof_read returns the summed elapsed ms and launch
+ * count since the last omds_prof_reset.                                                  */
+OMDS_API int omds_prof_enable(omds_ctx* ctx, int on);
+OMDS_API int omds_prof_reset(omds_ctx* ctx);
+OMDS_API int omds_prof_read(omds_ctx* ctx, double* pass1_ms, int64_t* pass1_launches, int64_t* pass1_rows);
+/* Asynchronous form used by bench loops: propagate + cost + weighted update enqueued without
+ * host round trips of rollout data; omds_sync waits for the stream.                       */
+OMDS_API int omds_sync(omds_ctx* ctx);
+OMDS_API int omds_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMDS_H */

@@ -1,0 +1,115 @@
+"""ctypes binding of libomds_hip.so (C-ABI declared in include/omds.h).
+
+This is exactly the binding a maintainer of the reference would add to call the MI355X path
+(see INTEGRATION.md).  There is no fallback: if the shared library is missing or a call fails,
+an exception is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libomds_hip.so")
+
+OMDS_MAX_DOF = 7
+F32P = C.POINTER(C.c_float)
+I32P = C.POINTER(C.c_int32)
+
+
+class OmdsConfig(C.Structure):
+    _fields_ = [("n_dof", C.c_int32), ("n_traj", C.c_int32), ("horizon", C.c_int32), ("n_kernel_max", C.c_int32),
+                ("max_obs", C.c_int32), ("n_closest", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32)]
+
+
+class OmdsParams(C.Structure):
+    _fields_ = [("dt", C.c_float), ("dst_thr", C.c_float), ("lin_thr", C.c_float), ("lvel", C.c_float * 5),
+                ("ln", C.c_float * 5), ("ltau", C.c_float * 5), ("goal_act_cut", C.c_float),
+                ("norm_clamp", C.c_float), ("coll_slow", C.c_float), ("coll_repulse", C.c_float),
+                ("softmax_k", C.c_float), ("rbf_p", C.c_float), ("ignored_links", C.c_uint32)]
+
+
+class OmdsError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); every symbol include/omds.h declares
+SIGNATURES = {
+    "omds_version": (C.c_int, []),
+    "omds_default_params": (None, [C.POINTER(OmdsParams)]),
+    "omds_create": (C.c_int, [C.POINTER(OmdsConfig), C.POINTER(C.c_void_p)]),
+    "omds_destroy": (None, [C.c_void_p]),
+    "omds_last_error": (C.c_char_p, [C.c_void_p]),
+    "omds_set_mlp": (C.c_int, [C.c_void_p, C.c_int, I32P, C.POINTER(F32P), C.POINTER(F32P), C.c_int, C.c_float]),
+    "omds_set_obstacles": (C.c_int, [C.c_void_p, F32P, C.c_int]),
+    "omds_set_ds": (C.c_int, [C.c_void_p, F32P]),
+    "omds_set_params": (C.c_int, [C.c_void_p, C.POINTER(OmdsParams)]),
+    "omds_set_cost": (C.c_int, [C.c_void_p, F32P, F32P, F32P]),
+    "omds_set_policy_samples": (C.c_int, [C.c_void_p, F32P, F32P, F32P, C.c_int]),
+    "omds_sample_policy": (C.c_int, [C.c_void_p, F32P, F32P, F32P, C.c_float, C.c_float, C.c_float, C.c_int,
+                                     C.c_uint64, C.c_int64]),
+    "omds_get_policy_samples": (C.c_int, [C.c_void_p, F32P, F32P, F32P]),
+    "omds_propagate": (C.c_int, [C.c_void_p, F32P, C.c_int]),
+    "omds_get_rollouts": (C.c_int, [C.c_void_p, F32P, F32P, F32P, F32P, F32P, F32P, F32P]),
+    "omds_dist_grad": (C.c_int, [C.c_void_p, F32P, C.c_int, F32P, F32P, F32P, I32P]),
+    "omds_mlp_forward_vjp": (C.c_int, [C.c_void_p, F32P, C.c_int, F32P, F32P, I32P]),
+    "omds_cost": (C.c_int, [C.c_void_p, F32P]),
+    "omds_weighted_update": (C.c_int, [C.c_void_p, C.c_float, C.c_float, F32P, F32P, F32P, I32P, F32P]),
+    "omds_get_qdot": (C.c_int, [C.c_void_p, C.c_int, F32P]),
+    "omds_cost_sum": (C.c_int, [C.c_void_p, F32P]),
+    "omds_red_count": (C.c_int, [C.c_void_p]),
+    "omds_local_sums": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_int, F32P]),
+    "omds_apply_update": (C.c_int, [C.c_int, C.c_int, C.c_int, F32P, C.c_float, C.c_float, C.c_float, F32P, F32P,
+                                    F32P, I32P]),
+    "omds_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "omds_prof_reset": (C.c_int, [C.c_void_p]),
+    "omds_prof_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "omds_sync": (C.c_int, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library and bind every entry point.  Fails loudly when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OmdsError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        f"or `make -C optimalmodulationds_amd/csrc` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def f32(a, shape=None):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def fptr(a):
+    return None if a is None else a.ctypes.data_as(F32P)
+
+
+def iptr(a):
+    return None if a is None else a.ctypes.data_as(I32P)
+
+
+def check(ctx, rc):
+    if rc != 0:
+        msg = load().omds_last_error(ctx)
+        raise OmdsError(f"omds error {rc}: {msg.decode() if msg else '?'}")
+
+
+def default_params() -> OmdsParams:
+    p = OmdsParams()
+    load().omds_default_params(C.byref(p))
+    return p

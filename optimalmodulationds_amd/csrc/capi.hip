@@ -1,0 +1,717 @@
+// C-ABI of libomds_hip.so (see include/omds.h for the contract and the reference interfaces
+// each entry point replaces).  Host-side orchestration only: packing weights into MFMA fragment
+// order, enqueueing the per-horizon-step kernel sequence on the context stream, layout
+// conversions for host copies, and the final O(K*n) policy update arithmetic.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "omds_internal.h"
+
+static thread_local std::string g_create_err;
+
+#define CK(expr) OMDS_HIP_CHECK(ctx, expr)
+#define REQUIRE(cond, code, msg)            \
+    do {                                    \
+        if (!(cond)) {                      \
+            ctx->err = (msg);               \
+            return (code);                  \
+        }                                   \
+    } while (0)
+
+template <typename T>
+static int upload(omds_ctx* ctx, const std::vector<T>& h, const T** dptr) {
+    void* p = nullptr;
+    CK(hipMalloc(&p, h.size() * sizeof(T)));
+    ctx->mlp_allocs.push_back(p);
+    CK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dptr = reinterpret_cast<const T*>(p);
+    return OMDS_OK;
+}
+
+extern "C" {
+
+int omds_version(void) { return 100; }
+
+void omds_default_params(omds_params* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->dt = 0.5f;
+    p->dst_thr = 0.5f;                                    // MPPI.py:59
+    p->lin_thr = 0.015f;                                  // LinDS.py:9
+    const float lvel[5] = {0.f, 1.f, -1.f, 0.f, 10.f};    // MPPI.py:132
+    const float ln[5] = {0.f, 1.f, 0.f, 0.1f, 100.f};     // MPPI.py:149-153
+    const float ltau[5] = {5.f, 1.f, 0.f, 0.1f, 100.f};   // MPPI.py:155 (y_min = ltau_max)
+    std::memcpy(p->lvel, lvel, sizeof(lvel));
+    std::memcpy(p->ln, ln, sizeof(ln));
+    std::memcpy(p->ltau, ltau, sizeof(ltau));
+    p->goal_act_cut = 0.5f;
+    p->norm_clamp = 0.5f;
+    p->coll_slow = 0.1f;
+    p->coll_repulse = 0.1f;
+    p->softmax_k = -10.f;
+    p->rbf_p = 2.f;
+    p->ignored_links = 0;
+}
+
+const char* omds_last_error(const omds_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+static void free_all(omds_ctx* ctx) {
+    void* ptrs[] = {ctx->d_obs, ctx->d_Bpre, ctx->d_radius, ctx->d_trajT, ctx->d_distT, ctx->d_dotT, ctx->d_actT,
+                    ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
+                    ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
+                    ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
+                    ctx->d_w, ctx->d_red, ctx->d_stage};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (void* p : ctx->mlp_allocs)
+        if (p) (void)hipFree(p);
+    if (ctx->h_red) (void)hipHostFree(ctx->h_red);
+    for (auto e : ctx->prof.start) (void)hipEventDestroy(e);
+    for (auto e : ctx->prof.stop) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+}
+
+int omds_create(const omds_config* cfg, omds_ctx** out) {
+    if (!cfg || !out) { g_create_err = "omds_create: null argument"; return OMDS_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (cfg->n_dof < 1 || cfg->n_dof > OMDS_MAX_DOF || cfg->n_traj < 1 || cfg->horizon < 1 || cfg->n_kernel_max < 1 ||
+        cfg->max_obs < 1 || cfg->n_closest < 1 || cfg->n_closest > 64) {
+        g_create_err = "omds_create: config out of range (1 <= n_dof <= 7, n_traj, horizon, n_kernel_max, max_obs >= 1, 1 <= n_closest <= 64)";
+        return OMDS_ERR_INVALID_ARG;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_err = std::string("omds_create: no HIP device available (") + hipGetErrorString(e) +
+                       "); this library has no CPU fallback";
+        return OMDS_ERR_HIP;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_create_err = "omds_create: device ordinal out of range"; return OMDS_ERR_INVALID_ARG; }
+    omds_ctx* ctx = new (std::nothrow) omds_ctx();
+    if (!ctx) { g_create_err = "omds_create: out of host memory"; return OMDS_ERR_INVALID_ARG; }
+    ctx->cfg = *cfg;
+    ctx->dev = cfg->device;
+    omds_default_params(&ctx->prm);
+    auto fail = [&](const std::string& m, int code) {
+        g_create_err = m;
+        free_all(ctx);
+        delete ctx;
+        return code;
+    };
+#define CKC(expr)                                                                         \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(_e), OMDS_ERR_HIP); \
+    } while (0)
+    CKC(hipSetDevice(ctx->dev));
+    CKC(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    const size_t N = cfg->n_traj, H = cfg->horizon, n = cfg->n_dof, Km = cfg->n_kernel_max, Om = cfg->max_obs,
+                 k = cfg->n_closest, d = n + 3;
+    const size_t rows2 = N * k;
+    CKC(hipMalloc(&ctx->d_obs, Om * 4 * 4));
+    CKC(hipMalloc(&ctx->d_Bpre, std::max(Om, rows2) * OMDS_WIDTH * 4));
+    CKC(hipMalloc(&ctx->d_radius, std::max(Om, rows2) * 4));
+    CKC(hipMalloc(&ctx->d_trajT, H * n * N * 4));
+    CKC(hipMalloc(&ctx->d_distT, H * N * 4));
+    CKC(hipMalloc(&ctx->d_dotT, H * N * 4));
+    CKC(hipMalloc(&ctx->d_actT, H * N * 4));
+    CKC(hipMalloc(&ctx->d_normalT, H * n * N * 4));
+    CKC(hipMalloc(&ctx->d_kvalT, H * Km * N * 4));
+    CKC(hipMalloc(&ctx->d_qdotT, n * N * 4));
+    CKC(hipMalloc(&ctx->d_maxact, Km * N * 4));
+    CKC(hipMalloc(&ctx->d_phisum0, Km * 4));
+    CKC(hipMalloc(&ctx->d_qstage, n * rows2 * 4));
+    CKC(hipMalloc(&ctx->d_muT, Km * n * N * 4));
+    CKC(hipMalloc(&ctx->d_sigmaT, Km * N * 4));
+    CKC(hipMalloc(&ctx->d_alphaT, Km * n * N * 4));
+    CKC(hipMalloc(&ctx->d_means, Km * (2 * n + 1) * 4));
+    CKC(hipMalloc(&ctx->d_Apre, rows2 * OMDS_WIDTH * 4));
+    CKC(hipMalloc(&ctx->d_Dmin, N * Om * 4));
+    CKC(hipMalloc(&ctx->d_idx, rows2 * 4));
+    CKC(hipMalloc(&ctx->d_gradx, rows2 * d * 4));
+    CKC(hipMalloc(&ctx->d_drow, rows2 * 4));
+    CKC(hipMalloc(&ctx->d_yraw, rows2 * OMDS_CPAD * 4));
+    CKC(hipMalloc(&ctx->d_minidx, rows2 * 4));
+    CKC(hipMalloc(&ctx->d_dist, N * 4));
+    CKC(hipMalloc(&ctx->d_nngrad, N * n * 4));
+    CKC(hipMalloc(&ctx->d_cost, N * 4));
+    CKC(hipMalloc(&ctx->d_w, N * 4));
+    const size_t redn = (size_t)omds_red_size((int)Km, (int)n) + 8;
+    CKC(hipMalloc(&ctx->d_red, redn * 4));
+    CKC(hipHostMalloc(&ctx->h_red, redn * 4));
+    ctx->stage_bytes = std::max({N * H * std::max(Km, n) * 4, N * Om * 4, Km * n * N * 4, rows2 * OMDS_CPAD * 4});
+    CKC(hipMalloc(&ctx->d_stage, ctx->stage_bytes));
+    CKC(hipMemsetAsync(ctx->d_trajT, 0, H * n * N * 4, ctx->stream));
+    CKC(hipMemsetAsync(ctx->d_kvalT, 0, H * Km * N * 4, ctx->stream));
+    CKC(hipMemsetAsync(ctx->d_maxact, 0, Km * N * 4, ctx->stream));
+    CKC(hipMemsetAsync(ctx->d_phisum0, 0, Km * 4, ctx->stream));
+    CKC(hipStreamSynchronize(ctx->stream));
+#undef CKC
+    *out = ctx;
+    return OMDS_OK;
+}
+
+void omds_destroy(omds_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->dev);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_all(ctx);
+    delete ctx;
+}
+
+int omds_sync(omds_ctx* ctx) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    CK(hipStreamSynchronize(ctx->stream));
+    return OMDS_OK;
+}
+
+// ---- weights -------------------------------------------------------------------------------------
+
+int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* const* W, const float* const* b, int act,
+                 float out_div) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(dims && W && b && n_linear >= 2, OMDS_ERR_INVALID_ARG, "omds_set_mlp: null argument or fewer than 2 Linear layers");
+    const int n = ctx->cfg.n_dof, d = n + 3;
+    REQUIRE(dims[0] == 3 * d, OMDS_ERR_INVALID_ARG, "omds_set_mlp: dims[0] must be 3*(n_dof+3) (NeRF encoding [x, sin x, cos x])");
+    REQUIRE(3 * d <= 32, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: 3*(n_dof+3) > 32 not supported");
+    const int nhid = n_linear - 1;
+    REQUIRE(nhid <= OMDS_MAX_HIDDEN, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: too many hidden layers");
+    for (int i = 1; i <= nhid; ++i)
+        REQUIRE(dims[i] == OMDS_WIDTH, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: only hidden width 256 is supported by the MFMA kernels");
+    const int C = dims[n_linear];
+    REQUIRE(C >= 1 && C <= OMDS_CPAD, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: 1 <= out_channels <= 16 required");
+    REQUIRE(act == OMDS_ACT_RELU, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: only ReLU networks are supported (all shipped reference weights are ReLU)");
+    REQUIRE(out_div != 0.f, OMDS_ERR_INVALID_ARG, "omds_set_mlp: out_div must be non-zero");
+    CK(hipSetDevice(ctx->dev));
+    CK(hipStreamSynchronize(ctx->stream));
+    for (void* p : ctx->mlp_allocs) (void)hipFree(p);
+    ctx->mlp_allocs.clear();
+    ctx->have_mlp = false;
+    MlpDev m{};
+    m.nhh = nhid - 1;
+    m.C = C;
+    m.d = d;
+    m.n_dof = n;
+    m.out_div = out_div;
+    const int Wd = OMDS_WIDTH;
+    // hidden->hidden: forward and transposed (backward) fragment packs
+    std::vector<float4> wf((size_t)std::max(m.nhh, 1) * OMDS_NCB * 32 * 64), wb(wf.size());
+    std::vector<float> bh((size_t)std::max(m.nhh, 1) * Wd, 0.f);
+    for (int l = 0; l < m.nhh; ++l) {
+        const float* Wl = W[l + 1];
+        for (int cb = 0; cb < OMDS_NCB; ++cb)
+            for (int c = 0; c < 32; ++c)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int j = 32 * cb + (lane & 31), k0 = 8 * c + 4 * (lane >> 5);
+                    const size_t o = (((size_t)l * OMDS_NCB + cb) * 32 + c) * 64 + lane;
+                    wf[o] = make_float4(Wl[j * Wd + k0], Wl[j * Wd + k0 + 1], Wl[j * Wd + k0 + 2], Wl[j * Wd + k0 + 3]);
+                    wb[o] = make_float4(Wl[(k0)*Wd + j], Wl[(k0 + 1) * Wd + j], Wl[(k0 + 2) * Wd + j], Wl[(k0 + 3) * Wd + j]);
+                }
+        std::memcpy(&bh[(size_t)l * Wd], b[l + 1], Wd * sizeof(float));
+    }
+    // last layer: 16x16x4 B-fragments, channels padded to 16
+    const float* WL = W[n_linear - 1];
+    std::vector<float4> wl(16 * 64);
+    for (int c = 0; c < 16; ++c)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int j = lane & 15, k0 = 16 * c + 4 * (lane >> 4);
+            float v[4] = {0, 0, 0, 0};
+            if (j < C)
+                for (int mm = 0; mm < 4; ++mm) v[mm] = WL[j * Wd + k0 + mm];
+            wl[c * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    std::vector<float> bl(OMDS_CPAD, 0.f), wlraw((size_t)C * Wd);
+    std::memcpy(bl.data(), b[n_linear - 1], C * sizeof(float));
+    std::memcpy(wlraw.data(), WL, (size_t)C * Wd * sizeof(float));
+    // first layer: transposed copy + backward pack over the 3d features (padded to 32 columns)
+    const int F = 3 * d;
+    std::vector<float> w1t((size_t)F * Wd), b1(Wd);
+    for (int c = 0; c < Wd; ++c)
+        for (int f = 0; f < F; ++f) w1t[(size_t)f * Wd + c] = W[0][c * F + f];
+    std::memcpy(b1.data(), b[0], Wd * sizeof(float));
+    std::vector<float4> w1b(32 * 64);
+    for (int c = 0; c < 32; ++c)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int f = lane & 31, k0 = 8 * c + 4 * (lane >> 5);
+            float v[4] = {0, 0, 0, 0};
+            if (f < F)
+                for (int mm = 0; mm < 4; ++mm) v[mm] = W[0][(k0 + mm) * F + f];
+            w1b[c * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    int rc;
+    if ((rc = upload(ctx, wf, &m.Wf))) return rc;
+    if ((rc = upload(ctx, wb, &m.Wb))) return rc;
+    if ((rc = upload(ctx, bh, &m.bh))) return rc;
+    if ((rc = upload(ctx, wl, &m.Wl))) return rc;
+    if ((rc = upload(ctx, bl, &m.bl))) return rc;
+    if ((rc = upload(ctx, wlraw, &m.Wlraw))) return rc;
+    if ((rc = upload(ctx, w1t, &m.W1t))) return rc;
+    if ((rc = upload(ctx, b1, &m.b1))) return rc;
+    if ((rc = upload(ctx, w1b, &m.W1b))) return rc;
+    ctx->mlp = m;
+    ctx->act = act;
+    ctx->have_mlp = true;
+    if (ctx->n_obs > 0) {  // re-derive the obstacle half of layer 1 for the new weights
+        omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, ctx->n_obs, ctx->d_Bpre, ctx->d_radius);
+        CK(hipGetLastError());
+        CK(hipStreamSynchronize(ctx->stream));
+    }
+    return OMDS_OK;
+}
+
+int omds_set_obstacles(omds_ctx* ctx, const float* xyzr, int n_obs) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(xyzr && n_obs >= 1 && n_obs <= ctx->cfg.max_obs, OMDS_ERR_INVALID_ARG,
+            "omds_set_obstacles: need 1 <= n_obs <= max_obs and a non-null [O,4] array");
+    REQUIRE(n_obs >= ctx->cfg.n_closest, OMDS_ERR_INVALID_ARG, "omds_set_obstacles: fewer obstacles than n_closest");
+    CK(hipSetDevice(ctx->dev));
+    CK(hipMemcpyAsync(ctx->d_obs, xyzr, (size_t)n_obs * 16, hipMemcpyHostToDevice, ctx->stream));
+    ctx->n_obs = n_obs;
+    if (ctx->have_mlp) {
+        omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, n_obs, ctx->d_Bpre, ctx->d_radius);
+        CK(hipGetLastError());
+    }
+    CK(hipStreamSynchronize(ctx->stream));
+    return OMDS_OK;
+}
+
+static void refresh_goal_fk(omds_ctx* ctx) {
+    if (ctx->have_ds && ctx->have_cost) omds_host_link_endpoints(ctx->qf, ctx->dh, ctx->cfg.n_dof, ctx->goal_fk);
+}
+
+int omds_set_ds(omds_ctx* ctx, const float* q_goal) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(q_goal, OMDS_ERR_INVALID_ARG, "omds_set_ds: null q_goal");
+    std::memcpy(ctx->qf, q_goal, ctx->cfg.n_dof * sizeof(float));
+    ctx->have_ds = true;
+    refresh_goal_fk(ctx);
+    return OMDS_OK;
+}
+
+int omds_set_params(omds_ctx* ctx, const omds_params* p) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(p, OMDS_ERR_INVALID_ARG, "omds_set_params: null params");
+    REQUIRE(p->rbf_p > 0.f, OMDS_ERR_INVALID_ARG, "omds_set_params: rbf_p must be positive");
+    ctx->prm = *p;
+    return OMDS_OK;
+}
+
+int omds_set_cost(omds_ctx* ctx, const float* dh_params, const float* q_min, const float* q_max) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(dh_params && q_min && q_max, OMDS_ERR_INVALID_ARG, "omds_set_cost: null argument");
+    const int n = ctx->cfg.n_dof;
+    std::memcpy(ctx->dh, dh_params, (size_t)(n + 1) * 4 * sizeof(float));
+    std::memcpy(ctx->qmin, q_min, n * sizeof(float));
+    std::memcpy(ctx->qmax, q_max, n * sizeof(float));
+    ctx->have_cost = true;
+    refresh_goal_fk(ctx);
+    return OMDS_OK;
+}
+
+// ---- policy samples -------------------------------------------------------------------------------
+int omds_set_policy_samples(omds_ctx* ctx, const float* mu, const float* sigma, const float* alpha, int K) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(K >= 0 && K <= ctx->cfg.n_kernel_max, OMDS_ERR_INVALID_ARG, "omds_set_policy_samples: 0 <= n_kernels <= n_kernel_max");
+    CK(hipSetDevice(ctx->dev));
+    ctx->n_kernels = K;
+    if (K == 0) return OMDS_OK;
+    REQUIRE(mu && sigma && alpha, OMDS_ERR_INVALID_ARG, "omds_set_policy_samples: null sample array");
+    const int N = ctx->cfg.n_traj, n = ctx->cfg.n_dof;
+    CK(hipMemcpyAsync(ctx->d_stage, mu, (size_t)N * K * n * 4, hipMemcpyHostToDevice, ctx->stream));
+    omds_launch_transpose(ctx->stream, ctx->d_stage, ctx->d_muT, N, K * n);
+    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipMemcpyAsync(ctx->d_stage, alpha, (size_t)N * K * n * 4, hipMemcpyHostToDevice, ctx->stream));
+    omds_launch_transpose(ctx->stream, ctx->d_stage, ctx->d_alphaT, N, K * n);
+    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipMemcpyAsync(ctx->d_stage, sigma, (size_t)N * K * 4, hipMemcpyHostToDevice, ctx->stream));
+    omds_launch_transpose(ctx->stream, ctx->d_stage, ctx->d_sigmaT, N, K);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(ctx->stream));
+    return OMDS_OK;
+}
+
+int omds_sample_policy(omds_ctx* ctx, const float* mu_c, const float* sigma_c, const float* alpha_c, float mu_s,
+                       float sigma_s, float alpha_s, int K, uint64_t seed, int64_t rollout_offset) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(K >= 0 && K <= ctx->cfg.n_kernel_max, OMDS_ERR_INVALID_ARG, "omds_sample_policy: 0 <= n_kernels <= n_kernel_max");
+    CK(hipSetDevice(ctx->dev));
+    ctx->n_kernels = K;
+    if (K == 0) return OMDS_OK;
+    REQUIRE(mu_c && sigma_c && alpha_c, OMDS_ERR_INVALID_ARG, "omds_sample_policy: null mean array");
+    const int N = ctx->cfg.n_traj, n = ctx->cfg.n_dof;
+    std::vector<float> means((size_t)K * (2 * n + 1));
+    std::memcpy(means.data(), mu_c, (size_t)K * n * 4);
+    std::memcpy(means.data() + (size_t)K * n, sigma_c, (size_t)K * 4);
+    std::memcpy(means.data() + (size_t)K * n + K, alpha_c, (size_t)K * n * 4);
+    CK(hipMemcpyAsync(ctx->d_means, means.data(), means.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));  // 'means' is pageable stack memory
+    omds_launch_sample(ctx->stream, N, n, K, ctx->d_means, mu_s, sigma_s, alpha_s, seed, rollout_offset, ctx->d_muT,
+                       ctx->d_sigmaT, ctx->d_alphaT);
+    CK(hipGetLastError());
+    return OMDS_OK;
+}
+
+int omds_get_policy_samples(omds_ctx* ctx, float* mu, float* sigma, float* alpha) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    CK(hipSetDevice(ctx->dev));
+    const int N = ctx->cfg.n_traj, n = ctx->cfg.n_dof, K = ctx->n_kernels;
+    if (K == 0) return OMDS_OK;
+    if (mu) {
+        omds_launch_transpose(ctx->stream, ctx->d_muT, ctx->d_stage, K * n, N);
+        CK(hipMemcpyAsync(mu, ctx->d_stage, (size_t)N * K * n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+    }
+    if (alpha) {
+        omds_launch_transpose(ctx->stream, ctx->d_alphaT, ctx->d_stage, K * n, N);
+        CK(hipMemcpyAsync(alpha, ctx->d_stage, (size_t)N * K * n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+    }
+    if (sigma) {
+        omds_launch_transpose(ctx->stream, ctx->d_sigmaT, ctx->d_stage, K, N);
+        CK(hipMemcpyAsync(sigma, ctx->d_stage, (size_t)N * K * 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+    }
+    return OMDS_OK;
+}
+
+// ---- distance network on a batch: Apre -> pass 1 -> top-k -> pass 2 ---------------------------------
+static int prof_begin(omds_ctx* ctx) {
+    if (!ctx->prof_on) return OMDS_OK;
+    ProfEvents& p = ctx->prof;
+    if (p.used == p.start.size()) {
+        hipEvent_t a, b;
+        CK(hipEventCreate(&a));
+        CK(hipEventCreate(&b));
+        p.start.push_back(a);
+        p.stop.push_back(b);
+    }
+    CK(hipEventRecord(p.start[p.used], ctx->stream));
+    return OMDS_OK;
+}
+static int prof_end(omds_ctx* ctx, int64_t rows) {
+    if (!ctx->prof_on) return OMDS_OK;
+    ProfEvents& p = ctx->prof;
+    CK(hipEventRecord(p.stop[p.used], ctx->stream));
+    p.used++;
+    p.launches++;
+    p.rows += rows;
+    return OMDS_OK;
+}
+static int prof_collect(omds_ctx* ctx) {
+    ProfEvents& p = ctx->prof;
+    for (size_t i = 0; i < p.used; ++i) {
+        float ms = 0.f;
+        CK(hipEventSynchronize(p.stop[i]));
+        CK(hipEventElapsedTime(&ms, p.start[i], p.stop[i]));
+        p.ms += ms;
+    }
+    p.used = 0;
+    return OMDS_OK;
+}
+
+static int enqueue_network(omds_ctx* ctx, const float* qT, int ldq, int B) {
+    const MlpDev& m = ctx->mlp;
+    const int O = ctx->n_obs, k = ctx->cfg.n_closest;
+    omds_launch_rollout_layer1(ctx->stream, m, qT, ldq, B, ctx->d_Apre);
+    int rc;
+    if ((rc = prof_begin(ctx))) return rc;
+    omds_launch_pass1(ctx->stream, m, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
+    if ((rc = prof_end(ctx, (int64_t)B * O))) return rc;
+    omds_launch_topk(ctx->stream, ctx->d_Dmin, B, O, k, ctx->d_idx);
+    omds_launch_pass2(ctx->stream, m, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_idx, B, k, qT, ldq,
+                      ctx->d_gradx, ctx->d_drow, nullptr, nullptr);
+    CK(hipGetLastError());
+    return OMDS_OK;
+}
+
+static int check_ready(omds_ctx* ctx, bool need_ds) {
+    REQUIRE(ctx->have_mlp, OMDS_ERR_NOT_INITIALISED, "distance network not set (omds_set_mlp)");
+    REQUIRE(ctx->n_obs > 0, OMDS_ERR_NOT_INITIALISED, "obstacles not set (omds_set_obstacles)");
+    if (need_ds) REQUIRE(ctx->have_ds, OMDS_ERR_NOT_INITIALISED, "nominal DS not set (omds_set_ds)");
+    return OMDS_OK;
+}
+
+int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(q_cur, OMDS_ERR_INVALID_ARG, "omds_propagate: null q_cur");
+    int rc;
+    if ((rc = check_ready(ctx, true))) return rc;
+    CK(hipSetDevice(ctx->dev));
+    const int N = ctx->cfg.n_traj, H = ctx->cfg.horizon, n = ctx->cfg.n_dof;
+    // all_traj[:, 0, :] = q_cur  (MPPI.py:99)
+    if (per_rollout) {
+        CK(hipMemcpyAsync(ctx->d_stage, q_cur, (size_t)N * n * 4, hipMemcpyHostToDevice, ctx->stream));
+        omds_launch_transpose(ctx->stream, ctx->d_stage, ctx->d_trajT, N, n);
+    } else {
+        CK(hipMemcpyAsync(ctx->d_means, q_cur, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        omds_launch_broadcast_q(ctx->stream, ctx->d_means, n, N, ctx->d_trajT);
+    }
+    CK(hipStreamSynchronize(ctx->stream));  // q_cur is caller memory; d_means is reused below by nobody until sample
+    StepArgs a{};
+    a.N = N; a.H = H; a.n = n; a.K = ctx->n_kernels; a.Kmax = ctx->cfg.n_kernel_max; a.k = ctx->cfg.n_closest; a.d = n + 3;
+    a.trajT = ctx->d_trajT; a.distT = ctx->d_distT; a.dotT = ctx->d_dotT; a.actT = ctx->d_actT; a.normalT = ctx->d_normalT;
+    a.kvalT = ctx->d_kvalT; a.qdotT = ctx->d_qdotT; a.maxact = ctx->d_maxact; a.phisum0 = ctx->d_phisum0;
+    a.muT = ctx->d_muT; a.sigmaT = ctx->d_sigmaT; a.alphaT = ctx->d_alphaT; a.gradx = ctx->d_gradx; a.drow = ctx->d_drow;
+    std::memcpy(a.qf, ctx->qf, sizeof(a.qf));
+    a.prm = ctx->prm;
+    for (int i = 1; i <= H; ++i) {   // MPPI.py:101: H network evaluations, the last velocity is not integrated
+        if ((rc = enqueue_network(ctx, ctx->d_trajT + (size_t)(i - 1) * n * N, N, N))) return rc;
+        a.step = i;
+        omds_launch_modulate(ctx->stream, a);
+    }
+    CK(hipGetLastError());
+    ctx->have_cost_vals = false;
+    CK(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof_on && (rc = prof_collect(ctx))) return rc;
+    return OMDS_OK;
+}
+
+int omds_get_rollouts(omds_ctx* ctx, float* all_traj, float* closest_dist_all, float* kernel_val_all, float* dot_products,
+                      float* kernel_activations, float* qdot, float* normal) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    CK(hipSetDevice(ctx->dev));
+    const int N = ctx->cfg.n_traj, H = ctx->cfg.horizon, n = ctx->cfg.n_dof, K = ctx->n_kernels, Km = ctx->cfg.n_kernel_max;
+    auto fetch = [&](const float* srcT, float* dst, int X, int Xld) -> int {
+        if (!dst || X == 0) return OMDS_OK;
+        omds_launch_permute_hxn_to_nhx(ctx->stream, srcT, ctx->d_stage, H, X, N, Xld);
+        CK(hipMemcpyAsync(dst, ctx->d_stage, (size_t)N * H * X * 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        return OMDS_OK;
+    };
+    int rc;
+    if ((rc = fetch(ctx->d_trajT, all_traj, n, n))) return rc;
+    if ((rc = fetch(ctx->d_distT, closest_dist_all, 1, 1))) return rc;
+    if ((rc = fetch(ctx->d_kvalT, kernel_val_all, K, Km))) return rc;
+    if ((rc = fetch(ctx->d_dotT, dot_products, 1, 1))) return rc;
+    if ((rc = fetch(ctx->d_actT, kernel_activations, 1, 1))) return rc;
+    if ((rc = fetch(ctx->d_normalT, normal, n, n))) return rc;
+    if (qdot) {
+        omds_launch_transpose(ctx->stream, ctx->d_qdotT, ctx->d_stage, n, N);
+        CK(hipMemcpyAsync(qdot, ctx->d_stage, (size_t)N * n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+    }
+    return OMDS_OK;
+}
+
+int omds_dist_grad(omds_ctx* ctx, const float* q, int B, float* distance, float* nn_grad, float* mindist,
+                   int32_t* closest_idx) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(q && B >= 1 && B <= ctx->cfg.n_traj, OMDS_ERR_INVALID_ARG, "omds_dist_grad: need 1 <= batch <= n_traj and non-null q");
+    int rc;
+    if ((rc = check_ready(ctx, false))) return rc;
+    CK(hipSetDevice(ctx->dev));
+    const int n = ctx->cfg.n_dof, k = ctx->cfg.n_closest, O = ctx->n_obs, d = n + 3;
+    CK(hipMemcpyAsync(ctx->d_stage, q, (size_t)B * n * 4, hipMemcpyHostToDevice, ctx->stream));
+    omds_launch_transpose(ctx->stream, ctx->d_stage, ctx->d_qstage, B, n);   // -> [n][B]
+    if ((rc = enqueue_network(ctx, ctx->d_qstage, B, B))) return rc;
+    omds_launch_blend(ctx->stream, ctx->d_gradx, ctx->d_drow, B, k, d, n, ctx->prm.softmax_k, ctx->d_dist, ctx->d_nngrad);
+    CK(hipGetLastError());
+    if (distance) CK(hipMemcpyAsync(distance, ctx->d_dist, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (nn_grad) CK(hipMemcpyAsync(nn_grad, ctx->d_nngrad, (size_t)B * n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (mindist) CK(hipMemcpyAsync(mindist, ctx->d_Dmin, (size_t)B * O * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (closest_idx) CK(hipMemcpyAsync(closest_idx, ctx->d_idx, (size_t)B * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof_on && (rc = prof_collect(ctx))) return rc;
+    return OMDS_OK;
+}
+
+int omds_mlp_forward_vjp(omds_ctx* ctx, const float* x, int B, float* y, float* grad, int32_t* min_idx) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    const int n = ctx->cfg.n_dof, d = n + 3;
+    const int cap = ctx->cfg.n_traj * ctx->cfg.n_closest;
+    REQUIRE(x && B >= 1 && B <= cap, OMDS_ERR_INVALID_ARG, "omds_mlp_forward_vjp: need 1 <= batch <= n_traj*n_closest and non-null x");
+    REQUIRE(ctx->have_mlp, OMDS_ERR_NOT_INITIALISED, "distance network not set (omds_set_mlp)");
+    CK(hipSetDevice(ctx->dev));
+    // every row is its own (rollout, obstacle) pair: Apre from x[:, :n], Bpre from x[:, n:], radius 0
+    std::vector<float> xyzr((size_t)B * 4, 0.f), qrow((size_t)B * n);
+    std::vector<int32_t> ident(B);
+    for (int r = 0; r < B; ++r) {
+        for (int j = 0; j < n; ++j) qrow[(size_t)r * n + j] = x[(size_t)r * d + j];
+        for (int j = 0; j < 3; ++j) xyzr[(size_t)r * 4 + j] = x[(size_t)r * d + n + j];
+        ident[r] = r;
+    }
+    float *d_xyzr = nullptr, *d_B = nullptr, *d_rad = nullptr;
+    CK(hipMalloc(&d_xyzr, (size_t)B * 16));
+    CK(hipMalloc(&d_B, (size_t)B * OMDS_WIDTH * 4));
+    CK(hipMalloc(&d_rad, (size_t)B * 4));
+    auto cleanup = [&]() { (void)hipFree(d_xyzr); (void)hipFree(d_B); (void)hipFree(d_rad); };
+    hipError_t e;
+#define CKL(expr) do { e = (expr); if (e != hipSuccess) { cleanup(); ctx->err = std::string(#expr) + ": " + hipGetErrorString(e); return OMDS_ERR_HIP; } } while (0)
+    CKL(hipMemcpyAsync(d_xyzr, xyzr.data(), (size_t)B * 16, hipMemcpyHostToDevice, ctx->stream));
+    CKL(hipMemcpyAsync(ctx->d_stage, qrow.data(), (size_t)B * n * 4, hipMemcpyHostToDevice, ctx->stream));
+    CKL(hipMemcpyAsync(ctx->d_idx, ident.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+    omds_launch_transpose(ctx->stream, ctx->d_stage, ctx->d_qstage, B, n);
+    omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Apre);
+    omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, d_xyzr, B, d_B, d_rad);
+    omds_launch_pass2(ctx->stream, ctx->mlp, ctx->d_Apre, d_B, d_rad, d_xyzr, ctx->d_idx, B, 1, ctx->d_qstage, B,
+                      ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx);
+    CKL(hipGetLastError());
+    CKL(hipStreamSynchronize(ctx->stream));
+    if (y) {
+        std::vector<float> ypad((size_t)B * OMDS_CPAD);
+        CKL(hipMemcpy(ypad.data(), ctx->d_yraw, ypad.size() * 4, hipMemcpyDeviceToHost));
+        for (int r = 0; r < B; ++r)
+            for (int c = 0; c < ctx->mlp.C; ++c) y[(size_t)r * ctx->mlp.C + c] = ypad[(size_t)r * OMDS_CPAD + c];
+    }
+    if (grad) CKL(hipMemcpy(grad, ctx->d_gradx, (size_t)B * d * 4, hipMemcpyDeviceToHost));
+    if (min_idx) CKL(hipMemcpy(min_idx, ctx->d_minidx, (size_t)B * 4, hipMemcpyDeviceToHost));
+#undef CKL
+    cleanup();
+    return OMDS_OK;
+}
+
+// ---- cost and the cost-weighted update --------------------------------------------------------------
+static int enqueue_cost(omds_ctx* ctx) {
+    CostArgs a{};
+    a.N = ctx->cfg.n_traj; a.H = ctx->cfg.horizon; a.n = ctx->cfg.n_dof;
+    a.trajT = ctx->d_trajT; a.distT = ctx->d_distT; a.cost = ctx->d_cost;
+    std::memcpy(a.qf, ctx->qf, sizeof(a.qf));
+    std::memcpy(a.qmin, ctx->qmin, sizeof(a.qmin));
+    std::memcpy(a.qmax, ctx->qmax, sizeof(a.qmax));
+    std::memcpy(a.dh, ctx->dh, sizeof(a.dh));
+    std::memcpy(a.goal_fk, ctx->goal_fk, sizeof(a.goal_fk));
+    omds_launch_cost(ctx->stream, a);
+    CK(hipGetLastError());
+    ctx->have_cost_vals = true;
+    return OMDS_OK;
+}
+
+int omds_cost(omds_ctx* ctx, float* cost_out) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(ctx->have_ds && ctx->have_cost, OMDS_ERR_NOT_INITIALISED, "omds_cost: call omds_set_ds and omds_set_cost first");
+    CK(hipSetDevice(ctx->dev));
+    int rc;
+    if ((rc = enqueue_cost(ctx))) return rc;
+    if (cost_out) {
+        CK(hipMemcpyAsync(cost_out, ctx->d_cost, (size_t)ctx->cfg.n_traj * 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+    }
+    return OMDS_OK;
+}
+
+// Local [sum(cost), N] of this shard.
+int omds_cost_sum(omds_ctx* ctx, float* out2) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(out2, OMDS_ERR_INVALID_ARG, "omds_cost_sum: null output");
+    REQUIRE(ctx->have_cost_vals, OMDS_ERR_NOT_INITIALISED, "no cost available: call omds_cost after omds_propagate");
+    CK(hipSetDevice(ctx->dev));
+    const int rs = omds_red_size(ctx->n_kernels, ctx->cfg.n_dof);
+    float* red2 = ctx->d_red + rs;  // [sum cost, N] lives behind the packed buffer
+    omds_launch_cost_sum(ctx->stream, ctx->d_cost, ctx->cfg.n_traj, red2);
+    CK(hipGetLastError());
+    CK(hipMemcpyAsync(ctx->h_red + rs, red2, 8, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    out2[0] = ctx->h_red[rs];
+    out2[1] = ctx->h_red[rs + 1];
+    return OMDS_OK;
+}
+
+int omds_red_count(const omds_ctx* ctx) { return ctx ? omds_red_size(ctx->n_kernels, ctx->cfg.n_dof) : 0; }
+
+// Packed partial sums of this shard for the GLOBAL beta = (sum_cost / n_total) / 50.
+int omds_local_sums(omds_ctx* ctx, float sum_cost, float n_total, int include_rollout0, float* red_out) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(red_out && n_total > 0.f, OMDS_ERR_INVALID_ARG, "omds_local_sums: null output or n_total <= 0");
+    REQUIRE(ctx->have_cost_vals, OMDS_ERR_NOT_INITIALISED, "no cost available: call omds_cost after omds_propagate");
+    CK(hipSetDevice(ctx->dev));
+    const int N = ctx->cfg.n_traj, n = ctx->cfg.n_dof, K = ctx->n_kernels;
+    const int rs = omds_red_size(K, n);
+    float* red2 = ctx->d_red + rs;
+    ctx->h_red[rs] = sum_cost;
+    ctx->h_red[rs + 1] = n_total;
+    CK(hipMemcpyAsync(red2, ctx->h_red + rs, 8, hipMemcpyHostToDevice, ctx->stream));
+    omds_launch_weights(ctx->stream, ctx->d_cost, N, red2, ctx->d_w, nullptr);
+    omds_launch_policy_sums(ctx->stream, N, n, K, ctx->d_w, ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_maxact,
+                            ctx->d_phisum0, ctx->d_qdotT, ctx->d_cost, include_rollout0, ctx->d_red);
+    CK(hipGetLastError());
+    CK(hipMemcpyAsync(ctx->h_red, ctx->d_red, (size_t)rs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    std::memcpy(red_out, ctx->h_red, (size_t)rs * 4);
+    return OMDS_OK;
+}
+
+// Pure host arithmetic, no context: masks + theta_c update from the (globally) reduced buffer.
+int omds_apply_update(int K, int n, int H, const float* red, float n_total, float rate, float ker_thr, float* mu_c,
+                      float* sigma_c, float* alpha_c, int32_t* mask_out) {
+    if (K < 0 || n < 1 || H < 1 || !red || n_total <= 0.f) return OMDS_ERR_INVALID_ARG;
+    if (K > 0 && (!mu_c || !sigma_c || !alpha_c)) return OMDS_ERR_INVALID_ARG;
+    const float sumw = red[0];
+    const float *s_mu = red + 1, *s_sg = s_mu + K * n, *s_al = s_sg + K, *s_mx = s_al + K * n, *s_ph = s_mx + K;
+    for (int kk = 0; kk < K; ++kk) {
+        // mask 1: mean over ALL rollouts of max_h(phi*act) > ker_thr; mask 2: mean_h phi of rollout 0 (MPPI.py:336-342)
+        const float m1 = s_mx[kk] / n_total, m2 = s_ph[kk] / (float)H;
+        const bool upd = (m1 > ker_thr) && (m2 > ker_thr);   // NaN compares false, like torch
+        if (mask_out) mask_out[kk] = upd ? 1 : 0;
+        const float u = upd ? rate : 0.f;
+        for (int j = 0; j < n; ++j) {
+            mu_c[kk * n + j] = (1.f - u) * mu_c[kk * n + j] + u * (s_mu[kk * n + j] / sumw);
+            alpha_c[kk * n + j] = (1.f - u) * alpha_c[kk * n + j] + u * (s_al[kk * n + j] / sumw);
+        }
+        sigma_c[kk] = (1.f - u) * sigma_c[kk] + u * (s_sg[kk] / sumw);
+    }
+    return OMDS_OK;
+}
+
+int omds_weighted_update(omds_ctx* ctx, float rate, float ker_thr, float* mu_c, float* sigma_c, float* alpha_c,
+                         int32_t* mask_out, float* weights_out) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    const int N = ctx->cfg.n_traj, n = ctx->cfg.n_dof, K = ctx->n_kernels, H = ctx->cfg.horizon;
+    REQUIRE(K == 0 || (mu_c && sigma_c && alpha_c), OMDS_ERR_INVALID_ARG, "omds_weighted_update: null mean array");
+    int rc;
+    float cs[2];
+    if ((rc = omds_cost_sum(ctx, cs))) return rc;
+    std::vector<float> red(omds_red_size(K, n));
+    if ((rc = omds_local_sums(ctx, cs[0], cs[1], 1, red.data()))) return rc;
+    if ((rc = omds_apply_update(K, n, H, red.data(), cs[1], rate, ker_thr, mu_c, sigma_c, alpha_c, mask_out))) {
+        ctx->err = "omds_apply_update: invalid argument";
+        return rc;
+    }
+    if (weights_out) {
+        std::vector<float> w(N);
+        CK(hipMemcpy(w.data(), ctx->d_w, (size_t)N * 4, hipMemcpyDeviceToHost));
+        for (int t = 0; t < N; ++t) weights_out[t] = w[t] / red[0];
+    }
+    return OMDS_OK;
+}
+
+int omds_get_qdot(omds_ctx* ctx, int mode, float* out) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(out && (mode == 0 || mode == 1), OMDS_ERR_INVALID_ARG, "omds_get_qdot: mode 0 ('best') or 1 ('weighted'), non-null out");
+    int rc;
+    float cs[2];
+    if ((rc = omds_cost_sum(ctx, cs))) return rc;
+    const int n = ctx->cfg.n_dof, K = ctx->n_kernels;
+    std::vector<float> red(omds_red_size(K, n));
+    if ((rc = omds_local_sums(ctx, cs[0], cs[1], 1, red.data()))) return rc;
+    const int o_qd = 1 + K * (2 * n + 3), o_best = o_qd + n;
+    for (int j = 0; j < n; ++j) out[j] = mode == 1 ? red[o_qd + j] / red[0] : red[o_best + 1 + j];
+    return OMDS_OK;
+}
+
+// ---- measurement -------------------------------------------------------------------------------------
+int omds_prof_enable(omds_ctx* ctx, int on) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    ctx->prof_on = on != 0;
+    return OMDS_OK;
+}
+int omds_prof_reset(omds_ctx* ctx) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    ctx->prof.ms = 0.0;
+    ctx->prof.launches = 0;
+    ctx->prof.rows = 0;
+    ctx->prof.used = 0;
+    return OMDS_OK;
+}
+int omds_prof_read(omds_ctx* ctx, double* pass1_ms, int64_t* pass1_launches, int64_t* pass1_rows) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    if (pass1_ms) *pass1_ms = ctx->prof.ms;
+    if (pass1_launches) *pass1_launches = ctx->prof.launches;
+    if (pass1_rows) *pass1_rows = ctx->prof.rows;
+    return OMDS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,542 @@
+// Distance-network kernels for gfx950 (MI355X): exact-fp32 MFMA, activations resident in LDS.
+//
+// What they replace in the reference (paths relative to python_scripts/):
+//   k_pass1          : MPPI.build_nn_input + model_jit.forward over all N*O (rollout, obstacle)
+//                      pairs + /100, -radius, link mask, min over links
+//                      (ds_mppi/functions/MPPI.py:93-95, 233-243; mlp_learn/sdf/network_macros_mod.py:137-146)
+//   k_topk           : mindist_matrix.sort(dim=1)[:, :k]                       (MPPI.py:245-247)
+//   k_pass2          : RobotSdfCollisionNet.functorch_vjp on the N*k closest rows: forward,
+//                      arg-min link over all raw outputs, analytic backward (ReLU masks + the
+//                      positional-encoding chain rule)                         (robot_sdf.py:153-158)
+//   k_blend          : softmax(-10 d) blend of the k gradients                 (MPPI.py:270-280)
+//
+// Design (MI355X-first, not a translation):
+//   * layer 1 is separable: z1[t,o] = (W1_q f(q_t) + b1) + W1_p f(p_o) = Apre[t] + Bpre[o], so the
+//     [N*O, n+4] input matrix is never materialised and sin/cos are evaluated per rollout and
+//     per obstacle, not per pair;
+//   * a workgroup owns MT consecutive rows of the virtual (rollout-major) row space, keeps the
+//     [MT x 256] activation tile in LDS (row stride 260 floats: conflict-free ds_read_b128 of
+//     MFMA A-fragments) across all layers, and streams the pre-packed weights straight from L2
+//     into VGPRs as MFMA B-fragments (1 KiB fully coalesced per wave-load, no LDS round trip);
+//   * v_mfma_f32_32x32x2_f32: the K order inside a dot product is free, so each lane loads four
+//     consecutive k (one ds_read_b128 / global_load_dwordx4) and feeds four MFMA steps;
+//   * accumulators stay in registers until the whole layer is done, so the tile is updated in
+//     place (one LDS buffer, two barriers per layer).
+#include "omds_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LDH OMDS_LDH
+
+// ------------------------------------------------------------------------------------------------
+// layer-1 halves
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rollout_layer1(MlpDev m, const float* __restrict__ qT, int ldq, int B,
+                                                        float* __restrict__ Apre) {
+    __shared__ float f[3 * OMDS_MAX_DOF];
+    const int t = blockIdx.x, c = threadIdx.x, n = m.n_dof, d = m.d;
+    if (c < n) {
+        const float q = qT[(size_t)c * ldq + t];
+        f[c] = q;
+        f[n + c] = sinf(q);
+        f[2 * n + c] = cosf(q);
+    }
+    __syncthreads();
+    float acc = m.b1[c];
+    for (int j = 0; j < n; ++j) acc = fmaf(m.W1t[(size_t)j * OMDS_WIDTH + c], f[j], acc);
+    for (int j = 0; j < n; ++j) acc = fmaf(m.W1t[(size_t)(d + j) * OMDS_WIDTH + c], f[n + j], acc);
+    for (int j = 0; j < n; ++j) acc = fmaf(m.W1t[(size_t)(2 * d + j) * OMDS_WIDTH + c], f[2 * n + j], acc);
+    Apre[(size_t)t * OMDS_WIDTH + c] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_obstacle_layer1(MlpDev m, const float* __restrict__ xyzr, int O,
+                                                         float* __restrict__ Bpre, float* __restrict__ radius) {
+    __shared__ float f[9];
+    const int o = blockIdx.x, c = threadIdx.x, n = m.n_dof, d = m.d;
+    if (c < 3) {
+        const float p = xyzr[o * 4 + c];
+        f[c] = p;
+        f[3 + c] = sinf(p);
+        f[6 + c] = cosf(p);
+    }
+    if (c == 3) radius[o] = xyzr[o * 4 + 3];
+    __syncthreads();
+    float acc = 0.f;
+    for (int j = 0; j < 3; ++j) acc = fmaf(m.W1t[(size_t)(n + j) * OMDS_WIDTH + c], f[j], acc);
+    for (int j = 0; j < 3; ++j) acc = fmaf(m.W1t[(size_t)(d + n + j) * OMDS_WIDTH + c], f[3 + j], acc);
+    for (int j = 0; j < 3; ++j) acc = fmaf(m.W1t[(size_t)(2 * d + n + j) * OMDS_WIDTH + c], f[6 + j], acc);
+    Bpre[(size_t)o * OMDS_WIDTH + c] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// [MR*32 x 256] . [256 x NR*32] on v_mfma_f32_32x32x2_f32
+//   A (activations) from LDS: lane l reads H[row = l&31 (+32 per row block)][8c + 4(l>>5) .. +3]
+//   B (weights) from global, packed so that lane l's float4 = W[32 cb + (l&31)][8c + 4(l>>5) .. +3]
+//   MFMA step m of chunk c contracts k = 8c + m (lanes 0-31) and k = 8c + 4 + m (lanes 32-63).
+// ------------------------------------------------------------------------------------------------
+template <int MR, int NR>
+__device__ __forceinline__ void mfma_chunk(const float4 (&a)[MR], const float4 (&w)[NR], f32x16 (&acc)[MR][NR]) {
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, w[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, w[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, w[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, w[j].w, acc[i][j], 0, 0, 0);
+}
+
+template <int MR, int NR>
+__device__ __forceinline__ void load_chunk(const float* arow, const float4* wp, int c, float4 (&a)[MR], float4 (&w)[NR]) {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) w[j] = wp[(size_t)j * (32 * 64) + c * 64];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) a[i] = *reinterpret_cast<const float4*>(arow + i * 32 * LDH + 8 * c);
+}
+
+// Software-pipelined by hand: the fragments of chunk c+1 (one global_load_dwordx4 per column block,
+// one ds_read_b128 per row block) are issued BEFORE the 4*MR*NR MFMAs of chunk c and pinned there
+// with sched_barrier (left alone, hipcc sinks the loads next to their use and waits vmcnt(0) per chunk).
+template <int MR, int NR>
+__device__ __forceinline__ void gemm256(const float* __restrict__ Hw, const float4* __restrict__ Wp, int cb0,
+                                        int lane, f32x16 (&acc)[MR][NR]) {
+    const float* arow = Hw + (lane & 31) * LDH + 4 * (lane >> 5);
+    const float4* wp = Wp + (size_t)cb0 * (32 * 64) + lane;
+    float4 a0[MR], a1[MR], w0[NR], w1[NR];
+    load_chunk<MR, NR>(arow, wp, 0, a0, w0);
+#pragma unroll 1
+    for (int c = 0; c < 32; c += 2) {
+        load_chunk<MR, NR>(arow, wp, c + 1, a1, w1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk<MR, NR>(a0, w0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk<MR, NR>(arow, wp, (c + 2) & 31, a0, w0);   // last iteration re-loads chunk 0 (harmless)
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk<MR, NR>(a1, w1, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// C/D layout of the 32x32 MFMA: lane l, register r -> row (r&3) + 8(r>>2) + 4(l>>5), col l&31.
+__device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+template <int MT, int MR, int NR>
+struct Geo {
+    static constexpr int WM = MT / (32 * MR);
+    static constexpr int WN = OMDS_NCB / NR;
+    static constexpr int NW = WM * WN;
+    static constexpr int NT = NW * 64;
+    static_assert(WM >= 1 && WN >= 1 && WM * 32 * MR == MT && WN * NR == OMDS_NCB, "bad tile geometry");
+};
+
+// ------------------------------------------------------------------------------------------------
+// pass 1: all (rollout, obstacle) pairs -> min link distance
+// ------------------------------------------------------------------------------------------------
+template <int MT, int MR, int NR>
+__global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const float* __restrict__ Apre,
+                                                               const float* __restrict__ Bpre,
+                                                               const float* __restrict__ radius, int O,
+                                                               long long total_rows, uint32_t ignored,
+                                                               float* __restrict__ Dmin) {
+    using G = Geo<MT, MR, NR>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Hs = smem;                                           // [MT][LDH]
+    int* rowO = reinterpret_cast<int*>(smem + MT * LDH);        // [MT] obstacle index of each row
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / G::WN, wn = wave % G::WN;
+    const long long row0 = (long long)blockIdx.x * MT;
+
+    // ---- layer 1: H1 = relu(Apre[t] + Bpre[o]), one float4 per thread-iteration -----------------
+    for (int idx = tid; idx < MT * 64; idx += G::NT) {
+        const int r = idx >> 6, c4 = idx & 63;
+        const long long R = row0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        int o = 0;
+        if (R < total_rows) {
+            const long long t = R / O;
+            o = (int)(R - t * O);
+            const float4 a = reinterpret_cast<const float4*>(Apre)[t * 64 + c4];
+            const float4 b = reinterpret_cast<const float4*>(Bpre)[(size_t)o * 64 + c4];
+            v.x = fmaxf(a.x + b.x, 0.f);
+            v.y = fmaxf(a.y + b.y, 0.f);
+            v.z = fmaxf(a.z + b.z, 0.f);
+            v.w = fmaxf(a.w + b.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(Hs + r * LDH + 4 * c4) = v;
+        if (c4 == 0) rowO[r] = o;
+    }
+    __syncthreads();
+
+    // ---- hidden -> hidden layers -----------------------------------------------------------------
+    const float* Hw = Hs + (wm * MR * 32) * LDH;
+    const int cb0 = wn * NR;
+    for (int l = 0; l < m.nhh; ++l) {
+        f32x16 acc[MR][NR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        gemm256<MR, NR>(Hw, m.Wf + (size_t)l * (OMDS_NCB * 32 * 64), cb0, lane, acc);
+        __syncthreads();  // every wave has finished reading the tile
+        const float* bias = m.bh + l * OMDS_WIDTH;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int col = (cb0 + j) * 32 + (lane & 31);
+            const float bv = bias[col];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Hs[((wm * MR + i) * 32 + crow(r, lane)) * LDH + col] = fmaxf(acc[i][j][r] + bv, 0.f);
+        }
+        __syncthreads();
+    }
+
+    // ---- last layer (256 -> C, padded to 16) on v_mfma_f32_16x16x4_f32, 16 rows per wave ----------
+    for (int rb = wave; rb < MT / 16; rb += G::NW) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = Hs + (rb * 16 + (lane & 15)) * LDH + 4 * (lane >> 4);
+#pragma unroll 4
+        for (int c = 0; c < 16; ++c) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + 16 * c);
+            const float4 w = m.Wl[c * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+        }
+        // C/D layout 16x16: col = lane&15 (link), row = 4(lane>>4) + reg
+        const int j = lane & 15;
+        const float bj = m.bl[j];
+        const bool pad = j >= m.C, ign = (ignored >> j) & 1u;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int r = rb * 16 + 4 * (lane >> 4) + reg;
+            float y = (acc[reg] + bj) / m.out_div - radius[rowO[r]];
+            y = pad ? __builtin_inff() : (ign ? 1e6f : y);
+            y = fminf(y, __shfl_xor(y, 1));
+            y = fminf(y, __shfl_xor(y, 2));
+            y = fminf(y, __shfl_xor(y, 4));
+            y = fminf(y, __shfl_xor(y, 8));
+            if (j == 0 && row0 + r < total_rows) Dmin[row0 + r] = y;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// top-k (ascending, ties by lower obstacle index): one wave per rollout
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_topk(const float* __restrict__ Dmin, int B, int O, int k,
+                                              int32_t* __restrict__ idx) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= B) return;
+    const float* row = Dmin + (size_t)t * O;
+    float pv = -__builtin_inff();
+    int pi = -1;
+    for (int j = 0; j < k; ++j) {
+        float bv = __builtin_inff();
+        int bi = 0x7fffffff;
+        for (int o = lane; o < O; o += 64) {
+            const float v = row[o];
+            const bool after = (v > pv) || (v == pv && o > pi);
+            if (after && ((v < bv) || (v == bv && o < bi))) { bv = v; bi = o; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            if ((ov < bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (bi == 0x7fffffff) bi = 0;
+        if (lane == 0) idx[(size_t)t * k + j] = bi;
+        pv = bv;
+        pi = bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 2: forward + analytic backward on the N*k closest rows. 32 rows per workgroup, 8 waves,
+// wave w owns output columns [32w, 32w+32). ReLU masks live in LDS as 16 bits per thread/layer
+// in the MFMA C-layout (the same lane owns the same (row, col) in every layer).
+// ------------------------------------------------------------------------------------------------
+constexpr int P2_MT = 32;
+constexpr int P2_NT = 512;
+
+__global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restrict__ Apre,
+                                                 const float* __restrict__ Bpre, const float* __restrict__ radius,
+                                                 const float* __restrict__ xyzr, const int32_t* __restrict__ idx,
+                                                 int total_rows, int k, const float* __restrict__ qT, int ldq,
+                                                 float* __restrict__ gradx, float* __restrict__ drow,
+                                                 float* __restrict__ yraw, int32_t* __restrict__ minidx) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Hs = smem;                                          // [32][LDH]
+    float* P = Hs + P2_MT * LDH;                               // [8][32][33] split-K partials
+    float* gf = P + 8 * 32 * 33;                               // [32][33] feature gradients
+    uint32_t* maskL = reinterpret_cast<uint32_t*>(gf + 32 * 33);   // [nhh+1][512]
+    int* rowT = reinterpret_cast<int*>(maskL + (m.nhh + 1) * P2_NT);  // [32]
+    int* rowO = rowT + P2_MT;                                  // [32]
+    int* rowMin = rowO + P2_MT;                                // [32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int R0 = blockIdx.x * P2_MT;
+    const int col = wave * 32 + (lane & 31);
+
+    if (tid < P2_MT) {
+        const int R = R0 + tid;
+        int t = -1, o = 0;
+        if (R < total_rows) { t = R / k; o = idx[R]; }
+        rowT[tid] = t;
+        rowO[tid] = o;
+    }
+    __syncthreads();
+
+    // ---- layer 1 in C-layout ------------------------------------------------------------------
+    {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = crow(r, lane);
+            const int t = rowT[row];
+            float z = 0.f;
+            if (t >= 0) z = Apre[(size_t)t * OMDS_WIDTH + col] + Bpre[(size_t)rowO[row] * OMDS_WIDTH + col];
+            bits |= (z > 0.f ? 1u : 0u) << r;
+            Hs[row * LDH + col] = fmaxf(z, 0.f);
+        }
+        maskL[tid] = bits;
+    }
+    __syncthreads();
+
+    // ---- forward through the hidden -> hidden layers -------------------------------------------
+    for (int l = 0; l < m.nhh; ++l) {
+        f32x16 acc[1][1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+        gemm256<1, 1>(Hs, m.Wf + (size_t)l * (OMDS_NCB * 32 * 64), wave, lane, acc);
+        __syncthreads();
+        const float bv = m.bh[l * OMDS_WIDTH + col];
+        uint32_t bits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float z = acc[0][0][r] + bv;
+            bits |= (z > 0.f ? 1u : 0u) << r;
+            Hs[crow(r, lane) * LDH + col] = fmaxf(z, 0.f);
+        }
+        maskL[(l + 1) * P2_NT + tid] = bits;
+        __syncthreads();
+    }
+
+    // ---- last layer, arg-min over ALL raw outputs (robot_sdf.py:155), distance of that link -------
+    if (wave < P2_MT / 16) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = Hs + (wave * 16 + (lane & 15)) * LDH + 4 * (lane >> 4);
+#pragma unroll 4
+        for (int c = 0; c < 16; ++c) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + 16 * c);
+            const float4 w = m.Wl[c * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+        }
+        const int j = lane & 15;
+        const float bj = m.bl[j];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int r = wave * 16 + 4 * (lane >> 4) + reg;
+            const int R = R0 + r;
+            const float y = acc[reg] + bj;
+            if (yraw != nullptr && R < total_rows) yraw[(size_t)R * OMDS_CPAD + j] = (j < m.C) ? y : 0.f;
+            float bv = (j < m.C) ? y : __builtin_inff();
+            int bi = j;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const float ov = __shfl_xor(bv, off);
+                const int oi = __shfl_xor(bi, off);
+                if ((ov < bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (j == 0) {
+                rowMin[r] = bi;
+                if (R < total_rows) {
+                    drow[R] = bv / m.out_div - radius[rowO[r]];
+                    if (minidx != nullptr) minidx[R] = bi;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- backward seed: dy[minIdx]/dH_last = Wlast[minIdx], masked by the last hidden layer ---------
+    {
+        const uint32_t bits = maskL[m.nhh * P2_NT + tid];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = crow(r, lane);
+            const float g = m.Wlraw[(size_t)rowMin[row] * OMDS_WIDTH + col];
+            Hs[row * LDH + col] = ((bits >> r) & 1u) ? g : 0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---- backward through the hidden -> hidden layers ------------------------------------------
+    for (int l = m.nhh - 1; l >= 0; --l) {
+        f32x16 acc[1][1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+        gemm256<1, 1>(Hs, m.Wb + (size_t)l * (OMDS_NCB * 32 * 64), wave, lane, acc);
+        __syncthreads();
+        const uint32_t bits = maskL[l * P2_NT + tid];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Hs[crow(r, lane) * LDH + col] = ((bits >> r) & 1u) ? acc[0][0][r] : 0.f;
+        __syncthreads();
+    }
+
+    // ---- first layer backward: g_f[row][f] = sum_c Gz1[row][c] W1[c][f], split-K over the 8 waves -------
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* arow = Hs + (lane & 31) * LDH + 4 * (lane >> 5);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int c = wave * 4 + cc;
+            const float4 a = *reinterpret_cast<const float4*>(arow + 8 * c);
+            const float4 w = m.W1b[c * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) P[(wave * 32 + crow(r, lane)) * 33 + (lane & 31)] = acc[r];
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += P2_NT) {
+        const int row = e >> 5, f = e & 31;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += P[(w * 32 + row) * 33 + f];
+        gf[row * 33 + f] = s;
+    }
+    __syncthreads();
+    // ---- positional-encoding chain rule: d/dx = g[x] + g[sin x] cos x - g[cos x] sin x --------------
+    const int d = m.d, n = m.n_dof;
+    if (tid < P2_MT * d) {
+        const int row = tid / d, jj = tid - row * d;
+        const int R = R0 + row;
+        if (R < total_rows) {
+            const float x = (jj < n) ? qT[(size_t)jj * ldq + rowT[row]] : xyzr[rowO[row] * 4 + (jj - n)];
+            gradx[(size_t)R * d + jj] = gf[row * 33 + jj] + gf[row * 33 + d + jj] * cosf(x) - gf[row * 33 + 2 * d + jj] * sinf(x);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// blend of the k closest gradients (MPPI.py:270-280), standalone form for omds_dist_grad
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blend(const float* __restrict__ gradx, const float* __restrict__ drow, int B,
+                                               int k, int d, int n, float softmax_k, float* __restrict__ dist,
+                                               float* __restrict__ nngrad) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B) return;
+    float mx = -__builtin_inff();
+    for (int j = 0; j < k; ++j) mx = fmaxf(mx, softmax_k * drow[t * k + j]);
+    float s = 0.f;
+    for (int j = 0; j < k; ++j) s += expf(softmax_k * drow[t * k + j] - mx);
+    for (int c = 0; c < n; ++c) {
+        float g = 0.f;
+        for (int j = 0; j < k; ++j) g += gradx[(size_t)(t * k + j) * d + c] * (expf(softmax_k * drow[t * k + j] - mx) / s);
+        nngrad[(size_t)t * n + c] = g;
+    }
+    dist[t] = drow[t * k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+void omds_launch_rollout_layer1(hipStream_t s, const MlpDev& m, const float* qT, int ldq, int B, float* Apre) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(k_rollout_layer1, dim3(B), dim3(256), 0, s, m, qT, ldq, B, Apre);
+}
+
+void omds_launch_obstacle_layer1(hipStream_t s, const MlpDev& m, const float* xyzr, int O, float* Bpre, float* radius) {
+    if (O <= 0) return;
+    hipLaunchKernelGGL(k_obstacle_layer1, dim3(O), dim3(256), 0, s, m, xyzr, O, Bpre, radius);
+}
+
+template <int MT, int MR, int NR>
+static void launch_pass1_t(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
+                           int O, long long total, uint32_t ignored, float* Dmin) {
+    using G = Geo<MT, MR, NR>;
+    const size_t lds = (size_t)MT * LDH * 4 + (size_t)MT * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<MT, MR, NR>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const long long tiles = (total + MT - 1) / MT;
+    hipLaunchKernelGGL((k_pass1<MT, MR, NR>), dim3((unsigned)tiles), dim3(G::NT), lds, s, m, Apre, Bpre, radius, O,
+                       total, ignored, Dmin);
+}
+
+// Tile choice: 128-row tiles (8 waves, each 128 rows x 32 columns) once there are enough tiles to
+// fill 256 CUs a few times over; 32-row tiles for small batches (planar configs, dist_grad calls).
+static int g_pass1_variant = -1;  // -1 = auto; set through OMDS_PASS1_VARIANT for experiments
+void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
+                       int O, int B, uint32_t ignored, float* Dmin) {
+    const long long total = (long long)B * O;
+    if (total <= 0) return;
+    if (g_pass1_variant == -1) {
+        const char* e = getenv("OMDS_PASS1_VARIANT");
+        g_pass1_variant = e ? atoi(e) : 0;
+    }
+    int v = g_pass1_variant;
+    if (v == 0) v = (total >= 128LL * 512) ? 1 : ((total >= 64LL * 512) ? 3 : 5);
+    switch (v) {
+        case 1: launch_pass1_t<128, 4, 1>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
+        case 2: launch_pass1_t<128, 2, 2>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
+        case 3: launch_pass1_t<64, 2, 1>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
+        case 4: launch_pass1_t<64, 2, 2>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
+        case 6: launch_pass1_t<128, 4, 2>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
+        default: launch_pass1_t<32, 1, 1>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
+    }
+}
+
+void omds_launch_topk(hipStream_t s, const float* Dmin, int B, int O, int k, int32_t* idx) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(k_topk, dim3((B + 3) / 4), dim3(256), 0, s, Dmin, B, O, k, idx);
+}
+
+void omds_launch_pass2(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
+                       const float* xyzr, const int32_t* idx, int B, int k, const float* qT, int ldq, float* gradx,
+                       float* drow, float* yraw, int32_t* minidx) {
+    const int total = B * k;
+    if (total <= 0) return;
+    const size_t lds = ((size_t)P2_MT * LDH + 8 * 32 * 33 + 32 * 33) * 4 + (size_t)(m.nhh + 1) * P2_NT * 4 + 3 * P2_MT * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(((size_t)P2_MT * LDH + 8 * 32 * 33 + 32 * 33) * 4 +
+                                        (size_t)(OMDS_MAX_HIDDEN + 1) * P2_NT * 4 + 3 * P2_MT * 4));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_pass2, dim3((total + P2_MT - 1) / P2_MT), dim3(P2_NT), lds, s, m, Apre, Bpre, radius, xyzr,
+                       idx, total, k, qT, ldq, gradx, drow, yraw, minidx);
+}
+
+void omds_launch_blend(hipStream_t s, const float* gradx, const float* drow, int B, int k, int d, int n,
+                       float softmax_k, float* dist, float* nngrad) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(k_blend, dim3((B + 255) / 256), dim3(256), 0, s, gradx, drow, B, k, d, n, softmax_k, dist, nngrad);
+}

@@ -1,0 +1,160 @@
+// Internal declarations shared by the HIP translation units of libomds_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "omds.h"
+
+constexpr int OMDS_WIDTH = 256;        // hidden width the MFMA kernels are specialised for
+constexpr int OMDS_LDH = 260;          // LDS row stride of the activation tile (floats): 256 + 4 pad
+constexpr int OMDS_CPAD = 16;          // output channels padded to one 16-wide MFMA tile
+constexpr int OMDS_MAX_HIDDEN = 8;     // hidden layers supported (reference nets: 4)
+constexpr int OMDS_NCB = OMDS_WIDTH / 32;  // 32-column blocks per hidden layer
+
+// Device-side view of the distance network, weights pre-packed into MFMA fragment order.
+struct MlpDev {
+    const float4* Wf;    // [nhh][8 colblk][32 kchunk][64 lane] forward pack of hidden->hidden layers
+    const float4* Wb;    // same shape, transposed pack for the backward pass
+    const float* bh;     // [nhh][256] hidden->hidden biases
+    const float4* Wl;    // [16 kchunk][64 lane] last layer, 16x16x4 B-fragments (channels padded to 16)
+    const float* bl;     // [16]
+    const float* Wlraw;  // [C][256] last layer, row-major (backward seed)
+    const float* W1t;    // [3d][256] first layer transposed
+    const float* b1;     // [256]
+    const float4* W1b;   // [32 kchunk][64 lane] first layer, backward pack (cols = 3d features, padded to 32)
+    int nhh;             // number of hidden->hidden layers (= hidden layers - 1)
+    int C;               // output channels (links)
+    int d;               // n_dof + 3 raw inputs
+    int n_dof;
+    float out_div;
+};
+
+struct ProfEvents {
+    std::vector<hipEvent_t> start, stop;
+    size_t used = 0;
+    double ms = 0.0;
+    int64_t launches = 0, rows = 0;
+};
+
+struct omds_ctx {
+    omds_config cfg{};
+    omds_params prm{};
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // network
+    bool have_mlp = false;
+    MlpDev mlp{};
+    std::vector<void*> mlp_allocs;
+    int act = OMDS_ACT_RELU;
+    // scene
+    int n_obs = 0;
+    float* d_obs = nullptr;      // [max_obs][4]
+    float* d_Bpre = nullptr;     // [max_obs][256] obstacle part of layer 1
+    float* d_radius = nullptr;   // [max_obs]
+    // DS / cost
+    bool have_ds = false, have_cost = false;
+    float qf[OMDS_MAX_DOF] = {0};
+    float qmin[OMDS_MAX_DOF] = {0}, qmax[OMDS_MAX_DOF] = {0};
+    float dh[(OMDS_MAX_DOF + 1) * 4] = {0};
+    float goal_fk[OMDS_MAX_DOF * 3] = {0};
+    // rollout state, SoA (rollout index fastest)
+    float* d_trajT = nullptr;    // [H][n][N]
+    float* d_distT = nullptr;    // [H][N]
+    float* d_dotT = nullptr;     // [H][N]
+    float* d_actT = nullptr;     // [H][N]
+    float* d_normalT = nullptr;  // [H][n][N]
+    float* d_kvalT = nullptr;    // [H][Kmax][N]
+    float* d_qdotT = nullptr;    // [n][N]
+    float* d_maxact = nullptr;   // [Kmax][N] running max_h(phi*act)
+    float* d_phisum0 = nullptr;  // [Kmax] sum_h phi of local rollout 0
+    float* d_qstage = nullptr;   // [n][N] staging for dist_grad batches / per-rollout starts
+    // policy samples, SoA
+    int n_kernels = 0;
+    float* d_muT = nullptr;      // [Kmax][n][N]
+    float* d_sigmaT = nullptr;   // [Kmax][N]
+    float* d_alphaT = nullptr;   // [Kmax][n][N]
+    float* d_means = nullptr;    // [Kmax*(2n+1)] mu_c, sigma_c, alpha_c staging
+    // network scratch
+    float* d_Apre = nullptr;     // [Nrows][256]
+    float* d_Dmin = nullptr;     // [N][max_obs]
+    int32_t* d_idx = nullptr;    // [N][k]
+    float* d_gradx = nullptr;    // [N*k][d]
+    float* d_drow = nullptr;     // [N*k]
+    float* d_yraw = nullptr;     // [N*k][16]
+    int32_t* d_minidx = nullptr; // [N*k]
+    float* d_dist = nullptr;     // [N]
+    float* d_nngrad = nullptr;   // [N][n]
+    // cost / reduction
+    float* d_cost = nullptr;     // [N]
+    float* d_w = nullptr;        // [N] unnormalised weights
+    float* d_red = nullptr;      // packed reduction buffer
+    float* h_red = nullptr;      // pinned mirror
+    bool have_cost_vals = false;
+    // staging
+    float* d_stage = nullptr;    // transposition staging for host copies
+    size_t stage_bytes = 0;
+    float* h_stage = nullptr;
+    // profiling
+    bool prof_on = false;
+    ProfEvents prof;
+};
+
+#define OMDS_HIP_CHECK(ctx, expr)                                                         \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);               \
+            return OMDS_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+
+// ---- launchers implemented in mlp_kernels.hip ------------------------------------------------
+void omds_launch_rollout_layer1(hipStream_t s, const MlpDev& m, const float* qT, int ldq, int B, float* Apre);
+void omds_launch_obstacle_layer1(hipStream_t s, const MlpDev& m, const float* xyzr, int O, float* Bpre, float* radius);
+void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
+                       int O, int B, uint32_t ignored_links, float* Dmin);
+void omds_launch_topk(hipStream_t s, const float* Dmin, int B, int O, int k, int32_t* idx);
+void omds_launch_pass2(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
+                       const float* xyzr, const int32_t* idx, int B, int k, const float* qT, int ldq,
+                       float* gradx, float* drow, float* yraw, int32_t* minidx);
+void omds_launch_blend(hipStream_t s, const float* gradx, const float* drow, int B, int k, int d, int n,
+                       float softmax_k, float* dist, float* nngrad);
+
+// ---- launchers implemented in rollout_kernels.hip ---------------------------------------------
+struct StepArgs {
+    int N, H, n, K, Kmax, k, d, step;   // step = i in 1..H
+    float* trajT; float* distT; float* dotT; float* actT; float* normalT; float* kvalT; float* qdotT;
+    float* maxact; float* phisum0;
+    const float* muT; const float* sigmaT; const float* alphaT;
+    const float* gradx; const float* drow;
+    float qf[OMDS_MAX_DOF];
+    omds_params prm;
+};
+void omds_launch_modulate(hipStream_t s, const StepArgs& a);
+struct CostArgs {
+    int N, H, n;
+    const float* trajT; const float* distT; float* cost;
+    float qf[OMDS_MAX_DOF], qmin[OMDS_MAX_DOF], qmax[OMDS_MAX_DOF];
+    float dh[(OMDS_MAX_DOF + 1) * 4];
+    float goal_fk[OMDS_MAX_DOF * 3];
+};
+void omds_launch_cost(hipStream_t s, const CostArgs& a);
+void omds_host_link_endpoints(const float* q, const float* dh, int n, float* pts);
+// reductions: red layout documented in rollout_kernels.hip
+void omds_launch_cost_sum(hipStream_t s, const float* cost, int N, float* red2);
+void omds_launch_weights(hipStream_t s, const float* cost, int N, const float* red2_global, float* w, float* red_sumw);
+int omds_red_size(int K, int n);
+void omds_launch_policy_sums(hipStream_t s, int N, int n, int K, const float* w, const float* muT, const float* sigmaT,
+                             const float* alphaT, const float* maxact, const float* phisum0, const float* qdotT,
+                             const float* cost, int include_rollout0, float* red);
+void omds_launch_sample(hipStream_t s, int N, int n, int K, const float* means, float mu_s, float sigma_s, float alpha_s,
+                        uint64_t seed, int64_t rollout_offset, float* muT, float* sigmaT, float* alphaT);
+void omds_launch_broadcast_q(hipStream_t s, const float* q_host_vals, int n, int N, float* dstT);
+// layout conversions between reference (AoS) and device (SoA) orders
+void omds_launch_transpose(hipStream_t s, const float* src, float* dst, int rows, int cols);  // dst[c][r] = src[r][c]
+void omds_launch_permute_hxn_to_nhx(hipStream_t s, const float* srcT, float* dst, int H, int X, int N, int Xld);
+

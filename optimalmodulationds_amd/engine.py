@@ -1,0 +1,216 @@
+"""Thin object wrapper over one ``omds_ctx`` (one per GPU): numpy in, numpy out.
+
+The reference-shaped classes (MPPI, TensorPolicyMPPI, ...) and bench.py sit on top of this."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class Engine:
+    def __init__(self, n_dof, n_traj, horizon, n_closest, max_obs, n_kernel_max=50, device=0):
+        self.lib = L.load()
+        self.n, self.N, self.H, self.k = int(n_dof), int(n_traj), int(horizon), int(n_closest)
+        self.max_obs, self.Kmax, self.device = int(max_obs), int(n_kernel_max), int(device)
+        cfg = L.OmdsConfig(self.n, self.N, self.H, self.Kmax, self.max_obs, self.k, self.device, 0)
+        h = C.c_void_p()
+        rc = self.lib.omds_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise L.OmdsError(f"omds_create failed ({rc}): {self.lib.omds_last_error(None).decode()}")
+        self.h = h
+        self.params = L.default_params()
+        self.K = 0
+        self.n_obs = 0
+        self.C = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.omds_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        L.check(self.h, rc)
+
+    # ---- configuration ------------------------------------------------------------------------
+    def set_mlp(self, weights, biases, act="relu", out_div=None):
+        Ws = [L.f32(w) for w in weights]
+        bs = [L.f32(b) for b in biases]
+        dims = np.array([Ws[0].shape[1]] + [w.shape[0] for w in Ws], dtype=np.int32)
+        nl = len(Ws)
+        Wp = (L.F32P * nl)(*[L.fptr(w) for w in Ws])
+        bp = (L.F32P * nl)(*[L.fptr(b) for b in bs])
+        self.C = int(dims[-1])
+        if out_div is None:
+            out_div = 100.0 if self.C == 9 else 1.0     # MPPI.py:236-237
+        self._ck(self.lib.omds_set_mlp(self.h, nl, L.iptr(dims), Wp, bp, 0 if act == "relu" else 1, float(out_div)))
+
+    def set_obstacles(self, obs):
+        obs = L.f32(obs).reshape(-1, 4)
+        self._ck(self.lib.omds_set_obstacles(self.h, L.fptr(obs), obs.shape[0]))
+        self.n_obs = obs.shape[0]
+
+    def set_ds(self, q_goal):
+        q = L.f32(q_goal).reshape(self.n)
+        self._ck(self.lib.omds_set_ds(self.h, L.fptr(q)))
+
+    def push_params(self):
+        self._ck(self.lib.omds_set_params(self.h, C.byref(self.params)))
+
+    def set_cost(self, dh_params, q_min, q_max):
+        dh = L.f32(dh_params).reshape(self.n + 1, 4)
+        lo, hi = L.f32(q_min).reshape(self.n), L.f32(q_max).reshape(self.n)
+        self._ck(self.lib.omds_set_cost(self.h, L.fptr(dh), L.fptr(lo), L.fptr(hi)))
+
+    # ---- policy samples -----------------------------------------------------------------------
+    def set_policy_samples(self, mu, sigma, alpha):
+        mu = L.f32(mu)
+        K = mu.shape[1] if mu.ndim == 3 else 0
+        if K == 0:
+            self._ck(self.lib.omds_set_policy_samples(self.h, None, None, None, 0))
+        else:
+            mu = mu.reshape(self.N, K, self.n)
+            sg = L.f32(sigma).reshape(self.N, K)
+            al = L.f32(alpha).reshape(self.N, K, self.n)
+            self._ck(self.lib.omds_set_policy_samples(self.h, L.fptr(mu), L.fptr(sg), L.fptr(al), K))
+        self.K = K
+
+    def sample_policy(self, mu_c, sigma_c, alpha_c, mu_s, sigma_s, alpha_s, K, seed, rollout_offset=0):
+        K = int(K)
+        if K == 0:
+            self._ck(self.lib.omds_sample_policy(self.h, None, None, None, 0, 0, 0, 0, int(seed), int(rollout_offset)))
+        else:
+            mu = L.f32(mu_c)[:K].reshape(K, self.n)
+            sg = L.f32(sigma_c)[:K].reshape(K)
+            al = L.f32(alpha_c)[:K].reshape(K, self.n)
+            mu, sg, al = (np.ascontiguousarray(x) for x in (mu, sg, al))
+            self._ck(self.lib.omds_sample_policy(self.h, L.fptr(mu), L.fptr(sg), L.fptr(al), float(mu_s), float(sigma_s),
+                                                 float(alpha_s), K, int(seed), int(rollout_offset)))
+        self.K = K
+
+    def get_policy_samples(self):
+        K = self.K
+        mu = np.zeros((self.N, K, self.n), np.float32)
+        sg = np.zeros((self.N, K), np.float32)
+        al = np.zeros((self.N, K, self.n), np.float32)
+        if K:
+            self._ck(self.lib.omds_get_policy_samples(self.h, L.fptr(mu), L.fptr(sg), L.fptr(al)))
+        return mu, sg, al
+
+    # ---- rollouts -----------------------------------------------------------------------------
+    def propagate(self, q_cur):
+        q = L.f32(q_cur)
+        per = 1 if q.ndim == 2 else 0
+        q = q.reshape(self.N, self.n) if per else q.reshape(self.n)
+        self._ck(self.lib.omds_propagate(self.h, L.fptr(q), per))
+
+    def get_rollouts(self, want=("all_traj", "closest_dist_all", "kernel_val_all", "dot_products",
+                                 "kernel_activations", "qdot", "normal")):
+        N, H, n, K = self.N, self.H, self.n, self.K
+        shapes = {"all_traj": (N, H, n), "closest_dist_all": (N, H), "kernel_val_all": (N, H, K),
+                  "dot_products": (N, H), "kernel_activations": (N, H), "qdot": (N, n), "normal": (N, H, n)}
+        out = {k: (np.zeros(shapes[k], np.float32) if k in want else None) for k in shapes}
+        order = ["all_traj", "closest_dist_all", "kernel_val_all", "dot_products", "kernel_activations", "qdot", "normal"]
+        ptrs = [L.fptr(out[k]) if (out[k] is not None and out[k].size) else None for k in order]
+        self._ck(self.lib.omds_get_rollouts(self.h, *ptrs))
+        return {k: v for k, v in out.items() if v is not None}
+
+    def dist_grad(self, q, want_mindist=False, want_idx=False):
+        q = L.f32(q).reshape(-1, self.n)
+        B = q.shape[0]
+        dist = np.zeros(B, np.float32)
+        grad = np.zeros((B, self.n), np.float32)
+        mind = np.zeros((B, self.n_obs), np.float32) if want_mindist else None
+        idx = np.zeros((B, self.k), np.int32) if want_idx else None
+        self._ck(self.lib.omds_dist_grad(self.h, L.fptr(q), B, L.fptr(dist), L.fptr(grad), L.fptr(mind), L.iptr(idx)))
+        return dist, grad, mind, idx
+
+    def mlp_forward_vjp(self, x):
+        x = L.f32(x).reshape(-1, self.n + 3)
+        B = x.shape[0]
+        y = np.zeros((B, self.C), np.float32)
+        g = np.zeros((B, self.n + 3), np.float32)
+        mi = np.zeros(B, np.int32)
+        self._ck(self.lib.omds_mlp_forward_vjp(self.h, L.fptr(x), B, L.fptr(y), L.fptr(g), L.iptr(mi)))
+        return y, g, mi
+
+    # ---- cost / update ------------------------------------------------------------------------
+    def cost(self, fetch=True):
+        c = np.zeros(self.N, np.float32) if fetch else None
+        self._ck(self.lib.omds_cost(self.h, L.fptr(c)))
+        return c
+
+    def weighted_update(self, rate, ker_thr, mu_c, sigma_c, alpha_c, want_weights=False):
+        K = self.K
+        mu = np.ascontiguousarray(L.f32(mu_c)[:K]).reshape(K, self.n)
+        sg = np.ascontiguousarray(L.f32(sigma_c)[:K]).reshape(K)
+        al = np.ascontiguousarray(L.f32(alpha_c)[:K]).reshape(K, self.n)
+        mask = np.zeros(K, np.int32)
+        w = np.zeros(self.N, np.float32) if want_weights else None
+        self._ck(self.lib.omds_weighted_update(self.h, float(rate), float(ker_thr), L.fptr(mu), L.fptr(sg), L.fptr(al),
+                                               L.iptr(mask), L.fptr(w)))
+        return mu, sg, al, mask.astype(bool), w
+
+    def get_qdot(self, mode="best"):
+        out = np.zeros(self.n, np.float32)
+        self._ck(self.lib.omds_get_qdot(self.h, 0 if mode == "best" else 1, L.fptr(out)))
+        return out
+
+    def cost_sum(self):
+        out = np.zeros(2, np.float32)
+        self._ck(self.lib.omds_cost_sum(self.h, L.fptr(out)))
+        return out
+
+    def local_sums(self, sum_cost, n_total, include_rollout0=True):
+        red = np.zeros(self.lib.omds_red_count(self.h), np.float32)
+        self._ck(self.lib.omds_local_sums(self.h, float(sum_cost), float(n_total), 1 if include_rollout0 else 0,
+                                          L.fptr(red)))
+        return red
+
+    # ---- measurement --------------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        self._ck(self.lib.omds_prof_enable(self.h, 1 if on else 0))
+
+    def prof_reset(self):
+        self._ck(self.lib.omds_prof_reset(self.h))
+
+    def prof_read(self):
+        ms, nl, nr = C.c_double(), C.c_int64(), C.c_int64()
+        self._ck(self.lib.omds_prof_read(self.h, C.byref(ms), C.byref(nl), C.byref(nr)))
+        return ms.value, nl.value, nr.value
+
+
+def red_layout(K, n):
+    """Offsets into the packed reduction buffer (include/omds.h, omds_local_sums)."""
+    o_mu = 1
+    o_sg = o_mu + K * n
+    o_al = o_sg + K
+    o_mx = o_al + K * n
+    o_ph = o_mx + K
+    o_qd = o_ph + K
+    o_best = o_qd + n
+    return dict(sumw=0, mu=o_mu, sigma=o_sg, alpha=o_al, maxact=o_mx, phi0=o_ph, qdot=o_qd, best=o_best,
+                n_sum=o_best, size=o_best + 1 + n)
+
+
+def apply_update(K, n, H, red, n_total, rate, ker_thr, mu_c, sigma_c, alpha_c):
+    """Host arithmetic of the policy update on the (globally) reduced buffer -- omds_apply_update."""
+    lib = L.load()
+    red = L.f32(red)
+    mu = np.ascontiguousarray(L.f32(mu_c)[:K]).reshape(K, n)
+    sg = np.ascontiguousarray(L.f32(sigma_c)[:K]).reshape(K)
+    al = np.ascontiguousarray(L.f32(alpha_c)[:K]).reshape(K, n)
+    mask = np.zeros(K, np.int32)
+    rc = lib.omds_apply_update(int(K), int(n), int(H), L.fptr(red), float(n_total), float(rate), float(ker_thr),
+                               L.fptr(mu), L.fptr(sg), L.fptr(al), L.iptr(mask))
+    if rc != 0:
+        raise L.OmdsError(f"omds_apply_update failed ({rc})")
+    return mu, sg, al, mask.astype(bool)

@@ -1,0 +1,195 @@
+"""MPPI controller -- mirrors ``ds_mppi/functions/MPPI.py`` (class MPPI, lines 21-350).
+
+Same constructor, methods and mutable attributes as the reference; every array computation of
+the hot path (distance network forward/backward over rollouts x obstacles, modulation, policy,
+Euler step, cost, cost-weighted reduction) runs in the HIP kernels behind ``Engine``.  Tensors
+handed back to the caller are torch CPU tensors in the reference's layouts."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .cost import Cost
+from .engine import Engine
+from .policy import TensorPolicyMPPI
+
+
+def _np(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy().astype(np.float32)
+    return np.asarray(x, dtype=np.float32)
+
+
+class MPPI:
+    def __init__(self, q0, qf, dh_params, obs, dt, dt_H, N_traj, DS_ARRAY, dh_a, nn_model, n_closest_obs,
+                 device=0, warmup=False, seed=1234, rollout_offset=0, max_obs=None):
+        self.tensor_args = {'device': 'cpu', 'dtype': torch.float32}
+        self.q0 = torch.as_tensor(_np(q0))
+        self.n_dof = self.q0.shape[0]
+        self.DS_idx = 0
+        self.DS_ARRAY = DS_ARRAY
+        self.DS = DS_ARRAY[self.DS_idx]
+        self.qf = self.DS.q_goal.squeeze()
+        self.dh_params = torch.as_tensor(_np(dh_params))
+        self.obs = torch.as_tensor(_np(obs)).reshape(-1, 4)
+        self.n_obs = self.obs.shape[0]
+        self.dt = dt
+        self.dt_H = dt_H
+        self.N_traj = N_traj
+        self.dh_a = dh_a
+        self.nn_model = nn_model
+        self.n_closest_obs = n_closest_obs
+        self.q_cur = self.q0
+        self.policy_upd_rate = 0.1                      # MPPI.py:58 (the rate that is actually used, :344)
+        self.dst_thr = 0.5
+        self.ker_thr = 1e-3
+        self.ignored_links = [0, 1, 2] if self.n_dof >= 7 else []
+        self._device = device
+        self._max_obs = int(max_obs or max(64, 2 * self.n_obs))
+        self._engine = Engine(self.n_dof, N_traj, dt_H, n_closest_obs, self._max_obs, device=device)
+        self._engine.set_mlp(nn_model.model.W, nn_model.model.b, nn_model.model.act)
+        self._engine.set_obstacles(self.obs.numpy())
+        self.Policy = TensorPolicyMPPI(N_traj, self.n_dof, self.tensor_args, engine=self._engine, seed=seed,
+                                       rollout_offset=rollout_offset)
+        self.Cost = Cost(self.qf, self.dh_params, owner=self)
+        self.cur_cost = None
+        self._cache = {}
+        self.all_traj = torch.zeros(N_traj, dt_H, self.n_dof)
+        self.closest_dist_all = 100 + torch.zeros(N_traj, dt_H)
+        self.qdot = torch.zeros(N_traj, self.n_dof)
+        if warmup:                                       # MPPI.py:69-73 (optional here)
+            for _ in range(5):
+                self.Policy.sample_policy()
+                self.propagate()
+
+    # ---- DS switching (MPPI.py:75-84) -------------------------------------------------------------
+    def reset_DS(self, DS):
+        self.DS = DS
+        self.qf = DS.q_goal.squeeze()
+        self.Cost = Cost(self.qf, self.dh_params, owner=self)
+
+    def switch_DS_idx(self, idx):
+        self.DS_idx = idx
+        self.DS = self.DS_ARRAY[idx]
+        self.qf = self.DS.q_goal.squeeze()
+        self.Cost = Cost(self.qf, self.dh_params, owner=self)
+
+    def update_obstacles(self, obs):
+        """MPPI.py:347-350."""
+        self.obs = torch.as_tensor(_np(obs)).reshape(-1, 4)
+        self.n_obs = self.obs.shape[0]
+        if self.n_obs > self._max_obs:
+            raise ValueError(f"{self.n_obs} obstacles exceed the context capacity {self._max_obs}; "
+                             f"construct MPPI with max_obs >= {self.n_obs}")
+        self._engine.set_obstacles(self.obs.numpy())
+        return 0
+
+    # ---- parameters -> device ----------------------------------------------------------------------
+    def _push(self):
+        e = self._engine
+        p = e.params
+        p.dt = float(self.dt)
+        p.dst_thr = float(self.dst_thr)
+        p.lin_thr = float(self.DS.lin_thr)
+        p.rbf_p = float(self.Policy.p)
+        mask = 0
+        for l in self.ignored_links:
+            mask |= 1 << int(l)
+        p.ignored_links = mask
+        e.push_params()
+        e.set_ds(_np(self.qf))
+        e.set_cost(_np(self.dh_params), _np(self.Cost.q_min), _np(self.Cost.q_max))
+
+    # ---- rollouts (MPPI.py:97-224) -------------------------------------------------------------------
+    def propagate(self, fetch=True):
+        self._push()
+        if self._engine.K != self.Policy.n_kernels:
+            # like the reference, propagate() consumes whatever sample tensors exist; with a changed
+            # kernel count and no sample_policy() call yet there is nothing valid to consume
+            raise RuntimeError("Policy.n_kernels changed since the last sample_policy()/set_samples()")
+        self._engine.propagate(_np(self.q_cur))
+        self._cache = {}
+        self.cur_cost = None
+        if not fetch:
+            return None
+        r = self._fetch()
+        return (self.all_traj, self.closest_dist_all, r["kernel_val_all"], r["dot_products"], r["kernel_activations"])
+
+    def _fetch(self):
+        if not self._cache:
+            r = {k: torch.from_numpy(v) for k, v in self._engine.get_rollouts().items()}
+            self._cache = r
+            self.all_traj = r["all_traj"]
+            self.closest_dist_all = r["closest_dist_all"]
+            self.kernel_val_all = r["kernel_val_all"]
+            self.dot_products = r["dot_products"]
+            self.kernel_activations = r["kernel_activations"]
+            self.qdot = r["qdot"]
+            self.normal_dirs = r["normal"]              # norm_basis[..., 0]
+            self.ker_w = r["kernel_val_all"][:, -1:, :].transpose(1, 2) if r["kernel_val_all"].numel() else None
+        return self._cache
+
+    @property
+    def norm_basis(self):
+        """[N, H, n, n] basis whose column 0 is the obstacle normal (MPPI.py:122-127).  Column 0 comes
+        from the device; the tangent completion (the reference's QR) is rebuilt on the host on demand --
+        nothing on the rollout path reads it (M v uses the closed form)."""
+        g = self._fetch()["normal"].numpy()
+        N, H, n = g.shape
+        A = np.tile(np.eye(n, dtype=np.float32), (N, H, 1, 1))
+        A[..., 0] = g
+        Q, _ = np.linalg.qr(A)
+        Q = Q.astype(np.float32)
+        Q[..., 0] = g
+        return torch.from_numpy(Q)
+
+    # ---- distance + gradient on arbitrary states (MPPI.py:227-282) ------------------------------------
+    def distance_repulsion_nn(self, q_prev, aot=False):
+        self._push()
+        q = _np(q_prev).reshape(-1, self.n_dof)
+        out_d, out_g = [], []
+        for s in range(0, q.shape[0], self.N_traj):
+            d, g, _, _ = self._engine.dist_grad(q[s:s + self.N_traj])
+            out_d.append(d)
+            out_g.append(g)
+        self.nn_grad = torch.from_numpy(np.concatenate(out_g))
+        return torch.from_numpy(np.concatenate(out_d)), self.nn_grad
+
+    def update_kernel_normal_bases(self):
+        """MPPI.py:284-304: re-evaluate the obstacle normal at every kernel centre."""
+        K = self.Policy.n_kernels
+        if K > 0:
+            _, grad = self.distance_repulsion_nn(self.Policy.mu_c[0:K])
+            g = grad.numpy()
+            A = np.tile(np.eye(self.n_dof, dtype=np.float32), (K, 1, 1))
+            A[:, :, 0] = g
+            Q, _ = np.linalg.qr(A)
+            Q = Q.astype(np.float32)
+            Q[:, :, 0] = g / np.linalg.norm(g, axis=1, keepdims=True)
+            self.Policy.kernel_obstacle_bases[0:K] = torch.from_numpy(Q)
+        return 0
+
+    # ---- cost and update (MPPI.py:315-345) -------------------------------------------------------------
+    def get_cost(self):
+        self._push()
+        self.cur_cost = torch.from_numpy(self._engine.cost())
+        return self.cur_cost
+
+    def get_qdot(self, mode='best'):
+        if self.cur_cost is None:
+            self.get_cost()
+        return torch.from_numpy(self._engine.get_qdot(mode))
+
+    def shift_policy_means(self):
+        if self.cur_cost is None:
+            self.get_cost()
+        P = self.Policy
+        K = P.n_kernels
+        mu, sg, al, mask, _ = self._engine.weighted_update(self.policy_upd_rate, self.ker_thr, P.mu_c.numpy(),
+                                                           P.sigma_c.numpy(), P.alpha_c.numpy())
+        if K > 0:
+            P.mu_c[:K] = torch.from_numpy(mu)
+            P.sigma_c[:K] = torch.from_numpy(sg)
+            P.alpha_c[:K] = torch.from_numpy(al)
+        self.update_mask = torch.from_numpy(mask)
+        return 0, int(mask.sum())

@@ -1,0 +1,112 @@
+"""Learned robot-to-point distance network -- mirrors ``mlp_learn/sdf/robot_sdf.py``
+(class RobotSdfCollisionNet, lines 13-166) and the NeRF-encoded MLP of
+``network_macros_mod.py:96-146``.  Weights are held as plain fp32 arrays; every evaluation
+goes through the HIP kernels (omds_mlp_forward_vjp)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .engine import Engine
+
+
+class _WeightBag:
+    """Stands in for ``nn_model.model``: holds W[i] ([out, in] like nn.Linear) and b[i]."""
+
+    def __init__(self, in_channels, out_channels, layers):
+        dims = [3 * in_channels] + list(layers) + [out_channels]
+        self.W = [np.zeros((dims[i + 1], dims[i]), np.float32) for i in range(len(dims) - 1)]
+        self.b = [np.zeros(dims[i + 1], np.float32) for i in range(len(dims) - 1)]
+        self.act = "relu"
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+
+class RobotSdfCollisionNet:
+    def __init__(self, in_channels, out_channels, skips, layers):
+        if len(skips) > 0:
+            raise NotImplementedError("skip connections are not supported (every reference driver uses skips=[])")
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.model = _WeightBag(in_channels, out_channels, layers)
+        self.model_jit = self          # drivers call nn_model.model_jit.forward(x)
+        self.order = list(range(out_channels))
+        self.norm_dict = None
+        self._engine = None
+        self._engine_cap = 0
+        self.device = 0
+
+    def set_link_order(self, order):
+        self.order = order
+
+    def load_weights(self, f_name, tensor_args=None):
+        """Accepts the reference's ``.pt`` checkpoints (state dict keys layers.0.<i>.0.weight/bias,
+        robot_sdf.py:39-41) or this repo's ``.npz`` exports (W<i>, b<i>)."""
+        if str(f_name).endswith(".npz"):
+            z = np.load(f_name)
+            n = len([k for k in z.files if k.startswith("W")])
+            W = [z[f"W{i}"].astype(np.float32) for i in range(n)]
+            b = [z[f"b{i}"].astype(np.float32) for i in range(n)]
+        else:
+            chk = torch.load(f_name, map_location=torch.device("cpu"), weights_only=False)
+            sd = chk["model_state_dict"]
+            self.norm_dict = chk.get("norm")
+            W, b, i = [], [], 0
+            while f"layers.0.{i}.0.weight" in sd:
+                W.append(sd[f"layers.0.{i}.0.weight"].numpy().astype(np.float32))
+                b.append(sd[f"layers.0.{i}.0.bias"].numpy().astype(np.float32))
+                i += 1
+        if [w.shape for w in W] != [w.shape for w in self.model.W]:
+            raise ValueError(f"checkpoint shapes {[w.shape for w in W]} do not match the declared network "
+                             f"{[w.shape for w in self.model.W]}")
+        self.model.W, self.model.b = W, b
+        self.tensor_args = tensor_args
+        self._engine = None
+        print("Weights loaded!")
+
+    # -- no-ops kept for call compatibility (robot_sdf.py:112-115,164-166; frankaPlanner.py:48-51)
+    def update_aot_lambda(self):
+        return 0
+
+    def allocate_gradients(self, N, tensor_args=None):
+        self.maxInputSize = N
+
+    def _eng(self, batch):
+        if self._engine is None or batch > self._engine_cap:
+            if self._engine is not None:
+                self._engine.close()
+            cap = max(256, int(batch))
+            n = self.in_channels - 3
+            self._engine = Engine(n, cap, 1, 1, 1, device=self.device)
+            self._engine.set_mlp(self.model.W, self.model.b, self.model.act)
+            self._engine_cap = cap
+        return self._engine
+
+    def forward(self, x):
+        """MLPRegression.forward (network_macros_mod.py:137-146): raw outputs [B, C]."""
+        x = np.asarray(x.detach().cpu() if isinstance(x, torch.Tensor) else x, dtype=np.float32)
+        y, _, _ = self._eng(x.shape[0]).mlp_forward_vjp(x)
+        return torch.from_numpy(y)
+
+    __call__ = forward
+
+    def compute_signed_distance(self, q):
+        return self.forward(q)[:, self.order]
+
+    def dist_grad_closest(self, q):
+        """(dists [B,C], grads [B,in,1], minIdx [B]) -- robot_sdf.py:117-137."""
+        x = np.asarray(q.detach().cpu() if isinstance(q, torch.Tensor) else q, dtype=np.float32)
+        y, g, mi = self._eng(x.shape[0]).mlp_forward_vjp(x)
+        return torch.from_numpy(y), torch.from_numpy(g).unsqueeze(2), torch.from_numpy(mi.astype(np.int64))
+
+    def functorch_vjp(self, points):
+        """(dists, grads [B,in], minIdx) -- robot_sdf.py:153-158."""
+        y, g, mi = self.dist_grad_closest(points)
+        return y, g.squeeze(2), mi
+
+    def dist_grad_closest_aot(self, q):
+        return self.functorch_vjp(q)

@@ -217,10 +217,55 @@ class RolloutOut:
     extras: dict = field(default_factory=dict)
 
 
+def modulation_step(q_prev, qf, distance_raw, g_raw, mu_tmp, sigma_tmp, alpha_tmp, prm: Params = Params()):
+    """Everything of one horizon step AFTER the distance network (FN/MPPI.py:102-217): nominal DS,
+    eigenvalues, RBF policy, activations, closed-form M v, normalisation, collision handling.
+    ``distance_raw`` is the network distance of the closest obstacle (before ``dst_thr``),
+    ``g_raw`` the blended joint-space gradient.  Returns a dict of per-rollout results."""
+    q_prev = np.asarray(q_prev, dtype=F32)
+    K = mu_tmp.shape[1]
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+        v = lin_ds_velocity(q_prev, qf, prm.lin_thr)                              # :106
+        vnorm = np.sqrt((v * v).sum(axis=1)).reshape(-1, 1)
+        vhat = v / vnorm
+        distance = (distance_raw - F32(prm.dst_thr)).astype(F32)                   # :117
+        ghat = (g_raw / np.sqrt((g_raw * g_raw).sum(axis=1))[:, None]).astype(F32)  # :126
+        dot = (ghat * vhat).sum(axis=-1)                                           # :129
+        l_vel = generalized_sigmoid(dot, *prm.lvel)                                # :132
+        l_n = generalized_sigmoid(distance, *prm.ln)
+        l_nv = l_vel * F32(1) + (F32(1) - l_vel) * l_n                              # :154
+        l_tau = generalized_sigmoid(distance, *prm.ltau)
+        if K > 0:                                                                  # :165-186
+            phi = eval_rbf(q_prev, mu_tmp, sigma_tmp, prm.p)
+            pol = (alpha_tmp * phi[:, :, None]).sum(axis=1).astype(F32)
+        else:
+            phi = np.zeros((q_prev.shape[0], 0), dtype=F32)
+            pol = v * F32(0)
+        ca = (F32(1) - l_n)[:, None]
+        va = (F32(1) - l_vel)[:, None]
+        ga = (np.sqrt(np.abs(q_prev - qf)).sum(axis=1) ** 2).clip(0, 1)[:, None].astype(F32)  # norm(p=0.5)
+        ga[ga < F32(prm.goal_act_cut)] = 0
+        act = ca * va * ga
+        v_tot = v + act * pol * vnorm                                              # :197-206
+        # M v with M = E diag(l_nv, l_tau, ...) E^T  ==  l_tau v + (l_nv - l_tau)(g.v) g   (:161,209)
+        u = l_tau[:, None] * v_tot + ((l_nv - l_tau) * (ghat * v_tot).sum(axis=1))[:, None] * ghat
+        unorm = np.sqrt((u * u).sum(axis=1)).reshape(-1, 1)
+        s = unorm.copy()
+        s[s <= F32(prm.norm_clamp)] = 1                                            # :212
+        u = nan_to_num(u / s)
+        coll = distance < 0
+        u[coll] *= F32(prm.coll_slow)                                              # :215
+        rep = ghat * vnorm * F32(prm.coll_repulse)
+        u[coll] += rep[coll]                                                       # :217
+    return dict(u=u.astype(F32), distance=distance, ghat=ghat, dot=dot.astype(F32), act=act[:, 0].astype(F32),
+                phi=phi, unorm=unorm[:, 0], ga=ga[:, 0])
+
+
 def propagate(m: Mlp, q_cur, qf, obs, *, N, H, dt, k, ignored_links, mu_tmp, sigma_tmp, alpha_tmp,
               prm: Params = Params()):
     """MPPI.propagate (FN/MPPI.py:97-224).  ``mu_tmp [N,K,n]``, ``sigma_tmp [N,K]``,
-    ``alpha_tmp [N,K,n]`` are the sampled policy tensors (first K kernels)."""
+    ``alpha_tmp [N,K,n]`` are the sampled policy tensors (first K kernels).  ``q_cur`` is [n]
+    (the reference) or [N, n] (per-rollout starts, used by teacher-forced tests)."""
     q_cur = np.asarray(q_cur, dtype=F32)
     qf = np.asarray(qf, dtype=F32)
     n = q_cur.shape[-1]
@@ -235,54 +280,36 @@ def propagate(m: Mlp, q_cur, qf, obs, *, N, H, dt, k, ignored_links, mu_tmp, sig
     nb = np.zeros((N, H, n, n), dtype=F32) if prm.want_basis else None
     qdot = np.zeros((N, n), dtype=F32)
     all_traj[:, 0, :] = q_cur
-    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
-        for i in range(1, H + 1):
-            q_prev = all_traj[:, i - 1, :]
-            v = lin_ds_velocity(q_prev, qf, prm.lin_thr)                              # :106
-            vnorm = np.sqrt((v * v).sum(axis=1)).reshape(-1, 1)
-            vhat = v / vnorm
-            distance, g_raw, _, _ = distance_repulsion_nn(m, q_prev, obs, k, ignored_links)   # :113
-            distance = (distance - F32(prm.dst_thr)).astype(F32)                       # :117
-            dist_all[:, i - 1] = distance
-            ghat = (g_raw / np.sqrt((g_raw * g_raw).sum(axis=1))[:, None]).astype(F32)  # :126
-            nb_n[:, i - 1] = ghat
-            if nb is not None:
+    for i in range(1, H + 1):
+        q_prev = all_traj[:, i - 1, :]
+        d_raw, g_raw, _, _ = distance_repulsion_nn(m, q_prev, obs, k, ignored_links)   # :113
+        st = modulation_step(q_prev, qf, d_raw, g_raw, mu_tmp, sigma_tmp, alpha_tmp, prm)
+        dist_all[:, i - 1] = st["distance"]
+        nb_n[:, i - 1] = st["ghat"]
+        if nb is not None:
+            with np.errstate(invalid="ignore", divide="ignore"):
                 nb[:, i - 1] = qr_basis(g_raw)
-            dot = (ghat * vhat).sum(axis=-1)                                           # :129
-            dots[:, i - 1] = dot
-            l_vel = generalized_sigmoid(dot, *prm.lvel)                                # :132
-            l_n = generalized_sigmoid(distance, *prm.ln)
-            l_nv = l_vel * F32(1) + (F32(1) - l_vel) * l_n                              # :154
-            l_tau = generalized_sigmoid(distance, *prm.ltau)
-            # policy (:165-186)
-            if K > 0:
-                phi = eval_rbf(q_prev, mu_tmp, sigma_tmp, prm.p)
-                kval_all[:, i - 1, :] = phi
-                pol = (alpha_tmp * phi[:, :, None]).sum(axis=1).astype(F32)
-            else:
-                pol = v * F32(0)
-            ca = (F32(1) - l_n)[:, None]
-            va = (F32(1) - l_vel)[:, None]
-            ga = (np.sqrt(np.abs(q_prev - qf)).sum(axis=1) ** 2).clip(0, 1)[:, None].astype(F32)  # norm(p=0.5)
-            ga[ga < F32(prm.goal_act_cut)] = 0
-            act = ca * va * ga
-            acts[:, i - 1] = act[:, 0]
-            v_tot = v + act * pol * vnorm                                              # :197-206
-            # M v with M = E diag(l_nv, l_tau, ...) E^T  ==  l_tau v + (l_nv - l_tau)(g.v) g   (:161,209)
-            u = l_tau[:, None] * v_tot + ((l_nv - l_tau) * (ghat * v_tot).sum(axis=1))[:, None] * ghat
-            s = np.sqrt((u * u).sum(axis=1)).reshape(-1, 1)
-            s[s <= F32(prm.norm_clamp)] = 1                                            # :212
-            u = nan_to_num(u / s)
-            coll = distance < 0
-            u[coll] *= F32(prm.coll_slow)                                              # :215
-            rep = ghat * vnorm * F32(prm.coll_repulse)
-            u[coll] += rep[coll]                                                       # :217
-            u = u.astype(F32)
-            if i < H:
-                all_traj[:, i, :] = all_traj[:, i - 1, :] + dt * u
-            if i == 1:
-                qdot = u.copy()
+        dots[:, i - 1] = st["dot"]
+        acts[:, i - 1] = st["act"]
+        if K > 0:
+            kval_all[:, i - 1, :] = st["phi"]
+        if i < H:
+            all_traj[:, i, :] = all_traj[:, i - 1, :] + dt * st["u"]              # :221
+        if i == 1:
+            qdot = st["u"].copy()
     return RolloutOut(all_traj, dist_all, kval_all, dots, acts, qdot, nb_n, nb)
+
+
+def relu_margin(m: Mlp, x):
+    """min over all hidden units of |pre-activation| per row: rows below fp32 rounding of the
+    accumulation (~1e-5 of the row's scale) may flip a ReLU mask and change the vjp discretely."""
+    h = positional_encoding(np.asarray(x, dtype=F32))
+    marg = np.full(h.shape[0], np.inf, dtype=F32)
+    for i in range(len(m.W) - 1):
+        z = h @ m.W[i].T + m.b[i]
+        marg = np.minimum(marg, np.abs(z).min(axis=1))
+        h = _act(z, m.act)
+    return marg
 
 
 # ---------------------------------------------------------------------------------------------

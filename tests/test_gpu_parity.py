@@ -1,0 +1,186 @@
+"""GPU parity tests (run on a real MI355X: ``pytest -m gpu``).  Everything goes through the C-ABI
+(libomds_hip.so via ctypes); the numpy oracle and the committed golden vectors are the checkers.
+
+Tolerances: 1e-5 relative fp32 on modulated velocities / next states (BASELINE.json north_star),
+teacher-forced per step so that rounding differences cannot compound; indices exact except at
+(near-)ties, where the selected distances must agree instead."""
+import numpy as np
+import pytest
+
+from helpers import MLP_KINDS, RTOL, SCENARIOS, assert_close, load, rel_err, weights_path
+from oracle import omds_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(fx, H=None, N=None):
+    from optimalmodulationds_amd.engine import Engine
+    m = orc.Mlp.from_npz(weights_path(str(fx["kind"])))
+    n = int(fx["q0"].shape[0])
+    eng = Engine(n, int(N or fx["N"]), int(H or fx["H"]), int(fx["k"]), max_obs=max(64, 2 * fx["obs"].shape[0]))
+    eng.set_mlp(m.W, m.b)
+    eng.set_obstacles(fx["obs"])
+    p = eng.params
+    p.dt = float(fx["dt"]); p.dst_thr = float(fx["dst_thr"]); p.lin_thr = float(fx["lin_thr"]); p.rbf_p = float(fx["p"])
+    mask = 0
+    for l in fx["ignored_links"]:
+        mask |= 1 << int(l)
+    p.ignored_links = mask
+    eng.push_params()
+    eng.set_ds(fx["qf"])
+    eng.set_cost(fx["dh_params"], fx["cost_q_min"], fx["cost_q_max"])
+    return eng, m
+
+
+@pytest.mark.parametrize("kind", MLP_KINDS)
+def test_mlp_forward_and_vjp(kind):
+    from optimalmodulationds_amd.engine import Engine
+    fx = load("mlp_" + kind)
+    m = orc.Mlp.from_npz(weights_path(kind))
+    n = fx["x"].shape[1] - 3
+    eng = Engine(n, 128, 1, 1, max_obs=8)
+    eng.set_mlp(m.W, m.b)
+    y, g, mi = eng.mlp_forward_vjp(fx["x"])
+    assert_close(y, fx["y"], RTOL, "mlp forward vs reference")
+    assert (mi == fx["min_idx"]).all()
+    safe = fx["min_abs_preact"] > 1e-4      # rows whose ReLU masks cannot flip under fp32 rounding
+    assert_close(g[safe], fx["grad"][safe], 2e-5, "vjp grad vs reference", floor=float(np.abs(fx["grad"]).max()))
+    # unsafe rows: still bounded (a flipped unit changes the gradient by one weight-path, not arbitrarily)
+    assert rel_err(g, fx["grad"], floor=float(np.abs(fx["grad"]).max())) < 5e-2
+    eng.close()
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_dist_grad_stages(name):
+    fx = load(name)
+    eng, m = _engine(fx)
+    d, g, mind, idx = eng.dist_grad(fx["st_q"], want_mindist=True, want_idx=True)
+    assert_close(mind, fx["st_mindist"], RTOL, "pass-1 min-distance matrix")
+    same = idx == fx["st_sort_idx"]
+    if not same.all():
+        picked = np.take_along_axis(mind, idx.astype(np.int64), axis=1)
+        assert_close(picked, fx["st_sort_dist"], RTOL, "sorted distances at differing indices")
+    assert (np.diff(np.take_along_axis(mind, idx.astype(np.int64), axis=1), axis=1) >= 0).all(), "top-k not ascending"
+    assert_close(d, fx["st_distance"], 2e-5, "distance")
+    assert_close(g, fx["st_nn_grad"], 1e-4, "blended gradient", floor=float(np.abs(fx["st_nn_grad"]).max()))
+    eng.close()
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_teacher_forced_steps(name):
+    """Every horizon step restarted from the reference's own state (H=1, per-rollout starts)."""
+    fx = load(name)
+    eng, m = _engine(fx, H=1)
+    H = int(fx["H"])
+    dt = np.float32(fx["dt"])
+    for it in range(int(fx["n_iter"])):
+        pre = f"it{it}_"
+        ref = fx[pre + "all_traj"]
+        eng.set_policy_samples(fx[pre + "mu_tmp"], fx[pre + "sigma_tmp"], fx[pre + "alpha_tmp"])
+        for i in range(1, H + 1):
+            eng.propagate(np.ascontiguousarray(ref[:, i - 1, :]))
+            r = eng.get_rollouts()
+            if i < H:
+                assert_close(ref[:, i - 1, :] + dt * r["qdot"], ref[:, i, :], RTOL, f"next state, step {i}")
+            if i == 1:
+                assert_close(r["qdot"], fx[pre + "qdot"], RTOL, "qdot (modulated velocity)")
+            assert_close(r["closest_dist_all"][:, 0], fx[pre + "closest_dist_all"][:, i - 1], RTOL, f"distance {i}")
+            assert_close(r["dot_products"][:, 0], fx[pre + "dot_products"][:, i - 1], 2e-5, f"dot {i}")
+            assert_close(r["kernel_activations"][:, 0], fx[pre + "kernel_activations"][:, i - 1], 3e-5, f"act {i}")
+            assert_close(r["kernel_val_all"][:, 0], fx[pre + "kernel_val_all"][:, i - 1], RTOL, f"rbf {i}")
+            assert_close(r["normal"][:, 0], fx[pre + "norm_basis_n"][:, i - 1], 3e-5, f"normal {i}")
+    eng.close()
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_free_running_cost_update(name):
+    fx = load(name)
+    eng, m = _engine(fx)
+    N, H, K = int(fx["N"]), int(fx["H"]), int(fx["K"])
+    for it in range(int(fx["n_iter"])):
+        pre = f"it{it}_"
+        eng.set_policy_samples(fx[pre + "mu_tmp"], fx[pre + "sigma_tmp"], fx[pre + "alpha_tmp"])
+        eng.propagate(fx[pre + "q_cur"])
+        r = eng.get_rollouts()
+        assert_close(r["qdot"], fx[pre + "qdot"], RTOL, "qdot (first step, no compounding)")
+        tol = 1e-2   # free-running rollouts compound rounding differences (see test_oracle_golden)
+        assert_close(r["all_traj"], fx[pre + "all_traj"], tol, "all_traj")
+        assert_close(r["closest_dist_all"], fx[pre + "closest_dist_all"], tol, "closest_dist_all")
+        assert_close(r["kernel_val_all"], fx[pre + "kernel_val_all"], tol, "kernel_val_all")
+        # cost: device vs oracle on the DEVICE's own rollouts (tight), and vs the reference (loose)
+        cost = eng.cost()
+        oc, _ = orc.evaluate_costs(r["all_traj"], r["closest_dist_all"], fx["qf"], fx["dh_params"], fx["cost_q_min"],
+                                   fx["cost_q_max"])
+        assert_close(cost, oc, RTOL, "cost vs oracle on device rollouts")
+        # update: device reduction vs oracle arithmetic on the device's own tensors
+        mu0, sg0, al0 = fx[pre + "mu_c"], fx[pre + "sigma_c"], fx[pre + "alpha_c"]
+        mu, sg, al, mask, w = eng.weighted_update(float(fx["policy_upd_rate"]), float(fx["ker_thr"]), mu0, sg0, al0,
+                                                  want_weights=True)
+        omu, osg, oal, omask, ow = orc.shift_policy_means(cost, r["kernel_val_all"], r["kernel_activations"], mu0, sg0,
+                                                          al0, fx[pre + "mu_tmp"], fx[pre + "sigma_tmp"],
+                                                          fx[pre + "alpha_tmp"], float(fx["ker_thr"]),
+                                                          float(fx["policy_upd_rate"]))
+        assert_close(w, ow, 2e-5, "mppi weights", floor=float(ow.max()))
+        assert abs(float(w.sum()) - 1.0) < 1e-5
+        assert (mask == omask).all()
+        assert_close(mu, omu, RTOL, "mu_c")
+        assert_close(sg, osg, RTOL, "sigma_c")
+        assert_close(al, oal, 2e-5, "alpha_c")
+        assert_close(eng.get_qdot("weighted"), orc.get_qdot(cost, r["qdot"], "weighted"), 2e-5, "weighted qdot")
+        assert_close(eng.get_qdot("best"), orc.get_qdot(cost, r["qdot"], "best"), 1e-6, "best qdot")
+        # against the reference's own numbers: same mask count, means close
+        assert int(mask.sum()) == int(fx[pre + "n_updated"])
+        assert_close(mu, fx[pre + "mu_c_new"], 1e-3, "mu_c vs reference")
+        assert_close(al, fx[pre + "alpha_c_new"], 5e-2, "alpha_c vs reference")
+    eng.close()
+
+
+def test_device_sampling_statistics():
+    from optimalmodulationds_amd.engine import Engine
+    N, n, K = 4096, 7, 6
+    eng = Engine(n, N, 2, 1, max_obs=8)
+    rng = np.random.RandomState(3)
+    mu_c = rng.standard_normal((K, n)).astype(np.float32)
+    sg_c = (1 + rng.rand(K)).astype(np.float32)
+    al_c = rng.standard_normal((K, n)).astype(np.float32)
+    eng.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 3.0, K, seed=42, rollout_offset=0)
+    mu, sg, al = eng.get_policy_samples()
+    assert np.abs(mu - mu_c[None]).max() == 0 and np.abs(sg - sg_c[None]).max() == 0   # mu_s = sigma_s = 0
+    assert np.abs(al[0] - al_c).max() == 0                                              # rollout 0 = mean policy
+    z = (al[1:] - al_c[None]) / 3.0
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02
+    assert abs(float(np.mean(z ** 3))) < 0.05 and abs(float(np.mean(z ** 4)) - 3.0) < 0.15
+    # a different shard (rollout_offset) draws different numbers; same seed + offset reproduces
+    eng.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 3.0, K, seed=42, rollout_offset=N)
+    _, _, al2 = eng.get_policy_samples()
+    assert np.abs(al2[1:] - al[1:]).mean() > 0.5 and np.abs(al2[0] - al_c).max() > 0
+    eng.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 3.0, K, seed=42, rollout_offset=0)
+    _, _, al3 = eng.get_policy_samples()
+    assert (al3 == al).all()
+    eng.close()
+
+
+def test_error_paths():
+    from optimalmodulationds_amd import _lib as L
+    from optimalmodulationds_amd.engine import Engine
+    with pytest.raises(L.OmdsError):
+        Engine(9, 8, 2, 1, max_obs=8)                       # n_dof > 7
+    eng = Engine(7, 8, 2, 2, max_obs=8)
+    with pytest.raises(L.OmdsError, match="network not set"):
+        eng.dist_grad(np.zeros((4, 7), np.float32))
+    m = orc.Mlp.from_npz(weights_path("franka"))
+    with pytest.raises(L.OmdsError, match="width 256"):
+        eng.set_mlp([m.W[0][:128], m.W[1][:128, :128], m.W[-1][:, :128]], [m.b[0][:128], m.b[1][:128], m.b[-1]])
+    eng.set_mlp(m.W, m.b)
+    with pytest.raises(L.OmdsError, match="max_obs"):
+        eng.set_obstacles(np.zeros((9, 4), np.float32))
+    with pytest.raises(L.OmdsError, match="n_closest"):
+        eng.set_obstacles(np.zeros((1, 4), np.float32))     # fewer obstacles than k
+    eng.set_obstacles(np.ones((4, 4), np.float32))
+    with pytest.raises(L.OmdsError, match="DS not set"):
+        eng.propagate(np.zeros(7, np.float32))
+    eng.set_ds(np.zeros(7, np.float32))
+    eng.propagate(np.ones(7, np.float32))
+    with pytest.raises(L.OmdsError, match="omds_set_cost"):
+        eng.cost()
+    eng.close()
