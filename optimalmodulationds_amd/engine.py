@@ -150,9 +150,10 @@ class Engine:
 
     def weighted_update(self, rate, ker_thr, mu_c, sigma_c, alpha_c, want_weights=False):
         K = self.K
-        mu = np.ascontiguousarray(L.f32(mu_c)[:K]).reshape(K, self.n)
-        sg = np.ascontiguousarray(L.f32(sigma_c)[:K]).reshape(K)
-        al = np.ascontiguousarray(L.f32(alpha_c)[:K]).reshape(K, self.n)
+        # copies: the C function updates the means in place and must not alias the caller's arrays
+        mu = np.array(np.asarray(mu_c, dtype=np.float32)[:K], dtype=np.float32, order="C", copy=True).reshape(K, self.n)
+        sg = np.array(np.asarray(sigma_c, dtype=np.float32)[:K], dtype=np.float32, order="C", copy=True).reshape(K)
+        al = np.array(np.asarray(alpha_c, dtype=np.float32)[:K], dtype=np.float32, order="C", copy=True).reshape(K, self.n)
         mask = np.zeros(K, np.int32)
         w = np.zeros(self.N, np.float32) if want_weights else None
         self._ck(self.lib.omds_weighted_update(self.h, float(rate), float(ker_thr), L.fptr(mu), L.fptr(sg), L.fptr(al),
@@ -205,9 +206,9 @@ def apply_update(K, n, H, red, n_total, rate, ker_thr, mu_c, sigma_c, alpha_c):
     """Host arithmetic of the policy update on the (globally) reduced buffer -- omds_apply_update."""
     lib = L.load()
     red = L.f32(red)
-    mu = np.ascontiguousarray(L.f32(mu_c)[:K]).reshape(K, n)
-    sg = np.ascontiguousarray(L.f32(sigma_c)[:K]).reshape(K)
-    al = np.ascontiguousarray(L.f32(alpha_c)[:K]).reshape(K, n)
+    mu = np.array(np.asarray(mu_c, dtype=np.float32)[:K], dtype=np.float32, order="C", copy=True).reshape(K, n)
+    sg = np.array(np.asarray(sigma_c, dtype=np.float32)[:K], dtype=np.float32, order="C", copy=True).reshape(K)
+    al = np.array(np.asarray(alpha_c, dtype=np.float32)[:K], dtype=np.float32, order="C", copy=True).reshape(K, n)
     mask = np.zeros(K, np.int32)
     rc = lib.omds_apply_update(int(K), int(n), int(H), L.fptr(red), float(n_total), float(rate), float(ker_thr),
                                L.fptr(mu), L.fptr(sg), L.fptr(al), L.iptr(mask))

