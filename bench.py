@@ -100,6 +100,10 @@ def main():
     ap.add_argument("--workload", default="franka_shelf_1024x32", choices=sorted(WORKLOADS))
     ap.add_argument("--kernels", type=int, default=10, help="active RBF navigation kernels K")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --share-gpu lets two ranks share one GPU to exercise the sharded path on a 1-GPU box")
+    ap.add_argument("--share-gpu", action="store_true")
+    ap.add_argument("--time-fetch", action="store_true", help="also report the cost of fetching all rollout tensors to the host")
     args = ap.parse_args()
 
     import torch
@@ -111,10 +115,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from optimalmodulationds_amd.dist import sharded_update
     from optimalmodulationds_amd.engine import Engine
@@ -164,10 +173,17 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], device="cuda")
+        t = torch.tensor([el], device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     p1_ms, p1_launches, p1_rows = eng.prof_read()
+    fetch_ms = None
+    if args.time_fetch:
+        eng.get_rollouts()
+        tf = time.perf_counter()
+        for _ in range(5):
+            eng.get_rollouts()
+        fetch_ms = (time.perf_counter() - tf) / 5 * 1e3
 
     if rank == 0:
         f_row = flops_per_row(W)
@@ -185,6 +201,8 @@ def main():
                          "launches": int(p1_launches), "avg_launch_ms": p1_ms / max(p1_launches, 1),
                          "flops_per_launch": f_row * p1_rows / max(p1_launches, 1)},
         }
+        if fetch_ms is not None:
+            out["fetch_all_rollouts_ms"] = fetch_ms
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, W, b, obs, q0, qf, K, 7)
         print(json.dumps(out))

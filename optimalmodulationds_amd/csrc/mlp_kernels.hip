@@ -490,8 +490,8 @@ static void launch_pass1_t(hipStream_t s, const MlpDev& m, const float* Apre, co
                        total, ignored, Dmin);
 }
 
-// Tile choice: 128-row tiles (8 waves, each 128 rows x 32 columns) once there are enough tiles to
-// fill 256 CUs a few times over; 32-row tiles for small batches (planar configs, dist_grad calls).
+// Tile choice: 64-row tiles (8 waves, each 64 rows x 32 columns, two workgroups per CU) once there are
+// enough tiles to fill 256 CUs; 32-row tiles for small batches (planar configs, dist_grad calls).
 static int g_pass1_variant = -1;  // -1 = auto; set through OMDS_PASS1_VARIANT for experiments
 void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
                        int O, int B, uint32_t ignored, float* Dmin) {
@@ -502,7 +502,9 @@ void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Apre, const 
         g_pass1_variant = e ? atoi(e) : 0;
     }
     int v = g_pass1_variant;
-    if (v == 0) v = (total >= 128LL * 512) ? 1 : ((total >= 64LL * 512) ? 3 : 5);
+    // measured on MI355X (profiles/): 64-row tiles (2 workgroups per CU) beat 128-row tiles at N*O = 301k rows
+    // (129 vs 123 TFLOP/s: shorter tail) and tie at 1.2M rows (134 TFLOP/s)
+    if (v == 0) v = (total >= 64LL * 512) ? 3 : 5;
     switch (v) {
         case 1: launch_pass1_t<128, 4, 1>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
         case 2: launch_pass1_t<128, 2, 2>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
