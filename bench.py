@@ -57,6 +57,16 @@ def setup(wl, rank):
     return w, W, b, obs, q0, qf, dh, qmin, qmax
 
 
+def pmc_traffic(workload):
+    """HBM bytes per k_pass1 launch from the committed rocprofv3 PMC summary of this workload
+    (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)[workload]["k_pass1"]["traffic_bytes"]
+    except Exception:
+        return None
+
+
 def flops_per_row(W):
     """Algorithmic FLOPs of one network forward: 2 * sum(in*out) over the Linear layers."""
     return 2 * sum(int(w.shape[0]) * int(w.shape[1]) for w in W)
@@ -197,7 +207,7 @@ def main():
                        "n_closest": w["k"], "active_kernels": K, "network": "x".join(str(x.shape[1]) for x in W) + f"x{W[-1].shape[0]} relu (shipped reference weights)",
                        "parallelism": f"rollout-sharded x{world}"},
             "roofline": {"bound": "mfma", "kernel": "k_pass1", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(args.workload),
                          "launches": int(p1_launches), "avg_launch_ms": p1_ms / max(p1_launches, 1),
                          "flops_per_launch": f_row * p1_rows / max(p1_launches, 1)},
         }

@@ -108,7 +108,7 @@ __device__ __forceinline__ void load_chunk(const float* arow, const float4* wp, 
 // with sched_barrier (left alone, hipcc sinks the loads next to their use and waits vmcnt(0) per chunk).
 template <int MR, int NR>
 __device__ __forceinline__ void gemm256(const float* __restrict__ Hw, const float4* __restrict__ Wp, int cb0,
-                                        int lane, f32x16 (&acc)[MR][NR]) {
+                                        int lane, f32x16 (&acc)[MR][NR], const bool prio = false) {
     const float* arow = Hw + (lane & 31) * LDH + 4 * (lane >> 5);
     const float4* wp = Wp + (size_t)cb0 * (32 * 64) + lane;
     float4 a0[MR], a1[MR], w0[NR], w1[NR];
@@ -117,11 +117,15 @@ __device__ __forceinline__ void gemm256(const float* __restrict__ Hw, const floa
     for (int c = 0; c < 32; c += 2) {
         load_chunk<MR, NR>(arow, wp, c + 1, a1, w1);
         __builtin_amdgcn_sched_barrier(0);
+        if (prio) __builtin_amdgcn_s_setprio(1);
         mfma_chunk<MR, NR>(a0, w0, acc);
+        if (prio) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         load_chunk<MR, NR>(arow, wp, (c + 2) & 31, a0, w0);   // last iteration re-loads chunk 0 (harmless)
         __builtin_amdgcn_sched_barrier(0);
+        if (prio) __builtin_amdgcn_s_setprio(1);
         mfma_chunk<MR, NR>(a1, w1, acc);
+        if (prio) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -146,7 +150,7 @@ __global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const
                                                                const float* __restrict__ Bpre,
                                                                const float* __restrict__ radius, int O,
                                                                long long total_rows, uint32_t ignored,
-                                                               float* __restrict__ Dmin) {
+                                                               float* __restrict__ Dmin, int tune) {
     using G = Geo<MT, MR, NR>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Hs = smem;                                           // [MT][LDH]
@@ -187,7 +191,7 @@ __global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const
             for (int j = 0; j < NR; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        gemm256<MR, NR>(Hw, m.Wf + (size_t)l * (OMDS_NCB * 32 * 64), cb0, lane, acc);
+        gemm256<MR, NR>(Hw, m.Wf + (size_t)l * (OMDS_NCB * 32 * 64), cb0, lane, acc, (tune & 1) != 0);
         __syncthreads();  // every wave has finished reading the tile
         const float* bias = m.bh + l * OMDS_WIDTH;
 #pragma unroll
@@ -486,8 +490,10 @@ static void launch_pass1_t(hipStream_t s, const MlpDev& m, const float* Apre, co
         attr_set = true;
     }
     const long long tiles = (total + MT - 1) / MT;
+    static int tune = -1;
+    if (tune < 0) { const char* e = getenv("OMDS_TUNE"); tune = e ? atoi(e) : 1; }  // bit 0: s_setprio(1) around MFMA clusters (+1 % measured)
     hipLaunchKernelGGL((k_pass1<MT, MR, NR>), dim3((unsigned)tiles), dim3(G::NT), lds, s, m, Apre, Bpre, radius, O,
-                       total, ignored, Dmin);
+                       total, ignored, Dmin, tune);
 }
 
 // Tile choice: 64-row tiles (8 waves, each 64 rows x 32 columns, two workgroups per CU) once there are
