@@ -139,6 +139,17 @@ OMDS_API int omds_weighted_update(omds_ctx* ctx, float rate, float ker_thr, floa
 /* MPPI.get_qdot (MPPI.py:319-329): mode 0 = 'best', 1 = 'weighted'; out [n]. */
 OMDS_API int omds_get_qdot(omds_ctx* ctx, int mode, float* out);
 
+/* TensorPolicyMPPI.check_traj_for_kernels (policy.py:153-175) on the device-resident rollouts of
+ * the last omds_propagate: candidate kernel centres = states (t, h) with closest_dist < thr_dist
+ * and dot_product < thr_dot whose largest RBF value w.r.t. the K existing kernels (mu_c [K,n],
+ * sigma_c [K], norm order = params.rbf_p) is < thr_kernel (K == 0: every close state).  Output
+ * in the reference's boolean-mask order (rollout-major, then horizon): cand_q [cap,n], cand_th
+ * [cap,2] = (t, h); *count = number found (may exceed cap, only min(count, cap) rows are written;
+ * cap <= N*H).                                                                              */
+OMDS_API int omds_kernel_candidates(omds_ctx* ctx, float thr_dist, float thr_kernel, float thr_dot, const float* mu_c,
+                                    const float* sigma_c, int n_kernels, int cap, float* cand_q, int32_t* cand_th,
+                                    int32_t* count);
+
 /* Multi-GPU (new work): rollouts shard across one process per GPU; the only exchange
  * is the cost-weighted update.  The library produces this shard's partial sums in two phases
  * and the host side (optimalmodulationds_amd/dist.py) all-reduces them with torch.distributed

@@ -64,7 +64,7 @@ static void free_all(omds_ctx* ctx) {
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
                     ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
                     ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
-                    ctx->d_w, ctx->d_red, ctx->d_stage};
+                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : ctx->mlp_allocs)
@@ -145,6 +145,9 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
     CKC(hipHostMalloc(&ctx->h_red, redn * 4));
     ctx->stage_bytes = std::max({N * H * std::max(Km, n) * 4, N * Om * 4, Km * n * N * 4, rows2 * OMDS_CPAD * 4});
     CKC(hipMalloc(&ctx->d_stage, ctx->stage_bytes));
+    CKC(hipMalloc(&ctx->d_cflags, N * H));
+    CKC(hipMalloc(&ctx->d_ccounts, N * 4));
+    CKC(hipMalloc(&ctx->d_coffsets, (N + 1) * 4));
     CKC(hipMemsetAsync(ctx->d_trajT, 0, H * n * N * 4, ctx->stream));
     CKC(hipMemsetAsync(ctx->d_kvalT, 0, H * Km * N * 4, ctx->stream));
     CKC(hipMemsetAsync(ctx->d_maxact, 0, Km * N * 4, ctx->stream));
@@ -689,6 +692,43 @@ int omds_get_qdot(omds_ctx* ctx, int mode, float* out) {
     if ((rc = omds_local_sums(ctx, cs[0], cs[1], 1, red.data()))) return rc;
     const int o_qd = 1 + K * (2 * n + 3), o_best = o_qd + n;
     for (int j = 0; j < n; ++j) out[j] = mode == 1 ? red[o_qd + j] / red[0] : red[o_best + 1 + j];
+    return OMDS_OK;
+}
+
+// ---- navigation-kernel candidates (policy.py:153-175) --------------------------------------------------
+int omds_kernel_candidates(omds_ctx* ctx, float thr_dist, float thr_kernel, float thr_dot, const float* mu_c,
+                           const float* sigma_c, int K, int cap, float* cand_q, int32_t* cand_th, int32_t* count) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(count && cap >= 0 && K >= 0 && K <= ctx->cfg.n_kernel_max, OMDS_ERR_INVALID_ARG,
+            "omds_kernel_candidates: bad arguments");
+    REQUIRE(K == 0 || (mu_c && sigma_c), OMDS_ERR_INVALID_ARG, "omds_kernel_candidates: null kernel means");
+    REQUIRE(cap == 0 || (cand_q && cand_th), OMDS_ERR_INVALID_ARG, "omds_kernel_candidates: null output with cap > 0");
+    CK(hipSetDevice(ctx->dev));
+    const int N = ctx->cfg.n_traj, H = ctx->cfg.horizon, n = ctx->cfg.n_dof;
+    const size_t need = (size_t)cap * n * 4 + (size_t)cap * 8;
+    REQUIRE(need <= ctx->stage_bytes, OMDS_ERR_INVALID_ARG, "omds_kernel_candidates: cap too large for the staging buffer (<= N*H)");
+    if (K > 0) {
+        std::vector<float> means((size_t)K * (n + 1));
+        std::memcpy(means.data(), mu_c, (size_t)K * n * 4);
+        std::memcpy(means.data() + (size_t)K * n, sigma_c, (size_t)K * 4);
+        CK(hipMemcpyAsync(ctx->d_means, means.data(), means.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+    }
+    float* d_q = ctx->d_stage;
+    int* d_th = reinterpret_cast<int*>(ctx->d_stage + (size_t)cap * n);
+    omds_launch_candidates(ctx->stream, N, H, n, K, ctx->d_trajT, ctx->d_distT, ctx->d_dotT, ctx->d_means, thr_dist,
+                           thr_kernel, thr_dot, ctx->prm.rbf_p, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, cap, d_q, d_th);
+    CK(hipGetLastError());
+    int32_t total = 0;
+    CK(hipMemcpyAsync(&total, ctx->d_coffsets + N, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    *count = total;
+    const int m = std::min<int>(total, cap);
+    if (m > 0) {
+        CK(hipMemcpyAsync(cand_q, d_q, (size_t)m * n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipMemcpyAsync(cand_th, d_th, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+    }
     return OMDS_OK;
 }
 

@@ -94,6 +94,10 @@ struct omds_ctx {
     float* d_red = nullptr;      // packed reduction buffer
     float* h_red = nullptr;      // pinned mirror
     bool have_cost_vals = false;
+    // kernel-candidate scratch
+    unsigned char* d_cflags = nullptr;  // [N][H]
+    int* d_ccounts = nullptr;           // [N]
+    int* d_coffsets = nullptr;          // [N+1]
     // staging
     float* d_stage = nullptr;    // transposition staging for host copies
     size_t stage_bytes = 0;
@@ -153,6 +157,10 @@ void omds_launch_policy_sums(hipStream_t s, int N, int n, int K, const float* w,
                              const float* cost, int include_rollout0, float* red);
 void omds_launch_sample(hipStream_t s, int N, int n, int K, const float* means, float mu_s, float sigma_s, float alpha_s,
                         uint64_t seed, int64_t rollout_offset, float* muT, float* sigmaT, float* alphaT);
+void omds_launch_candidates(hipStream_t s, int N, int H, int n, int K, const float* trajT, const float* distT,
+                            const float* dotT, const float* means, float thr_dist, float thr_kernel, float thr_dot,
+                            float rbf_p, unsigned char* flags, int* counts, int* offsets, int cap, float* cand_q,
+                            int* cand_th);
 void omds_launch_broadcast_q(hipStream_t s, const float* q_host_vals, int n, int N, float* dstT);
 // layout conversions between reference (AoS) and device (SoA) orders
 void omds_launch_transpose(hipStream_t s, const float* src, float* dst, int rows, int cols);  // dst[c][r] = src[r][c]

@@ -484,6 +484,111 @@ void omds_launch_sample(hipStream_t s, int N, int n, int K, const float* means, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// navigation-kernel candidates (TensorPolicyMPPI.check_traj_for_kernels, policy.py:153-175) on the
+// device-resident rollouts; output order = the reference's boolean-mask order (rollout, then horizon)
+// ------------------------------------------------------------------------------------------------
+template <int ND>
+__global__ __launch_bounds__(256) void k_cand_flags(int N, int H, int K, const float* __restrict__ trajT,
+                                                    const float* __restrict__ distT, const float* __restrict__ dotT,
+                                                    const float* __restrict__ means /* mu_c [K][n] | sigma_c [K] */,
+                                                    float thr_dist, float thr_kernel, float thr_dot, float rbf_p,
+                                                    unsigned char* __restrict__ flags, int* __restrict__ counts) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    int cnt = 0;
+    for (int h = 0; h < H; ++h) {
+        bool cand = (distT[(size_t)h * N + t] < thr_dist) && (dotT[(size_t)h * N + t] < thr_dot);
+        if (cand && K > 0) {
+            float q[ND];
+#pragma unroll
+            for (int j = 0; j < ND; ++j) q[j] = trajT[((size_t)h * ND + j) * N + t];
+            float best = -__builtin_inff();
+            for (int kk = 0; kk < K; ++kk) {
+                float nrm;
+                if (rbf_p == 2.f) {
+                    float s2 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < ND; ++j) { const float df = q[j] - means[kk * ND + j]; s2 += df * df; }
+                    nrm = sqrtf(s2);
+                } else {
+                    float sp = 0.f;
+#pragma unroll
+                    for (int j = 0; j < ND; ++j) sp += powf(fabsf(q[j] - means[kk * ND + j]), rbf_p);
+                    nrm = powf(sp, 1.f / rbf_p);
+                }
+                best = fmaxf(best, expf(-means[K * ND + kk] * (nrm * nrm)));
+            }
+            cand = best < thr_kernel;
+        }
+        flags[(size_t)t * H + h] = cand ? 1 : 0;
+        cnt += cand ? 1 : 0;
+    }
+    counts[t] = cnt;
+}
+
+// exclusive scan of counts[N] -> offsets[N], total in offsets[N]; single block
+__global__ __launch_bounds__(1024) void k_cand_scan(const int* __restrict__ counts, int N, int* __restrict__ offsets) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (N + 1023) / 1024;
+    const int lo = tid * per, hi = min(N, lo + per);
+    int s = 0;
+    for (int t = lo; t < hi; ++t) s += counts[t];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int base = part[tid] - s;
+    for (int t = lo; t < hi; ++t) { offsets[t] = base; base += counts[t]; }
+    if (tid == 1023) offsets[N] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_cand_write(int N, int H, int n, const float* __restrict__ trajT,
+                                                    const unsigned char* __restrict__ flags, const int* __restrict__ offsets,
+                                                    int cap, float* __restrict__ cand_q, int* __restrict__ cand_th) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    int o = offsets[t];
+    for (int h = 0; h < H; ++h) {
+        if (!flags[(size_t)t * H + h]) continue;
+        if (o < cap) {
+            for (int j = 0; j < n; ++j) cand_q[(size_t)o * n + j] = trajT[((size_t)h * n + j) * N + t];
+            cand_th[2 * o] = t;
+            cand_th[2 * o + 1] = h;
+        }
+        ++o;
+    }
+}
+
+template <int ND>
+static void launch_cand_flags_t(hipStream_t s, int N, int H, int K, const float* trajT, const float* distT, const float* dotT,
+                                const float* means, float a, float b, float c, float p, unsigned char* flags, int* counts) {
+    hipLaunchKernelGGL(k_cand_flags<ND>, dim3((N + 255) / 256), dim3(256), 0, s, N, H, K, trajT, distT, dotT, means, a, b, c, p,
+                       flags, counts);
+}
+
+void omds_launch_candidates(hipStream_t s, int N, int H, int n, int K, const float* trajT, const float* distT,
+                            const float* dotT, const float* means, float thr_dist, float thr_kernel, float thr_dot,
+                            float rbf_p, unsigned char* flags, int* counts, int* offsets, int cap, float* cand_q,
+                            int* cand_th) {
+    switch (n) {
+        case 1: launch_cand_flags_t<1>(s, N, H, K, trajT, distT, dotT, means, thr_dist, thr_kernel, thr_dot, rbf_p, flags, counts); break;
+        case 2: launch_cand_flags_t<2>(s, N, H, K, trajT, distT, dotT, means, thr_dist, thr_kernel, thr_dot, rbf_p, flags, counts); break;
+        case 3: launch_cand_flags_t<3>(s, N, H, K, trajT, distT, dotT, means, thr_dist, thr_kernel, thr_dot, rbf_p, flags, counts); break;
+        case 4: launch_cand_flags_t<4>(s, N, H, K, trajT, distT, dotT, means, thr_dist, thr_kernel, thr_dot, rbf_p, flags, counts); break;
+        case 5: launch_cand_flags_t<5>(s, N, H, K, trajT, distT, dotT, means, thr_dist, thr_kernel, thr_dot, rbf_p, flags, counts); break;
+        case 6: launch_cand_flags_t<6>(s, N, H, K, trajT, distT, dotT, means, thr_dist, thr_kernel, thr_dot, rbf_p, flags, counts); break;
+        default: launch_cand_flags_t<7>(s, N, H, K, trajT, distT, dotT, means, thr_dist, thr_kernel, thr_dot, rbf_p, flags, counts); break;
+    }
+    hipLaunchKernelGGL(k_cand_scan, dim3(1), dim3(1024), 0, s, counts, N, offsets);
+    hipLaunchKernelGGL(k_cand_write, dim3((N + 255) / 256), dim3(256), 0, s, N, H, n, trajT, flags, offsets, cap, cand_q, cand_th);
+}
+
+// ------------------------------------------------------------------------------------------------
 // layout conversions
 // ------------------------------------------------------------------------------------------------
 __global__ void k_broadcast_q(const float* __restrict__ q, int n, int N, float* __restrict__ dstT) {

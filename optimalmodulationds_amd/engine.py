@@ -176,6 +176,20 @@ class Engine:
                                           L.fptr(red)))
         return red
 
+    def kernel_candidates(self, thr_dist, thr_kernel, thr_dot, mu_c, sigma_c, K, cap=None):
+        """Device-side TensorPolicyMPPI.check_traj_for_kernels: (cand_q [m,n], cand_th [m,2], total)."""
+        K = int(K)
+        cap = int(self.N * self.H if cap is None else cap)
+        mu = np.array(np.asarray(mu_c, dtype=np.float32)[:K], dtype=np.float32, order="C").reshape(K, self.n)
+        sg = np.array(np.asarray(sigma_c, dtype=np.float32)[:K], dtype=np.float32, order="C").reshape(K)
+        q = np.zeros((cap, self.n), np.float32)
+        th = np.zeros((cap, 2), np.int32)
+        cnt = C.c_int32(0)
+        self._ck(self.lib.omds_kernel_candidates(self.h, float(thr_dist), float(thr_kernel), float(thr_dot), L.fptr(mu),
+                                                 L.fptr(sg), K, cap, L.fptr(q), L.iptr(th), C.byref(cnt)))
+        m = min(cnt.value, cap)
+        return q[:m], th[:m], cnt.value
+
     # ---- measurement --------------------------------------------------------------------------
     def prof_enable(self, on=True):
         self._ck(self.lib.omds_prof_enable(self.h, 1 if on else 0))

@@ -20,6 +20,46 @@ def _np(x):
     return np.asarray(x, dtype=np.float32)
 
 
+def _qr_complete(g):
+    """E = qr([g, e_2 .. e_n]).Q with column 0 := g, batched over the leading axes of g [..., n]."""
+    n = g.shape[-1]
+    A = np.broadcast_to(np.eye(n, dtype=np.float32), g.shape[:-1] + (n, n)).copy()
+    A[..., 0] = g
+    Q, _ = np.linalg.qr(A)
+    Q = Q.astype(np.float32)
+    Q[..., 0] = g
+    return torch.from_numpy(Q)
+
+
+class _LazyBasis:
+    """Indexable stand-in for the reference's ``norm_basis`` tensor; ``[i, h]`` builds one basis,
+    any other index (or ``.tensor()``) materialises the selection."""
+
+    def __init__(self, normals):
+        self._g = normals                                   # [N, H, n]
+        self.shape = normals.shape + (normals.shape[-1],)
+
+    def __getitem__(self, idx):
+        if not isinstance(idx, tuple):
+            idx = (idx,)
+        lead = tuple(int(i) if isinstance(i, torch.Tensor) and i.ndim == 0 else i for i in idx[:2])
+        out = _qr_complete(np.asarray(self._g[lead]))
+        return out[(Ellipsis,) + tuple(idx[2:])] if len(idx) > 2 else out
+
+    def tensor(self):
+        return _qr_complete(self._g)
+
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        args = tuple(a.tensor() if isinstance(a, _LazyBasis) else a for a in args)
+        return func(*args, **(kwargs or {}))
+
+    def transpose(self, *a):
+        return self.tensor().transpose(*a)
+
+    def __matmul__(self, other):
+        return self.tensor() @ (other.tensor() if isinstance(other, _LazyBasis) else other)
+
+
 class MPPI:
     def __init__(self, q0, qf, dh_params, obs, dt, dt_H, N_traj, DS_ARRAY, dh_a, nn_model, n_closest_obs,
                  device=0, warmup=False, seed=1234, rollout_offset=0, max_obs=None):
@@ -51,6 +91,7 @@ class MPPI:
         self._engine.set_obstacles(self.obs.numpy())
         self.Policy = TensorPolicyMPPI(N_traj, self.n_dof, self.tensor_args, engine=self._engine, seed=seed,
                                        rollout_offset=rollout_offset)
+        self.Policy._owner = self
         self.Cost = Cost(self.qf, self.dh_params, owner=self)
         self.cur_cost = None
         self._cache = {}
@@ -132,16 +173,11 @@ class MPPI:
     @property
     def norm_basis(self):
         """[N, H, n, n] basis whose column 0 is the obstacle normal (MPPI.py:122-127).  Column 0 comes
-        from the device; the tangent completion (the reference's QR) is rebuilt on the host on demand --
-        nothing on the rollout path reads it (M v uses the closed form)."""
-        g = self._fetch()["normal"].numpy()
-        N, H, n = g.shape
-        A = np.tile(np.eye(n, dtype=np.float32), (N, H, 1, 1))
-        A[..., 0] = g
-        Q, _ = np.linalg.qr(A)
-        Q = Q.astype(np.float32)
-        Q[..., 0] = g
-        return torch.from_numpy(Q)
+        from the device (normal_dirs); the tangent completion is the same LAPACK QR the reference calls
+        (geqrf/orgqr via numpy), evaluated lazily and only for the entries a caller indexes -- nothing
+        on the rollout path reads it (M v uses the closed form), the drivers read ONE entry per
+        iteration (frankaPlanner.py:162)."""
+        return _LazyBasis(self._fetch()["normal"].numpy())
 
     # ---- distance + gradient on arbitrary states (MPPI.py:227-282) ------------------------------------
     def distance_repulsion_nn(self, q_prev, aot=False):

@@ -126,7 +126,19 @@ class TensorPolicyMPPI:
             print('Not adding new kernel at: maximum number of kernels reached', q)
 
     def check_traj_for_kernels(self, all_traj, closests_dist_all, dotproducts_all, thr_dist, thr_kernel, thr_dot):
-        """policy.py:153-175: candidate kernel centres (host-side; device version is a later row)."""
+        """policy.py:153-175: candidate kernel centres.  When the tensors are the owner MPPI's current
+        rollouts (what every reference driver passes) the search runs on the device-resident copies
+        (omds_kernel_candidates: flags + prefix sum + gather, reference order) and only the candidates
+        cross PCIe; for foreign tensors the same logic runs on the host."""
+        own = getattr(self, "_owner", None)
+        if own is not None and all_traj is own.all_traj and closests_dist_all is own.closest_dist_all \
+                and dotproducts_all is own.dot_products and self._engine is not None:
+            self._engine.params.rbf_p = float(self.p)
+            self._engine.push_params()
+            q, th, total = self._engine.kernel_candidates(thr_dist, thr_kernel, thr_dot, self.mu_c.numpy(),
+                                                          self.sigma_c.numpy(), self.n_kernels)
+            self.last_candidate_index = torch.from_numpy(th.astype(np.int64))   # (t, h) of every candidate
+            return torch.from_numpy(q)
         all_traj = torch.as_tensor(all_traj)
         idx_close = torch.as_tensor(closests_dist_all) < thr_dist
         idx_dot = torch.as_tensor(dotproducts_all) < thr_dot

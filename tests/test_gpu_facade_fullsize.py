@@ -75,8 +75,10 @@ def test_planner_loop_like_the_reference_driver():
             n_added += 1
         mppi.q_cur = mppi.q_cur + mppi.get_qdot('best') * 0.05
     assert n_added >= 1 and mppi.Policy.n_kernels == n_added
-    nb = mppi.norm_basis
+    assert mppi.norm_basis[3, 2].shape == (n, n)
+    nb = mppi.norm_basis.tensor()
     assert nb.shape == (N, H, n, n)
+    assert torch.equal(nb[3, 2], mppi.norm_basis[3, 2]) and torch.equal(nb[..., 0], mppi.normal_dirs)
     eye = torch.eye(n).expand(N, H, n, n)
     assert torch.allclose(nb.transpose(-1, -2) @ nb, eye, atol=2e-4)               # orthonormal, column 0 = normal
     # update_obstacles + update_kernel_normal_bases (frankaPlanner.py:125-130)

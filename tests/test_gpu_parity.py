@@ -177,6 +177,34 @@ def test_free_running_cost_update(name):
     eng.close()
 
 
+@pytest.mark.parametrize("name", ["franka_shelf_K6", "franka_sub40_K4", "planar7_K4", "planar2_c1_K0", "franka_at_goal_K2"])
+def test_kernel_candidates(name):
+    """Device-side check_traj_for_kernels vs the oracle on the device's own rollouts: same set, same
+    (rollout-major) order, except states whose max RBF value sits within rounding of the threshold."""
+    fx = load(name)
+    eng, m = _engine(fx)
+    K = int(fx["K"])
+    eng.set_policy_samples(fx["it0_mu_tmp"], fx["it0_sigma_tmp"], fx["it0_alpha_tmp"])
+    eng.propagate(fx["it0_q_cur"])
+    r = eng.get_rollouts()
+    for thr_dist, thr_kernel, thr_dot in ((0.02, 0.3, -0.9), (0.25, 0.05, -0.5), (10.0, 2.0, 2.0), (-10.0, 0.3, -0.9)):
+        q, th, total = eng.kernel_candidates(thr_dist, thr_kernel, thr_dot, fx["it0_mu_c"], fx["it0_sigma_c"], K)
+        want = orc.check_traj_for_kernels(r["all_traj"], r["closest_dist_all"], r["dot_products"], fx["it0_mu_c"],
+                                          fx["it0_sigma_c"], thr_dist, thr_kernel, thr_dot, int(fx["p"]))
+        assert total == q.shape[0] == th.shape[0]
+        assert np.array_equal(q, r["all_traj"][th[:, 0], th[:, 1]])                     # gather is consistent
+        assert (np.diff(th[:, 0] * 10000 + th[:, 1]) > 0).all()                          # reference order
+        if q.shape == want.shape:
+            assert np.array_equal(q, want)
+        else:   # only threshold-straddling states may differ
+            a = {tuple(x) for x in q.round(6).tolist()}; b = {tuple(x) for x in want.round(6).tolist()}
+            assert len(a ^ b) <= max(2, 0.01 * len(b))
+    # capacity smaller than the number found: count still reports the total
+    q, th, total = eng.kernel_candidates(10.0, 2.0, 2.0, fx["it0_mu_c"], fx["it0_sigma_c"], K, cap=5)
+    assert q.shape[0] == min(5, total) and total == int((~np.isnan(r["dot_products"])).sum())
+    eng.close()
+
+
 def test_device_sampling_statistics():
     from optimalmodulationds_amd.engine import Engine
     N, n, K = 4096, 7, 6
