@@ -64,7 +64,7 @@ static void free_all(omds_ctx* ctx) {
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
                     ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
                     ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
-                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets};
+                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : ctx->mlp_allocs)
@@ -187,7 +187,7 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
         REQUIRE(dims[i] == OMDS_WIDTH, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: only hidden width 256 is supported by the MFMA kernels");
     const int C = dims[n_linear];
     REQUIRE(C >= 1 && C <= OMDS_CPAD, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: 1 <= out_channels <= 16 required");
-    REQUIRE(act == OMDS_ACT_RELU, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: only ReLU networks are supported (all shipped reference weights are ReLU)");
+    REQUIRE(act == OMDS_ACT_RELU || act == OMDS_ACT_TANH, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: act must be OMDS_ACT_RELU or OMDS_ACT_TANH");
     REQUIRE(out_div != 0.f, OMDS_ERR_INVALID_ARG, "omds_set_mlp: out_div must be non-zero");
     CK(hipSetDevice(ctx->dev));
     CK(hipStreamSynchronize(ctx->stream));
@@ -200,6 +200,12 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
     m.d = d;
     m.n_dof = n;
     m.out_div = out_div;
+    m.act = act;
+    if (ctx->d_dscr) { (void)hipFree(ctx->d_dscr); ctx->d_dscr = nullptr; }
+    if (act == OMDS_ACT_TANH) {   // pass 2 keeps 1 - h^2 of every hidden layer for the backward (ReLU uses LDS bit masks)
+        const size_t rows = ((size_t)ctx->cfg.n_traj * ctx->cfg.n_closest + 31) / 32 * 32;
+        CK(hipMalloc(&ctx->d_dscr, (size_t)nhid * rows * OMDS_WIDTH * 4));
+    }
     const int Wd = OMDS_WIDTH;
     // hidden->hidden: forward and transposed (backward) fragment packs
     std::vector<float4> wf((size_t)std::max(m.nhh, 1) * OMDS_NCB * 32 * 64), wb(wf.size());
@@ -426,7 +432,7 @@ static int enqueue_network(omds_ctx* ctx, const float* qT, int ldq, int B) {
     if ((rc = prof_end(ctx, (int64_t)B * O))) return rc;
     omds_launch_topk(ctx->stream, ctx->d_Dmin, B, O, k, ctx->d_idx);
     omds_launch_pass2(ctx->stream, m, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_idx, B, k, qT, ldq,
-                      ctx->d_gradx, ctx->d_drow, nullptr, nullptr);
+                      ctx->d_gradx, ctx->d_drow, nullptr, nullptr, ctx->d_dscr);
     CK(hipGetLastError());
     return OMDS_OK;
 }
@@ -551,7 +557,7 @@ int omds_mlp_forward_vjp(omds_ctx* ctx, const float* x, int B, float* y, float* 
     omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Apre);
     omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, d_xyzr, B, d_B, d_rad);
     omds_launch_pass2(ctx->stream, ctx->mlp, ctx->d_Apre, d_B, d_rad, d_xyzr, ctx->d_idx, B, 1, ctx->d_qstage, B,
-                      ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx);
+                      ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dscr);
     CKL(hipGetLastError());
     CKL(hipStreamSynchronize(ctx->stream));
     if (y) {

@@ -29,6 +29,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define LDH OMDS_LDH
 
+// hidden activation: ReLU (all shipped reference networks) or tanh (MATLAB-prototype style nets)
+__device__ __forceinline__ float actf(float z, int act) { return act == OMDS_ACT_RELU ? fmaxf(z, 0.f) : tanhf(z); }
+
 // ------------------------------------------------------------------------------------------------
 // layer-1 halves
 // ------------------------------------------------------------------------------------------------
@@ -170,10 +173,10 @@ __global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const
             o = (int)(R - t * O);
             const float4 a = reinterpret_cast<const float4*>(Apre)[t * 64 + c4];
             const float4 b = reinterpret_cast<const float4*>(Bpre)[(size_t)o * 64 + c4];
-            v.x = fmaxf(a.x + b.x, 0.f);
-            v.y = fmaxf(a.y + b.y, 0.f);
-            v.z = fmaxf(a.z + b.z, 0.f);
-            v.w = fmaxf(a.w + b.w, 0.f);
+            v.x = actf(a.x + b.x, m.act);
+            v.y = actf(a.y + b.y, m.act);
+            v.z = actf(a.z + b.z, m.act);
+            v.w = actf(a.w + b.w, m.act);
         }
         *reinterpret_cast<float4*>(Hs + r * LDH + 4 * c4) = v;
         if (c4 == 0) rowO[r] = o;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const
             for (int i = 0; i < MR; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    Hs[((wm * MR + i) * 32 + crow(r, lane)) * LDH + col] = fmaxf(acc[i][j][r] + bv, 0.f);
+                    Hs[((wm * MR + i) * 32 + crow(r, lane)) * LDH + col] = actf(acc[i][j][r] + bv, m.act);
         }
         __syncthreads();
     }
@@ -283,7 +286,9 @@ __global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restri
                                                  const float* __restrict__ xyzr, const int32_t* __restrict__ idx,
                                                  int total_rows, int k, const float* __restrict__ qT, int ldq,
                                                  float* __restrict__ gradx, float* __restrict__ drow,
-                                                 float* __restrict__ yraw, int32_t* __restrict__ minidx) {
+                                                 float* __restrict__ yraw, int32_t* __restrict__ minidx,
+                                                 float* __restrict__ dscr) {
+    // dscr (tanh only): [nhh+1][rows padded to 32][256] activation derivatives 1 - h^2, L2-resident scratch
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Hs = smem;                                          // [32][LDH]
     float* P = Hs + P2_MT * LDH;                               // [8][32][33] split-K partials
@@ -295,6 +300,8 @@ __global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int R0 = blockIdx.x * P2_MT;
     const int col = wave * 32 + (lane & 31);
+    const bool relu = m.act == OMDS_ACT_RELU;
+    const size_t dlayer = (size_t)gridDim.x * P2_MT * OMDS_WIDTH;   // scratch stride between layers
 
     if (tid < P2_MT) {
         const int R = R0 + tid;
@@ -315,7 +322,9 @@ __global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restri
             float z = 0.f;
             if (t >= 0) z = Apre[(size_t)t * OMDS_WIDTH + col] + Bpre[(size_t)rowO[row] * OMDS_WIDTH + col];
             bits |= (z > 0.f ? 1u : 0u) << r;
-            Hs[row * LDH + col] = fmaxf(z, 0.f);
+            const float h = actf(z, m.act);
+            Hs[row * LDH + col] = h;
+            if (!relu) dscr[(size_t)(R0 + row) * OMDS_WIDTH + col] = 1.f - h * h;
         }
         maskL[tid] = bits;
     }
@@ -334,7 +343,9 @@ __global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restri
         for (int r = 0; r < 16; ++r) {
             const float z = acc[0][0][r] + bv;
             bits |= (z > 0.f ? 1u : 0u) << r;
-            Hs[crow(r, lane) * LDH + col] = fmaxf(z, 0.f);
+            const float h = actf(z, m.act);
+            Hs[crow(r, lane) * LDH + col] = h;
+            if (!relu) dscr[(l + 1) * dlayer + (size_t)(R0 + crow(r, lane)) * OMDS_WIDTH + col] = 1.f - h * h;
         }
         maskL[(l + 1) * P2_NT + tid] = bits;
         __syncthreads();
@@ -387,7 +398,9 @@ __global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restri
         for (int r = 0; r < 16; ++r) {
             const int row = crow(r, lane);
             const float g = m.Wlraw[(size_t)rowMin[row] * OMDS_WIDTH + col];
-            Hs[row * LDH + col] = ((bits >> r) & 1u) ? g : 0.f;
+            const float dv = relu ? (((bits >> r) & 1u) ? 1.f : 0.f)
+                                  : dscr[m.nhh * dlayer + (size_t)(R0 + row) * OMDS_WIDTH + col];
+            Hs[row * LDH + col] = g * dv;
         }
     }
     __syncthreads();
@@ -401,7 +414,11 @@ __global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restri
         __syncthreads();
         const uint32_t bits = maskL[l * P2_NT + tid];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Hs[crow(r, lane) * LDH + col] = ((bits >> r) & 1u) ? acc[0][0][r] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+            const float dv = relu ? (((bits >> r) & 1u) ? 1.f : 0.f)
+                                  : dscr[l * dlayer + (size_t)(R0 + crow(r, lane)) * OMDS_WIDTH + col];
+            Hs[crow(r, lane) * LDH + col] = acc[0][0][r] * dv;
+        }
         __syncthreads();
     }
 
@@ -528,7 +545,7 @@ void omds_launch_topk(hipStream_t s, const float* Dmin, int B, int O, int k, int
 
 void omds_launch_pass2(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
                        const float* xyzr, const int32_t* idx, int B, int k, const float* qT, int ldq, float* gradx,
-                       float* drow, float* yraw, int32_t* minidx) {
+                       float* drow, float* yraw, int32_t* minidx, float* dscr) {
     const int total = B * k;
     if (total <= 0) return;
     const size_t lds = ((size_t)P2_MT * LDH + 8 * 32 * 33 + 32 * 33) * 4 + (size_t)(m.nhh + 1) * P2_NT * 4 + 3 * P2_MT * 4;
@@ -540,7 +557,7 @@ void omds_launch_pass2(hipStream_t s, const MlpDev& m, const float* Apre, const 
         attr_set = true;
     }
     hipLaunchKernelGGL(k_pass2, dim3((total + P2_MT - 1) / P2_MT), dim3(P2_NT), lds, s, m, Apre, Bpre, radius, xyzr,
-                       idx, total, k, qT, ldq, gradx, drow, yraw, minidx);
+                       idx, total, k, qT, ldq, gradx, drow, yraw, minidx, dscr);
 }
 
 void omds_launch_blend(hipStream_t s, const float* gradx, const float* drow, int B, int k, int d, int n,

@@ -30,6 +30,7 @@ struct MlpDev {
     int d;               // n_dof + 3 raw inputs
     int n_dof;
     float out_div;
+    int act;             // OMDS_ACT_RELU | OMDS_ACT_TANH
 };
 
 struct ProfEvents {
@@ -86,6 +87,7 @@ struct omds_ctx {
     float* d_drow = nullptr;     // [N*k]
     float* d_yraw = nullptr;     // [N*k][16]
     int32_t* d_minidx = nullptr; // [N*k]
+    float* d_dscr = nullptr;     // tanh only: [hidden layers][N*k padded to 32][256] activation derivatives
     float* d_dist = nullptr;     // [N]
     float* d_nngrad = nullptr;   // [N][n]
     // cost / reduction
@@ -124,7 +126,7 @@ void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Apre, const 
 void omds_launch_topk(hipStream_t s, const float* Dmin, int B, int O, int k, int32_t* idx);
 void omds_launch_pass2(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
                        const float* xyzr, const int32_t* idx, int B, int k, const float* qT, int ldq,
-                       float* gradx, float* drow, float* yraw, int32_t* minidx);
+                       float* gradx, float* drow, float* yraw, int32_t* minidx, float* dscr);
 void omds_launch_blend(hipStream_t s, const float* gradx, const float* drow, int B, int k, int d, int n,
                        float softmax_k, float* dist, float* nngrad);
 

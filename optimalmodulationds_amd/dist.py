@@ -26,7 +26,7 @@ def _dev_for_backend(group=None):
 
 
 def all_reduce_sum(x: np.ndarray, group=None) -> np.ndarray:
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return x
     t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(_dev_for_backend(group))
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
@@ -34,7 +34,7 @@ def all_reduce_sum(x: np.ndarray, group=None) -> np.ndarray:
 
 
 def all_gather(x: np.ndarray, group=None) -> np.ndarray:
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return x[None]
     t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(_dev_for_backend(group))
     outs = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]

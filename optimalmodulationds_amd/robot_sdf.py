@@ -51,6 +51,8 @@ class RobotSdfCollisionNet:
             n = len([k for k in z.files if k.startswith("W")])
             W = [z[f"W{i}"].astype(np.float32) for i in range(n)]
             b = [z[f"b{i}"].astype(np.float32) for i in range(n)]
+            if "act" in z.files:
+                self.model.act = str(z["act"])
         else:
             chk = torch.load(f_name, map_location=torch.device("cpu"), weights_only=False)
             sd = chk["model_state_dict"]

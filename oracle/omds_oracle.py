@@ -307,6 +307,8 @@ def relu_margin(m: Mlp, x):
     section 7 hard part b); parity tests use this to flag such rows."""
     h = positional_encoding(np.asarray(x, dtype=F32))
     marg = np.full(h.shape[0], np.inf, dtype=F32)
+    if m.act != "relu":
+        return marg                      # smooth activation: no masks to flip
     for i in range(len(m.W) - 1):
         z = h @ m.W[i].T + m.b[i]
         az = np.abs(z)

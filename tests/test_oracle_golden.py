@@ -20,7 +20,7 @@ def test_mlp_forward_and_vjp(kind):
     assert_close(y2, fx["y_vjp"], RTOL, "vjp forward")
     assert (mi == fx["min_idx"]).all()
     # rows whose smallest |pre-activation| is within fp32 rounding of 0 may flip a ReLU mask
-    safe = fx["min_abs_preact"] > 1e-4
+    safe = (fx["min_abs_preact"] > 1e-4) | (m.act != "relu")
     assert safe.sum() > 0.8 * len(safe)
     assert_close(grad[safe], fx["grad"][safe], 2e-5, "vjp grad", floor=float(np.abs(fx["grad"]).max()))
 

@@ -42,6 +42,10 @@ MODELS = {
     "franka": ("franka_collision_model.pt", 7, 9),
     "planar7": ("7dof_sdf_256x5_mesh.pt", 7, 7),
     "planar2": ("2dof_sdf_256x5_mesh.pt", 2, 2),
+    # BASELINE.json config 3 names a "256-256-256 tanh" SDF; no such weights ship with the reference
+    # (SURVEY 0.1), so this one is the reference's own MLPRegression class with act_fn=Tanh and seeded
+    # synthetic weights -- it pins the tanh forward/backward arithmetic, not a trained model
+    "franka_tanh": (None, 7, 9),
 }
 
 
@@ -51,6 +55,21 @@ def quiet():
 
 def load_model(kind):
     fname, dof, out = MODELS[kind]
+    if fname is None:
+        from sdf.network_macros_mod import MLPRegression
+        from torch.nn import Tanh
+        nn_model = RobotSdfCollisionNet(in_channels=dof + 3, out_channels=out, layers=[256] * 3, skips=[])
+        torch.manual_seed(20240)
+        nn_model.model = MLPRegression(dof + 3, out, [256] * 3, [], act_fn=Tanh, nerf=True)
+        with torch.no_grad():
+            last = nn_model.model.layers[0][-1][0]
+            last.weight.mul_(40.0)          # outputs are read as centimetres (C == 9): spread them
+            last.bias.add_(12.0)
+        nn_model.model.eval()
+        nn_model.model.to(**PARAMS)
+        nn_model.model_jit = torch.jit.optimize_for_inference(torch.jit.script(nn_model.model))
+        nn_model.aot_lambda = nn_model.functorch_vjp
+        return nn_model
     nn_model = RobotSdfCollisionNet(in_channels=dof + 3, out_channels=out, layers=[256] * 4, skips=[])
     with quiet():
         nn_model.load_weights(REF + "/mlp_learn/models/" + fname, PARAMS)
@@ -68,7 +87,7 @@ def export_weights(kind, nn_model):
         arrs[f"W{i}"] = sd[f"layers.0.{i}.0.weight"].numpy().astype(np.float32)
         arrs[f"b{i}"] = sd[f"layers.0.{i}.0.bias"].numpy().astype(np.float32)
         i += 1
-    arrs["act"] = np.array("relu")
+    arrs["act"] = np.array("tanh" if kind.endswith("tanh") else "relu")
     os.makedirs(os.path.join(OUT, "weights"), exist_ok=True)
     np.savez(os.path.join(OUT, "weights", kind + ".npz"), **arrs)
 
@@ -78,7 +97,7 @@ def t2n(x):
 
 
 def robot_setup(kind):
-    if kind == "franka":
+    if kind.startswith("franka"):
         dh = torch.from_numpy(scenes.franka_dh_params())
         dh_a = dh[:, 2].clone()
     elif kind == "planar7":
@@ -206,7 +225,7 @@ def mlp_vectors(kind, nn_model, seed):
     _, dof, out = MODELS[kind]
     B = 96
     x = torch.empty(B, dof + 3).uniform_(-2.5, 2.5)
-    if kind == "franka":
+    if kind.startswith("franka"):
         x[:, dof:] = torch.empty(B, 3).uniform_(-0.2, 1.0)
     else:
         x[:, dof:] = torch.empty(B, 3).uniform_(-7, 7); x[:, -1] = 0
@@ -220,7 +239,7 @@ def mlp_vectors(kind, nn_model, seed):
     for li in range(len(seq) - 1):
         z = seq[li][0](hcur)
         zmin = torch.minimum(zmin, z.abs().min(dim=1)[0].detach())
-        hcur = torch.relu(z)
+        hcur = seq[li][1](z)
     np.savez_compressed(os.path.join(OUT, f"mlp_{kind}.npz"), x=t2n(x), y=t2n(y), y_vjp=t2n(y2), grad=t2n(g),
                         min_idx=t2n(mi).astype(np.int32), min_abs_preact=t2n(zmin))
     print(f"mlp_{kind}: y range [{float(y.min()):.3f}, {float(y.max()):.3f}]  min|z|={float(zmin.min()):.2e}")
@@ -263,6 +282,9 @@ def main():
                  **{**fr, "alpha_s": 0.0, "dt": 0.01, "dst_thr": 0.03})
     run_scenario("franka_sub40_K50", N=32, H=5, obs=shelf[::7][:40], k=5, K=50, seed=13, **fr)
     run_scenario("franka_at_goal_K2", N=16, H=4, obs=shelf[::7][:40], k=5, K=2, seed=14, q_cur=scenes.FRANKA_QF, **fr)
+    # tanh 256x3 network (synthetic weights) on the shelf scene
+    run_scenario("franka_tanh_shelf_K4", N=48, H=6, obs=shelf, k=5, K=4, seed=15, **{**fr, "kind": "franka_tanh",
+                                                                                      "nn_model": models["franka_tanh"]})
 
 
 if __name__ == "__main__":
