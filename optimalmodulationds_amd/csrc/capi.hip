@@ -203,7 +203,8 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
     m.act = act;
     if (ctx->d_dscr) { (void)hipFree(ctx->d_dscr); ctx->d_dscr = nullptr; }
     if (act == OMDS_ACT_TANH) {   // pass 2 keeps 1 - h^2 of every hidden layer for the backward (ReLU uses LDS bit masks)
-        const size_t rows = ((size_t)ctx->cfg.n_traj * ctx->cfg.n_closest + 31) / 32 * 32;
+        const size_t rows = std::max(((size_t)ctx->cfg.n_traj * ctx->cfg.n_closest + 31) / 32 * 32,
+                                     (size_t)omds_tail_workgroups(ctx->cfg.n_traj, ctx->cfg.n_closest) * 32);
         CK(hipMalloc(&ctx->d_dscr, (size_t)nhid * rows * OMDS_WIDTH * 4));
     }
     const int Wd = OMDS_WIDTH;
@@ -467,10 +468,26 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
     a.muT = ctx->d_muT; a.sigmaT = ctx->d_sigmaT; a.alphaT = ctx->d_alphaT; a.gradx = ctx->d_gradx; a.drow = ctx->d_drow;
     std::memcpy(a.qf, ctx->qf, sizeof(a.qf));
     a.prm = ctx->prm;
-    for (int i = 1; i <= H; ++i) {   // MPPI.py:101: H network evaluations, the last velocity is not integrated
-        if ((rc = enqueue_network(ctx, ctx->d_trajT + (size_t)(i - 1) * n * N, N, N))) return rc;
-        a.step = i;
-        omds_launch_modulate(ctx->stream, a);
+    static int fused = -1;   // OMDS_FUSED_TAIL=0 selects the five-kernel step (kept for A/B runs and as the generic path)
+    if (fused < 0) { const char* e = getenv("OMDS_FUSED_TAIL"); fused = e ? atoi(e) : 1; }
+    if (fused && omds_tail_supported(n, a.k)) {
+        // two launches per step: k_pass1 over all (rollout, obstacle) pairs, then the rollout-local tail
+        omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, ctx->d_Apre);
+        for (int i = 1; i <= H; ++i) {
+            if ((rc = prof_begin(ctx))) return rc;
+            omds_launch_pass1(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
+                              ctx->prm.ignored_links, ctx->d_Dmin);
+            if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs))) return rc;
+            a.step = i;
+            omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, ctx->d_Apre,
+                             ctx->d_dscr, ctx->n_obs, a);
+        }
+    } else {
+        for (int i = 1; i <= H; ++i) {   // MPPI.py:101: H network evaluations, the last velocity is not integrated
+            if ((rc = enqueue_network(ctx, ctx->d_trajT + (size_t)(i - 1) * n * N, N, N))) return rc;
+            a.step = i;
+            omds_launch_modulate(ctx->stream, a);
+        }
     }
     CK(hipGetLastError());
     ctx->have_cost_vals = false;

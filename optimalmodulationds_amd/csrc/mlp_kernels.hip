@@ -22,15 +22,7 @@
 //     consecutive k (one ds_read_b128 / global_load_dwordx4) and feeds four MFMA steps;
 //   * accumulators stay in registers until the whole layer is done, so the tile is updated in
 //     place (one LDS buffer, two barriers per layer).
-#include "omds_internal.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define LDH OMDS_LDH
-
-// hidden activation: ReLU (all shipped reference networks) or tanh (MATLAB-prototype style nets)
-__device__ __forceinline__ float actf(float z, int act) { return act == OMDS_ACT_RELU ? fmaxf(z, 0.f) : tanhf(z); }
+#include "mlp_device.h"
 
 // ------------------------------------------------------------------------------------------------
 // layer-1 halves
@@ -71,70 +63,6 @@ __global__ __launch_bounds__(256) void k_obstacle_layer1(MlpDev m, const float* 
     for (int j = 0; j < 3; ++j) acc = fmaf(m.W1t[(size_t)(2 * d + n + j) * OMDS_WIDTH + c], f[6 + j], acc);
     Bpre[(size_t)o * OMDS_WIDTH + c] = acc;
 }
-
-// ------------------------------------------------------------------------------------------------
-// [MR*32 x 256] . [256 x NR*32] on v_mfma_f32_32x32x2_f32
-//   A (activations) from LDS: lane l reads H[row = l&31 (+32 per row block)][8c + 4(l>>5) .. +3]
-//   B (weights) from global, packed so that lane l's float4 = W[32 cb + (l&31)][8c + 4(l>>5) .. +3]
-//   MFMA step m of chunk c contracts k = 8c + m (lanes 0-31) and k = 8c + 4 + m (lanes 32-63).
-// ------------------------------------------------------------------------------------------------
-template <int MR, int NR>
-__device__ __forceinline__ void mfma_chunk(const float4 (&a)[MR], const float4 (&w)[NR], f32x16 (&acc)[MR][NR]) {
-#pragma unroll
-    for (int i = 0; i < MR; ++i)
-#pragma unroll
-        for (int j = 0; j < NR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, w[j].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < MR; ++i)
-#pragma unroll
-        for (int j = 0; j < NR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, w[j].y, acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < MR; ++i)
-#pragma unroll
-        for (int j = 0; j < NR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, w[j].z, acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < MR; ++i)
-#pragma unroll
-        for (int j = 0; j < NR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, w[j].w, acc[i][j], 0, 0, 0);
-}
-
-template <int MR, int NR>
-__device__ __forceinline__ void load_chunk(const float* arow, const float4* wp, int c, float4 (&a)[MR], float4 (&w)[NR]) {
-#pragma unroll
-    for (int j = 0; j < NR; ++j) w[j] = wp[(size_t)j * (32 * 64) + c * 64];
-#pragma unroll
-    for (int i = 0; i < MR; ++i) a[i] = *reinterpret_cast<const float4*>(arow + i * 32 * LDH + 8 * c);
-}
-
-// Software-pipelined by hand: the fragments of chunk c+1 (one global_load_dwordx4 per column block,
-// one ds_read_b128 per row block) are issued BEFORE the 4*MR*NR MFMAs of chunk c and pinned there
-// with sched_barrier (left alone, hipcc sinks the loads next to their use and waits vmcnt(0) per chunk).
-template <int MR, int NR>
-__device__ __forceinline__ void gemm256(const float* __restrict__ Hw, const float4* __restrict__ Wp, int cb0,
-                                        int lane, f32x16 (&acc)[MR][NR], const bool prio = false) {
-    const float* arow = Hw + (lane & 31) * LDH + 4 * (lane >> 5);
-    const float4* wp = Wp + (size_t)cb0 * (32 * 64) + lane;
-    float4 a0[MR], a1[MR], w0[NR], w1[NR];
-    load_chunk<MR, NR>(arow, wp, 0, a0, w0);
-#pragma unroll 1
-    for (int c = 0; c < 32; c += 2) {
-        load_chunk<MR, NR>(arow, wp, c + 1, a1, w1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (prio) __builtin_amdgcn_s_setprio(1);
-        mfma_chunk<MR, NR>(a0, w0, acc);
-        if (prio) __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_chunk<MR, NR>(arow, wp, (c + 2) & 31, a0, w0);   // last iteration re-loads chunk 0 (harmless)
-        __builtin_amdgcn_sched_barrier(0);
-        if (prio) __builtin_amdgcn_s_setprio(1);
-        mfma_chunk<MR, NR>(a1, w1, acc);
-        if (prio) __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// C/D layout of the 32x32 MFMA: lane l, register r -> row (r&3) + 8(r>>2) + 4(l>>5), col l&31.
-__device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 template <int MT, int MR, int NR>
 struct Geo {
@@ -278,9 +206,6 @@ __global__ __launch_bounds__(256) void k_topk(const float* __restrict__ Dmin, in
 // wave w owns output columns [32w, 32w+32). ReLU masks live in LDS as 16 bits per thread/layer
 // in the MFMA C-layout (the same lane owns the same (row, col) in every layer).
 // ------------------------------------------------------------------------------------------------
-constexpr int P2_MT = 32;
-constexpr int P2_NT = 512;
-
 __global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restrict__ Apre,
                                                  const float* __restrict__ Bpre, const float* __restrict__ radius,
                                                  const float* __restrict__ xyzr, const int32_t* __restrict__ idx,
@@ -290,176 +215,26 @@ __global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restri
                                                  float* __restrict__ dscr) {
     // dscr (tanh only): [nhh+1][rows padded to 32][256] activation derivatives 1 - h^2, L2-resident scratch
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Hs = smem;                                          // [32][LDH]
-    float* P = Hs + P2_MT * LDH;                               // [8][32][33] split-K partials
-    float* gf = P + 8 * 32 * 33;                               // [32][33] feature gradients
-    uint32_t* maskL = reinterpret_cast<uint32_t*>(gf + 32 * 33);   // [nhh+1][512]
-    int* rowT = reinterpret_cast<int*>(maskL + (m.nhh + 1) * P2_NT);  // [32]
-    int* rowO = rowT + P2_MT;                                  // [32]
-    int* rowMin = rowO + P2_MT;                                // [32]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    P2Smem sm;
+    sm.Hs = smem;
+    sm.P = sm.Hs + P2_MT * LDH;
+    sm.gf = sm.P + 8 * 32 * 33;
+    sm.maskL = reinterpret_cast<uint32_t*>(sm.gf + 32 * 33);
+    sm.rowT = reinterpret_cast<int*>(sm.maskL + (m.nhh + 1) * P2_NT);
+    sm.rowO = sm.rowT + P2_MT;
+    sm.rowMin = sm.rowO + P2_MT;
+    const int tid = threadIdx.x;
     const int R0 = blockIdx.x * P2_MT;
-    const int col = wave * 32 + (lane & 31);
-    const bool relu = m.act == OMDS_ACT_RELU;
-    const size_t dlayer = (size_t)gridDim.x * P2_MT * OMDS_WIDTH;   // scratch stride between layers
-
     if (tid < P2_MT) {
         const int R = R0 + tid;
         int t = -1, o = 0;
         if (R < total_rows) { t = R / k; o = idx[R]; }
-        rowT[tid] = t;
-        rowO[tid] = o;
+        sm.rowT[tid] = t;
+        sm.rowO[tid] = o;
     }
     __syncthreads();
-
-    // ---- layer 1 in C-layout ------------------------------------------------------------------
-    {
-        uint32_t bits = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = crow(r, lane);
-            const int t = rowT[row];
-            float z = 0.f;
-            if (t >= 0) z = Apre[(size_t)t * OMDS_WIDTH + col] + Bpre[(size_t)rowO[row] * OMDS_WIDTH + col];
-            bits |= (z > 0.f ? 1u : 0u) << r;
-            const float h = actf(z, m.act);
-            Hs[row * LDH + col] = h;
-            if (!relu) dscr[(size_t)(R0 + row) * OMDS_WIDTH + col] = 1.f - h * h;
-        }
-        maskL[tid] = bits;
-    }
-    __syncthreads();
-
-    // ---- forward through the hidden -> hidden layers -------------------------------------------
-    for (int l = 0; l < m.nhh; ++l) {
-        f32x16 acc[1][1];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-        gemm256<1, 1>(Hs, m.Wf + (size_t)l * (OMDS_NCB * 32 * 64), wave, lane, acc);
-        __syncthreads();
-        const float bv = m.bh[l * OMDS_WIDTH + col];
-        uint32_t bits = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float z = acc[0][0][r] + bv;
-            bits |= (z > 0.f ? 1u : 0u) << r;
-            const float h = actf(z, m.act);
-            Hs[crow(r, lane) * LDH + col] = h;
-            if (!relu) dscr[(l + 1) * dlayer + (size_t)(R0 + crow(r, lane)) * OMDS_WIDTH + col] = 1.f - h * h;
-        }
-        maskL[(l + 1) * P2_NT + tid] = bits;
-        __syncthreads();
-    }
-
-    // ---- last layer, arg-min over ALL raw outputs (robot_sdf.py:155), distance of that link -------
-    if (wave < P2_MT / 16) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* arow = Hs + (wave * 16 + (lane & 15)) * LDH + 4 * (lane >> 4);
-#pragma unroll 4
-        for (int c = 0; c < 16; ++c) {
-            const float4 a = *reinterpret_cast<const float4*>(arow + 16 * c);
-            const float4 w = m.Wl[c * 64 + lane];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
-        }
-        const int j = lane & 15;
-        const float bj = m.bl[j];
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int r = wave * 16 + 4 * (lane >> 4) + reg;
-            const int R = R0 + r;
-            const float y = acc[reg] + bj;
-            if (yraw != nullptr && R < total_rows) yraw[(size_t)R * OMDS_CPAD + j] = (j < m.C) ? y : 0.f;
-            float bv = (j < m.C) ? y : __builtin_inff();
-            int bi = j;
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                const float ov = __shfl_xor(bv, off);
-                const int oi = __shfl_xor(bi, off);
-                if ((ov < bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
-            if (j == 0) {
-                rowMin[r] = bi;
-                if (R < total_rows) {
-                    drow[R] = bv / m.out_div - radius[rowO[r]];
-                    if (minidx != nullptr) minidx[R] = bi;
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- backward seed: dy[minIdx]/dH_last = Wlast[minIdx], masked by the last hidden layer ---------
-    {
-        const uint32_t bits = maskL[m.nhh * P2_NT + tid];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = crow(r, lane);
-            const float g = m.Wlraw[(size_t)rowMin[row] * OMDS_WIDTH + col];
-            const float dv = relu ? (((bits >> r) & 1u) ? 1.f : 0.f)
-                                  : dscr[m.nhh * dlayer + (size_t)(R0 + row) * OMDS_WIDTH + col];
-            Hs[row * LDH + col] = g * dv;
-        }
-    }
-    __syncthreads();
-
-    // ---- backward through the hidden -> hidden layers ------------------------------------------
-    for (int l = m.nhh - 1; l >= 0; --l) {
-        f32x16 acc[1][1];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-        gemm256<1, 1>(Hs, m.Wb + (size_t)l * (OMDS_NCB * 32 * 64), wave, lane, acc);
-        __syncthreads();
-        const uint32_t bits = maskL[l * P2_NT + tid];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float dv = relu ? (((bits >> r) & 1u) ? 1.f : 0.f)
-                                  : dscr[l * dlayer + (size_t)(R0 + crow(r, lane)) * OMDS_WIDTH + col];
-            Hs[crow(r, lane) * LDH + col] = acc[0][0][r] * dv;
-        }
-        __syncthreads();
-    }
-
-    // ---- first layer backward: g_f[row][f] = sum_c Gz1[row][c] W1[c][f], split-K over the 8 waves -------
-    {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* arow = Hs + (lane & 31) * LDH + 4 * (lane >> 5);
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            const int c = wave * 4 + cc;
-            const float4 a = *reinterpret_cast<const float4*>(arow + 8 * c);
-            const float4 w = m.W1b[c * 64 + lane];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) P[(wave * 32 + crow(r, lane)) * 33 + (lane & 31)] = acc[r];
-    }
-    __syncthreads();
-    for (int e = tid; e < 32 * 32; e += P2_NT) {
-        const int row = e >> 5, f = e & 31;
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) s += P[(w * 32 + row) * 33 + f];
-        gf[row * 33 + f] = s;
-    }
-    __syncthreads();
-    // ---- positional-encoding chain rule: d/dx = g[x] + g[sin x] cos x - g[cos x] sin x --------------
-    const int d = m.d, n = m.n_dof;
-    if (tid < P2_MT * d) {
-        const int row = tid / d, jj = tid - row * d;
-        const int R = R0 + row;
-        if (R < total_rows) {
-            const float x = (jj < n) ? qT[(size_t)jj * ldq + rowT[row]] : xyzr[rowO[row] * 4 + (jj - n)];
-            gradx[(size_t)R * d + jj] = gf[row * 33 + jj] + gf[row * 33 + d + jj] * cosf(x) - gf[row * 33 + 2 * d + jj] * sinf(x);
-        }
-    }
+    pass2_body(m, sm, Apre, Bpre, radius, xyzr, R0, total_rows, qT, ldq, gradx, drow, R0, yraw, minidx, dscr,
+               (size_t)gridDim.x * P2_MT * OMDS_WIDTH, R0);
 }
 
 // ------------------------------------------------------------------------------------------------

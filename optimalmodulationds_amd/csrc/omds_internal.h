@@ -141,6 +141,11 @@ struct StepArgs {
     omds_params prm;
 };
 void omds_launch_modulate(hipStream_t s, const StepArgs& a);
+// fused per-step tail (tail_kernel.hip): top-k + pass 2 + blend + modulation + next-step layer-1 half
+bool omds_tail_supported(int n_dof, int k);
+int omds_tail_workgroups(int N, int k);
+void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
+                      const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st);
 struct CostArgs {
     int N, H, n;
     const float* trajT; const float* distT; float* cost;

@@ -20,155 +20,14 @@
 
 #include <cmath>
 
-#define FLT_MAX_F 3.402823466e+38f
-
-__device__ __forceinline__ float nan_to_num_f(float x) {
-    if (x != x) return 0.f;
-    if (x == __builtin_inff()) return FLT_MAX_F;
-    if (x == -__builtin_inff()) return -FLT_MAX_F;
-    return x;
-}
-
-// generalized_sigmoid (MPPI.py:352-353); s = (y_min, y_max, x0, x1, k)
-__device__ __forceinline__ float gsig(float x, const float* s) {
-    const float c = (s[2] + s[3]) * 0.5f;
-    return s[0] + (s[1] - s[0]) / (1.f + expf(s[4] * (-x + c)));
-}
+#include "step_device.h"
 
 template <int ND>
 __global__ __launch_bounds__(256) void k_modulate(StepArgs a) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int N = a.N;
-    if (t >= N) return;
-    const int i = a.step;
-    const omds_params& p = a.prm;
-    float q[ND], v[ND], vhat[ND], g[ND], vt[ND], u[ND], pol[ND];
-    const float* qp = a.trajT + (size_t)(i - 1) * ND * N;
-#pragma unroll
-    for (int j = 0; j < ND; ++j) q[j] = qp[(size_t)j * N + t];
-
-    // nominal DS (LinDS.py:11-21) and its norm (MPPI.py:106-108)
-    float dst2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < ND; ++j) { const float xd = q[j] - a.qf[j]; v[j] = -xd; dst2 += xd * xd; }
-    const float dst = sqrtf(dst2);
-    if (dst > p.lin_thr) {
-#pragma unroll
-        for (int j = 0; j < ND; ++j) v[j] = v[j] / dst;
-    }
-    float vn2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < ND; ++j) vn2 += v[j] * v[j];
-    const float vnorm = sqrtf(vn2);
-#pragma unroll
-    for (int j = 0; j < ND; ++j) vhat[j] = v[j] / vnorm;
-
-    // softmax(-10 d) blend of the k closest gradients; distance of the closest (MPPI.py:270-280)
-    const int k = a.k, d = a.d;
-    const float* dr = a.drow + (size_t)t * k;
-    float mx = -__builtin_inff();
-    for (int jj = 0; jj < k; ++jj) mx = fmaxf(mx, p.softmax_k * dr[jj]);
-    float ssum = 0.f;
-    for (int jj = 0; jj < k; ++jj) ssum += expf(p.softmax_k * dr[jj] - mx);
-#pragma unroll
-    for (int j = 0; j < ND; ++j) g[j] = 0.f;
-    for (int jj = 0; jj < k; ++jj) {
-        const float w = expf(p.softmax_k * dr[jj] - mx) / ssum;
-        const float* gr = a.gradx + (size_t)(t * k + jj) * d;
-#pragma unroll
-        for (int j = 0; j < ND; ++j) g[j] += gr[j] * w;
-    }
-    const float distance = dr[0] - p.dst_thr;                               // MPPI.py:117
-    a.distT[(size_t)(i - 1) * N + t] = distance;
-    float gn2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < ND; ++j) gn2 += g[j] * g[j];
-    const float gn = sqrtf(gn2);
-    float dot = 0.f;
-#pragma unroll
-    for (int j = 0; j < ND; ++j) {
-        g[j] = g[j] / gn;                                                    // E[:, :, 0]  (MPPI.py:126)
-        a.normalT[((size_t)(i - 1) * ND + j) * N + t] = g[j];
-        dot += g[j] * vhat[j];
-    }
-    a.dotT[(size_t)(i - 1) * N + t] = dot;
-    const float l_vel = gsig(dot, p.lvel);
-    const float l_n = gsig(distance, p.ln);
-    const float l_nv = l_vel * 1.f + (1.f - l_vel) * l_n;
-    const float l_tau = gsig(distance, p.ltau);
-
-    // activations (MPPI.py:190-196) -- they do not depend on the policy value
-    const float ca = 1.f - l_n, va = 1.f - l_vel;
-    float gs = 0.f;
-#pragma unroll
-    for (int j = 0; j < ND; ++j) gs += sqrtf(fabsf(q[j] - a.qf[j]));
-    float ga = gs * gs;                                                     // norm(p=0.5)
-    ga = ga < 0.f ? 0.f : (ga > 1.f ? 1.f : ga);
-    if (ga < p.goal_act_cut) ga = 0.f;
-    const float act = ca * va * ga;
-    a.actT[(size_t)(i - 1) * N + t] = act;
-
-    // RBF policy (policy.py:186-199, MPPI.py:165-186) + running statistics for the update mask
-#pragma unroll
-    for (int j = 0; j < ND; ++j) pol[j] = 0.f;
-    for (int kk = 0; kk < a.K; ++kk) {
-        const float* mu = a.muT + (size_t)kk * ND * N + t;
-        const float* al = a.alphaT + (size_t)kk * ND * N + t;
-        float nrm;
-        if (p.rbf_p == 2.f) {
-            float s2 = 0.f;
-#pragma unroll
-            for (int j = 0; j < ND; ++j) { const float df = q[j] - mu[(size_t)j * N]; s2 += df * df; }
-            nrm = sqrtf(s2);
-        } else {
-            float sp = 0.f;
-#pragma unroll
-            for (int j = 0; j < ND; ++j) sp += powf(fabsf(q[j] - mu[(size_t)j * N]), p.rbf_p);
-            nrm = powf(sp, 1.f / p.rbf_p);
-        }
-        const float phi = expf(-a.sigmaT[(size_t)kk * N + t] * (nrm * nrm));
-        a.kvalT[((size_t)(i - 1) * a.Kmax + kk) * N + t] = phi;
-#pragma unroll
-        for (int j = 0; j < ND; ++j) pol[j] += al[(size_t)j * N] * phi;
-        const float pa = phi * act;
-        float* mp = a.maxact + (size_t)kk * N + t;
-        if (i == 1) {
-            *mp = pa;
-        } else {
-            const float old = *mp;
-            *mp = (old != old || pa != pa) ? __builtin_nanf("") : fmaxf(old, pa);
-        }
-        if (t == 0) a.phisum0[kk] = (i == 1 ? 0.f : a.phisum0[kk]) + phi;
-    }
-
-    // total velocity, closed-form M v, normalisation, collision handling (MPPI.py:197-217)
-    float gv = 0.f;
-#pragma unroll
-    for (int j = 0; j < ND; ++j) {
-        const float pv = (act * pol[j]) * vnorm;
-        vt[j] = v[j] + pv;
-        gv += g[j] * vt[j];
-    }
-    float un2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < ND; ++j) { u[j] = l_tau * vt[j] + ((l_nv - l_tau) * gv) * g[j]; un2 += u[j] * u[j]; }
-    float s = sqrtf(un2);
-    if (s <= p.norm_clamp) s = 1.f;
-#pragma unroll
-    for (int j = 0; j < ND; ++j) u[j] = nan_to_num_f(u[j] / s);
-    if (distance < 0.f) {
-#pragma unroll
-        for (int j = 0; j < ND; ++j) { u[j] *= p.coll_slow; u[j] += (g[j] * vnorm) * p.coll_repulse; }
-    }
-    if (i < a.H) {
-        float* qn = a.trajT + (size_t)i * ND * N;
-#pragma unroll
-        for (int j = 0; j < ND; ++j) qn[(size_t)j * N + t] = q[j] + p.dt * u[j];
-    }
-    if (i == 1) {
-#pragma unroll
-        for (int j = 0; j < ND; ++j) a.qdotT[(size_t)j * N + t] = u[j];
-    }
+    if (t >= a.N) return;
+    float qn[ND];
+    modulate_core<ND, 1>(a, t, 0, a.gradx, a.drow, t * a.k, qn);
 }
 
 template <int ND>

@@ -1,0 +1,146 @@
+// Fused per-step "tail" kernel for gfx950: everything of one horizon step that is local to a rollout
+// once the pass-1 min-distance matrix exists -- top-k over the obstacles (MPPI.py:245-247), forward +
+// analytic backward on the k closest rows (robot_sdf.py:153-158), softmax blend, modulation / policy /
+// Euler step (MPPI.py:102-223) and the rollout half of layer 1 for the NEXT step.  A workgroup owns
+// floor(32/k) rollouts (<= 32 network rows), so a horizon step is two launches: k_pass1 + k_tail.
+// The stand-alone kernels (k_topk, k_pass2, k_modulate, k_rollout_layer1) remain for the batch entry
+// points (omds_dist_grad, omds_mlp_forward_vjp) and for n_dof / k combinations not instantiated here.
+#include "mlp_device.h"
+#include "step_device.h"
+
+struct TailArgs {
+    MlpDev m;
+    const float* Bpre;
+    const float* radius;
+    const float* xyzr;
+    const float* Dmin;   // [N][O]
+    float* Apre;         // [N][256] in: this step, out: next step (rows of the workgroup's own rollouts)
+    float* dscr;         // tanh derivative scratch
+    int O;
+    StepArgs st;
+};
+
+template <int ND>
+__global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const MlpDev& m = a.m;
+    P2Smem sm;
+    sm.Hs = smem;
+    sm.P = sm.Hs + P2_MT * LDH;
+    sm.gf = sm.P + 8 * 32 * 33;
+    sm.maskL = reinterpret_cast<uint32_t*>(sm.gf + 32 * 33);
+    sm.rowT = reinterpret_cast<int*>(sm.maskL + (m.nhh + 1) * P2_NT);
+    sm.rowO = sm.rowT + P2_MT;
+    sm.rowMin = sm.rowO + P2_MT;
+    float* gx = reinterpret_cast<float*>(sm.rowMin + P2_MT);   // [32][d]
+    float* dr = gx + 32 * 12;                                   // [32]
+    float* feat = dr + 32;                                      // [32][3*ND]: q_next, sin, cos
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = a.st.N, k = a.st.k, O = a.O;
+    const int RW = P2_MT / k;                 // rollouts per workgroup
+    const int t_base = blockIdx.x * RW;
+
+    // ---- top-k of each rollout's min-distance row (ascending, ties by lower obstacle index) -------
+    if (tid < P2_MT) { sm.rowT[tid] = -1; sm.rowO[tid] = 0; }
+    __syncthreads();
+    for (int rl = wave; rl < RW; rl += 8) {
+        const int t = t_base + rl;
+        if (t >= N) break;
+        const float* row = a.Dmin + (size_t)t * O;
+        float pv = -__builtin_inff();
+        int pi = -1;
+        for (int j = 0; j < k; ++j) {
+            float bv = __builtin_inff();
+            int bi = 0x7fffffff;
+            for (int o = lane; o < O; o += 64) {
+                const float v = row[o];
+                const bool after = (v > pv) || (v == pv && o > pi);
+                if (after && ((v < bv) || (v == bv && o < bi))) { bv = v; bi = o; }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ov = __shfl_xor(bv, off);
+                const int oi = __shfl_xor(bi, off);
+                if ((ov < bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (bi == 0x7fffffff) bi = 0;
+            if (lane == 0) { sm.rowT[rl * k + j] = t; sm.rowO[rl * k + j] = bi; }
+            pv = bv;
+            pi = bi;
+        }
+    }
+    __syncthreads();
+
+    // ---- forward + backward on the selected rows; gradients and distances stay in LDS ------------
+    const float* qT = a.st.trajT + (size_t)(a.st.step - 1) * ND * N;
+    pass2_body(m, sm, a.Apre, a.Bpre, a.radius, a.xyzr, t_base * k, N * k, qT, N, gx, dr, 0, nullptr, nullptr, a.dscr,
+               (size_t)gridDim.x * P2_MT * OMDS_WIDTH, blockIdx.x * P2_MT);
+    __syncthreads();
+
+    // ---- modulation / policy / Euler step: 16 lanes per rollout -------------------------------------
+    {
+        const int rl = tid >> 4, sub = tid & 15;
+        const int t = t_base + rl;
+        if (rl < RW && t < N) {
+            float qn[ND];
+            modulate_core<ND, 16>(a.st, t, sub, gx, dr, rl * k, qn);
+            if (sub < ND) {
+                float v = qn[0];
+#pragma unroll
+                for (int j = 1; j < ND; ++j) v = (sub == j) ? qn[j] : v;
+                feat[rl * 3 * ND + sub] = v;
+                feat[rl * 3 * ND + ND + sub] = sinf(v);
+                feat[rl * 3 * ND + 2 * ND + sub] = cosf(v);
+            }
+        }
+    }
+    if (a.st.step >= a.st.H) return;   // last step: nothing is integrated, no next network evaluation
+    __syncthreads();
+
+    // ---- rollout half of layer 1 for the next step (same arithmetic order as k_rollout_layer1) --------
+    {
+        const int c = tid & 255, d = m.d;
+        for (int rl = tid >> 8; rl < RW; rl += 2) {
+            const int t = t_base + rl;
+            if (t >= N) break;
+            const float* f = feat + rl * 3 * ND;
+            float acc = m.b1[c];
+#pragma unroll
+            for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)j * OMDS_WIDTH + c], f[j], acc);
+#pragma unroll
+            for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)(d + j) * OMDS_WIDTH + c], f[ND + j], acc);
+#pragma unroll
+            for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)(2 * d + j) * OMDS_WIDTH + c], f[2 * ND + j], acc);
+            a.Apre[(size_t)t * OMDS_WIDTH + c] = acc;
+        }
+    }
+}
+
+static size_t tail_lds_bytes(int nhid) {
+    return ((size_t)P2_MT * LDH + 8 * 32 * 33 + 32 * 33) * 4 + (size_t)nhid * P2_NT * 4 + 3 * P2_MT * 4 +
+           (32 * 12 + 32 + 32 * 3 * OMDS_MAX_DOF) * 4;
+}
+
+template <int ND>
+static void launch_tail_t(hipStream_t s, const TailArgs& a) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<ND>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)tail_lds_bytes(OMDS_MAX_HIDDEN + 1));
+        attr_set = true;
+    }
+    const int RW = P2_MT / a.st.k;
+    hipLaunchKernelGGL(k_tail<ND>, dim3((a.st.N + RW - 1) / RW), dim3(P2_NT), tail_lds_bytes(a.m.nhh + 1), s, a);
+}
+
+bool omds_tail_supported(int n_dof, int k) { return (n_dof == 7 || n_dof == 2) && k >= 1 && k <= P2_MT; }
+
+int omds_tail_workgroups(int N, int k) { const int RW = P2_MT / k; return (N + RW - 1) / RW; }
+
+void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
+                      const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st) {
+    TailArgs a;
+    a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Dmin = Dmin; a.Apre = Apre; a.dscr = dscr; a.O = O; a.st = st;
+    if (st.n == 7) launch_tail_t<7>(s, a);
+    else launch_tail_t<2>(s, a);
+}

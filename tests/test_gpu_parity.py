@@ -254,3 +254,18 @@ def test_error_paths():
     with pytest.raises(L.OmdsError, match="omds_set_cost"):
         eng.cost()
     eng.close()
+
+
+def test_unfused_step_path_still_passes():
+    """The five-kernel step (k_topk / k_pass2 / k_modulate / k_rollout_layer1; the generic path for n_dof
+    other than 2 and 7) is selected with OMDS_FUSED_TAIL=0 and must pass the same staged parity tests."""
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT
+    env = dict(os.environ, OMDS_FUSED_TAIL="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu",
+                        "-k", "(teacher_forced or free_running) and (franka_shelf_K6 or planar2_c1_K3 or franka_tanh)"],
+                       env=env, capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "6 passed" in r.stdout, r.stdout[-500:]
