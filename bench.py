@@ -102,44 +102,11 @@ def cpu_baseline(w, W, b, obs, q0, qf, K, seed):
             "sample": f"numpy oracle propagate, {Ns} rollouts x {Hs} steps x {obs.shape[0]} obstacles, {reps} reps in {el:.1f}s"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="franka_shelf_1024x32", choices=sorted(WORKLOADS))
-    ap.add_argument("--kernels", type=int, default=10, help="active RBF navigation kernels K")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo + --share-gpu lets two ranks share one GPU to exercise the sharded path on a 1-GPU box")
-    ap.add_argument("--share-gpu", action="store_true")
-    ap.add_argument("--time-fetch", action="store_true", help="also report the cost of fetching all rollout tensors to the host")
-    args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    if args.share_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # under torchrun, also at N=1
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-
+def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, dist, torch, time_fetch=False):
+    """Times `steps` planner iterations of `workload` on this rank's GPU; returns a dict of raw numbers."""
     from optimalmodulationds_amd.dist import sharded_update
     from optimalmodulationds_amd.engine import Engine
-
-    w, W, b, obs, q0, qf, dh, qmin, qmax = setup(args.workload, rank)
+    w, W, b, obs, q0, qf, dh, qmin, qmax = setup(workload, rank)
     N, H, n, K = w["N"], w["H"], q0.shape[0], args.kernels
     eng = Engine(n, N, H, w["k"], max_obs=max(64, obs.shape[0]), device=local_rank)
     eng.set_mlp(W, b)
@@ -172,14 +139,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for it in range(args.warmup):
+    for it in range(warmup):
         iteration(it)
     eng.prof_enable(True)
     eng.prof_reset()
     barrier()
     t0 = time.perf_counter()
-    for it in range(args.steps):
-        iteration(args.warmup + it)
+    for it in range(steps):
+        iteration(warmup + it)
     eng.lib.omds_sync(eng.h)
     barrier()
     el = time.perf_counter() - t0
@@ -189,13 +156,62 @@ def main():
         el = float(t.item())
     p1_ms, p1_launches, p1_rows = eng.prof_read()
     fetch_ms = None
-    if args.time_fetch:
+    if time_fetch:
         eng.get_rollouts()
         tf = time.perf_counter()
         for _ in range(5):
             eng.get_rollouts()
         fetch_ms = (time.perf_counter() - tf) / 5 * 1e3
 
+    eng.close()
+    return dict(w=w, W=W, b=b, obs=obs, q0=q0, qf=qf, N=N, H=H, K=K, el=el, p1_ms=p1_ms, p1_launches=p1_launches,
+                p1_rows=p1_rows, fetch_ms=fetch_ms)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="franka_shelf_1024x32", choices=sorted(WORKLOADS))
+    ap.add_argument("--kernels", type=int, default=10, help="active RBF navigation kernels K")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short planar7_1024x32 measurement reported under 'also'")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --share-gpu lets two ranks share one GPU to exercise the sharded path on a 1-GPU box")
+    ap.add_argument("--share-gpu", action="store_true")
+    ap.add_argument("--time-fetch", action="store_true", help="also report the cost of fetching all rollout tensors to the host")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # under torchrun, also at N=1
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    r = measure(args, args.workload, args.steps, args.warmup, rank, world, local_rank, use_dist, dist, torch, args.time_fetch)
+    w, W, b, obs, q0, qf, N, H, K, el = (r[k] for k in ("w", "W", "b", "obs", "q0", "qf", "N", "H", "K", "el"))
+    p1_ms, p1_launches, p1_rows, fetch_ms = r["p1_ms"], r["p1_launches"], r["p1_rows"], r["fetch_ms"]
+    also = None
+    if not args.no_secondary and args.workload != "planar7_1024x32":
+        # BASELINE.json configs[1] (planar 7-DoF, 1024 x 32, 8 obstacles): a launch-latency-bound shape, reported beside
+        r2 = measure(args, "planar7_1024x32", 5, 1, rank, world, local_rank, use_dist, dist, torch)
+        also = {"workload": "planar7_1024x32", "value": world * r2["N"] * r2["H"] * 5 / r2["el"], "unit": "rollout-steps/s",
+                "ms_per_step": 1e3 * r2["el"] / 5}
     if rank == 0:
         f_row = flops_per_row(W)
         ach = (p1_rows * f_row) / (p1_ms * 1e-3) / 1e12 if p1_ms > 0 else 0.0
@@ -214,6 +230,8 @@ def main():
         }
         if fetch_ms is not None:
             out["fetch_all_rollouts_ms"] = fetch_ms
+        if also is not None:
+            out["also"] = also
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, W, b, obs, q0, qf, K, 7)
         print(json.dumps(out))

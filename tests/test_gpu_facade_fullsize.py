@@ -250,3 +250,46 @@ def test_fullsize_update_sums(big):
     assert_close(mu, mu_c, 1e-6, "mu_c unchanged when mu_s = 0")
     cs = eng.cost_sum()
     assert cs[1] == big["N"]
+
+
+def _mk(N, H, k, obs, m):
+    from optimalmodulationds_amd import scenes
+    from optimalmodulationds_amd.engine import Engine
+    eng = Engine(7, N, H, k, max_obs=max(8, obs.shape[0]))
+    eng.set_mlp(m.W, m.b, act=m.act)
+    eng.set_obstacles(obs)
+    eng.params.dt = 0.5; eng.params.dst_thr = 0.01; eng.params.ignored_links = 0b111
+    eng.push_params()
+    eng.set_ds(scenes.FRANKA_QF)
+    return eng
+
+
+@pytest.mark.parametrize("N,H,k,O", [(1000, 3, 5, 294), (77, 2, 7, 33), (8192, 2, 5, 294), (130, 2, 5, 5), (65, 3, 1, 1)])
+def test_ragged_and_large_shapes(N, H, k, O):
+    """Sizes that are not multiples of any tile (rows per pass-1 tile 64/32, rollouts per tail workgroup
+    floor(32/k)), O == k, O == 1, and a large N: a 40-rollout sample must match the oracle step by step."""
+    from optimalmodulationds_amd import scenes
+    m = orc.Mlp.from_npz(weights_path("franka"))
+    obs = scenes.shelf_scene()[np.linspace(0, 293, O).astype(int)]
+    rng = np.random.RandomState(N)
+    K = 3
+    eng = _mk(N, H, k, obs, m)
+    q0 = (scenes.FRANKA_Q0 + 0.4 * rng.standard_normal((N, 7))).astype(np.float32)
+    mu = (scenes.FRANKA_Q0 + 0.3 * rng.standard_normal((N, K, 7))).astype(np.float32)
+    sg = np.ones((N, K), np.float32)
+    al = rng.standard_normal((N, K, 7)).astype(np.float32)
+    eng.set_policy_samples(mu, sg, al)
+    eng.propagate(q0)
+    r = eng.get_rollouts()
+    assert np.isfinite(r["all_traj"]).all() and np.isfinite(r["closest_dist_all"]).all()
+    sel = np.unique(np.concatenate(([0, 1, N - 2, N - 1], rng.choice(N, 36, replace=False))))
+    for h in range(H):
+        q = r["all_traj"][sel, h]
+        d, g, _, idx = orc.distance_repulsion_nn(m, q, obs, k, [0, 1, 2])
+        assert_close(r["closest_dist_all"][sel, h], d - np.float32(0.01), RTOL, f"distance h={h}")
+        st = orc.modulation_step(q, scenes.FRANKA_QF, d, g, mu[sel], sg[sel], al[sel], orc.Params(dst_thr=0.01))
+        ok = orc.rollout_relu_margin(m, q, obs, idx) >= 5e-6
+        assert_close(r["normal"][sel, h][ok], st["ghat"][ok], 5e-5, f"normal h={h}")
+        if h + 1 < H:
+            assert_close((r["all_traj"][sel, h + 1] - q)[ok] / 0.5, st["u"][ok], 5e-4, f"velocity h={h}")
+    eng.close()
