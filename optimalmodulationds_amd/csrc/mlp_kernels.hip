@@ -76,7 +76,7 @@ struct Geo {
 // ------------------------------------------------------------------------------------------------
 // pass 1: all (rollout, obstacle) pairs -> min link distance
 // ------------------------------------------------------------------------------------------------
-template <int MT, int MR, int NR>
+template <int MT, int MR, int NR, int ACT>
 __global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const float* __restrict__ Apre,
                                                                const float* __restrict__ Bpre,
                                                                const float* __restrict__ radius, int O,
@@ -90,24 +90,48 @@ __global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const
     const int wm = wave / G::WN, wn = wave % G::WN;
     const long long row0 = (long long)blockIdx.x * MT;
 
-    // ---- layer 1: H1 = relu(Apre[t] + Bpre[o]), one float4 per thread-iteration -----------------
-    for (int idx = tid; idx < MT * 64; idx += G::NT) {
-        const int r = idx >> 6, c4 = idx & 63;
-        const long long R = row0 + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        int o = 0;
-        if (R < total_rows) {
-            const long long t = R / O;
-            o = (int)(R - t * O);
-            const float4 a = reinterpret_cast<const float4*>(Apre)[t * 64 + c4];
-            const float4 b = reinterpret_cast<const float4*>(Bpre)[(size_t)o * 64 + c4];
-            v.x = actf(a.x + b.x, m.act);
-            v.y = actf(a.y + b.y, m.act);
-            v.z = actf(a.z + b.z, m.act);
-            v.w = actf(a.w + b.w, m.act);
+    // ---- layer 1: H1 = act(Apre[t] + Bpre[o]); one float4 per thread and iteration, all loads of the
+    //      tile issued before the first use (the loop is fully unrolled, no 64-bit division per row) -------
+    {
+        constexpr int IT = MT * 64 / G::NT;                     // iterations per thread
+        const long long t0 = row0 / O;                          // wave-uniform, once per workgroup
+        const int o0 = (int)(row0 - t0 * O);
+        const int rows_here = (int)((total_rows - row0 < MT) ? (total_rows - row0) : MT);
+        constexpr int BI = IT < 8 ? IT : 8;                     // loads in flight per thread and batch
+#pragma unroll 1
+        for (int base = 0; base < IT; base += BI) {
+            float4 av[BI], bv[BI];
+            int oo[BI];
+#pragma unroll
+            for (int it = 0; it < BI; ++it) {
+                const int idx = tid + (base + it) * G::NT;
+                const int r = idx >> 6, c4 = idx & 63;
+                const int oq = o0 + r;                          // < O + MT
+                const int dt = oq / O;                          // 32-bit
+                const int o = oq - dt * O;
+                oo[it] = o;
+                if (r < rows_here) {
+                    av[it] = reinterpret_cast<const float4*>(Apre)[(t0 + dt) * 64 + c4];
+                    bv[it] = reinterpret_cast<const float4*>(Bpre)[(size_t)o * 64 + c4];
+                } else {
+                    av[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    bv[it] = av[it];
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < BI; ++it) {
+                const int idx = tid + (base + it) * G::NT;
+                const int r = idx >> 6, c4 = idx & 63;
+                float4 v;
+                v.x = actf(av[it].x + bv[it].x, ACT);
+                v.y = actf(av[it].y + bv[it].y, ACT);
+                v.z = actf(av[it].z + bv[it].z, ACT);
+                v.w = actf(av[it].w + bv[it].w, ACT);
+                if (r >= rows_here) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(Hs + r * LDH + 4 * c4) = v;
+                if (c4 == 0) rowO[r] = (r < rows_here) ? oo[it] : 0;
+            }
         }
-        *reinterpret_cast<float4*>(Hs + r * LDH + 4 * c4) = v;
-        if (c4 == 0) rowO[r] = o;
     }
     __syncthreads();
 
@@ -133,7 +157,7 @@ __global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const
             for (int i = 0; i < MR; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    Hs[((wm * MR + i) * 32 + crow(r, lane)) * LDH + col] = actf(acc[i][j][r] + bv, m.act);
+                    Hs[((wm * MR + i) * 32 + crow(r, lane)) * LDH + col] = actf(acc[i][j][r] + bv, ACT);
         }
         __syncthreads();
     }
@@ -270,22 +294,29 @@ void omds_launch_obstacle_layer1(hipStream_t s, const MlpDev& m, const float* xy
     hipLaunchKernelGGL(k_obstacle_layer1, dim3(O), dim3(256), 0, s, m, xyzr, O, Bpre, radius);
 }
 
-template <int MT, int MR, int NR>
-static void launch_pass1_t(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
+template <int MT, int MR, int NR, int ACT>
+static void launch_pass1_a(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
                            int O, long long total, uint32_t ignored, float* Dmin) {
     using G = Geo<MT, MR, NR>;
     const size_t lds = (size_t)MT * LDH * 4 + (size_t)MT * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<MT, MR, NR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<MT, MR, NR, ACT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const long long tiles = (total + MT - 1) / MT;
     static int tune = -1;
     if (tune < 0) { const char* e = getenv("OMDS_TUNE"); tune = e ? atoi(e) : 1; }  // bit 0: s_setprio(1) around MFMA clusters (+1 % measured)
-    hipLaunchKernelGGL((k_pass1<MT, MR, NR>), dim3((unsigned)tiles), dim3(G::NT), lds, s, m, Apre, Bpre, radius, O,
+    hipLaunchKernelGGL((k_pass1<MT, MR, NR, ACT>), dim3((unsigned)tiles), dim3(G::NT), lds, s, m, Apre, Bpre, radius, O,
                        total, ignored, Dmin, tune);
+}
+
+template <int MT, int MR, int NR>
+static void launch_pass1_t(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
+                           int O, long long total, uint32_t ignored, float* Dmin) {
+    if (m.act == OMDS_ACT_RELU) launch_pass1_a<MT, MR, NR, OMDS_ACT_RELU>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin);
+    else launch_pass1_a<MT, MR, NR, OMDS_ACT_TANH>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin);
 }
 
 // Tile choice: 64-row tiles (8 waves, each 64 rows x 32 columns, two workgroups per CU) once there are
