@@ -85,7 +85,7 @@ __global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const
     using G = Geo<MT, MR, NR>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Hs = smem;                                           // [MT][LDH]
-    int* rowO = reinterpret_cast<int*>(smem + MT * LDH);        // [MT] obstacle index of each row
+    float* rowRad = smem + MT * LDH;                            // [MT] obstacle radius of each row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / G::WN, wn = wave % G::WN;
     const long long row0 = (long long)blockIdx.x * MT;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const
                 v.w = actf(av[it].w + bv[it].w, ACT);
                 if (r >= rows_here) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(Hs + r * LDH + 4 * c4) = v;
-                if (c4 == 0) rowO[r] = (r < rows_here) ? oo[it] : 0;
+                if (c4 == 0) rowRad[r] = (r < rows_here) ? radius[oo[it]] : 0.f;
             }
         }
     }
@@ -146,13 +146,15 @@ __global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const
             for (int j = 0; j < NR; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        float bvj[NR];   // biases fetched before the GEMM so that the epilogue does not start with an L2 round trip
+#pragma unroll
+        for (int j = 0; j < NR; ++j) bvj[j] = m.bh[l * OMDS_WIDTH + (cb0 + j) * 32 + (lane & 31)];
         gemm256<MR, NR>(Hw, m.Wf + (size_t)l * (OMDS_NCB * 32 * 64), cb0, lane, acc, (tune & 1) != 0);
         __syncthreads();  // every wave has finished reading the tile
-        const float* bias = m.bh + l * OMDS_WIDTH;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const int col = (cb0 + j) * 32 + (lane & 31);
-            const float bv = bias[col];
+            const float bv = bvj[j];
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -182,7 +184,7 @@ __global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int r = rb * 16 + 4 * (lane >> 4) + reg;
-            float y = (acc[reg] + bj) / m.out_div - radius[rowO[r]];
+            float y = (acc[reg] + bj) / m.out_div - rowRad[r];
             y = pad ? __builtin_inff() : (ign ? 1e6f : y);
             y = fminf(y, __shfl_xor(y, 1));
             y = fminf(y, __shfl_xor(y, 2));
