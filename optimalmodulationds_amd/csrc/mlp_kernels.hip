@@ -77,18 +77,15 @@ struct Geo {
 // pass 1: all (rollout, obstacle) pairs -> min link distance
 // ------------------------------------------------------------------------------------------------
 template <int MT, int MR, int NR, int ACT>
-__global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const float* __restrict__ Apre,
-                                                               const float* __restrict__ Bpre,
-                                                               const float* __restrict__ radius, int O,
-                                                               long long total_rows, uint32_t ignored,
-                                                               float* __restrict__ Dmin, int tune) {
+__device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const float* __restrict__ Apre,
+                                           const float* __restrict__ Bpre, const float* __restrict__ radius, int O,
+                                           long long total_rows, uint32_t ignored, float* __restrict__ Dmin, int tune,
+                                           const long long row0) {
     using G = Geo<MT, MR, NR>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Hs = smem;                                           // [MT][LDH]
     float* rowRad = smem + MT * LDH;                            // [MT] obstacle radius of each row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / G::WN, wn = wave % G::WN;
-    const long long row0 = (long long)blockIdx.x * MT;
 
     // ---- layer 1: H1 = act(Apre[t] + Bpre[o]); one float4 per thread and iteration, all loads of the
     //      tile issued before the first use (the loop is fully unrolled, no 64-bit division per row) -------
@@ -192,6 +189,34 @@ __global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const
             y = fminf(y, __shfl_xor(y, 8));
             if (j == 0 && row0 + r < total_rows) Dmin[row0 + r] = y;
         }
+    }
+}
+
+template <int MT, int MR, int NR, int ACT>
+__global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const float* __restrict__ Apre,
+                                                               const float* __restrict__ Bpre,
+                                                               const float* __restrict__ radius, int O,
+                                                               long long total_rows, uint32_t ignored,
+                                                               float* __restrict__ Dmin, int tune) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    pass1_tile<MT, MR, NR, ACT>(m, smem, Apre, Bpre, radius, O, total_rows, ignored, Dmin, tune, (long long)blockIdx.x * MT);
+}
+
+// Mixed-granularity launch: the first n_big workgroups take 64-row tiles, the rest cover the remaining rows
+// in 32-row tiles.  Workgroups are dispatched in index order, so the kernel ends on small tiles and the
+// drain phase (slots idling while the last tiles finish) shrinks with the tile size.
+template <int ACT>
+__global__ __launch_bounds__(512) void k_pass1_mixed(MlpDev m, const float* __restrict__ Apre,
+                                                     const float* __restrict__ Bpre, const float* __restrict__ radius,
+                                                     int O, long long total_rows, uint32_t ignored,
+                                                     float* __restrict__ Dmin, int tune, int n_big) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    if (b < n_big) {
+        pass1_tile<64, 2, 1, ACT>(m, smem, Apre, Bpre, radius, O, total_rows, ignored, Dmin, tune, (long long)b * 64);
+    } else {
+        pass1_tile<32, 1, 1, ACT>(m, smem, Apre, Bpre, radius, O, total_rows, ignored, Dmin, tune,
+                                  (long long)n_big * 64 + (long long)(b - n_big) * 32);
     }
 }
 
@@ -323,6 +348,27 @@ static void launch_pass1_t(hipStream_t s, const MlpDev& m, const float* Apre, co
 
 // Tile choice: 64-row tiles (8 waves, each 64 rows x 32 columns, two workgroups per CU) once there are
 // enough tiles to fill 256 CUs; 32-row tiles for small batches (planar configs, dist_grad calls).
+template <int ACT>
+static void launch_pass1_mixed(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
+                               int O, long long total, uint32_t ignored, float* Dmin, int small_rounds) {
+    const size_t lds = (size_t)64 * LDH * 4 + 64 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1_mixed<ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    static int tune = -1;
+    if (tune < 0) { const char* e = getenv("OMDS_TUNE"); tune = e ? atoi(e) : 1; }
+    // keep `small_rounds` x 512 x 64 rows (in units of resident 64-row workgroups) for the 32-row tail tiles
+    long long tiles64 = total / 64;
+    long long keep = (long long)small_rounds * 512 / 2;   // 64-row tiles' worth of rows given to small tiles
+    long long n_big = tiles64 > keep ? tiles64 - keep : 0;
+    const long long rest = total - n_big * 64;
+    const long long n_small = (rest + 31) / 32;
+    hipLaunchKernelGGL((k_pass1_mixed<ACT>), dim3((unsigned)(n_big + n_small)), dim3(512), lds, s, m, Apre, Bpre, radius, O,
+                       total, ignored, Dmin, tune, (int)n_big);
+}
+
 static int g_pass1_variant = -1;  // -1 = auto; set through OMDS_PASS1_VARIANT for experiments
 void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
                        int O, int B, uint32_t ignored, float* Dmin) {
@@ -335,7 +381,13 @@ void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Apre, const 
     int v = g_pass1_variant;
     // measured on MI355X (profiles/): 64-row tiles (2 workgroups per CU) beat 128-row tiles at N*O = 301k rows
     // (129 vs 123 TFLOP/s: shorter tail) and tie at 1.2M rows (134 TFLOP/s)
-    if (v == 0) v = (total >= 64LL * 512) ? 3 : 5;
+    // and ending the launch on one "round" of 32-row tiles (variant 11) shortens the drain: 135 vs 133 TFLOP/s
+    if (v == 0) v = (total >= 64LL * 1024) ? 11 : ((total >= 64LL * 512) ? 3 : 5);
+    if (v >= 10) {   // 10 + r: mixed tiles, the last r "rounds" of 512 workgroups use 32-row tiles
+        if (m.act == OMDS_ACT_RELU) launch_pass1_mixed<OMDS_ACT_RELU>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin, v - 10);
+        else launch_pass1_mixed<OMDS_ACT_TANH>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin, v - 10);
+        return;
+    }
     switch (v) {
         case 1: launch_pass1_t<128, 4, 1>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
         case 2: launch_pass1_t<128, 2, 2>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
