@@ -77,6 +77,50 @@ __device__ __forceinline__ void gemm256(const float* __restrict__ Hw, const floa
 __device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 
+// k smallest entries of row[0..O) in ascending order (ties by lower index), one wave per row.
+// emit(j, index) is called by lane 0.  Rows of up to 512 entries are held in registers.
+template <typename Emit>
+__device__ __forceinline__ void topk_row(const float* __restrict__ row, int O, int k, int lane, Emit emit) {
+    constexpr int NV = 8;
+    float v[NV];
+    const bool in_regs = O <= 64 * NV;
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { const int o = lane + 64 * i; v[i] = (o < O) ? row[o] : __builtin_nanf(""); }
+    }
+    float pv = -__builtin_inff();
+    int pi = -1;
+    for (int j = 0; j < k; ++j) {
+        float bv = __builtin_inff();
+        int bi = 0x7fffffff;
+        if (in_regs) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int o = lane + 64 * i;
+                const float x = v[i];                      // NaN (padding) fails every comparison
+                const bool after = (x > pv) || (x == pv && o > pi);
+                if (after && ((x < bv) || (x == bv && o < bi))) { bv = x; bi = o; }
+            }
+        } else {
+            for (int o = lane; o < O; o += 64) {
+                const float x = row[o];
+                const bool after = (x > pv) || (x == pv && o > pi);
+                if (after && ((x < bv) || (x == bv && o < bi))) { bv = x; bi = o; }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            if ((ov < bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (bi == 0x7fffffff) bi = 0;
+        if (lane == 0) emit(j, bi);
+        pv = bv;
+        pi = bi;
+    }
+}
+
 constexpr int P2_MT = 32;
 constexpr int P2_NT = 512;
 
@@ -135,9 +179,9 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
         f32x16 acc[1][1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+        const float bv = m.bh[l * OMDS_WIDTH + col];   // before the GEMM: no L2 round trip at the head of the epilogue
         gemm256<1, 1>(Hs, m.Wf + (size_t)l * (OMDS_NCB * 32 * 64), wave, lane, acc);
         __syncthreads();
-        const float bv = m.bh[l * OMDS_WIDTH + col];
         uint32_t bits = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -155,17 +199,20 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
     if (wave < P2_MT / 16) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* arow = Hs + (wave * 16 + (lane & 15)) * LDH + 4 * (lane >> 4);
-#pragma unroll 4
+        const int j = lane & 15;
+        const float bj = m.bl[j];
+        float4 wl[16];   // all 16 weight fragments in flight at once (the chain below is latency-bound otherwise)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) wl[c] = m.Wl[c * 64 + lane];
+#pragma unroll
         for (int c = 0; c < 16; ++c) {
             const float4 a = *reinterpret_cast<const float4*>(arow + 16 * c);
-            const float4 w = m.Wl[c * 64 + lane];
+            const float4 w = wl[c];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
         }
-        const int j = lane & 15;
-        const float bj = m.bl[j];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int r = wave * 16 + 4 * (lane >> 4) + reg;

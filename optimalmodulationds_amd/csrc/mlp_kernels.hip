@@ -228,28 +228,7 @@ __global__ __launch_bounds__(256) void k_topk(const float* __restrict__ Dmin, in
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= B) return;
-    const float* row = Dmin + (size_t)t * O;
-    float pv = -__builtin_inff();
-    int pi = -1;
-    for (int j = 0; j < k; ++j) {
-        float bv = __builtin_inff();
-        int bi = 0x7fffffff;
-        for (int o = lane; o < O; o += 64) {
-            const float v = row[o];
-            const bool after = (v > pv) || (v == pv && o > pi);
-            if (after && ((v < bv) || (v == bv && o < bi))) { bv = v; bi = o; }
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float ov = __shfl_xor(bv, off);
-            const int oi = __shfl_xor(bi, off);
-            if ((ov < bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-        if (bi == 0x7fffffff) bi = 0;
-        if (lane == 0) idx[(size_t)t * k + j] = bi;
-        pv = bv;
-        pi = bi;
-    }
+    topk_row(Dmin + (size_t)t * O, O, k, lane, [&](int j, int bi) { idx[(size_t)t * k + j] = bi; });
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -17,6 +17,7 @@ struct TailArgs {
     float* Apre;         // [N][256] in: this step, out: next step (rows of the workgroup's own rollouts)
     float* dscr;         // tanh derivative scratch
     int O;
+    int dbg_stop;        // timing experiments only (OMDS_TAIL_STOP): return after phase 1 / 2 / 3
     StepArgs st;
 };
 
@@ -46,36 +47,17 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
     for (int rl = wave; rl < RW; rl += 8) {
         const int t = t_base + rl;
         if (t >= N) break;
-        const float* row = a.Dmin + (size_t)t * O;
-        float pv = -__builtin_inff();
-        int pi = -1;
-        for (int j = 0; j < k; ++j) {
-            float bv = __builtin_inff();
-            int bi = 0x7fffffff;
-            for (int o = lane; o < O; o += 64) {
-                const float v = row[o];
-                const bool after = (v > pv) || (v == pv && o > pi);
-                if (after && ((v < bv) || (v == bv && o < bi))) { bv = v; bi = o; }
-            }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const float ov = __shfl_xor(bv, off);
-                const int oi = __shfl_xor(bi, off);
-                if ((ov < bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
-            if (bi == 0x7fffffff) bi = 0;
-            if (lane == 0) { sm.rowT[rl * k + j] = t; sm.rowO[rl * k + j] = bi; }
-            pv = bv;
-            pi = bi;
-        }
+        topk_row(a.Dmin + (size_t)t * O, O, k, lane, [&](int j, int bi) { sm.rowT[rl * k + j] = t; sm.rowO[rl * k + j] = bi; });
     }
     __syncthreads();
+    if (a.dbg_stop == 1) return;
 
     // ---- forward + backward on the selected rows; gradients and distances stay in LDS ------------
     const float* qT = a.st.trajT + (size_t)(a.st.step - 1) * ND * N;
     pass2_body(m, sm, a.Apre, a.Bpre, a.radius, a.xyzr, t_base * k, N * k, qT, N, gx, dr, 0, nullptr, nullptr, a.dscr,
                (size_t)gridDim.x * P2_MT * OMDS_WIDTH, blockIdx.x * P2_MT);
     __syncthreads();
+    if (a.dbg_stop == 2) return;
 
     // ---- modulation / policy / Euler step: 16 lanes per rollout -------------------------------------
     {
@@ -94,7 +76,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
             }
         }
     }
-    if (a.st.step >= a.st.H) return;   // last step: nothing is integrated, no next network evaluation
+    if (a.st.step >= a.st.H || a.dbg_stop == 3) return;   // last step: nothing is integrated, no next network evaluation
     __syncthreads();
 
     // ---- rollout half of layer 1 for the next step (same arithmetic order as k_rollout_layer1) --------
@@ -140,6 +122,9 @@ int omds_tail_workgroups(int N, int k) { const int RW = P2_MT / k; return (N + R
 void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
                       const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st) {
     TailArgs a;
+    static int stop = -1;
+    if (stop < 0) { const char* e = getenv("OMDS_TAIL_STOP"); stop = e ? atoi(e) : 0; }
+    a.dbg_stop = stop;
     a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Dmin = Dmin; a.Apre = Apre; a.dscr = dscr; a.O = O; a.st = st;
     if (st.n == 7) launch_tail_t<7>(s, a);
     else launch_tail_t<2>(s, a);
