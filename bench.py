@@ -155,6 +155,7 @@ def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, di
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     p1_ms, p1_launches, p1_rows = eng.prof_read()
+    _, _, p1_flops, p1_kernel = eng.prof_read_ex()
     fetch_ms = None
     if time_fetch:
         eng.get_rollouts()
@@ -165,7 +166,7 @@ def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, di
 
     eng.close()
     return dict(w=w, W=W, b=b, obs=obs, q0=q0, qf=qf, N=N, H=H, K=K, el=el, p1_ms=p1_ms, p1_launches=p1_launches,
-                p1_rows=p1_rows, fetch_ms=fetch_ms)
+                p1_rows=p1_rows, p1_flops=p1_flops, p1_kernel=p1_kernel, fetch_ms=fetch_ms)
 
 
 def main():
@@ -213,8 +214,7 @@ def main():
         also = {"workload": "planar7_1024x32", "value": world * r2["N"] * r2["H"] * 5 / r2["el"], "unit": "rollout-steps/s",
                 "ms_per_step": 1e3 * r2["el"] / 5}
     if rank == 0:
-        f_row = flops_per_row(W)
-        ach = (p1_rows * f_row) / (p1_ms * 1e-3) / 1e12 if p1_ms > 0 else 0.0
+        ach = r["p1_flops"] / (p1_ms * 1e-3) / 1e12 if p1_ms > 0 else 0.0
         out = {
             "metric": "modulated rollout-steps/sec", "value": world * N * H * args.steps / el,
             "unit": "rollout-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -223,10 +223,10 @@ def main():
             "config": {"workload": args.workload, "rollouts_per_gpu": N, "horizon": H, "obstacles": int(obs.shape[0]),
                        "n_closest": w["k"], "active_kernels": K, "network": "x".join(str(x.shape[1]) for x in W) + f"x{W[-1].shape[0]} relu (shipped reference weights)",
                        "parallelism": f"rollout-sharded x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "k_pass1", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "kernel": r["p1_kernel"], "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(args.workload),
                          "launches": int(p1_launches), "avg_launch_ms": p1_ms / max(p1_launches, 1),
-                         "flops_per_launch": f_row * p1_rows / max(p1_launches, 1)},
+                         "flops_per_launch": r["p1_flops"] / max(p1_launches, 1)},
         }
         if fetch_ms is not None:
             out["fetch_all_rollouts_ms"] = fetch_ms

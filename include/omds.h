@@ -174,6 +174,9 @@ OMDS_API int omds_apply_update(int n_kernels, int n_dof, int horizon, const floa
 OMDS_API int omds_prof_enable(omds_ctx* ctx, int on);
 OMDS_API int omds_prof_reset(omds_ctx* ctx);
 OMDS_API int omds_prof_read(omds_ctx* ctx, double* pass1_ms, int64_t* pass1_launches, int64_t* pass1_rows);
+/* Same, for whichever kernel dominated the bracketed launches (k_pass1, or k_horizon when one persistent
+ * launch runs the whole horizon): summed ms, launches, algorithmic FLOPs and the kernel's name. */
+OMDS_API int omds_prof_read_ex(omds_ctx* ctx, double* ms, int64_t* launches, double* flops, const char** kernel);
 /* Asynchronous form used by bench loops: propagate + cost + weighted update enqueued without
  * host round trips of rollout data; omds_sync waits for the stream.                       */
 OMDS_API int omds_sync(omds_ctx* ctx);

@@ -67,6 +67,8 @@ SIGNATURES = {
     "omds_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "omds_prof_reset": (C.c_int, [C.c_void_p]),
     "omds_prof_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "omds_prof_read_ex": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_char_p)]),
     "omds_sync": (C.c_int, [C.c_void_p]),
 }
 

@@ -264,6 +264,9 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
     if ((rc = upload(ctx, w1b, &m.W1b))) return rc;
     ctx->mlp = m;
     ctx->act = act;
+    ctx->f_fwd = 0.0;
+    for (int i = 0; i < n_linear; ++i) ctx->f_fwd += 2.0 * dims[i] * dims[i + 1];
+    ctx->f_bwd = ctx->f_fwd - 2.0 * dims[n_linear - 1] * dims[n_linear];   // no weight-gradient, no last-layer GEMM
     ctx->have_mlp = true;
     if (ctx->n_obs > 0) {  // re-derive the obstacle half of layer 1 for the new weights
         omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, ctx->n_obs, ctx->d_Bpre, ctx->d_radius);
@@ -402,13 +405,15 @@ static int prof_begin(omds_ctx* ctx) {
     CK(hipEventRecord(p.start[p.used], ctx->stream));
     return OMDS_OK;
 }
-static int prof_end(omds_ctx* ctx, int64_t rows) {
+static int prof_end(omds_ctx* ctx, int64_t rows, double flops = -1.0, const char* kernel = "k_pass1") {
     if (!ctx->prof_on) return OMDS_OK;
     ProfEvents& p = ctx->prof;
     CK(hipEventRecord(p.stop[p.used], ctx->stream));
     p.used++;
     p.launches++;
     p.rows += rows;
+    p.flops += flops >= 0.0 ? flops : (double)rows * ctx->f_fwd;
+    p.kernel = kernel;
     return OMDS_OK;
 }
 static int prof_collect(omds_ctx* ctx) {
@@ -766,7 +771,16 @@ int omds_prof_reset(omds_ctx* ctx) {
     ctx->prof.ms = 0.0;
     ctx->prof.launches = 0;
     ctx->prof.rows = 0;
+    ctx->prof.flops = 0.0;
     ctx->prof.used = 0;
+    return OMDS_OK;
+}
+int omds_prof_read_ex(omds_ctx* ctx, double* ms, int64_t* launches, double* flops, const char** kernel) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    if (ms) *ms = ctx->prof.ms;
+    if (launches) *launches = ctx->prof.launches;
+    if (flops) *flops = ctx->prof.flops;
+    if (kernel) *kernel = ctx->prof.kernel;
     return OMDS_OK;
 }
 int omds_prof_read(omds_ctx* ctx, double* pass1_ms, int64_t* pass1_launches, int64_t* pass1_rows) {

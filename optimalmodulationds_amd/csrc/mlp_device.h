@@ -77,6 +77,134 @@ __device__ __forceinline__ void gemm256(const float* __restrict__ Hw, const floa
 __device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 
+template <int MT, int MR, int NR>
+struct Geo {
+    static constexpr int WM = MT / (32 * MR);
+    static constexpr int WN = OMDS_NCB / NR;
+    static constexpr int NW = WM * WN;
+    static constexpr int NT = NW * 64;
+    static_assert(WM >= 1 && WN >= 1 && WM * 32 * MR == MT && WN * NR == OMDS_NCB, "bad tile geometry");
+};
+
+// ------------------------------------------------------------------------------------------------
+// pass 1: all (rollout, obstacle) pairs -> min link distance
+// ------------------------------------------------------------------------------------------------
+template <int MT, int MR, int NR, int ACT>
+__device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const float* __restrict__ Apre,
+                                           const float* __restrict__ Bpre, const float* __restrict__ radius, int O,
+                                           long long total_rows, uint32_t ignored, float* __restrict__ Dmin, int tune,
+                                           const long long row0) {
+    using G = Geo<MT, MR, NR>;
+    float* Hs = smem;                                           // [MT][LDH]
+    float* rowRad = smem + MT * LDH;                            // [MT] obstacle radius of each row
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / G::WN, wn = wave % G::WN;
+
+    // ---- layer 1: H1 = act(Apre[t] + Bpre[o]); one float4 per thread and iteration, all loads of the
+    //      tile issued before the first use (the loop is fully unrolled, no 64-bit division per row) -------
+    {
+        constexpr int IT = MT * 64 / G::NT;                     // iterations per thread
+        const long long t0 = row0 / O;                          // wave-uniform, once per workgroup
+        const int o0 = (int)(row0 - t0 * O);
+        const int rows_here = (int)((total_rows - row0 < MT) ? (total_rows - row0) : MT);
+        constexpr int BI = IT < 8 ? IT : 8;                     // loads in flight per thread and batch
+#pragma unroll 1
+        for (int base = 0; base < IT; base += BI) {
+            float4 av[BI], bv[BI];
+            int oo[BI];
+#pragma unroll
+            for (int it = 0; it < BI; ++it) {
+                const int idx = tid + (base + it) * G::NT;
+                const int r = idx >> 6, c4 = idx & 63;
+                const int oq = o0 + r;                          // < O + MT
+                const int dt = oq / O;                          // 32-bit
+                const int o = oq - dt * O;
+                oo[it] = o;
+                if (r < rows_here) {
+                    av[it] = reinterpret_cast<const float4*>(Apre)[(t0 + dt) * 64 + c4];
+                    bv[it] = reinterpret_cast<const float4*>(Bpre)[(size_t)o * 64 + c4];
+                } else {
+                    av[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    bv[it] = av[it];
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < BI; ++it) {
+                const int idx = tid + (base + it) * G::NT;
+                const int r = idx >> 6, c4 = idx & 63;
+                float4 v;
+                v.x = actf(av[it].x + bv[it].x, ACT);
+                v.y = actf(av[it].y + bv[it].y, ACT);
+                v.z = actf(av[it].z + bv[it].z, ACT);
+                v.w = actf(av[it].w + bv[it].w, ACT);
+                if (r >= rows_here) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(Hs + r * LDH + 4 * c4) = v;
+                if (c4 == 0) rowRad[r] = (r < rows_here) ? radius[oo[it]] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- hidden -> hidden layers -----------------------------------------------------------------
+    const float* Hw = Hs + (wm * MR * 32) * LDH;
+    const int cb0 = wn * NR;
+    for (int l = 0; l < m.nhh; ++l) {
+        f32x16 acc[MR][NR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        float bvj[NR];   // biases fetched before the GEMM so that the epilogue does not start with an L2 round trip
+#pragma unroll
+        for (int j = 0; j < NR; ++j) bvj[j] = m.bh[l * OMDS_WIDTH + (cb0 + j) * 32 + (lane & 31)];
+        gemm256<MR, NR>(Hw, m.Wf + (size_t)l * (OMDS_NCB * 32 * 64), cb0, lane, acc, (tune & 1) != 0);
+        __syncthreads();  // every wave has finished reading the tile
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int col = (cb0 + j) * 32 + (lane & 31);
+            const float bv = bvj[j];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Hs[((wm * MR + i) * 32 + crow(r, lane)) * LDH + col] = actf(acc[i][j][r] + bv, ACT);
+        }
+        __syncthreads();
+    }
+
+    // ---- last layer (256 -> C, padded to 16) on v_mfma_f32_16x16x4_f32, 16 rows per wave ----------
+    for (int rb = wave; rb < MT / 16; rb += G::NW) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = Hs + (rb * 16 + (lane & 15)) * LDH + 4 * (lane >> 4);
+#pragma unroll 4
+        for (int c = 0; c < 16; ++c) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + 16 * c);
+            const float4 w = m.Wl[c * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+        }
+        // C/D layout 16x16: col = lane&15 (link), row = 4(lane>>4) + reg
+        const int j = lane & 15;
+        const float bj = m.bl[j];
+        const bool pad = j >= m.C, ign = (ignored >> j) & 1u;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int r = rb * 16 + 4 * (lane >> 4) + reg;
+            float y = (acc[reg] + bj) / m.out_div - rowRad[r];
+            y = pad ? __builtin_inff() : (ign ? 1e6f : y);
+            y = fminf(y, __shfl_xor(y, 1));
+            y = fminf(y, __shfl_xor(y, 2));
+            y = fminf(y, __shfl_xor(y, 4));
+            y = fminf(y, __shfl_xor(y, 8));
+            if (j == 0 && row0 + r < total_rows) Dmin[row0 + r] = y;
+        }
+    }
+}
+
 // k smallest entries of row[0..O) in ascending order (ties by lower index), one wave per row.
 // emit(j, index) is called by lane 0.  Rows of up to 512 entries are held in registers.
 template <typename Emit>
@@ -127,9 +255,9 @@ constexpr int P2_NT = 512;
 
 struct P2Smem {
     float* Hs;        // [32][LDH]
-    float* P;         // [8][32][33] split-K partials of the first-layer backward
+    float* P;         // [8][32][32] split-K partials of the first-layer backward
     float* gf;        // [32][33] feature gradients
-    uint32_t* maskL;  // [nhh+1][512] ReLU masks, 16 bits per thread and layer
+    uint16_t* maskL;  // [nhh+1][512] ReLU masks, 16 bits per thread and layer
     int* rowT;        // [32] rollout of each row (-1: padding row)
     int* rowO;        // [32] obstacle of each row
     int* rowMin;      // [32] arg-min link of each row
@@ -138,6 +266,7 @@ struct P2Smem {
 // Body of pass 2 for the 32 rows described by sm.rowT / sm.rowO (already in LDS, barrier done by the
 // caller).  R0 = global index of row 0 (tanh scratch, yraw, minidx); outputs go to
 // gradx[(dbase + row) * d + j] and drow[dbase + row] (global memory or LDS).
+template <bool LOWREG = false>
 __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, const float* __restrict__ Apre,
                                            const float* __restrict__ Bpre, const float* __restrict__ radius,
                                            const float* __restrict__ xyzr, int R0, int total_rows,
@@ -148,7 +277,7 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
     float* Hs = sm.Hs;
     float* P = sm.P;
     float* gf = sm.gf;
-    uint32_t* maskL = sm.maskL;
+    uint16_t* maskL = sm.maskL;
     int* rowT = sm.rowT;
     int* rowO = sm.rowO;
     int* rowMin = sm.rowMin;
@@ -170,7 +299,7 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
             Hs[row * LDH + col] = h;
             if (!relu) dscr[(size_t)(S0 + row) * OMDS_WIDTH + col] = 1.f - h * h;
         }
-        maskL[tid] = bits;
+        maskL[tid] = (uint16_t)bits;
     }
     __syncthreads();
 
@@ -191,7 +320,7 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
             Hs[crow(r, lane) * LDH + col] = h;
             if (!relu) dscr[(l + 1) * dlayer + (size_t)(S0 + crow(r, lane)) * OMDS_WIDTH + col] = 1.f - h * h;
         }
-        maskL[(l + 1) * P2_NT + tid] = bits;
+        maskL[(l + 1) * P2_NT + tid] = (uint16_t)bits;
         __syncthreads();
     }
 
@@ -201,17 +330,23 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
         const float* arow = Hs + (wave * 16 + (lane & 15)) * LDH + 4 * (lane >> 4);
         const int j = lane & 15;
         const float bj = m.bl[j];
-        float4 wl[16];   // all 16 weight fragments in flight at once (the chain below is latency-bound otherwise)
+        // weight fragments in flight in batches (all 16 at once unless registers are tight): the chain below is
+        // latency-bound otherwise
+        constexpr int WB = LOWREG ? 4 : 16;
+#pragma unroll 1
+        for (int c0 = 0; c0 < 16; c0 += WB) {
+            float4 wl[WB];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) wl[c] = m.Wl[c * 64 + lane];
+            for (int c = 0; c < WB; ++c) wl[c] = m.Wl[(c0 + c) * 64 + lane];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const float4 a = *reinterpret_cast<const float4*>(arow + 16 * c);
-            const float4 w = wl[c];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+            for (int c = 0; c < WB; ++c) {
+                const float4 a = *reinterpret_cast<const float4*>(arow + 16 * (c0 + c));
+                const float4 w = wl[c];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -286,14 +421,14 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) P[(wave * 32 + crow(r, lane)) * 33 + (lane & 31)] = acc[r];
+        for (int r = 0; r < 16; ++r) P[(wave * 32 + crow(r, lane)) * 32 + (lane & 31)] = acc[r];
     }
     __syncthreads();
     for (int e = tid; e < 32 * 32; e += P2_NT) {
         const int row = e >> 5, f = e & 31;
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) s += P[(w * 32 + row) * 33 + f];
+        for (int w = 0; w < 8; ++w) s += P[(w * 32 + row) * 32 + f];
         gf[row * 33 + f] = s;
     }
     __syncthreads();

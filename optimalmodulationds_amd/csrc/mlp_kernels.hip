@@ -64,134 +64,6 @@ __global__ __launch_bounds__(256) void k_obstacle_layer1(MlpDev m, const float* 
     Bpre[(size_t)o * OMDS_WIDTH + c] = acc;
 }
 
-template <int MT, int MR, int NR>
-struct Geo {
-    static constexpr int WM = MT / (32 * MR);
-    static constexpr int WN = OMDS_NCB / NR;
-    static constexpr int NW = WM * WN;
-    static constexpr int NT = NW * 64;
-    static_assert(WM >= 1 && WN >= 1 && WM * 32 * MR == MT && WN * NR == OMDS_NCB, "bad tile geometry");
-};
-
-// ------------------------------------------------------------------------------------------------
-// pass 1: all (rollout, obstacle) pairs -> min link distance
-// ------------------------------------------------------------------------------------------------
-template <int MT, int MR, int NR, int ACT>
-__device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const float* __restrict__ Apre,
-                                           const float* __restrict__ Bpre, const float* __restrict__ radius, int O,
-                                           long long total_rows, uint32_t ignored, float* __restrict__ Dmin, int tune,
-                                           const long long row0) {
-    using G = Geo<MT, MR, NR>;
-    float* Hs = smem;                                           // [MT][LDH]
-    float* rowRad = smem + MT * LDH;                            // [MT] obstacle radius of each row
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / G::WN, wn = wave % G::WN;
-
-    // ---- layer 1: H1 = act(Apre[t] + Bpre[o]); one float4 per thread and iteration, all loads of the
-    //      tile issued before the first use (the loop is fully unrolled, no 64-bit division per row) -------
-    {
-        constexpr int IT = MT * 64 / G::NT;                     // iterations per thread
-        const long long t0 = row0 / O;                          // wave-uniform, once per workgroup
-        const int o0 = (int)(row0 - t0 * O);
-        const int rows_here = (int)((total_rows - row0 < MT) ? (total_rows - row0) : MT);
-        constexpr int BI = IT < 8 ? IT : 8;                     // loads in flight per thread and batch
-#pragma unroll 1
-        for (int base = 0; base < IT; base += BI) {
-            float4 av[BI], bv[BI];
-            int oo[BI];
-#pragma unroll
-            for (int it = 0; it < BI; ++it) {
-                const int idx = tid + (base + it) * G::NT;
-                const int r = idx >> 6, c4 = idx & 63;
-                const int oq = o0 + r;                          // < O + MT
-                const int dt = oq / O;                          // 32-bit
-                const int o = oq - dt * O;
-                oo[it] = o;
-                if (r < rows_here) {
-                    av[it] = reinterpret_cast<const float4*>(Apre)[(t0 + dt) * 64 + c4];
-                    bv[it] = reinterpret_cast<const float4*>(Bpre)[(size_t)o * 64 + c4];
-                } else {
-                    av[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    bv[it] = av[it];
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < BI; ++it) {
-                const int idx = tid + (base + it) * G::NT;
-                const int r = idx >> 6, c4 = idx & 63;
-                float4 v;
-                v.x = actf(av[it].x + bv[it].x, ACT);
-                v.y = actf(av[it].y + bv[it].y, ACT);
-                v.z = actf(av[it].z + bv[it].z, ACT);
-                v.w = actf(av[it].w + bv[it].w, ACT);
-                if (r >= rows_here) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(Hs + r * LDH + 4 * c4) = v;
-                if (c4 == 0) rowRad[r] = (r < rows_here) ? radius[oo[it]] : 0.f;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- hidden -> hidden layers -----------------------------------------------------------------
-    const float* Hw = Hs + (wm * MR * 32) * LDH;
-    const int cb0 = wn * NR;
-    for (int l = 0; l < m.nhh; ++l) {
-        f32x16 acc[MR][NR];
-#pragma unroll
-        for (int i = 0; i < MR; ++i)
-#pragma unroll
-            for (int j = 0; j < NR; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        float bvj[NR];   // biases fetched before the GEMM so that the epilogue does not start with an L2 round trip
-#pragma unroll
-        for (int j = 0; j < NR; ++j) bvj[j] = m.bh[l * OMDS_WIDTH + (cb0 + j) * 32 + (lane & 31)];
-        gemm256<MR, NR>(Hw, m.Wf + (size_t)l * (OMDS_NCB * 32 * 64), cb0, lane, acc, (tune & 1) != 0);
-        __syncthreads();  // every wave has finished reading the tile
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            const int col = (cb0 + j) * 32 + (lane & 31);
-            const float bv = bvj[j];
-#pragma unroll
-            for (int i = 0; i < MR; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    Hs[((wm * MR + i) * 32 + crow(r, lane)) * LDH + col] = actf(acc[i][j][r] + bv, ACT);
-        }
-        __syncthreads();
-    }
-
-    // ---- last layer (256 -> C, padded to 16) on v_mfma_f32_16x16x4_f32, 16 rows per wave ----------
-    for (int rb = wave; rb < MT / 16; rb += G::NW) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* arow = Hs + (rb * 16 + (lane & 15)) * LDH + 4 * (lane >> 4);
-#pragma unroll 4
-        for (int c = 0; c < 16; ++c) {
-            const float4 a = *reinterpret_cast<const float4*>(arow + 16 * c);
-            const float4 w = m.Wl[c * 64 + lane];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
-        }
-        // C/D layout 16x16: col = lane&15 (link), row = 4(lane>>4) + reg
-        const int j = lane & 15;
-        const float bj = m.bl[j];
-        const bool pad = j >= m.C, ign = (ignored >> j) & 1u;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int r = rb * 16 + 4 * (lane >> 4) + reg;
-            float y = (acc[reg] + bj) / m.out_div - rowRad[r];
-            y = pad ? __builtin_inff() : (ign ? 1e6f : y);
-            y = fminf(y, __shfl_xor(y, 1));
-            y = fminf(y, __shfl_xor(y, 2));
-            y = fminf(y, __shfl_xor(y, 4));
-            y = fminf(y, __shfl_xor(y, 8));
-            if (j == 0 && row0 + r < total_rows) Dmin[row0 + r] = y;
-        }
-    }
-}
-
 template <int MT, int MR, int NR, int ACT>
 __global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const float* __restrict__ Apre,
                                                                const float* __restrict__ Bpre,
@@ -249,8 +121,8 @@ __global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restri
     sm.Hs = smem;
     sm.P = sm.Hs + P2_MT * LDH;
     sm.gf = sm.P + 8 * 32 * 33;
-    sm.maskL = reinterpret_cast<uint32_t*>(sm.gf + 32 * 33);
-    sm.rowT = reinterpret_cast<int*>(sm.maskL + (m.nhh + 1) * P2_NT);
+    sm.maskL = reinterpret_cast<uint16_t*>(sm.gf + 32 * 33);
+    sm.rowT = reinterpret_cast<int*>(sm.maskL + ((m.nhh + 2) / 2 * 2) * P2_NT);
     sm.rowO = sm.rowT + P2_MT;
     sm.rowMin = sm.rowO + P2_MT;
     const int tid = threadIdx.x;

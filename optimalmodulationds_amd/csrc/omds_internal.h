@@ -38,6 +38,8 @@ struct ProfEvents {
     size_t used = 0;
     double ms = 0.0;
     int64_t launches = 0, rows = 0;
+    double flops = 0.0;          // algorithmic FLOPs of the bracketed launches
+    const char* kernel = "k_pass1";
 };
 
 struct omds_ctx {
@@ -51,6 +53,7 @@ struct omds_ctx {
     MlpDev mlp{};
     std::vector<void*> mlp_allocs;
     int act = OMDS_ACT_RELU;
+    double f_fwd = 0.0, f_bwd = 0.0;   // algorithmic FLOPs of one network forward / backward row
     // scene
     int n_obs = 0;
     float* d_obs = nullptr;      // [max_obs][4]

@@ -21,18 +21,17 @@ __device__ __forceinline__ float gsig(float x, const float* s) {
 // One rollout t, handled by NSUB cooperating lanes (sub = 0..NSUB-1, consecutive lanes of one wave): every
 // lane evaluates the scalar part redundantly, the loop over the K navigation kernels is strided over the
 // lanes and its policy sum is combined with shuffles; lane 0 writes the per-rollout outputs.  gradx/drow
-// hold the k gradient rows of this rollout starting at row grow0 (global memory or LDS).  q_next receives
+// hold the k gradient rows of this rollout starting at row grow0 (global memory or LDS).  q_in is the state
+// all_traj[t, i-1]; q_next receives
 // the integrated state (all lanes).
 template <int ND, int NSUB>
-__device__ __forceinline__ void modulate_core(const StepArgs& a, int t, int sub, const float* gradx, const float* drow,
-                                              int grow0, float (&q_next)[ND]) {
+__device__ __forceinline__ void modulate_core(const StepArgs& a, const int i, int t, int sub, const float* gradx, const float* drow,
+                                              int grow0, const float (&q_in)[ND], float (&q_next)[ND]) {
     const int N = a.N;
-    const int i = a.step;
     const omds_params& p = a.prm;
     float q[ND], v[ND], vhat[ND], g[ND], vt[ND], u[ND], pol[ND];
-    const float* qp = a.trajT + (size_t)(i - 1) * ND * N;
 #pragma unroll
-    for (int j = 0; j < ND; ++j) q[j] = qp[(size_t)j * N + t];
+    for (int j = 0; j < ND; ++j) q[j] = q_in[j];
 
     // nominal DS (LinDS.py:11-21) and its norm (MPPI.py:106-108)
     float dst2 = 0.f;

@@ -29,8 +29,8 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
     sm.Hs = smem;
     sm.P = sm.Hs + P2_MT * LDH;
     sm.gf = sm.P + 8 * 32 * 33;
-    sm.maskL = reinterpret_cast<uint32_t*>(sm.gf + 32 * 33);
-    sm.rowT = reinterpret_cast<int*>(sm.maskL + (m.nhh + 1) * P2_NT);
+    sm.maskL = reinterpret_cast<uint16_t*>(sm.gf + 32 * 33);
+    sm.rowT = reinterpret_cast<int*>(sm.maskL + ((m.nhh + 2) / 2 * 2) * P2_NT);
     sm.rowO = sm.rowT + P2_MT;
     sm.rowMin = sm.rowO + P2_MT;
     float* gx = reinterpret_cast<float*>(sm.rowMin + P2_MT);   // [32][d]
@@ -64,8 +64,10 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
         const int rl = tid >> 4, sub = tid & 15;
         const int t = t_base + rl;
         if (rl < RW && t < N) {
-            float qn[ND];
-            modulate_core<ND, 16>(a.st, t, sub, gx, dr, rl * k, qn);
+            float q[ND], qn[ND];
+#pragma unroll
+            for (int j = 0; j < ND; ++j) q[j] = qT[(size_t)j * N + t];
+            modulate_core<ND, 16>(a.st, a.st.step, t, sub, gx, dr, rl * k, q, qn);
             if (sub < ND) {
                 float v = qn[0];
 #pragma unroll

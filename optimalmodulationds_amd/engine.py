@@ -203,6 +203,15 @@ class Engine:
         return ms.value, nl.value, nr.value
 
 
+def _prof_read_ex(self):
+    ms, nl, fl, name = C.c_double(), C.c_int64(), C.c_double(), C.c_char_p()
+    self._ck(self.lib.omds_prof_read_ex(self.h, C.byref(ms), C.byref(nl), C.byref(fl), C.byref(name)))
+    return ms.value, nl.value, fl.value, (name.value or b"").decode()
+
+
+Engine.prof_read_ex = _prof_read_ex
+
+
 def red_layout(K, n):
     """Offsets into the packed reduction buffer (include/omds.h, omds_local_sums)."""
     o_mu = 1
