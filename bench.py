@@ -32,6 +32,10 @@ WORKLOADS = {
                                  sigma=1.0, ignored=[0, 1, 2]),
     "planar7_1024x32": dict(kind="planar7", N=1024, H=32, dt=0.3, k=1, dst_thr=0.25, ker_thr=1e-3, alpha_s=0.75,
                             sigma=0.5, ignored=[]),
+    # BASELINE configs[4] per GPU: the obstacle set is replaced every iteration (update_obstacles), kernel
+    # normals are re-evaluated (update_kernel_normal_bases) and kernel candidates are searched on the device
+    "franka_dynamic_1024x32": dict(kind="franka", N=1024, H=32, dt=0.5, k=5, dst_thr=0.01, ker_thr=0.1, alpha_s=3.0,
+                                   sigma=1.0, ignored=[0, 1, 2], dynamic=True),
 }
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 FLOP/clk
 
@@ -127,12 +131,22 @@ def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, di
 
     def iteration(it):
         nonlocal mu_c, sg_c, al_c, q_cur
+        if w.get("dynamic"):
+            # shelf translated by a slow sinusoid (the obstacle streamer's mechanism, obstacleStreamer.py:120-142),
+            # then distance/normal at the K kernel centres (MPPI.update_kernel_normal_bases, MPPI.py:284-304)
+            moved = obs.copy()
+            moved[:, 1] += 0.05 * np.sin(0.3 * it)
+            eng.set_obstacles(moved)
+            if K:
+                eng.dist_grad(mu_c)
         eng.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, w["alpha_s"], K, seed=1234 * 1000003 + it, rollout_offset=rank * N)
         eng.propagate(q_cur)
         eng.cost(fetch=False)
         mu_c, sg_c, al_c, mask, qd_w, qd_best = sharded_update(eng.cost_sum, eng.local_sums, K, n, H, 0.1, w["ker_thr"],
                                                                mu_c, sg_c, al_c)
         q_cur = (q_cur + 0.1 * w["dt"] * qd_best).astype(np.float32)   # drift along the best rollout: non-degenerate states
+        if w.get("dynamic"):   # Policy.check_traj_for_kernels on the device (policy.py:153-175); only candidates cross PCIe
+            eng.kernel_candidates(0.03 - w["dst_thr"], 0.3, -0.9, mu_c, sg_c, K, cap=256)
 
     def barrier():
         if use_dist:
