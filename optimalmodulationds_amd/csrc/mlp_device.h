@@ -266,14 +266,14 @@ struct P2Smem {
 // Body of pass 2 for the 32 rows described by sm.rowT / sm.rowO (already in LDS, barrier done by the
 // caller).  R0 = global index of row 0 (tanh scratch, yraw, minidx); outputs go to
 // gradx[(dbase + row) * d + j] and drow[dbase + row] (global memory or LDS).
-template <bool LOWREG = false>
+template <int ACT, bool LOWREG = false>
 __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, const float* __restrict__ Apre,
                                            const float* __restrict__ Bpre, const float* __restrict__ radius,
                                            const float* __restrict__ xyzr, int R0, int total_rows,
                                            const float* __restrict__ qT, int ldq, float* gradx, float* drow, int dbase,
                                            float* __restrict__ yraw, int32_t* __restrict__ minidx,
-                                           float* __restrict__ dscr, size_t dlayer, int S0) {
-    // S0 = first row of this workgroup's private 32-row slot in the tanh scratch
+                                           float* __restrict__ dscr, size_t dlayer, int S0, int dbg = 0) {
+    // dbg: timing experiments only (return after a stage).  S0 = first row of this workgroup's private 32-row slot in the tanh scratch
     float* Hs = sm.Hs;
     float* P = sm.P;
     float* gf = sm.gf;
@@ -283,25 +283,32 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
     int* rowMin = sm.rowMin;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = wave * 32 + (lane & 31);
-    const bool relu = m.act == OMDS_ACT_RELU;
+    constexpr bool relu = ACT == OMDS_ACT_RELU;
 
     // ---- layer 1 in C-layout ------------------------------------------------------------------
     {
         uint32_t bits = 0;
+        float za[16], zb[16];   // all 32 loads in flight before the first use (padding rows read row 0)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = crow(r, lane);
             const int t = rowT[row];
-            float z = 0.f;
-            if (t >= 0) z = Apre[(size_t)t * OMDS_WIDTH + col] + Bpre[(size_t)rowO[row] * OMDS_WIDTH + col];
+            za[r] = Apre[(size_t)(t < 0 ? 0 : t) * OMDS_WIDTH + col];
+            zb[r] = Bpre[(size_t)rowO[row] * OMDS_WIDTH + col];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = crow(r, lane);
+            const float z = (rowT[row] >= 0) ? za[r] + zb[r] : 0.f;
             bits |= (z > 0.f ? 1u : 0u) << r;
-            const float h = actf(z, m.act);
+            const float h = actf(z, ACT);
             Hs[row * LDH + col] = h;
             if (!relu) dscr[(size_t)(S0 + row) * OMDS_WIDTH + col] = 1.f - h * h;
         }
         maskL[tid] = (uint16_t)bits;
     }
     __syncthreads();
+    if (dbg == 10) return;
 
     // ---- forward through the hidden -> hidden layers -------------------------------------------
     for (int l = 0; l < m.nhh; ++l) {
@@ -316,7 +323,7 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
         for (int r = 0; r < 16; ++r) {
             const float z = acc[0][0][r] + bv;
             bits |= (z > 0.f ? 1u : 0u) << r;
-            const float h = actf(z, m.act);
+            const float h = actf(z, ACT);
             Hs[crow(r, lane) * LDH + col] = h;
             if (!relu) dscr[(l + 1) * dlayer + (size_t)(S0 + crow(r, lane)) * OMDS_WIDTH + col] = 1.f - h * h;
         }
@@ -324,6 +331,7 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
         __syncthreads();
     }
 
+    if (dbg == 11) return;
     // ---- last layer, arg-min over ALL raw outputs (robot_sdf.py:155), distance of that link -------
     if (wave < P2_MT / 16) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -372,6 +380,7 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
         }
     }
     __syncthreads();
+    if (dbg == 12) return;
 
     // ---- backward seed: dy[minIdx]/dH_last = Wlast[minIdx], masked by the last hidden layer ---------
     {
@@ -386,6 +395,7 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
         }
     }
     __syncthreads();
+    if (dbg == 13) return;
 
     // ---- backward through the hidden -> hidden layers ------------------------------------------
     for (int l = m.nhh - 1; l >= 0; --l) {
@@ -404,6 +414,7 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
         __syncthreads();
     }
 
+    if (dbg == 14) return;
     // ---- first layer backward: g_f[row][f] = sum_c Gz1[row][c] W1[c][f], split-K over the 8 waves -------
     {
         f32x16 acc;
@@ -424,6 +435,7 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
         for (int r = 0; r < 16; ++r) P[(wave * 32 + crow(r, lane)) * 32 + (lane & 31)] = acc[r];
     }
     __syncthreads();
+    if (dbg == 15) return;
     for (int e = tid; e < 32 * 32; e += P2_NT) {
         const int row = e >> 5, f = e & 31;
         float s = 0.f;

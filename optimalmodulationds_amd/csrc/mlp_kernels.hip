@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void k_topk(const float* __restrict__ Dmin, in
 // wave w owns output columns [32w, 32w+32). ReLU masks live in LDS as 16 bits per thread/layer
 // in the MFMA C-layout (the same lane owns the same (row, col) in every layer).
 // ------------------------------------------------------------------------------------------------
+template <int ACT>
 __global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restrict__ Apre,
                                                  const float* __restrict__ Bpre, const float* __restrict__ radius,
                                                  const float* __restrict__ xyzr, const int32_t* __restrict__ idx,
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restri
         sm.rowO[tid] = o;
     }
     __syncthreads();
-    pass2_body(m, sm, Apre, Bpre, radius, xyzr, R0, total_rows, qT, ldq, gradx, drow, R0, yraw, minidx, dscr,
+    pass2_body<ACT>(m, sm, Apre, Bpre, radius, xyzr, R0, total_rows, qT, ldq, gradx, drow, R0, yraw, minidx, dscr,
                (size_t)gridDim.x * P2_MT * OMDS_WIDTH, R0);
 }
 
@@ -260,15 +261,20 @@ void omds_launch_pass2(hipStream_t s, const MlpDev& m, const float* Apre, const 
     const int total = B * k;
     if (total <= 0) return;
     const size_t lds = ((size_t)P2_MT * LDH + 8 * 32 * 33 + 32 * 33) * 4 + (size_t)(m.nhh + 1) * P2_NT * 4 + 3 * P2_MT * 4;
+    const int maxlds = (int)(((size_t)P2_MT * LDH + 8 * 32 * 33 + 32 * 33) * 4 + (size_t)(OMDS_MAX_HIDDEN + 1) * P2_NT * 4 + 3 * P2_MT * 4);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(((size_t)P2_MT * LDH + 8 * 32 * 33 + 32 * 33) * 4 +
-                                        (size_t)(OMDS_MAX_HIDDEN + 1) * P2_NT * 4 + 3 * P2_MT * 4));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<OMDS_ACT_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<OMDS_ACT_TANH>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_pass2, dim3((total + P2_MT - 1) / P2_MT), dim3(P2_NT), lds, s, m, Apre, Bpre, radius, xyzr,
-                       idx, total, k, qT, ldq, gradx, drow, yraw, minidx, dscr);
+    const dim3 grid((total + P2_MT - 1) / P2_MT);
+    if (m.act == OMDS_ACT_RELU)
+        hipLaunchKernelGGL(k_pass2<OMDS_ACT_RELU>, grid, dim3(P2_NT), lds, s, m, Apre, Bpre, radius, xyzr, idx, total, k, qT, ldq,
+                           gradx, drow, yraw, minidx, dscr);
+    else
+        hipLaunchKernelGGL(k_pass2<OMDS_ACT_TANH>, grid, dim3(P2_NT), lds, s, m, Apre, Bpre, radius, xyzr, idx, total, k, qT, ldq,
+                           gradx, drow, yraw, minidx, dscr);
 }
 
 void omds_launch_blend(hipStream_t s, const float* gradx, const float* drow, int B, int k, int d, int n,

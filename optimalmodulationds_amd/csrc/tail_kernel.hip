@@ -21,7 +21,7 @@ struct TailArgs {
     StepArgs st;
 };
 
-template <int ND>
+template <int ND, int ACT>
 __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const MlpDev& m = a.m;
@@ -54,8 +54,8 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
 
     // ---- forward + backward on the selected rows; gradients and distances stay in LDS ------------
     const float* qT = a.st.trajT + (size_t)(a.st.step - 1) * ND * N;
-    pass2_body(m, sm, a.Apre, a.Bpre, a.radius, a.xyzr, t_base * k, N * k, qT, N, gx, dr, 0, nullptr, nullptr, a.dscr,
-               (size_t)gridDim.x * P2_MT * OMDS_WIDTH, blockIdx.x * P2_MT);
+    pass2_body<ACT>(m, sm, a.Apre, a.Bpre, a.radius, a.xyzr, t_base * k, N * k, qT, N, gx, dr, 0, nullptr, nullptr, a.dscr,
+               (size_t)gridDim.x * P2_MT * OMDS_WIDTH, blockIdx.x * P2_MT, a.dbg_stop);
     __syncthreads();
     if (a.dbg_stop == 2) return;
 
@@ -105,16 +105,22 @@ static size_t tail_lds_bytes(int nhid) {
            (32 * 12 + 32 + 32 * 3 * OMDS_MAX_DOF) * 4;
 }
 
-template <int ND>
-static void launch_tail_t(hipStream_t s, const TailArgs& a) {
+template <int ND, int ACT>
+static void launch_tail_a(hipStream_t s, const TailArgs& a) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<ND>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<ND, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)tail_lds_bytes(OMDS_MAX_HIDDEN + 1));
         attr_set = true;
     }
     const int RW = P2_MT / a.st.k;
-    hipLaunchKernelGGL(k_tail<ND>, dim3((a.st.N + RW - 1) / RW), dim3(P2_NT), tail_lds_bytes(a.m.nhh + 1), s, a);
+    hipLaunchKernelGGL((k_tail<ND, ACT>), dim3((a.st.N + RW - 1) / RW), dim3(P2_NT), tail_lds_bytes(a.m.nhh + 1), s, a);
+}
+
+template <int ND>
+static void launch_tail_t(hipStream_t s, const TailArgs& a) {
+    if (a.m.act == OMDS_ACT_RELU) launch_tail_a<ND, OMDS_ACT_RELU>(s, a);
+    else launch_tail_a<ND, OMDS_ACT_TANH>(s, a);
 }
 
 bool omds_tail_supported(int n_dof, int k) { return (n_dof == 7 || n_dof == 2) && k >= 1 && k <= P2_MT; }
