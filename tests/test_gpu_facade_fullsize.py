@@ -293,3 +293,20 @@ def test_ragged_and_large_shapes(N, H, k, O):
         if h + 1 < H:
             assert_close((r["all_traj"][sel, h + 1] - q)[ok] / 0.5, st["u"][ok], 5e-4, f"velocity h={h}")
     eng.close()
+
+
+def test_example_drivers_run():
+    """examples/: the reference's two driver loops (Franka planner, planar 2-DoF stand-alone) on the facade."""
+    import importlib.util
+    import os
+    from helpers import ROOT
+    mods = {}
+    for name in ("franka_planner_loop", "standalone_planar2d"):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "examples", name + ".py"))
+        mods[name] = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mods[name])
+    mppi = mods["franka_planner_loop"].main(iters=6, n_traj=128, horizon=8, moving=True, quiet=True)
+    assert torch.isfinite(mppi.q_cur).all() and mppi.Policy.n_kernels <= 6
+    mppi2, n_iter = mods["standalone_planar2d"].main(max_iter=60, quiet=True)
+    d0 = float(torch.norm(torch.tensor([-3.14, 0.0]) - torch.tensor([3.14, 0.0])))
+    assert float(torch.norm(mppi2.q_cur - torch.tensor([3.14, 0.0]))) < d0        # it moves towards the goal

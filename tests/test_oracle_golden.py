@@ -117,3 +117,33 @@ def test_propagate_cost_update(name):
                      RTOL, "weighted qdot")
         assert_close(orc.get_qdot(fx[pre + "cost"], fx[pre + "qdot"], "best"), fx[pre + "qdot_best"],
                      RTOL, "best qdot")
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_kernel_candidates_and_add_kernel(name):
+    """check_traj_for_kernels / add_kernel (policy.py:129-175) as captured from the reference: the oracle
+    and the facade's host-side bookkeeping reproduce the candidate list (same order) and the policy
+    after adding the candidate closest to q_cur."""
+    import torch
+    from optimalmodulationds_amd.policy import TensorPolicyMPPI
+    fx = load(name)
+    K, n, N = int(fx["K"]), fx["q0"].shape[0], int(fx["N"])
+    thr = fx["cand_thr"]
+    want = fx["cand_q"]
+    got = orc.check_traj_for_kernels(fx["it0_all_traj"], fx["it0_closest_dist_all"], fx["it0_dot_products"], fx["it0_mu_c"],
+                                     fx["it0_sigma_c"], thr[0], thr[1], thr[2], int(fx["p"]))
+    assert got.shape == want.shape and np.array_equal(got, want)
+    P = TensorPolicyMPPI(N, n)
+    P.n_kernels = K
+    P.mu_c[:K] = torch.from_numpy(fx["it0_mu_c"]); P.sigma_c[:K] = torch.from_numpy(fx["it0_sigma_c"])
+    P.alpha_c[:K] = torch.from_numpy(fx["it0_alpha_c"]); P.p = int(fx["p"])
+    c2 = P.check_traj_for_kernels(torch.from_numpy(fx["it0_all_traj"]), torch.from_numpy(fx["it0_closest_dist_all"]),
+                                  torch.from_numpy(fx["it0_dot_products"]), float(thr[0]), float(thr[1]), float(thr[2]))
+    assert np.array_equal(c2.numpy(), want)
+    if "add_mu_c" in fx:
+        ci, ti, hi = (int(x) for x in fx["add_idx"])
+        P.sigma_c_nominal = float(fx["add_sigma_c"][-1])
+        P.add_kernel(c2[ci], fx["it0_closest_dist_all"][ti, hi], fx["add_basis"][-1])
+        assert P.n_kernels == int(fx["add_n_kernels"]) == K + 1
+        assert np.array_equal(P.mu_c[:K + 1].numpy(), fx["add_mu_c"]) and np.array_equal(P.alpha_c[:K + 1].numpy(), fx["add_alpha_c"])
+        assert np.array_equal(P.sigma_c[:K + 1].numpy(), fx["add_sigma_c"]) and np.array_equal(P.kernel_gammas[:K + 1].numpy(), fx["add_gammas"])

@@ -187,6 +187,27 @@ def run_scenario(name, kind, nn_model, *, N, H, dt, obs, k, q0, qf, dst_thr, ker
         fx[pre + "w"] = t2n(w)
         fx[pre + "qdot_weighted"] = t2n(mppi.get_qdot("weighted"))
         fx[pre + "qdot_best"] = t2n(mppi.get_qdot("best"))
+        # kernel-candidate search + kernel adding exactly as the planner does it (frankaPlanner.py:147-163),
+        # on a COPY of the policy so that the scenario itself is not perturbed
+        if it == 0:
+            # thresholds at the medians of this scenario's own data, so that the candidate set is neither empty
+            # nor everything (the drivers' -0.9 dot threshold selects almost nothing in such short runs)
+            thr = (float(np.nanmedian(t2n(dist_all))), 0.5, float(np.nanmedian(t2n(dots))) if not np.isnan(t2n(dots)).all() else 0.0)
+            cands = P.check_traj_for_kernels(all_traj, dist_all, dots, thr[0], thr[1], thr[2])
+            fx["cand_thr"] = np.array(thr, np.float32)
+            fx["cand_q"] = t2n(cands)
+            if len(cands) > 0:
+                import copy
+                P2 = copy.deepcopy(P)
+                norm, closest_idx = torch.norm(cands - mppi.q_cur, 2, -1).min(dim=0)
+                idx_i, idx_h = torch.where((all_traj == cands[closest_idx]).all(dim=-1))
+                with quiet():
+                    P2.add_kernel(cands[closest_idx], dist_all[idx_i[0], idx_h[0]], mppi.norm_basis[idx_i[0], idx_h[0]].squeeze())
+                fx["add_idx"] = np.array([int(closest_idx), int(idx_i[0]), int(idx_h[0])], np.int32)
+                fx["add_n_kernels"] = int(P2.n_kernels)
+                fx["add_mu_c"] = t2n(P2.mu_c[:P2.n_kernels]); fx["add_sigma_c"] = t2n(P2.sigma_c[:P2.n_kernels])
+                fx["add_alpha_c"] = t2n(P2.alpha_c[:P2.n_kernels]); fx["add_gammas"] = t2n(P2.kernel_gammas[:P2.n_kernels])
+                fx["add_basis"] = t2n(P2.kernel_obstacle_bases[:P2.n_kernels])
         with quiet():
             _, n_upd = mppi.shift_policy_means()
         fx[pre + "n_updated"] = int(n_upd)
