@@ -106,7 +106,7 @@ def cpu_baseline(w, W, b, obs, q0, qf, K, seed):
             "sample": f"numpy oracle propagate, {Ns} rollouts x {Hs} steps x {obs.shape[0]} obstacles, {reps} reps in {el:.1f}s"}
 
 
-def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, dist, torch, time_fetch=False):
+def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, dist, torch, time_fetch=False, prof=True):
     """Times `steps` planner iterations of `workload` on this rank's GPU; returns a dict of raw numbers."""
     from optimalmodulationds_amd.dist import sharded_update
     from optimalmodulationds_amd.engine import Engine
@@ -155,7 +155,7 @@ def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, di
 
     for it in range(warmup):
         iteration(it)
-    eng.prof_enable(True)
+    eng.prof_enable(prof)     # per-launch HIP events around the dominant kernel (keeps a batch on ONE stream)
     eng.prof_reset()
     barrier()
     t0 = time.perf_counter()
@@ -224,7 +224,7 @@ def main():
     also = None
     if not args.no_secondary and args.workload != "planar7_1024x32":
         # BASELINE.json configs[1] (planar 7-DoF, 1024 x 32, 8 obstacles): a launch-latency-bound shape, reported beside
-        r2 = measure(args, "planar7_1024x32", 5, 1, rank, world, local_rank, use_dist, dist, torch)
+        r2 = measure(args, "planar7_1024x32", 5, 1, rank, world, local_rank, use_dist, dist, torch, prof=False)
         also = {"workload": "planar7_1024x32", "value": world * r2["N"] * r2["H"] * 5 / r2["el"], "unit": "rollout-steps/s",
                 "ms_per_step": 1e3 * r2["el"] / 5}
     if rank == 0:

@@ -476,7 +476,9 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
     static int fused = -1;   // OMDS_FUSED_TAIL=0 selects the five-kernel step (kept for A/B runs and as the generic path)
     if (fused < 0) { const char* e = getenv("OMDS_FUSED_TAIL"); fused = e ? atoi(e) : 1; }
     if (fused && omds_tail_supported(n, a.k)) {
-        // two launches per step: k_pass1 over all (rollout, obstacle) pairs, then the rollout-local tail
+        // two launches per step: k_pass1 over all (rollout, obstacle) pairs, then the rollout-local tail.
+        // (Splitting small batches into independent rollout groups on separate HIP streams was measured and
+        // rejected: planar7_1024x32 ran 9.0 M rollout-steps/s on one stream, 7.1 / 3.3 / 2.4 M on 2 / 4 / 8.)
         omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, ctx->d_Apre);
         for (int i = 1; i <= H; ++i) {
             if ((rc = prof_begin(ctx))) return rc;
@@ -485,7 +487,7 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
             if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs))) return rc;
             a.step = i;
             omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, ctx->d_Apre,
-                             ctx->d_dscr, ctx->n_obs, a);
+                             ctx->d_dscr, ctx->n_obs, a, 0, N);
         }
     } else {
         for (int i = 1; i <= H; ++i) {   // MPPI.py:101: H network evaluations, the last velocity is not integrated

@@ -147,8 +147,9 @@ void omds_launch_modulate(hipStream_t s, const StepArgs& a);
 // fused per-step tail (tail_kernel.hip): top-k + pass 2 + blend + modulation + next-step layer-1 half
 bool omds_tail_supported(int n_dof, int k);
 int omds_tail_workgroups(int N, int k);
+int omds_tail_rollouts_per_wg(int k);
 void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
-                      const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st);
+                      const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st, int t_begin, int t_end);
 struct CostArgs {
     int N, H, n;
     const float* trajT; const float* distT; float* cost;

@@ -17,6 +17,9 @@ struct TailArgs {
     float* Apre;         // [N][256] in: this step, out: next step (rows of the workgroup's own rollouts)
     float* dscr;         // tanh derivative scratch
     int O;
+    int t_begin, t_end;  // rollout range of this launch (a group of the rollouts; the whole batch = [0, N))
+    int slot0;           // first 32-row slot of this launch in the tanh scratch
+    int n_slots;         // slots of the whole batch (scratch stride between layers)
     int dbg_stop;        // timing experiments only (OMDS_TAIL_STOP): return after phase 1 / 2 / 3
     StepArgs st;
 };
@@ -39,14 +42,15 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.st.N, k = a.st.k, O = a.O;
     const int RW = P2_MT / k;                 // rollouts per workgroup
-    const int t_base = blockIdx.x * RW;
+    const int t_base = a.t_begin + blockIdx.x * RW;
+    const int t_end = a.t_end;
 
     // ---- top-k of each rollout's min-distance row (ascending, ties by lower obstacle index) -------
     if (tid < P2_MT) { sm.rowT[tid] = -1; sm.rowO[tid] = 0; }
     __syncthreads();
     for (int rl = wave; rl < RW; rl += 8) {
         const int t = t_base + rl;
-        if (t >= N) break;
+        if (t >= t_end) break;
         topk_row(a.Dmin + (size_t)t * O, O, k, lane, [&](int j, int bi) { sm.rowT[rl * k + j] = t; sm.rowO[rl * k + j] = bi; });
     }
     __syncthreads();
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
     // ---- forward + backward on the selected rows; gradients and distances stay in LDS ------------
     const float* qT = a.st.trajT + (size_t)(a.st.step - 1) * ND * N;
     pass2_body<ACT>(m, sm, a.Apre, a.Bpre, a.radius, a.xyzr, t_base * k, N * k, qT, N, gx, dr, 0, nullptr, nullptr, a.dscr,
-               (size_t)gridDim.x * P2_MT * OMDS_WIDTH, blockIdx.x * P2_MT, a.dbg_stop);
+               (size_t)a.n_slots * P2_MT * OMDS_WIDTH, (a.slot0 + (int)blockIdx.x) * P2_MT, a.dbg_stop);
     __syncthreads();
     if (a.dbg_stop == 2) return;
 
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
     {
         const int rl = tid >> 4, sub = tid & 15;
         const int t = t_base + rl;
-        if (rl < RW && t < N) {
+        if (rl < RW && t < t_end) {
             float q[ND], qn[ND];
 #pragma unroll
             for (int j = 0; j < ND; ++j) q[j] = qT[(size_t)j * N + t];
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
         const int c = tid & 255, d = m.d;
         for (int rl = tid >> 8; rl < RW; rl += 2) {
             const int t = t_base + rl;
-            if (t >= N) break;
+            if (t >= t_end) break;
             const float* f = feat + rl * 3 * ND;
             float acc = m.b1[c];
 #pragma unroll
@@ -114,7 +118,7 @@ static void launch_tail_a(hipStream_t s, const TailArgs& a) {
         attr_set = true;
     }
     const int RW = P2_MT / a.st.k;
-    hipLaunchKernelGGL((k_tail<ND, ACT>), dim3((a.st.N + RW - 1) / RW), dim3(P2_NT), tail_lds_bytes(a.m.nhh + 1), s, a);
+    hipLaunchKernelGGL((k_tail<ND, ACT>), dim3((a.t_end - a.t_begin + RW - 1) / RW), dim3(P2_NT), tail_lds_bytes(a.m.nhh + 1), s, a);
 }
 
 template <int ND>
@@ -127,9 +131,15 @@ bool omds_tail_supported(int n_dof, int k) { return (n_dof == 7 || n_dof == 2) &
 
 int omds_tail_workgroups(int N, int k) { const int RW = P2_MT / k; return (N + RW - 1) / RW; }
 
+int omds_tail_rollouts_per_wg(int k) { return P2_MT / k; }
+
 void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
-                      const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st) {
+                      const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st, int t_begin, int t_end) {
     TailArgs a;
+    const int RW = P2_MT / st.k;
+    a.t_begin = t_begin; a.t_end = t_end;          // t_begin must be a multiple of RW
+    a.slot0 = t_begin / RW;
+    a.n_slots = (st.N + RW - 1) / RW;
     static int stop = -1;
     if (stop < 0) { const char* e = getenv("OMDS_TAIL_STOP"); stop = e ? atoi(e) : 0; }
     a.dbg_stop = stop;
