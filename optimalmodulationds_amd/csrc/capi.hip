@@ -184,11 +184,34 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
     const int nhid = n_linear - 1;
     REQUIRE(nhid <= OMDS_MAX_HIDDEN, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: too many hidden layers");
     for (int i = 1; i <= nhid; ++i)
-        REQUIRE(dims[i] == OMDS_WIDTH, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: only hidden width 256 is supported by the MFMA kernels");
+        REQUIRE(dims[i] >= 1 && dims[i] <= OMDS_WIDTH, OMDS_ERR_UNSUPPORTED,
+                "omds_set_mlp: hidden widths above 256 are not supported by the MFMA kernels (narrower layers are zero-padded to width 256)");
     const int C = dims[n_linear];
     REQUIRE(C >= 1 && C <= OMDS_CPAD, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: 1 <= out_channels <= 16 required");
     REQUIRE(act == OMDS_ACT_RELU || act == OMDS_ACT_TANH, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: act must be OMDS_ACT_RELU or OMDS_ACT_TANH");
     REQUIRE(out_div != 0.f, OMDS_ERR_INVALID_ARG, "omds_set_mlp: out_div must be non-zero");
+    // Narrower hidden layers (the reference also ships 128-wide nets) are zero-padded to the kernels' width:
+    // padded units have zero weights and biases on both sides, so relu/tanh(0) = 0 feeds nothing forward and
+    // receives no gradient -- outputs and gradients are unchanged (the padded MFMA work is wasted, not wrong).
+    std::vector<std::vector<float>> Wpad(n_linear), bpad(n_linear);
+    std::vector<const float*> Wp(n_linear), bp(n_linear);
+    std::vector<int32_t> pdims(dims, dims + n_linear + 1);
+    for (int i = 1; i <= nhid; ++i) pdims[i] = OMDS_WIDTH;
+    for (int i = 0; i < n_linear; ++i) {
+        const int in = dims[i], out = dims[i + 1], pin = pdims[i], pout = pdims[i + 1];
+        Wpad[i].assign((size_t)pout * pin, 0.f);
+        bpad[i].assign((size_t)pout, 0.f);
+        for (int o = 0; o < out; ++o) {
+            std::memcpy(&Wpad[i][(size_t)o * pin], &W[i][(size_t)o * in], (size_t)in * sizeof(float));
+            bpad[i][o] = b[i][o];
+        }
+        Wp[i] = Wpad[i].data();
+        bp[i] = bpad[i].data();
+    }
+    const int32_t* true_dims = dims;
+    dims = pdims.data();
+    W = Wp.data();
+    b = bp.data();
     CK(hipSetDevice(ctx->dev));
     CK(hipStreamSynchronize(ctx->stream));
     for (void* p : ctx->mlp_allocs) (void)hipFree(p);
@@ -265,8 +288,8 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
     ctx->mlp = m;
     ctx->act = act;
     ctx->f_fwd = 0.0;
-    for (int i = 0; i < n_linear; ++i) ctx->f_fwd += 2.0 * dims[i] * dims[i + 1];
-    ctx->f_bwd = ctx->f_fwd - 2.0 * dims[n_linear - 1] * dims[n_linear];   // no weight-gradient, no last-layer GEMM
+    for (int i = 0; i < n_linear; ++i) ctx->f_fwd += 2.0 * true_dims[i] * true_dims[i + 1];   // algorithmic: un-padded
+    ctx->f_bwd = ctx->f_fwd - 2.0 * true_dims[n_linear - 1] * true_dims[n_linear];   // no weight-gradient, no last-layer GEMM
     ctx->have_mlp = true;
     if (ctx->n_obs > 0) {  // re-derive the obstacle half of layer 1 for the new weights
         omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, ctx->n_obs, ctx->d_Bpre, ctx->d_radius);

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 SCENARIOS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
                    if not os.path.basename(p).startswith("mlp_"))
-MLP_KINDS = ["franka", "planar7", "planar2", "franka_tanh"]
+MLP_KINDS = ["franka", "planar7", "planar2", "franka_tanh", "planar7_128"]
 # tolerance named by BASELINE.json's north_star: 1e-5 relative fp32 on modulated velocities
 RTOL = 1e-5
 

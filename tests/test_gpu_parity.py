@@ -239,8 +239,10 @@ def test_error_paths():
     with pytest.raises(L.OmdsError, match="network not set"):
         eng.dist_grad(np.zeros((4, 7), np.float32))
     m = orc.Mlp.from_npz(weights_path("franka"))
-    with pytest.raises(L.OmdsError, match="width 256"):
-        eng.set_mlp([m.W[0][:128], m.W[1][:128, :128], m.W[-1][:, :128]], [m.b[0][:128], m.b[1][:128], m.b[-1]])
+    wide = np.zeros((384, 384), np.float32)
+    with pytest.raises(L.OmdsError, match="above 256"):
+        eng.set_mlp([np.zeros((384, 30), np.float32), wide, np.zeros((9, 384), np.float32)],
+                    [np.zeros(384, np.float32), np.zeros(384, np.float32), np.zeros(9, np.float32)])
     eng.set_mlp(m.W, m.b)
     with pytest.raises(L.OmdsError, match="max_obs"):
         eng.set_obstacles(np.zeros((9, 4), np.float32))

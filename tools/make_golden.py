@@ -46,6 +46,8 @@ MODELS = {
     # (SURVEY 0.1), so this one is the reference's own MLPRegression class with act_fn=Tanh and seeded
     # synthetic weights -- it pins the tanh forward/backward arithmetic, not a trained model
     "franka_tanh": (None, 7, 9),
+    # the reference's narrower shipped net (30-128-128-7): exercises the zero-padding of hidden layers to width 256
+    "planar7_128": ("7dof_sdf_128x3_mesh.pt", 7, 7),
 }
 
 
@@ -70,7 +72,8 @@ def load_model(kind):
         nn_model.model_jit = torch.jit.optimize_for_inference(torch.jit.script(nn_model.model))
         nn_model.aot_lambda = nn_model.functorch_vjp
         return nn_model
-    nn_model = RobotSdfCollisionNet(in_channels=dof + 3, out_channels=out, layers=[256] * 4, skips=[])
+    layers = [128] * 2 if kind.endswith("_128") else [256] * 4
+    nn_model = RobotSdfCollisionNet(in_channels=dof + 3, out_channels=out, layers=layers, skips=[])
     with quiet():
         nn_model.load_weights(REF + "/mlp_learn/models/" + fname, PARAMS)
     nn_model.model.to(**PARAMS)
@@ -100,7 +103,7 @@ def robot_setup(kind):
     if kind.startswith("franka"):
         dh = torch.from_numpy(scenes.franka_dh_params())
         dh_a = dh[:, 2].clone()
-    elif kind == "planar7":
+    elif kind.startswith("planar7"):
         dh = torch.from_numpy(scenes.planar_dh_params(7, 1.0))
         dh_a = dh[:, 2].clone()
     else:
@@ -287,6 +290,8 @@ def main():
               alpha_s=0.75, sigma_nom=0.5, ignored_links=[])
     run_scenario("planar7_K0", N=64, H=8, obs=scenes.planar7_scene(), k=1, K=0, seed=4, **p7)
     run_scenario("planar7_K4", N=64, H=8, obs=scenes.planar7_scene(), k=1, K=4, seed=5, **p7)
+    run_scenario("planar7_128_K3", N=64, H=8, obs=scenes.planar7_scene(), k=2, K=3, seed=16,
+                 **{**p7, "kind": "planar7_128", "nn_model": models["planar7_128"]})
     # --- Franka shelf (BASELINE config 3, reduced N/H) -----------------------------------------
     fr = dict(kind="franka", nn_model=models["franka"], dt=0.5, q0=scenes.FRANKA_Q0, qf=scenes.FRANKA_QF,
               dst_thr=0.01, ker_thr=0.1, alpha_s=3.0, sigma_nom=1.0)
