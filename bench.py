@@ -215,6 +215,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            try:   # first collective = communicator creation; the payloads here are tiny (<= 3.4 KB per iteration)
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world
+            except Exception as e:   # RCCL unusable on this node: the exchange is latency-bound anyway, use gloo
+                print(f"[bench] RCCL all-reduce failed on rank {rank} ({e}); falling back to gloo", file=sys.stderr)
+                dist.destroy_process_group()
+                args.dist_backend = "gloo"
+                dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
@@ -236,7 +246,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "rollouts_per_gpu": N, "horizon": H, "obstacles": int(obs.shape[0]),
                        "n_closest": w["k"], "active_kernels": K, "network": "x".join(str(x.shape[1]) for x in W) + f"x{W[-1].shape[0]} relu (shipped reference weights)",
-                       "parallelism": f"rollout-sharded x{world}"},
+                       "parallelism": f"rollout-sharded x{world}", "collectives": (args.dist_backend if use_dist else "none")},
             "roofline": {"bound": "mfma", "kernel": r["p1_kernel"], "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(args.workload),
                          "launches": int(p1_launches), "avg_launch_ms": p1_ms / max(p1_launches, 1),
