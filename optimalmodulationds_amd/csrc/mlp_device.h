@@ -56,21 +56,32 @@ __device__ __forceinline__ void gemm256(const float* __restrict__ Hw, const floa
     const float4* wp = Wp + (size_t)cb0 * (32 * 64) + lane;
     float4 a0[MR], a1[MR], w0[NR], w1[NR];
     load_chunk<MR, NR>(arow, wp, 0, a0, w0);
+    // One load (the weight fragment first, then the LDS reads) is slotted after every MFMA of the first half
+    // of a cluster via sched_group_barrier: in the isolated loop (tools/ubench/gemm_loop.hip) this issues at
+    // 68.6 cycles per MFMA against 70.3 for "all loads, then the cluster" and 75 for hipcc's own schedule.
+#define OMDS_INTERLEAVE()                                                             \
+    _Pragma("unroll") for (int q_ = 0; q_ < NR; ++q_) {                               \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                              \
+        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);                             \
+    }                                                                                 \
+    _Pragma("unroll") for (int q_ = 0; q_ < MR; ++q_) {                               \
+        __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);                              \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
+    }                                                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x8, 4 * MR * NR - NR - 2 * MR, 0);          \
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
     for (int c = 0; c < 32; c += 2) {
+        if (prio) __builtin_amdgcn_s_setprio(1);
         load_chunk<MR, NR>(arow, wp, c + 1, a1, w1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (prio) __builtin_amdgcn_s_setprio(1);
         mfma_chunk<MR, NR>(a0, w0, acc);
-        if (prio) __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
+        OMDS_INTERLEAVE()
         load_chunk<MR, NR>(arow, wp, (c + 2) & 31, a0, w0);   // last iteration re-loads chunk 0 (harmless)
-        __builtin_amdgcn_sched_barrier(0);
-        if (prio) __builtin_amdgcn_s_setprio(1);
         mfma_chunk<MR, NR>(a1, w1, acc);
+        OMDS_INTERLEAVE()
         if (prio) __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
     }
+#undef OMDS_INTERLEAVE
 }
 
 // C/D layout of the 32x32 MFMA: lane l, register r -> row (r&3) + 8(r>>2) + 4(l>>5), col l&31.

@@ -186,7 +186,7 @@ static void launch_pass1_a(hipStream_t s, const MlpDev& m, const float* Apre, co
     }
     const long long tiles = (total + MT - 1) / MT;
     static int tune = -1;
-    if (tune < 0) { const char* e = getenv("OMDS_TUNE"); tune = e ? atoi(e) : 1; }  // bit 0: s_setprio(1) around MFMA clusters (+1 % measured)
+    if (tune < 0) { const char* e = getenv("OMDS_TUNE"); tune = e ? atoi(e) : 0; }  // bit 0: s_setprio(1) around the GEMM loop body (no gain once loads are interleaved)
     hipLaunchKernelGGL((k_pass1<MT, MR, NR, ACT>), dim3((unsigned)tiles), dim3(G::NT), lds, s, m, Apre, Bpre, radius, O,
                        total, ignored, Dmin, tune);
 }
@@ -210,7 +210,7 @@ static void launch_pass1_mixed(hipStream_t s, const MlpDev& m, const float* Apre
         attr_set = true;
     }
     static int tune = -1;
-    if (tune < 0) { const char* e = getenv("OMDS_TUNE"); tune = e ? atoi(e) : 1; }
+    if (tune < 0) { const char* e = getenv("OMDS_TUNE"); tune = e ? atoi(e) : 0; }
     // keep `small_rounds` x 512 x 64 rows (in units of resident 64-row workgroups) for the 32-row tail tiles
     long long tiles64 = total / 64;
     long long keep = (long long)small_rounds * 512 / 2;   // 64-row tiles' worth of rows given to small tiles
