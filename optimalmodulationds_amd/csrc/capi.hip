@@ -500,8 +500,10 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
     if (fused < 0) { const char* e = getenv("OMDS_FUSED_TAIL"); fused = e ? atoi(e) : 1; }
     if (fused && omds_tail_supported(n, a.k)) {
         // two launches per step: k_pass1 over all (rollout, obstacle) pairs, then the rollout-local tail.
-        // (Splitting small batches into independent rollout groups on separate HIP streams was measured and
-        // rejected: planar7_1024x32 ran 9.0 M rollout-steps/s on one stream, 7.1 / 3.3 / 2.4 M on 2 / 4 / 8.)
+        // (Measured and rejected: independent rollout groups on separate HIP streams for small batches --
+        // planar7_1024x32 ran 9.0 M rollout-steps/s on one stream, 7.1 / 3.3 / 2.4 M on 2 / 4 / 8 -- and a two-half
+        // ping-pong for large batches with event-chained pass-1 launches so that one half's tail runs under the
+        // other half's pass 1: parity-green, but the half-size launches drain twice per step, 1.00 M vs 1.03 M.)
         omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, ctx->d_Apre);
         for (int i = 1; i <= H; ++i) {
             if ((rc = prof_begin(ctx))) return rc;
