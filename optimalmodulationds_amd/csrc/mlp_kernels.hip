@@ -242,10 +242,7 @@ void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Apre, const 
     }
     switch (v) {
         case 1: launch_pass1_t<128, 4, 1>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
-        case 2: launch_pass1_t<128, 2, 2>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
         case 3: launch_pass1_t<64, 2, 1>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
-        case 4: launch_pass1_t<64, 2, 2>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
-        case 6: launch_pass1_t<128, 4, 2>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
         default: launch_pass1_t<32, 1, 1>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
     }
 }
