@@ -80,6 +80,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and os.environ.get("OMDS_NO_AUTOBUILD") != "1":
+        # the library is built in-tree by __graft_entry__.build(); if a checkout arrives without it, build it
+        # here (hipcc, gfx950) -- still no fallback of any kind: without the library nothing runs
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], check=False)
     if not os.path.exists(LIB_PATH):
         raise OmdsError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         f"or `make -C optimalmodulationds_amd/csrc` (there is no CPU fallback)")
