@@ -142,9 +142,10 @@ def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, di
         eng.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, w["alpha_s"], K, seed=1234 * 1000003 + it, rollout_offset=rank * N)
         eng.propagate(q_cur)
         eng.cost(fetch=False)
-        mu_c, sg_c, al_c, mask, qd_w, qd_best = sharded_update(eng.cost_sum, eng.local_sums, K, n, H, 0.1, w["ker_thr"],
-                                                               mu_c, sg_c, al_c)
-        q_cur = (q_cur + 0.1 * w["dt"] * qd_best).astype(np.float32)   # drift along the best rollout: non-degenerate states
+        # two tiny all-reduces; the MINLOC gather for get_qdot('best') is not part of a planner iteration
+        mu_c, sg_c, al_c, mask, qd_w, _ = sharded_update(eng.cost_sum, eng.local_sums, K, n, H, 0.1, w["ker_thr"],
+                                                         mu_c, sg_c, al_c, want_best=False)
+        q_cur = (q_cur + 0.1 * w["dt"] * qd_w).astype(np.float32)   # drift along the weighted rollout velocity: non-degenerate states
         if w.get("dynamic"):   # Policy.check_traj_for_kernels on the device (policy.py:153-175); only candidates cross PCIe
             eng.kernel_candidates(0.03 - w["dst_thr"], 0.3, -0.9, mu_c, sg_c, K, cap=256)
 

@@ -42,19 +42,22 @@ def all_gather(x: np.ndarray, group=None) -> np.ndarray:
     return torch.stack(outs).cpu().numpy()
 
 
-def sharded_update(cost_sum_fn, local_sums_fn, K, n, H, rate, ker_thr, mu_c, sigma_c, alpha_c, group=None):
+def sharded_update(cost_sum_fn, local_sums_fn, K, n, H, rate, ker_thr, mu_c, sigma_c, alpha_c, group=None, want_best=True):
     """One cost-weighted update over all shards.
 
     cost_sum_fn() -> [sum cost, N_local] of this shard;
     local_sums_fn(sum_cost_global, n_total, include_rollout0) -> packed partial buffer (layout
-    ``engine.red_layout``).  Returns (mu, sigma, alpha, mask, qdot_weighted, qdot_best)."""
+    ``engine.red_layout``).  Returns (mu, sigma, alpha, mask, qdot_weighted, qdot_best); with
+    ``want_best=False`` only two collectives run and qdot_best is this shard's own best rollout."""
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     cs = all_reduce_sum(np.asarray(cost_sum_fn(), dtype=np.float32), group)
     red = np.asarray(local_sums_fn(float(cs[0]), float(cs[1]), rank == 0), dtype=np.float32).copy()
     lay = red_layout(K, n)
     assert red.shape[0] == lay["size"], (red.shape, lay)
     red[:lay["n_sum"]] = all_reduce_sum(red[:lay["n_sum"]], group)
-    best = all_gather(red[lay["n_sum"]:], group)            # [G, 1+n]
+    # get_qdot('best') needs a MINLOC over the shards; the planner iteration itself (frankaPlanner.py:132-145)
+    # never asks for it, so callers that do not need it skip this third collective
+    best = all_gather(red[lay["n_sum"]:], group) if want_best else red[None, lay["n_sum"]:]    # [G, 1+n]
     b = int(np.argmin(best[:, 0]))                          # lowest rank on ties, like a global argmin
     mu, sg, al, mask = apply_update(K, n, H, red, float(cs[1]), rate, ker_thr, mu_c, sigma_c, alpha_c)
     qdot_w = red[lay["qdot"]:lay["qdot"] + n] / red[0]
