@@ -38,10 +38,19 @@ __device__ __forceinline__ void mfma_chunk(const float4 (&a)[MR], const float4 (
         for (int j = 0; j < NR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, w[j].w, acc[i][j], 0, 0, 0);
 }
 
+// Weight fragments come through a buffer descriptor (SGPR base + per-lane byte offset + SCALAR chunk offset):
+// a flat global_load needs 64-bit VALU address arithmetic per load, and VALU instructions take issue slots away
+// from the MFMAs of the same SIMD -- in the isolated loop (tools/ubench/gemm_loop.hip) buffer loads issue at 65.7
+// cycles per MFMA (the MFMA-only floor is 65.3), global loads at 68.7.
+typedef float omds_f4 __attribute__((ext_vector_type(4)));
 template <int MR, int NR>
-__device__ __forceinline__ void load_chunk(const float* arow, const float4* wp, int c, float4 (&a)[MR], float4 (&w)[NR]) {
+__device__ __forceinline__ void load_chunk(const float* arow, __amdgpu_buffer_rsrc_t wrsrc, int wvoff, int c,
+                                           float4 (&a)[MR], float4 (&w)[NR]) {
 #pragma unroll
-    for (int j = 0; j < NR; ++j) w[j] = wp[(size_t)j * (32 * 64) + c * 64];
+    for (int j = 0; j < NR; ++j) {
+        const omds_f4 v = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, (j * (32 * 64) + c * 64) * 16, 0));
+        w[j] = make_float4(v.x, v.y, v.z, v.w);
+    }
 #pragma unroll
     for (int i = 0; i < MR; ++i) a[i] = *reinterpret_cast<const float4*>(arow + i * 32 * LDH + 8 * c);
 }
@@ -53,9 +62,12 @@ template <int MR, int NR>
 __device__ __forceinline__ void gemm256(const float* __restrict__ Hw, const float4* __restrict__ Wp, int cb0,
                                         int lane, f32x16 (&acc)[MR][NR], const bool prio = false) {
     const float* arow = Hw + (lane & 31) * LDH + 4 * (lane >> 5);
-    const float4* wp = Wp + (size_t)cb0 * (32 * 64) + lane;
+    // cb0 derives from the wave index: wave-uniform, but only readfirstlane makes that provable to the compiler
+    const float4* wbase = Wp + (size_t)__builtin_amdgcn_readfirstlane(cb0) * (32 * 64);
+    const __amdgpu_buffer_rsrc_t wp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wbase), 0, NR * 32 * 64 * 16, 0x00020000);
+    const int wv = lane * 16;
     float4 a0[MR], a1[MR], w0[NR], w1[NR];
-    load_chunk<MR, NR>(arow, wp, 0, a0, w0);
+    load_chunk<MR, NR>(arow, wp, wv, 0, a0, w0);
     // One load (the weight fragment first, then the LDS reads) is slotted after every MFMA of the first half
     // of a cluster via sched_group_barrier: in the isolated loop (tools/ubench/gemm_loop.hip) this issues at
     // 68.6 cycles per MFMA against 70.3 for "all loads, then the cluster" and 75 for hipcc's own schedule.
@@ -73,10 +85,10 @@ __device__ __forceinline__ void gemm256(const float* __restrict__ Hw, const floa
 #pragma unroll 1
     for (int c = 0; c < 32; c += 2) {
         if (prio) __builtin_amdgcn_s_setprio(1);
-        load_chunk<MR, NR>(arow, wp, c + 1, a1, w1);
+        load_chunk<MR, NR>(arow, wp, wv, c + 1, a1, w1);
         mfma_chunk<MR, NR>(a0, w0, acc);
         OMDS_INTERLEAVE()
-        load_chunk<MR, NR>(arow, wp, (c + 2) & 31, a0, w0);   // last iteration re-loads chunk 0 (harmless)
+        load_chunk<MR, NR>(arow, wp, wv, (c + 2) & 31, a0, w0);   // last iteration re-loads chunk 0 (harmless)
         mfma_chunk<MR, NR>(a1, w1, acc);
         OMDS_INTERLEAVE()
         if (prio) __builtin_amdgcn_s_setprio(0);

@@ -166,6 +166,52 @@ __device__ __forceinline__ void gemm_deep(const float* Hw, const float4* Wp, int
 #undef ST
 }
 
+#define IL_() __builtin_amdgcn_sched_group_barrier(0x8, 2, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x8, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           \
+    __builtin_amdgcn_sched_group_barrier(0x8, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           \
+    __builtin_amdgcn_sched_group_barrier(0x8, 2, 0); __builtin_amdgcn_sched_barrier(0);
+
+__device__ __forceinline__ void gemm_u4(const float* Hw, const float4* Wp, int cb0, int lane, f32x16 (&acc)[2][1]) {
+    constexpr int MR = 2, NR = 1;
+    const float* ar = Hw + (lane & 31) * LDH + 4 * (lane >> 5);
+    const float4* wp = Wp + (size_t)cb0 * (32 * 64) + lane;
+    float4 a0[MR], a1[MR], w0[NR], w1[NR];
+    load_chunk<MR, NR>(ar, wp, 0, a0, w0);
+#pragma unroll 1
+    for (int c = 0; c < 32; c += 4) {
+        load_chunk<MR, NR>(ar, wp, c + 1, a1, w1); mfma_chunk<MR, NR>(a0, w0, acc); IL_()
+        load_chunk<MR, NR>(ar, wp, c + 2, a0, w0); mfma_chunk<MR, NR>(a1, w1, acc); IL_()
+        load_chunk<MR, NR>(ar, wp, c + 3, a1, w1); mfma_chunk<MR, NR>(a0, w0, acc); IL_()
+        load_chunk<MR, NR>(ar, wp, (c + 4) & 31, a0, w0); mfma_chunk<MR, NR>(a1, w1, acc); IL_()
+    }
+}
+
+// buffer loads for the weights: SGPR descriptor + per-lane byte offset, immediate chunk offsets
+__device__ __forceinline__ void gemm_buf(const float* Hw, const float4* Wp, int cb0, int lane, f32x16 (&acc)[2][1]) {
+    constexpr int MR = 2, NR = 1;
+    const float* ar = Hw + (lane & 31) * LDH + 4 * (lane >> 5);
+    const float4* base = Wp + (size_t)__builtin_amdgcn_readfirstlane(cb0) * (32 * 64);
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 32 * 64 * 16, 0x00020000);
+    const int voff = lane * 16;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    auto ldw = [&](int c) -> float4 { f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, c * 1024, 0)); return make_float4(v.x, v.y, v.z, v.w); };
+    float4 a0[MR], a1[MR], w0[NR], w1[NR];
+    w0[0] = ldw(0);
+#pragma unroll
+    for (int i = 0; i < MR; ++i) a0[i] = *reinterpret_cast<const float4*>(ar + i * 32 * LDH);
+#pragma unroll 1
+    for (int c = 0; c < 32; c += 2) {
+        w1[0] = ldw(c + 1);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) a1[i] = *reinterpret_cast<const float4*>(ar + i * 32 * LDH + 8 * (c + 1));
+        mfma_chunk<MR, NR>(a0, w0, acc); IL_()
+        w0[0] = ldw((c + 2) & 31);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) a0[i] = *reinterpret_cast<const float4*>(ar + i * 32 * LDH + 8 * ((c + 2) & 31));
+        mfma_chunk<MR, NR>(a1, w1, acc); IL_()
+    }
+}
+
 template <int VAR>
 __global__ __launch_bounds__(512) void k(const float4* W, float* out, int reps) {
     extern __shared__ __attribute__((aligned(16))) float Hs[];
@@ -178,7 +224,9 @@ __global__ __launch_bounds__(512) void k(const float4* W, float* out, int reps) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
     for (int r = 0; r < reps; ++r) {
-        if (VAR == 5) gemm_deep(Hs, W + (size_t)(r % 3) * (8 * 32 * 64), wave, lane, acc);
+        if (VAR == 14) gemm_u4(Hs, W + (size_t)(r % 3) * (8 * 32 * 64), wave, lane, acc);
+        else if (VAR == 15) gemm_buf(Hs, W + (size_t)(r % 3) * (8 * 32 * 64), wave, lane, acc);
+        else if (VAR == 5) gemm_deep(Hs, W + (size_t)(r % 3) * (8 * 32 * 64), wave, lane, acc);
         else gemm_var<VAR>(Hs, W + (size_t)(r % 3) * (8 * 32 * 64), wave, lane, acc);
     }
     float s = 0.f;
@@ -219,6 +267,8 @@ int main() {
         run<6>("mfma | both loads | mfma", W, out, g);
         run<7>("no sched barriers", W, out, g);
         run<8>("sched_group_barrier interleave", W, out, g);
+        run<14>("interleave, 4 stages per iteration", W, out, g);
+        run<15>("interleave, buffer_load weights", W, out, g);
         run<9>("M1 V1 M1 D1 M1 D1 M5", W, out, g);
         run<10>("M2 V1 M2 D1 M2 D1 M2", W, out, g);
         run<11>("M5 V1 M1 D1 M1 D1 M1", W, out, g);
