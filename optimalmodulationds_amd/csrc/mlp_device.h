@@ -82,16 +82,15 @@ __device__ __forceinline__ void gemm256(const float* __restrict__ Hw, const floa
     }                                                                                 \
     __builtin_amdgcn_sched_group_barrier(0x8, 4 * MR * NR - NR - 2 * MR, 0);          \
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-    for (int c = 0; c < 32; c += 2) {
-        if (prio) __builtin_amdgcn_s_setprio(1);
+    (void)prio;   // s_setprio around the loop body bought nothing once the loads were interleaved
+#pragma unroll
+    for (int c = 0; c < 32; c += 2) {   // fully unrolled: every LDS / buffer offset is an immediate or an SGPR, no VALU in the loop
         load_chunk<MR, NR>(arow, wp, wv, c + 1, a1, w1);
         mfma_chunk<MR, NR>(a0, w0, acc);
         OMDS_INTERLEAVE()
         load_chunk<MR, NR>(arow, wp, wv, (c + 2) & 31, a0, w0);   // last iteration re-loads chunk 0 (harmless)
         mfma_chunk<MR, NR>(a1, w1, acc);
         OMDS_INTERLEAVE()
-        if (prio) __builtin_amdgcn_s_setprio(0);
     }
 #undef OMDS_INTERLEAVE
 }
