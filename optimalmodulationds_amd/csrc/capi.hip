@@ -172,6 +172,16 @@ int omds_sync(omds_ctx* ctx) {
     return OMDS_OK;
 }
 
+#ifdef OMDS_TIMELINE
+// Diagnostic build only (not in include/omds.h): phase timestamps of the last k_pass1 launch, see tools/pass1_timeline.py.
+extern "C" OMDS_API int omds_timeline_fetch(omds_ctx* ctx, unsigned long long* host, int n_workgroups) {
+    if (!ctx || !ctx->mlp.tl || n_workgroups > (1 << 16)) return OMDS_ERR_INVALID_ARG;
+    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipMemcpy(host, ctx->mlp.tl, (size_t)n_workgroups * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return OMDS_OK;
+}
+#endif
+
 // ---- weights -------------------------------------------------------------------------------------
 
 int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* const* W, const float* const* b, int act,
@@ -285,6 +295,14 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
     if ((rc = upload(ctx, w1t, &m.W1t))) return rc;
     if ((rc = upload(ctx, b1, &m.b1))) return rc;
     if ((rc = upload(ctx, w1b, &m.W1b))) return rc;
+#ifdef OMDS_TIMELINE
+    {
+        static unsigned long long* tl = nullptr;
+        if (!tl) { CK(hipMalloc(&tl, (size_t)(1 << 16) * 16 * sizeof(unsigned long long))); }
+        CK(hipMemset(tl, 0, (size_t)(1 << 16) * 16 * sizeof(unsigned long long)));
+        m.tl = tl;
+    }
+#endif
     ctx->mlp = m;
     ctx->act = act;
     ctx->f_fwd = 0.0;

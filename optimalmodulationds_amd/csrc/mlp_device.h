@@ -111,6 +111,15 @@ struct Geo {
 // ------------------------------------------------------------------------------------------------
 // pass 1: all (rollout, obstacle) pairs -> min link distance
 // ------------------------------------------------------------------------------------------------
+// Diagnostic build (make timeline): workgroup phase timestamps, read by tools/pass1_timeline.py.  Compiles to nothing otherwise.
+#ifdef OMDS_TIMELINE
+#define OMDS_TL(i) do { if (m.tl && threadIdx.x == 0) m.tl[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#define OMDS_TL_WAIT(what) asm volatile("s_waitcnt " what ::: "memory")
+#else
+#define OMDS_TL(i) do { } while (0)
+#define OMDS_TL_WAIT(what) do { } while (0)
+#endif
+
 template <int MT, int MR, int NR, int ACT>
 __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const float* __restrict__ Apre,
                                            const float* __restrict__ Bpre, const float* __restrict__ radius, int O,
@@ -121,6 +130,12 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
     float* rowRad = smem + MT * LDH;                            // [MT] obstacle radius of each row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / G::WN, wn = wave % G::WN;
+    OMDS_TL(0);
+#ifdef OMDS_TIMELINE
+    if (m.tl && threadIdx.x == 0)   // HW_ID and XCC_ID: which CU this workgroup landed on
+        m.tl[(size_t)blockIdx.x * 16 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |
+                                            ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+#endif
 
     // ---- layer 1: H1 = act(Apre[t] + Bpre[o]); one float4 per thread and iteration, all loads of the
     //      tile issued before the first use (the loop is fully unrolled, no 64-bit division per row) -------
@@ -150,6 +165,8 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                     bv[it] = av[it];
                 }
             }
+            OMDS_TL_WAIT("vmcnt(0)");
+            OMDS_TL(8);
 #pragma unroll
             for (int it = 0; it < BI; ++it) {
                 const int idx = tid + (base + it) * G::NT;
@@ -165,7 +182,10 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
             }
         }
     }
+    OMDS_TL_WAIT("lgkmcnt(0)");
+    OMDS_TL(9);
     __syncthreads();
+    OMDS_TL(1);
 
     // ---- hidden -> hidden layers -----------------------------------------------------------------
     const float* Hw = Hs + (wm * MR * 32) * LDH;
@@ -183,6 +203,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
         for (int j = 0; j < NR; ++j) bvj[j] = m.bh[l * OMDS_WIDTH + (cb0 + j) * 32 + (lane & 31)];
         gemm256<MR, NR>(Hw, m.Wf + (size_t)l * (OMDS_NCB * 32 * 64), cb0, lane, acc, (tune & 1) != 0);
         __syncthreads();  // every wave has finished reading the tile
+        if (l == 0) OMDS_TL(6);
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const int col = (cb0 + j) * 32 + (lane & 31);
@@ -194,6 +215,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                     Hs[((wm * MR + i) * 32 + crow(r, lane)) * LDH + col] = actf(acc[i][j][r] + bv, ACT);
         }
         __syncthreads();
+        OMDS_TL(2 + l);
     }
 
     // ---- last layer (256 -> C, padded to 16) on v_mfma_f32_16x16x4_f32, 16 rows per wave ----------
@@ -209,6 +231,10 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
         }
+#ifdef OMDS_TIMELINE
+        asm volatile("s_nop 0" ::"v"(acc[0]) : "memory");
+        OMDS_TL(10);
+#endif
         // C/D layout 16x16: col = lane&15 (link), row = 4(lane>>4) + reg
         const int j = lane & 15;
         const float bj = m.bl[j];
@@ -225,6 +251,10 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
             if (j == 0 && row0 + r < total_rows) Dmin[row0 + r] = y;
         }
     }
+#ifdef OMDS_TIMELINE
+    __syncthreads();
+    OMDS_TL(5);
+#endif
 }
 
 // k smallest entries of row[0..O) in ascending order (ties by lower index), one wave per row.

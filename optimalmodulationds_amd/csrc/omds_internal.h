@@ -31,6 +31,9 @@ struct MlpDev {
     int n_dof;
     float out_div;
     int act;             // OMDS_ACT_RELU | OMDS_ACT_TANH
+#ifdef OMDS_TIMELINE
+    unsigned long long* tl;   // diagnostic build only (make TIMELINE=1): [workgroup][8] phase timestamps of k_pass1
+#endif
 };
 
 struct ProfEvents {
