@@ -71,7 +71,21 @@ typedef struct {
     float softmax_k;       /* -10: weights of the k closest gradients (:277)               */
     float rbf_p;           /* Policy.p, RBF norm order (policy.py:41), 2                   */
     uint32_t ignored_links;/* bit c set: link c is masked in pass 1 (MPPI.py:241)          */
+    uint32_t variant;      /* OMDS_VARIANT_* bits; 0 = MPPI.py, see below                  */
+    uint32_t cost_terms;   /* OMDS_COST_* bits summed by Cost.evaluate_costs; default all  */
 } omds_params;
+
+/* ds_mppi/functions/MPPI_toy.py (the 2-D toy drivers' variant of MPPI.py) differs from MPPI.py in constants
+ * (all of them fields above) and in two behaviours:                                                        */
+#define OMDS_VARIANT_KVAL_TIMES_ACT 1u /* kernel_val_all holds phi * activation (MPPI_toy.py:178-179)       */
+#define OMDS_VARIANT_NO_BASE_MASK   2u /* update mask without the rollout-0 term (MPPI_toy.py:318-321)      */
+/* Cost.evaluate_costs terms (cost.py:14-21); cost_toy.py:14-18 sums GOAL | COLLISION | STAGNATION only.    */
+#define OMDS_COST_GOAL         1u
+#define OMDS_COST_COLLISION    2u
+#define OMDS_COST_JOINT_LIMITS 4u
+#define OMDS_COST_STAGNATION   8u
+#define OMDS_COST_FK          16u
+#define OMDS_COST_ALL         31u
 
 OMDS_API void omds_default_params(omds_params* p);
 
@@ -84,7 +98,9 @@ OMDS_API const char* omds_last_error(const omds_ctx* ctx);
 /* RobotSdfCollisionNet.load_weights + model preparation (robot_sdf.py:31-51,
  * frankaPlanner.py:43-51).  n_linear Linear layers; dims[n_linear+1] = {3(n+3), hidden...,
  * C}; W[i] is [dims[i+1], dims[i]] row-major like torch, b[i] is [dims[i+1]].  act =
- * OMDS_ACT_*; out_div = 100 when C == 9 (cm -> m, MPPI.py:236-237) else 1.                */
+ * OMDS_ACT_*; out_div = 100 when C == 9 (cm -> m, MPPI.py:236-237) else 1.  dims[0] may also
+ * be 3(n+2): the toy networks take planar obstacle points (in_channels = DOF+2,
+ * scripts/standaloneToy2d.py:33); the z column of the obstacle array is then ignored.    */
 OMDS_API int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* const* W,
                           const float* const* b, int act, float out_div);
 
@@ -92,6 +108,9 @@ OMDS_API int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, cons
 OMDS_API int omds_set_obstacles(omds_ctx* ctx, const float* xyzr, int n_obs);
 /* LinDS(q_goal) / MPPI.reset_DS / switch_DS_idx (LinDS.py:7-10, MPPI.py:76-84). */
 OMDS_API int omds_set_ds(omds_ctx* ctx, const float* q_goal);
+/* MPPI_toy's nominal DS (MPPI_toy.py:89-91): velocity = (q - q_goal) @ A, A [n,n] row-major, not
+ * normalised.  A == NULL switches back to LinDS.                                            */
+OMDS_API int omds_set_ds_matrix(omds_ctx* ctx, const float* q_goal, const float* A);
 OMDS_API int omds_set_params(omds_ctx* ctx, const omds_params* p);
 /* Cost(q_f, dh_params) + the q_min/q_max attributes (cost.py:5-12): dh_params [n+1,4]
  * rows (d, theta, a, alpha); q_min/q_max [n].                                             */
@@ -161,12 +180,14 @@ OMDS_API int omds_kernel_candidates(omds_ctx* ctx, float thr_dist, float thr_ker
  *        only on the shard that owns it) | sum w' qdot (n)            (all-reduce SUM)
  *        | min cost of the shard, qdot of its arg-min (1+n)          (all-gather, MINLOC)
  *   omds_apply_update: pure host arithmetic on the reduced buffer (masks MPPI.py:336-342 +
- *        TensorPolicyMPPI.update_policy policy.py:88-113); needs no context / no GPU.      */
+ *        TensorPolicyMPPI.update_policy policy.py:88-113); needs no context / no GPU.
+ *        variant = omds_params.variant (OMDS_VARIANT_NO_BASE_MASK drops the rollout-0 mask). */
 OMDS_API int omds_cost_sum(omds_ctx* ctx, float* out2);
 OMDS_API int omds_red_count(const omds_ctx* ctx);
 OMDS_API int omds_local_sums(omds_ctx* ctx, float sum_cost, float n_total, int include_rollout0, float* red_out);
 OMDS_API int omds_apply_update(int n_kernels, int n_dof, int horizon, const float* red, float n_total, float rate,
-                               float ker_thr, float* mu_c, float* sigma_c, float* alpha_c, int32_t* mask_out);
+                               float ker_thr, uint32_t variant, float* mu_c, float* sigma_c, float* alpha_c,
+                               int32_t* mask_out);
 
 /* Measurement: when enabled, every launch of the dominant kernel (mlp_pass1) is bracketed by
  * HIP events on the context stream; omds_prof_read returns the summed elapsed ms and launch

@@ -27,7 +27,14 @@ class OmdsParams(C.Structure):
     _fields_ = [("dt", C.c_float), ("dst_thr", C.c_float), ("lin_thr", C.c_float), ("lvel", C.c_float * 5),
                 ("ln", C.c_float * 5), ("ltau", C.c_float * 5), ("goal_act_cut", C.c_float),
                 ("norm_clamp", C.c_float), ("coll_slow", C.c_float), ("coll_repulse", C.c_float),
-                ("softmax_k", C.c_float), ("rbf_p", C.c_float), ("ignored_links", C.c_uint32)]
+                ("softmax_k", C.c_float), ("rbf_p", C.c_float), ("ignored_links", C.c_uint32),
+                ("variant", C.c_uint32), ("cost_terms", C.c_uint32)]
+
+
+# omds_params.variant / cost_terms bits (include/omds.h)
+VARIANT_KVAL_TIMES_ACT = 1
+VARIANT_NO_BASE_MASK = 2
+COST_GOAL, COST_COLLISION, COST_JOINT_LIMITS, COST_STAGNATION, COST_FK, COST_ALL = 1, 2, 4, 8, 16, 31
 
 
 class OmdsError(RuntimeError):
@@ -44,6 +51,7 @@ SIGNATURES = {
     "omds_set_mlp": (C.c_int, [C.c_void_p, C.c_int, I32P, C.POINTER(F32P), C.POINTER(F32P), C.c_int, C.c_float]),
     "omds_set_obstacles": (C.c_int, [C.c_void_p, F32P, C.c_int]),
     "omds_set_ds": (C.c_int, [C.c_void_p, F32P]),
+    "omds_set_ds_matrix": (C.c_int, [C.c_void_p, F32P, F32P]),
     "omds_set_params": (C.c_int, [C.c_void_p, C.POINTER(OmdsParams)]),
     "omds_set_cost": (C.c_int, [C.c_void_p, F32P, F32P, F32P]),
     "omds_set_policy_samples": (C.c_int, [C.c_void_p, F32P, F32P, F32P, C.c_int]),
@@ -62,8 +70,8 @@ SIGNATURES = {
     "omds_cost_sum": (C.c_int, [C.c_void_p, F32P]),
     "omds_red_count": (C.c_int, [C.c_void_p]),
     "omds_local_sums": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_int, F32P]),
-    "omds_apply_update": (C.c_int, [C.c_int, C.c_int, C.c_int, F32P, C.c_float, C.c_float, C.c_float, F32P, F32P,
-                                    F32P, I32P]),
+    "omds_apply_update": (C.c_int, [C.c_int, C.c_int, C.c_int, F32P, C.c_float, C.c_float, C.c_float, C.c_uint32,
+                                    F32P, F32P, F32P, I32P]),
     "omds_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "omds_prof_reset": (C.c_int, [C.c_void_p]),
     "omds_prof_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

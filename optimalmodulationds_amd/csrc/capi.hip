@@ -55,6 +55,8 @@ void omds_default_params(omds_params* p) {
     p->softmax_k = -10.f;
     p->rbf_p = 2.f;
     p->ignored_links = 0;
+    p->variant = 0;
+    p->cost_terms = OMDS_COST_ALL;                        // cost.py:21
 }
 
 const char* omds_last_error(const omds_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
@@ -64,7 +66,7 @@ static void free_all(omds_ctx* ctx) {
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
                     ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
                     ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
-                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr};
+                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : ctx->mlp_allocs)
@@ -113,6 +115,7 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
                  k = cfg->n_closest, d = n + 3;
     const size_t rows2 = N * k;
     CKC(hipMalloc(&ctx->d_obs, Om * 4 * 4));
+    CKC(hipMalloc(&ctx->d_A, OMDS_MAX_DOF * OMDS_MAX_DOF * 4));
     CKC(hipMalloc(&ctx->d_Bpre, std::max(Om, rows2) * OMDS_WIDTH * 4));
     CKC(hipMalloc(&ctx->d_radius, std::max(Om, rows2) * 4));
     CKC(hipMalloc(&ctx->d_trajT, H * n * N * 4));
@@ -188,8 +191,10 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
                  float out_div) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
     REQUIRE(dims && W && b && n_linear >= 2, OMDS_ERR_INVALID_ARG, "omds_set_mlp: null argument or fewer than 2 Linear layers");
-    const int n = ctx->cfg.n_dof, d = n + 3;
-    REQUIRE(dims[0] == 3 * d, OMDS_ERR_INVALID_ARG, "omds_set_mlp: dims[0] must be 3*(n_dof+3) (NeRF encoding [x, sin x, cos x])");
+    const int n = ctx->cfg.n_dof;
+    REQUIRE(dims[0] == 3 * (n + 3) || dims[0] == 3 * (n + 2), OMDS_ERR_INVALID_ARG,
+            "omds_set_mlp: dims[0] must be 3*(n_dof+3), or 3*(n_dof+2) for planar obstacle points (NeRF encoding [x, sin x, cos x])");
+    const int d = dims[0] / 3;
     REQUIRE(3 * d <= 32, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: 3*(n_dof+3) > 32 not supported");
     const int nhid = n_linear - 1;
     REQUIRE(nhid <= OMDS_MAX_HIDDEN, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: too many hidden layers");
@@ -342,7 +347,18 @@ int omds_set_ds(omds_ctx* ctx, const float* q_goal) {
     REQUIRE(q_goal, OMDS_ERR_INVALID_ARG, "omds_set_ds: null q_goal");
     std::memcpy(ctx->qf, q_goal, ctx->cfg.n_dof * sizeof(float));
     ctx->have_ds = true;
+    ctx->have_A = false;
     refresh_goal_fk(ctx);
+    return OMDS_OK;
+}
+
+int omds_set_ds_matrix(omds_ctx* ctx, const float* q_goal, const float* A) {
+    int rc = omds_set_ds(ctx, q_goal);
+    if (rc || !A) return rc;
+    const int n = ctx->cfg.n_dof;
+    CK(hipSetDevice(ctx->dev));
+    CK(hipMemcpy(ctx->d_A, A, (size_t)n * n * sizeof(float), hipMemcpyHostToDevice));
+    ctx->have_A = true;
     return OMDS_OK;
 }
 
@@ -350,6 +366,8 @@ int omds_set_params(omds_ctx* ctx, const omds_params* p) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
     REQUIRE(p, OMDS_ERR_INVALID_ARG, "omds_set_params: null params");
     REQUIRE(p->rbf_p > 0.f, OMDS_ERR_INVALID_ARG, "omds_set_params: rbf_p must be positive");
+    REQUIRE((p->cost_terms & ~OMDS_COST_ALL) == 0 && (p->variant & ~3u) == 0, OMDS_ERR_INVALID_ARG,
+            "omds_set_params: unknown bits in cost_terms / variant");
     ctx->prm = *p;
     return OMDS_OK;
 }
@@ -508,11 +526,12 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
     }
     CK(hipStreamSynchronize(ctx->stream));  // q_cur is caller memory; d_means is reused below by nobody until sample
     StepArgs a{};
-    a.N = N; a.H = H; a.n = n; a.K = ctx->n_kernels; a.Kmax = ctx->cfg.n_kernel_max; a.k = ctx->cfg.n_closest; a.d = n + 3;
+    a.N = N; a.H = H; a.n = n; a.K = ctx->n_kernels; a.Kmax = ctx->cfg.n_kernel_max; a.k = ctx->cfg.n_closest; a.d = ctx->mlp.d;
     a.trajT = ctx->d_trajT; a.distT = ctx->d_distT; a.dotT = ctx->d_dotT; a.actT = ctx->d_actT; a.normalT = ctx->d_normalT;
     a.kvalT = ctx->d_kvalT; a.qdotT = ctx->d_qdotT; a.maxact = ctx->d_maxact; a.phisum0 = ctx->d_phisum0;
     a.muT = ctx->d_muT; a.sigmaT = ctx->d_sigmaT; a.alphaT = ctx->d_alphaT; a.gradx = ctx->d_gradx; a.drow = ctx->d_drow;
     std::memcpy(a.qf, ctx->qf, sizeof(a.qf));
+    a.A = ctx->have_A ? ctx->d_A : nullptr;
     a.prm = ctx->prm;
     static int fused = -1;   // OMDS_FUSED_TAIL=0 selects the five-kernel step (kept for A/B runs and as the generic path)
     if (fused < 0) { const char* e = getenv("OMDS_FUSED_TAIL"); fused = e ? atoi(e) : 1; }
@@ -580,7 +599,7 @@ int omds_dist_grad(omds_ctx* ctx, const float* q, int B, float* distance, float*
     int rc;
     if ((rc = check_ready(ctx, false))) return rc;
     CK(hipSetDevice(ctx->dev));
-    const int n = ctx->cfg.n_dof, k = ctx->cfg.n_closest, O = ctx->n_obs, d = n + 3;
+    const int n = ctx->cfg.n_dof, k = ctx->cfg.n_closest, O = ctx->n_obs, d = ctx->mlp.d;
     CK(hipMemcpyAsync(ctx->d_stage, q, (size_t)B * n * 4, hipMemcpyHostToDevice, ctx->stream));
     omds_launch_transpose(ctx->stream, ctx->d_stage, ctx->d_qstage, B, n);   // -> [n][B]
     if ((rc = enqueue_network(ctx, ctx->d_qstage, B, B))) return rc;
@@ -597,17 +616,18 @@ int omds_dist_grad(omds_ctx* ctx, const float* q, int B, float* distance, float*
 
 int omds_mlp_forward_vjp(omds_ctx* ctx, const float* x, int B, float* y, float* grad, int32_t* min_idx) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    const int n = ctx->cfg.n_dof, d = n + 3;
+    const int n = ctx->cfg.n_dof;
     const int cap = ctx->cfg.n_traj * ctx->cfg.n_closest;
     REQUIRE(x && B >= 1 && B <= cap, OMDS_ERR_INVALID_ARG, "omds_mlp_forward_vjp: need 1 <= batch <= n_traj*n_closest and non-null x");
     REQUIRE(ctx->have_mlp, OMDS_ERR_NOT_INITIALISED, "distance network not set (omds_set_mlp)");
+    const int d = ctx->mlp.d;
     CK(hipSetDevice(ctx->dev));
     // every row is its own (rollout, obstacle) pair: Apre from x[:, :n], Bpre from x[:, n:], radius 0
     std::vector<float> xyzr((size_t)B * 4, 0.f), qrow((size_t)B * n);
     std::vector<int32_t> ident(B);
     for (int r = 0; r < B; ++r) {
         for (int j = 0; j < n; ++j) qrow[(size_t)r * n + j] = x[(size_t)r * d + j];
-        for (int j = 0; j < 3; ++j) xyzr[(size_t)r * 4 + j] = x[(size_t)r * d + n + j];
+        for (int j = 0; j < d - n; ++j) xyzr[(size_t)r * 4 + j] = x[(size_t)r * d + n + j];
         ident[r] = r;
     }
     float *d_xyzr = nullptr, *d_B = nullptr, *d_rad = nullptr;
@@ -645,6 +665,7 @@ static int enqueue_cost(omds_ctx* ctx) {
     CostArgs a{};
     a.N = ctx->cfg.n_traj; a.H = ctx->cfg.horizon; a.n = ctx->cfg.n_dof;
     a.trajT = ctx->d_trajT; a.distT = ctx->d_distT; a.cost = ctx->d_cost;
+    a.terms = ctx->prm.cost_terms;
     std::memcpy(a.qf, ctx->qf, sizeof(a.qf));
     std::memcpy(a.qmin, ctx->qmin, sizeof(a.qmin));
     std::memcpy(a.qmax, ctx->qmax, sizeof(a.qmax));
@@ -711,8 +732,8 @@ int omds_local_sums(omds_ctx* ctx, float sum_cost, float n_total, int include_ro
 }
 
 // Pure host arithmetic, no context: masks + theta_c update from the (globally) reduced buffer.
-int omds_apply_update(int K, int n, int H, const float* red, float n_total, float rate, float ker_thr, float* mu_c,
-                      float* sigma_c, float* alpha_c, int32_t* mask_out) {
+int omds_apply_update(int K, int n, int H, const float* red, float n_total, float rate, float ker_thr, uint32_t variant,
+                      float* mu_c, float* sigma_c, float* alpha_c, int32_t* mask_out) {
     if (K < 0 || n < 1 || H < 1 || !red || n_total <= 0.f) return OMDS_ERR_INVALID_ARG;
     if (K > 0 && (!mu_c || !sigma_c || !alpha_c)) return OMDS_ERR_INVALID_ARG;
     const float sumw = red[0];
@@ -720,7 +741,7 @@ int omds_apply_update(int K, int n, int H, const float* red, float n_total, floa
     for (int kk = 0; kk < K; ++kk) {
         // mask 1: mean over ALL rollouts of max_h(phi*act) > ker_thr; mask 2: mean_h phi of rollout 0 (MPPI.py:336-342)
         const float m1 = s_mx[kk] / n_total, m2 = s_ph[kk] / (float)H;
-        const bool upd = (m1 > ker_thr) && (m2 > ker_thr);   // NaN compares false, like torch
+        const bool upd = (m1 > ker_thr) && ((variant & OMDS_VARIANT_NO_BASE_MASK) || (m2 > ker_thr));   // NaN compares false, like torch
         if (mask_out) mask_out[kk] = upd ? 1 : 0;
         const float u = upd ? rate : 0.f;
         for (int j = 0; j < n; ++j) {
@@ -742,7 +763,7 @@ int omds_weighted_update(omds_ctx* ctx, float rate, float ker_thr, float* mu_c, 
     if ((rc = omds_cost_sum(ctx, cs))) return rc;
     std::vector<float> red(omds_red_size(K, n));
     if ((rc = omds_local_sums(ctx, cs[0], cs[1], 1, red.data()))) return rc;
-    if ((rc = omds_apply_update(K, n, H, red.data(), cs[1], rate, ker_thr, mu_c, sigma_c, alpha_c, mask_out))) {
+    if ((rc = omds_apply_update(K, n, H, red.data(), cs[1], rate, ker_thr, ctx->prm.variant, mu_c, sigma_c, alpha_c, mask_out))) {
         ctx->err = "omds_apply_update: invalid argument";
         return rc;
     }

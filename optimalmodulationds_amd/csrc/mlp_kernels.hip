@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256) void k_rollout_layer1(MlpDev m, const float* _
 __global__ __launch_bounds__(256) void k_obstacle_layer1(MlpDev m, const float* __restrict__ xyzr, int O,
                                                          float* __restrict__ Bpre, float* __restrict__ radius) {
     __shared__ float f[9];
-    const int o = blockIdx.x, c = threadIdx.x, n = m.n_dof, d = m.d;
-    if (c < 3) {
+    const int o = blockIdx.x, c = threadIdx.x, n = m.n_dof, d = m.d, po = d - n;   // po = 3 (x, y, z) or 2 (toy networks)
+    if (c < po) {
         const float p = xyzr[o * 4 + c];
         f[c] = p;
         f[3 + c] = sinf(p);
@@ -58,9 +58,9 @@ __global__ __launch_bounds__(256) void k_obstacle_layer1(MlpDev m, const float* 
     if (c == 3) radius[o] = xyzr[o * 4 + 3];
     __syncthreads();
     float acc = 0.f;
-    for (int j = 0; j < 3; ++j) acc = fmaf(m.W1t[(size_t)(n + j) * OMDS_WIDTH + c], f[j], acc);
-    for (int j = 0; j < 3; ++j) acc = fmaf(m.W1t[(size_t)(d + n + j) * OMDS_WIDTH + c], f[3 + j], acc);
-    for (int j = 0; j < 3; ++j) acc = fmaf(m.W1t[(size_t)(2 * d + n + j) * OMDS_WIDTH + c], f[6 + j], acc);
+    for (int j = 0; j < po; ++j) acc = fmaf(m.W1t[(size_t)(n + j) * OMDS_WIDTH + c], f[j], acc);
+    for (int j = 0; j < po; ++j) acc = fmaf(m.W1t[(size_t)(d + n + j) * OMDS_WIDTH + c], f[3 + j], acc);
+    for (int j = 0; j < po; ++j) acc = fmaf(m.W1t[(size_t)(2 * d + n + j) * OMDS_WIDTH + c], f[6 + j], acc);
     Bpre[(size_t)o * OMDS_WIDTH + c] = acc;
 }
 
@@ -178,11 +178,10 @@ static void launch_pass1_a(hipStream_t s, const MlpDev& m, const float* Apre, co
                            int O, long long total, uint32_t ignored, float* Dmin) {
     using G = Geo<MT, MR, NR>;
     const size_t lds = (size_t)MT * LDH * 4 + (size_t)MT * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> configured{0};
+    if (omds_first_use_on_device(configured)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<MT, MR, NR, ACT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const long long tiles = (total + MT - 1) / MT;
     static int tune = -1;
@@ -204,10 +203,9 @@ template <int ACT>
 static void launch_pass1_mixed(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
                                int O, long long total, uint32_t ignored, float* Dmin, int small_rounds) {
     const size_t lds = (size_t)64 * LDH * 4 + 64 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> configured{0};
+    if (omds_first_use_on_device(configured)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1_mixed<ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     static int tune = -1;
     if (tune < 0) { const char* e = getenv("OMDS_TUNE"); tune = e ? atoi(e) : 0; }
@@ -259,11 +257,10 @@ void omds_launch_pass2(hipStream_t s, const MlpDev& m, const float* Apre, const 
     if (total <= 0) return;
     const size_t lds = ((size_t)P2_MT * LDH + 8 * 32 * 33 + 32 * 33) * 4 + (size_t)(m.nhh + 1) * P2_NT * 4 + 3 * P2_MT * 4;
     const int maxlds = (int)(((size_t)P2_MT * LDH + 8 * 32 * 33 + 32 * 33) * 4 + (size_t)(OMDS_MAX_HIDDEN + 1) * P2_NT * 4 + 3 * P2_MT * 4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> configured{0};
+    if (omds_first_use_on_device(configured)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<OMDS_ACT_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<OMDS_ACT_TANH>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
-        attr_set = true;
     }
     const dim3 grid((total + P2_MT - 1) / P2_MT);
     if (m.act == OMDS_ACT_RELU)

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "omds.h"
@@ -27,7 +28,7 @@ struct MlpDev {
     const float4* W1b;   // [32 kchunk][64 lane] first layer, backward pack (cols = 3d features, padded to 32)
     int nhh;             // number of hidden->hidden layers (= hidden layers - 1)
     int C;               // output channels (links)
-    int d;               // n_dof + 3 raw inputs
+    int d;               // raw inputs: n_dof + 3 (obstacle x, y, z), or n_dof + 2 for the toy networks (x, y)
     int n_dof;
     float out_div;
     int act;             // OMDS_ACT_RELU | OMDS_ACT_TANH
@@ -35,6 +36,14 @@ struct MlpDev {
     unsigned long long* tl;   // diagnostic build only (make TIMELINE=1): [workgroup][8] phase timestamps of k_pass1
 #endif
 };
+
+// hipFuncSetAttribute applies to the current device only: true the first time a kernel is launched on each device.
+inline bool omds_first_use_on_device(std::atomic<uint64_t>& mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    return (mask.fetch_or(bit) & bit) == 0;
+}
 
 struct ProfEvents {
     std::vector<hipEvent_t> start, stop;
@@ -65,6 +74,8 @@ struct omds_ctx {
     // DS / cost
     bool have_ds = false, have_cost = false;
     float qf[OMDS_MAX_DOF] = {0};
+    float* d_A = nullptr;        // [n][n] MPPI_toy nominal DS matrix (omds_set_ds_matrix), used when have_A
+    bool have_A = false;
     float qmin[OMDS_MAX_DOF] = {0}, qmax[OMDS_MAX_DOF] = {0};
     float dh[(OMDS_MAX_DOF + 1) * 4] = {0};
     float goal_fk[OMDS_MAX_DOF * 3] = {0};
@@ -144,6 +155,7 @@ struct StepArgs {
     const float* muT; const float* sigmaT; const float* alphaT;
     const float* gradx; const float* drow;
     float qf[OMDS_MAX_DOF];
+    const float* A;   // [n][n] nominal DS matrix of MPPI_toy (velocity = (q - qf) @ A), nullptr = LinDS
     omds_params prm;
 };
 void omds_launch_modulate(hipStream_t s, const StepArgs& a);
@@ -155,6 +167,7 @@ void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const f
                       const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st, int t_begin, int t_end);
 struct CostArgs {
     int N, H, n;
+    uint32_t terms;   // OMDS_COST_* bits
     const float* trajT; const float* distT; float* cost;
     float qf[OMDS_MAX_DOF], qmin[OMDS_MAX_DOF], qmax[OMDS_MAX_DOF];
     float dh[(OMDS_MAX_DOF + 1) * 4];

@@ -126,7 +126,13 @@ __global__ __launch_bounds__(256) void k_cost(CostArgs a) {
                     dz = pts[l * 3 + 2] - a.goal_fk[l * 3 + 2];
         fk += sqrtf(dx * dx + dy * dy + dz * dz);
     }
-    a.cost[t] = goal + coll + jl + stag + 10.f * fk;
+    // the reference sums left to right (cost.py:21); cost_toy.py:18 leaves out the joint-limit and FK terms
+    float total = (a.terms & OMDS_COST_GOAL) ? goal : 0.f;
+    if (a.terms & OMDS_COST_COLLISION) total += coll;
+    if (a.terms & OMDS_COST_JOINT_LIMITS) total += jl;
+    if (a.terms & OMDS_COST_STAGNATION) total += stag;
+    if (a.terms & OMDS_COST_FK) total += 10.f * fk;
+    a.cost[t] = total;
 }
 
 template <int ND>

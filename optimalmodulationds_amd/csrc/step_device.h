@@ -34,13 +34,23 @@ __device__ __forceinline__ void modulate_core(const StepArgs& a, const int i, in
     for (int j = 0; j < ND; ++j) q[j] = q_in[j];
 
     // nominal DS (LinDS.py:11-21) and its norm (MPPI.py:106-108)
-    float dst2 = 0.f;
+    if (a.A == nullptr) {
+        float dst2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < ND; ++j) { const float xd = q[j] - a.qf[j]; v[j] = -xd; dst2 += xd * xd; }
-    const float dst = sqrtf(dst2);
-    if (dst > p.lin_thr) {
+        for (int j = 0; j < ND; ++j) { const float xd = q[j] - a.qf[j]; v[j] = -xd; dst2 += xd * xd; }
+        const float dst = sqrtf(dst2);
+        if (dst > p.lin_thr) {
 #pragma unroll
-        for (int j = 0; j < ND; ++j) v[j] = v[j] / dst;
+            for (int j = 0; j < ND; ++j) v[j] = v[j] / dst;
+        }
+    } else {   // MPPI_toy.py:89: (q - qf) @ A, not normalised
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int r = 0; r < ND; ++r) acc += (q[r] - a.qf[r]) * a.A[r * ND + j];
+            v[j] = acc;
+        }
     }
     float vn2 = 0.f;
 #pragma unroll
@@ -113,7 +123,8 @@ __device__ __forceinline__ void modulate_core(const StepArgs& a, const int i, in
             nrm = powf(sp, 1.f / p.rbf_p);
         }
         const float phi = expf(-a.sigmaT[(size_t)kk * N + t] * (nrm * nrm));
-        a.kvalT[((size_t)(i - 1) * a.Kmax + kk) * N + t] = phi;
+        // MPPI_toy.py:178-179 multiplies the stored kernel values by the activation in place
+        a.kvalT[((size_t)(i - 1) * a.Kmax + kk) * N + t] = (p.variant & OMDS_VARIANT_KVAL_TIMES_ACT) ? phi * act : phi;
 #pragma unroll
         for (int j = 0; j < ND; ++j) pol[j] += al[(size_t)j * N] * phi;
         const float pa = phi * act;

@@ -111,11 +111,10 @@ static size_t tail_lds_bytes(int nhid) {
 
 template <int ND, int ACT>
 static void launch_tail_a(hipStream_t s, const TailArgs& a) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> configured{0};
+    if (omds_first_use_on_device(configured)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<ND, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)tail_lds_bytes(OMDS_MAX_HIDDEN + 1));
-        attr_set = true;
     }
     const int RW = P2_MT / a.st.k;
     hipLaunchKernelGGL((k_tail<ND, ACT>), dim3((a.t_end - a.t_begin + RW - 1) / RW), dim3(P2_NT), tail_lds_bytes(a.m.nhh + 1), s, a);

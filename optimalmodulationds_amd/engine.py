@@ -49,6 +49,7 @@ class Engine:
         Wp = (L.F32P * nl)(*[L.fptr(w) for w in Ws])
         bp = (L.F32P * nl)(*[L.fptr(b) for b in bs])
         self.C = int(dims[-1])
+        self.d = int(dims[0]) // 3                      # raw network inputs: n + 3, or n + 2 for the toy networks
         if out_div is None:
             out_div = 100.0 if self.C == 9 else 1.0     # MPPI.py:236-237
         self._ck(self.lib.omds_set_mlp(self.h, nl, L.iptr(dims), Wp, bp, 0 if act == "relu" else 1, float(out_div)))
@@ -61,6 +62,12 @@ class Engine:
     def set_ds(self, q_goal):
         q = L.f32(q_goal).reshape(self.n)
         self._ck(self.lib.omds_set_ds(self.h, L.fptr(q)))
+
+    def set_ds_matrix(self, q_goal, A):
+        """MPPI_toy's nominal DS: velocity = (q - q_goal) @ A (MPPI_toy.py:89)."""
+        q = L.f32(q_goal).reshape(self.n)
+        a = L.f32(A).reshape(self.n, self.n)
+        self._ck(self.lib.omds_set_ds_matrix(self.h, L.fptr(q), L.fptr(a)))
 
     def push_params(self):
         self._ck(self.lib.omds_set_params(self.h, C.byref(self.params)))
@@ -134,10 +141,10 @@ class Engine:
         return dist, grad, mind, idx
 
     def mlp_forward_vjp(self, x):
-        x = L.f32(x).reshape(-1, self.n + 3)
+        x = L.f32(x).reshape(-1, self.d)
         B = x.shape[0]
         y = np.zeros((B, self.C), np.float32)
-        g = np.zeros((B, self.n + 3), np.float32)
+        g = np.zeros((B, self.d), np.float32)
         mi = np.zeros(B, np.int32)
         self._ck(self.lib.omds_mlp_forward_vjp(self.h, L.fptr(x), B, L.fptr(y), L.fptr(g), L.iptr(mi)))
         return y, g, mi
@@ -225,7 +232,7 @@ def red_layout(K, n):
                 n_sum=o_best, size=o_best + 1 + n)
 
 
-def apply_update(K, n, H, red, n_total, rate, ker_thr, mu_c, sigma_c, alpha_c):
+def apply_update(K, n, H, red, n_total, rate, ker_thr, mu_c, sigma_c, alpha_c, variant=0):
     """Host arithmetic of the policy update on the (globally) reduced buffer -- omds_apply_update."""
     lib = L.load()
     red = L.f32(red)
@@ -234,7 +241,7 @@ def apply_update(K, n, H, red, n_total, rate, ker_thr, mu_c, sigma_c, alpha_c):
     al = np.array(np.asarray(alpha_c, dtype=np.float32)[:K], dtype=np.float32, order="C", copy=True).reshape(K, n)
     mask = np.zeros(K, np.int32)
     rc = lib.omds_apply_update(int(K), int(n), int(H), L.fptr(red), float(n_total), float(rate), float(ker_thr),
-                               L.fptr(mu), L.fptr(sg), L.fptr(al), L.iptr(mask))
+                               int(variant), L.fptr(mu), L.fptr(sg), L.fptr(al), L.iptr(mask))
     if rc != 0:
         raise L.OmdsError(f"omds_apply_update failed ({rc})")
     return mu, sg, al, mask.astype(bool)

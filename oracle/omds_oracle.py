@@ -202,6 +202,9 @@ class Params:
     coll_repulse: float = 0.1                          # :216
     softmax_k: float = -10.0                           # :277
     want_basis: bool = False
+    # FN/MPPI_toy.py variant: nominal DS (q - qf) @ A (:89) and kernel values stored times activation (:178-179)
+    A: object = None
+    kval_times_act: bool = False
 
 
 @dataclass
@@ -225,7 +228,10 @@ def modulation_step(q_prev, qf, distance_raw, g_raw, mu_tmp, sigma_tmp, alpha_tm
     q_prev = np.asarray(q_prev, dtype=F32)
     K = mu_tmp.shape[1]
     with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
-        v = lin_ds_velocity(q_prev, qf, prm.lin_thr)                              # :106
+        if prm.A is None:
+            v = lin_ds_velocity(q_prev, qf, prm.lin_thr)                          # :106
+        else:
+            v = ((q_prev - qf).astype(F32) @ np.asarray(prm.A, dtype=F32)).astype(F32)   # MPPI_toy.py:89
         vnorm = np.sqrt((v * v).sum(axis=1)).reshape(-1, 1)
         vhat = v / vnorm
         distance = (distance_raw - F32(prm.dst_thr)).astype(F32)                   # :117
@@ -292,7 +298,7 @@ def propagate(m: Mlp, q_cur, qf, obs, *, N, H, dt, k, ignored_links, mu_tmp, sig
         dots[:, i - 1] = st["dot"]
         acts[:, i - 1] = st["act"]
         if K > 0:
-            kval_all[:, i - 1, :] = st["phi"]
+            kval_all[:, i - 1, :] = st["phi"] * st["act"][:, None] if prm.kval_times_act else st["phi"]
         if i < H:
             all_traj[:, i, :] = all_traj[:, i - 1, :] + dt * st["u"]              # :221
         if i == 1:
@@ -352,8 +358,8 @@ def link_endpoints(q, dh_params):
     return pts
 
 
-def evaluate_costs(all_traj, closest_dist_all, qf, dh_params, q_min, q_max):
-    """Cost.evaluate_costs (FN/cost.py:13-46)."""
+def evaluate_costs(all_traj, closest_dist_all, qf, dh_params, q_min, q_max, terms=("goal", "coll", "jl", "stag", "fk")):
+    """Cost.evaluate_costs (FN/cost.py:13-46); FN/cost_toy.py:14-18 sums ("goal", "coll", "stag") only."""
     q_end = all_traj[:, -1, :]
     goal = F32(10) * np.sqrt(((q_end - qf) ** 2).sum(axis=1))
     coll = F32(100) * (closest_dist_all < 0).sum(axis=1)
@@ -368,7 +374,11 @@ def evaluate_costs(all_traj, closest_dist_all, qf, dh_params, q_min, q_max):
         diff = link_endpoints(q_end[t], dh_params) - goal_fk
         fk[t] = np.sqrt((diff * diff).sum(axis=1)).sum()
     fk = F32(10) * fk
-    total = goal + coll + jl + stag + fk
+    parts = dict(goal=goal, coll=coll, jl=jl, stag=stag, fk=fk)
+    total = np.zeros_like(goal)
+    for name in ("goal", "coll", "jl", "stag", "fk"):          # left to right like the reference
+        if name in terms:
+            total = total + parts[name]
     return total.astype(F32), dict(goal=goal.astype(F32), coll=coll, jl=jl, stag=stag, fk=fk.astype(F32))
 
 
@@ -382,18 +392,21 @@ def mppi_weights(cost):
 
 
 def shift_policy_means(cost, kernel_val_all, kernel_activations, mu_c, sigma_c, alpha_c,
-                       mu_tmp, sigma_tmp, alpha_tmp, ker_thr, rate):
-    """Returns new (mu_c, sigma_c, alpha_c), update mask, weights.  K = mu_c.shape[0]."""
+                       mu_tmp, sigma_tmp, alpha_tmp, ker_thr, rate, toy=False):
+    """Returns new (mu_c, sigma_c, alpha_c), update mask, weights.  K = mu_c.shape[0].
+    toy=True: FN/MPPI_toy.py:314-323 -- kernel_val_all already holds phi*activation and there is no
+    rollout-0 mask."""
     w = mppi_weights(cost)
     K = mu_c.shape[0]
     if K == 0:
         return mu_c, sigma_c, alpha_c, np.zeros(0, dtype=bool), w
     with np.errstate(invalid="ignore"):
-        prod = kernel_val_all * kernel_activations[:, :, None]
+        prod = kernel_val_all if toy else kernel_val_all * kernel_activations[:, :, None]
         mx = np.where(np.isnan(prod).any(axis=1), np.nan, np.nanmax(np.where(np.isnan(prod), -np.inf, prod), axis=1))
         mask = mx.mean(axis=0) > F32(ker_thr)                                   # FN/MPPI.py:336-339
         mask_base = kernel_val_all[0].mean(axis=0) > F32(ker_thr)               # :341
-    mask = mask & mask_base
+    if not toy:
+        mask = mask & mask_base
     upd = np.where(mask, F32(rate), F32(0)).astype(F32)
     mu_sum = (w[:, None, None] * mu_tmp).sum(axis=0)
     sg_sum = (w[:, None] * sigma_tmp).sum(axis=0)

@@ -80,5 +80,23 @@ for s in np.unique(slot):
             lat.append(nx[0] - e)
 lat = np.array(lat)
 print(f"slot refill latency (end -> next start on that CU): mean {lat.mean():.2f} us, p50 {np.percentile(lat, 50):.2f}, p90 {np.percentile(lat, 90):.2f}")
+# matrix-pipe coverage per CU: time during which 0 / 1 / 2 resident workgroups are inside a GEMM loop
+EPI = 0.7   # epilogue + barriers per hidden layer, from the layer-1 split above
+cov = np.zeros(3); span_tot = 0.0
+for s_ in np.unique(slot):
+    idx = np.where(slot == s_)[0]
+    ev = []
+    for i in idx:
+        for a, b_ in ((us[i, 1], us[i, 6]), (us[i, 2], us[i, 3] - EPI), (us[i, 3], us[i, 4] - EPI)):
+            ev.append((a, +1)); ev.append((b_, -1))
+    ev.sort()
+    cur = 0; last = us[idx, 0].min()
+    for (tt, d) in ev:
+        cov[min(cur, 2)] += tt - last
+        cur += d; last = tt
+    cov[0] += us[idx, 5].max() - last
+    span_tot += us[idx, 5].max() - us[idx, 0].min()
+print("share of each CU's busy span with 0 / 1 / 2 workgroups inside a GEMM loop: " + " / ".join(f"{100 * c / span_tot:.1f} %" for c in cov))
+print(f"mean CU busy span {span_tot / len(np.unique(slot)):.1f} us of launch span {us[:, 5].max():.1f} us")
 wpc = np.bincount(slot)[np.unique(slot)]
 print(f"workgroups per CU: min {wpc.min()} max {wpc.max()}")
