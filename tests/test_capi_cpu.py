@@ -107,3 +107,24 @@ def test_apply_update_matches_reference(lib, name):
         assert_close(al, fx[pre + "alpha_c_new"], 1e-5, "alpha_c")
         lay = red_layout(K, n)
         assert_close(red[lay["qdot"]:lay["best"]] / red[0], fx[pre + "qdot_weighted"], 1e-5, "weighted qdot")
+
+
+def test_fk_num_mirror_matches_reference_vectors():
+    """optimalmodulationds_amd.fk_num (host helper of the drivers' visualisation payloads) against vectors captured
+    from the reference's numeric_fk_model(_vec) (tools/make_golden.py fk_vectors), and the oracle's link end points
+    (the FK cost's restatement) against the same vectors."""
+    import torch
+    from helpers import load
+    from optimalmodulationds_amd.fk_num import dh_fk, numeric_fk_model, numeric_fk_model_vec
+    from oracle import omds_oracle as orc
+    fx = load("fk_num")
+    for kind in ("franka", "planar2"):
+        q, dh = torch.from_numpy(fx[kind + "_q"]), torch.from_numpy(fx[kind + "_dh"])
+        links, pint = numeric_fk_model_vec(q, dh, 4)
+        assert np.abs(links.numpy() - fx[kind + "_links4"]).max() < 2e-6
+        assert np.abs(pint.numpy() - fx[kind + "_int4"]).max() < 1e-7
+        l1, p1 = numeric_fk_model(q[0], dh, 2)
+        assert np.abs(l1.numpy() - fx[kind + "_links2_q0"]).max() < 2e-6 and np.abs(p1.numpy() - fx[kind + "_int2_q0"]).max() < 1e-7
+        assert len(dh_fk(q[0], dh)) == q.shape[1] + 1
+        for b in range(q.shape[0]):   # last sample point of every link = the end point the FK cost compares
+            assert np.abs(orc.link_endpoints(fx[kind + "_q"][b], fx[kind + "_dh"]) - fx[kind + "_links4"][b, :, -1, :]).max() < 2e-6

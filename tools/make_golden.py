@@ -269,8 +269,28 @@ def mlp_vectors(kind, nn_model, seed):
     print(f"mlp_{kind}: y range [{float(y.min()):.3f}, {float(y.max()):.3f}]  min|z|={float(zmin.min()):.2e}")
 
 
+def fk_vectors():
+    """numeric_fk_model / numeric_fk_model_vec (fk_num.py:50-89): link sample points for the drivers' visualisation
+    payloads (frankaPlanner.py:162-177) and the FK cost."""
+    from fk_num import numeric_fk_model, numeric_fk_model_vec
+    torch.manual_seed(5)
+    out = {}
+    for kind, n in (("franka", 7), ("planar2", 2)):
+        dh, _ = robot_setup(kind)
+        q = torch.empty(6, n).uniform_(-2.0, 2.0)
+        links, pts_int = numeric_fk_model_vec(q, dh, 4)
+        l1, p1 = numeric_fk_model(q[0], dh, 2)
+        out.update({kind + "_q": t2n(q), kind + "_dh": t2n(dh), kind + "_links4": t2n(links), kind + "_int4": t2n(pts_int),
+                    kind + "_links2_q0": t2n(l1), kind + "_int2_q0": t2n(p1)})
+    np.savez_compressed(os.path.join(OUT, "fk_num.npz"), **out)
+    print("fk_num:", {k: v.shape for k, v in out.items() if "links" in k})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-fk" in sys.argv:
+        return fk_vectors()
+    fk_vectors()
     models = {k: load_model(k) for k in MODELS}
     for k, m in models.items():
         export_weights(k, m)
