@@ -85,6 +85,10 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
         g_create_err = "omds_create: config out of range (1 <= n_dof <= 7, n_traj, horizon, n_kernel_max, max_obs >= 1, 1 <= n_closest <= 64)";
         return OMDS_ERR_INVALID_ARG;
     }
+    if ((long long)cfg->n_traj * cfg->max_obs >= (1LL << 31) || (long long)cfg->n_traj * cfg->n_closest >= (1LL << 31)) {
+        g_create_err = "omds_create: n_traj * max_obs (rows of the pair space) must stay below 2^31";
+        return OMDS_ERR_INVALID_ARG;
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {

@@ -137,50 +137,55 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                                             ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
 #endif
 
-    // ---- layer 1: H1 = act(Apre[t] + Bpre[o]); one float4 per thread and iteration, all loads of the
-    //      tile issued before the first use (the loop is fully unrolled, no 64-bit division per row) -------
+    // ---- layer 1: H1 = act(Apre[t] + Bpre[o]).  A wave builds one whole row (64 lanes x float4) per step, so the
+    //      row bookkeeping (rollout t, obstacle o, bounds) is wave-uniform and stays on the scalar unit, and the two
+    //      row fetches are buffer loads with scalar row offsets: the build is ~20 instructions per row instead of
+    //      ~100.  That matters more than it looks: next to a co-resident workgroup that streams MFMAs these
+    //      instructions issue at roughly one per MFMA slot (tools/ubench/corun.hip), and the matrix pipe idles
+    //      whenever both residents of a CU are outside their GEMM loops (tools/pass1_timeline.py). ----------------
     {
-        constexpr int IT = MT * 64 / G::NT;                     // iterations per thread
-        const long long t0 = row0 / O;                          // wave-uniform, once per workgroup
-        const int o0 = (int)(row0 - t0 * O);
+        constexpr int IT = MT / G::NW;                          // rows per wave
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const unsigned row0u = (unsigned)row0;                  // the launcher keeps total_rows below 2^31
+        const unsigned t0 = row0u / (unsigned)O;                // once per workgroup
         const int rows_here = (int)((total_rows - row0 < MT) ? (total_rows - row0) : MT);
-        constexpr int BI = IT < 8 ? IT : 8;                     // loads in flight per thread and batch
-#pragma unroll 1
-        for (int base = 0; base < IT; base += BI) {
-            float4 av[BI], bv[BI];
-            int oo[BI];
+        const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Apre) + (size_t)t0 * OMDS_WIDTH, 0,
+                                                                            0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bpre), 0, 0x7fffffff, 0x00020000);
+        const int lv = lane * 16;
+        int o = (int)(row0u - t0 * (unsigned)O) + wv, dt = 0;   // row r = wv + it * NW is pair (t0 + dt, o)
+        while (o >= O) { o -= O; ++dt; }
+        omds_f4 av[IT], bv[IT];
+        float rad[IT];
 #pragma unroll
-            for (int it = 0; it < BI; ++it) {
-                const int idx = tid + (base + it) * G::NT;
-                const int r = idx >> 6, c4 = idx & 63;
-                const int oq = o0 + r;                          // < O + MT
-                const int dt = oq / O;                          // 32-bit
-                const int o = oq - dt * O;
-                oo[it] = o;
-                if (r < rows_here) {
-                    av[it] = reinterpret_cast<const float4*>(Apre)[(t0 + dt) * 64 + c4];
-                    bv[it] = reinterpret_cast<const float4*>(Bpre)[(size_t)o * 64 + c4];
-                } else {
-                    av[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    bv[it] = av[it];
-                }
+        for (int it = 0; it < IT; ++it) {
+            if (wv + it * G::NW < rows_here) {
+                av[it] = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(ar, lv, dt * (OMDS_WIDTH * 4), 0));
+                bv[it] = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(br, lv, o * (OMDS_WIDTH * 4), 0));
+                rad[it] = radius[o];
+            } else {
+                av[it] = omds_f4{0.f, 0.f, 0.f, 0.f};
+                bv[it] = av[it];
+                rad[it] = 0.f;
             }
-            OMDS_TL_WAIT("vmcnt(0)");
-            OMDS_TL(8);
-#pragma unroll
-            for (int it = 0; it < BI; ++it) {
-                const int idx = tid + (base + it) * G::NT;
-                const int r = idx >> 6, c4 = idx & 63;
-                float4 v;
-                v.x = actf(av[it].x + bv[it].x, ACT);
-                v.y = actf(av[it].y + bv[it].y, ACT);
-                v.z = actf(av[it].z + bv[it].z, ACT);
-                v.w = actf(av[it].w + bv[it].w, ACT);
-                if (r >= rows_here) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(Hs + r * LDH + 4 * c4) = v;
-                if (c4 == 0) rowRad[r] = (r < rows_here) ? radius[oo[it]] : 0.f;
-            }
+            o += G::NW;
+            while (o >= O) { o -= O; ++dt; }
         }
+        OMDS_TL_WAIT("vmcnt(0)");
+        OMDS_TL(8);
+        float* hrow = Hs + wv * LDH + 4 * lane;
+        float myrad = 0.f;                                      // lane it of the wave collects the radius of its row it
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            float4 v;                                           // rows past the end were loaded as zeros: act(0) = 0
+            v.x = actf(av[it].x + bv[it].x, ACT);
+            v.y = actf(av[it].y + bv[it].y, ACT);
+            v.z = actf(av[it].z + bv[it].z, ACT);
+            v.w = actf(av[it].w + bv[it].w, ACT);
+            *reinterpret_cast<float4*>(hrow + it * G::NW * LDH) = v;
+            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(myrad) : "s"(rad[it]), "n"(it));
+        }
+        if (lane < IT) rowRad[wv + lane * G::NW] = myrad;
     }
     OMDS_TL_WAIT("lgkmcnt(0)");
     OMDS_TL(9);
@@ -218,14 +223,17 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
         OMDS_TL(2 + l);
     }
 
-    // ---- last layer (256 -> C, padded to 16) on v_mfma_f32_16x16x4_f32, 16 rows per wave ----------
-    for (int rb = wave; rb < MT / 16; rb += G::NW) {
+    // ---- last layer (256 -> C, padded to 16) on v_mfma_f32_16x16x4_f32, 16 rows per wave.  Kept short on purpose
+    //      (buffer loads with constant offsets, DPP min over the 16 link lanes, one 16-byte store per 4 rows): like
+    //      the layer-1 build it mostly runs starved next to the other resident workgroup's GEMM ----------------
+    const __amdgpu_buffer_rsrc_t wlr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(m.Wl), 0, 16 * 64 * 16, 0x00020000);
+    for (int rb = __builtin_amdgcn_readfirstlane(wave); rb < MT / 16; rb += G::NW) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* arow = Hs + (rb * 16 + (lane & 15)) * LDH + 4 * (lane >> 4);
-#pragma unroll 4
+#pragma unroll
         for (int c = 0; c < 16; ++c) {
             const float4 a = *reinterpret_cast<const float4*>(arow + 16 * c);
-            const float4 w = m.Wl[c * 64 + lane];
+            const omds_f4 w = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(wlr, lane * 16, c * 64 * 16, 0));
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
@@ -239,16 +247,30 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
         const int j = lane & 15;
         const float bj = m.bl[j];
         const bool pad = j >= m.C, ign = (ignored >> j) & 1u;
+        const int r4 = rb * 16 + 4 * (lane >> 4);
+        const float4 rr = *reinterpret_cast<const float4*>(rowRad + r4);
+        const float rad[4] = {rr.x, rr.y, rr.z, rr.w};
+        float y[4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int r = rb * 16 + 4 * (lane >> 4) + reg;
-            float y = (acc[reg] + bj) / m.out_div - rowRad[r];
-            y = pad ? __builtin_inff() : (ign ? 1e6f : y);
-            y = fminf(y, __shfl_xor(y, 1));
-            y = fminf(y, __shfl_xor(y, 2));
-            y = fminf(y, __shfl_xor(y, 4));
-            y = fminf(y, __shfl_xor(y, 8));
-            if (j == 0 && row0 + r < total_rows) Dmin[row0 + r] = y;
+            float v = (acc[reg] + bj) / m.out_div - rad[reg];
+            v = pad ? __builtin_inff() : (ign ? 1e6f : v);
+            // min over the 16 lanes of the row group: xor 1, xor 2 inside the quad, then mirror within 8 and within 16
+            v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false)));
+            v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false)));
+            v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false)));
+            v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false)));
+            y[reg] = v;
+        }
+        if (j == 0) {
+            const long long g = row0 + r4;
+            if (g + 3 < total_rows) {
+                *reinterpret_cast<float4*>(Dmin + g) = make_float4(y[0], y[1], y[2], y[3]);   // row0 and r4 are multiples of 4
+            } else {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    if (g + reg < total_rows) Dmin[g + reg] = y[reg];
+            }
         }
     }
 #ifdef OMDS_TIMELINE

@@ -11,6 +11,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 enum { B_VALU = 0, B_LDSW = 1, B_LDSR = 2, B_VMEM = 3, B_PERM = 4, B_MFMA16 = 5, B_N = 6 };
 static const char* names[B_N] = {"VALU fma chain", "ds_write_b128", "ds_read_b128", "global_load_dwordx4 (L2)", "ds_bpermute", "dependent 16x16x4 MFMA"};
 
+// s_nop k idles the wave for (k+1) x 4 clocks.  AMODE = 10 + idle clocks / 4 after EVERY MFMA: the wave does not present its next
+// MFMA (which would sit in the VALU issue stage and block the other waves' VALU) until shortly before the pipe frees.
+template <int AMODE>
+__device__ __forceinline__ void spacer() {
+    if constexpr (AMODE >= 10) {
+        constexpr int q = AMODE - 10;            // quad-cycles
+        if constexpr (q >= 16) asm volatile("s_nop 15");
+        if constexpr (q >= 32) asm volatile("s_nop 15");
+        if constexpr (q % 16 == 4) asm volatile("s_nop 3");
+        if constexpr (q % 16 == 8) asm volatile("s_nop 7");
+        if constexpr (q % 16 == 12) asm volatile("s_nop 11");
+    }
+}
+
 template <int AMODE>
 __global__ __launch_bounds__(1024) void k(int a_on, int a_iters, int b_kind, int b_ops, int prio, int a_first,
                                            const float4* __restrict__ src, float* out, long long* tim) {
@@ -30,8 +44,10 @@ __global__ __launch_bounds__(1024) void k(int a_on, int a_iters, int b_kind, int
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(1.f, 1.f, acc0, 0, 0, 0);
+                spacer<AMODE>();
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(1.f, 1.f, acc1, 0, 0, 0);
                 if (AMODE == 4) asm volatile("s_nop 0");          // one idle issue slot after every MFMA pair
+                spacer<AMODE>();
             }
             if (AMODE == 1) __builtin_amdgcn_s_sleep(1);            // ~64 cycles every 16 MFMAs
             if (AMODE == 2) asm volatile("s_nop 15");
@@ -127,8 +143,11 @@ int main(int argc, char** argv) {
     (void)hipMemset(src, 0, (size_t)16384 * 64 * 16);
     run_mode<0>("back-to-back MFMA", out, tim, src, ops, a_iters);
     run_mode<1>("s_sleep 1 every 16 MFMAs", out, tim, src, ops, a_iters);
-    run_mode<2>("s_nop 15 every 16 MFMAs", out, tim, src, ops, a_iters);
-    run_mode<4>("s_nop 0 after every 2 MFMAs", out, tim, src, ops, a_iters);
-    run_mode<5>("s_sleep 0 every 16 MFMAs", out, tim, src, ops, a_iters);
+    run_mode<10 + 8>("32 idle clocks after every MFMA", out, tim, src, ops, a_iters);
+    run_mode<10 + 12>("48 idle clocks after every MFMA", out, tim, src, ops, a_iters);
+    run_mode<10 + 16>("64 idle clocks after every MFMA", out, tim, src, ops, a_iters);
+    run_mode<10 + 20>("80 idle clocks after every MFMA", out, tim, src, ops, a_iters);
+    run_mode<10 + 24>("96 idle clocks after every MFMA", out, tim, src, ops, a_iters);
+    run_mode<10 + 28>("112 idle clocks after every MFMA", out, tim, src, ops, a_iters);
     return 0;
 }
