@@ -137,6 +137,11 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                                             ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
 #endif
 
+    const int cb0 = wn * NR;
+    float bcur[NR];   // bias of the first hidden->hidden layer: in flight across the whole layer-1 build
+#pragma unroll
+    for (int j = 0; j < NR; ++j) bcur[j] = m.nhh > 0 ? m.bh[(cb0 + j) * 32 + (lane & 31)] : 0.f;
+
     // ---- layer 1: H1 = act(Apre[t] + Bpre[o]).  A wave builds one whole row (64 lanes x float4) per step, so the
     //      row bookkeeping (rollout t, obstacle o, bounds) is wave-uniform and stays on the scalar unit, and the two
     //      row fetches are buffer loads with scalar row offsets: the build is ~20 instructions per row instead of
@@ -192,9 +197,9 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
     __syncthreads();
     OMDS_TL(1);
 
-    // ---- hidden -> hidden layers -----------------------------------------------------------------
+    // ---- hidden -> hidden layers.  The accumulators start at the bias (fetched one layer ahead), so the epilogue
+    //      is activation + LDS write only -----------------------------------------------------------------
     const float* Hw = Hs + (wm * MR * 32) * LDH;
-    const int cb0 = wn * NR;
     for (int l = 0; l < m.nhh; ++l) {
         f32x16 acc[MR][NR];
 #pragma unroll
@@ -202,22 +207,22 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
 #pragma unroll
             for (int j = 0; j < NR; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        float bvj[NR];   // biases fetched before the GEMM so that the epilogue does not start with an L2 round trip
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = bcur[j];
+        if (l + 1 < m.nhh) {
 #pragma unroll
-        for (int j = 0; j < NR; ++j) bvj[j] = m.bh[l * OMDS_WIDTH + (cb0 + j) * 32 + (lane & 31)];
+            for (int j = 0; j < NR; ++j) bcur[j] = m.bh[(l + 1) * OMDS_WIDTH + (cb0 + j) * 32 + (lane & 31)];
+        }
         gemm256<MR, NR>(Hw, m.Wf + (size_t)l * (OMDS_NCB * 32 * 64), cb0, lane, acc, (tune & 1) != 0);
         __syncthreads();  // every wave has finished reading the tile
         if (l == 0) OMDS_TL(6);
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const int col = (cb0 + j) * 32 + (lane & 31);
-            const float bv = bvj[j];
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    Hs[((wm * MR + i) * 32 + crow(r, lane)) * LDH + col] = actf(acc[i][j][r] + bv, ACT);
+                    Hs[((wm * MR + i) * 32 + crow(r, lane)) * LDH + col] = actf(acc[i][j][r], ACT);
         }
         __syncthreads();
         OMDS_TL(2 + l);
