@@ -9,9 +9,37 @@
 #include <cstring>
 #include <new>
 
+#include <dlfcn.h>
+
 #include "omds_internal.h"
 
 static thread_local std::string g_create_err;
+
+// Optional roctx ranges named like the reference's torch.profiler record_function tags (MPPI.py:102-268,
+// frankaPlanner.py:135-145), so that a `rocprofv3 --marker-trace --kernel-trace` timeline reads like the reference's
+// Chrome trace.  Enabled with OMDS_ROCTX=1; the roctx library is dlopen'ed, never linked.
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* e = getenv("OMDS_ROCTX");
+        if (!e || atoi(e) == 0) return;
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+struct RoctxRange {
+    static Roctx& api() { static Roctx r; return r; }
+    bool on;
+    explicit RoctxRange(const char* name) : on(api().push != nullptr) { if (on) api().push(name); }
+    ~RoctxRange() { if (on) api().pop(); }
+};
+}  // namespace
 
 #define CK(expr) OMDS_HIP_CHECK(ctx, expr)
 #define REQUIRE(cond, code, msg)            \
@@ -514,6 +542,7 @@ static int check_ready(omds_ctx* ctx, bool need_ds) {
 }
 
 int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
+    RoctxRange range("TAG: general propagation");
     if (!ctx) return OMDS_ERR_INVALID_ARG;
     REQUIRE(q_cur, OMDS_ERR_INVALID_ARG, "omds_propagate: null q_cur");
     int rc;
@@ -547,10 +576,14 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
         // other half's pass 1: parity-green, but the half-size launches drain twice per step, 1.00 M vs 1.03 M.)
         omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, ctx->d_Apre);
         for (int i = 1; i <= H; ++i) {
-            if ((rc = prof_begin(ctx))) return rc;
-            omds_launch_pass1(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
-                              ctx->prm.ignored_links, ctx->d_Dmin);
-            if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs))) return rc;
+            {
+                RoctxRange r1("TAG: evaluate NN_2 (forward pass)");
+                if ((rc = prof_begin(ctx))) return rc;
+                omds_launch_pass1(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
+                                  ctx->prm.ignored_links, ctx->d_Dmin);
+                if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs))) return rc;
+            }
+            RoctxRange r2("TAG: evaluate NN_3-5 + Modulation-propagation");
             a.step = i;
             omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, ctx->d_Apre,
                              ctx->d_dscr, ctx->n_obs, a, 0, N);
@@ -682,6 +715,7 @@ static int enqueue_cost(omds_ctx* ctx) {
 }
 
 int omds_cost(omds_ctx* ctx, float* cost_out) {
+    RoctxRange range("TAG: cost calculation");
     if (!ctx) return OMDS_ERR_INVALID_ARG;
     REQUIRE(ctx->have_ds && ctx->have_cost, OMDS_ERR_NOT_INITIALISED, "omds_cost: call omds_set_ds and omds_set_cost first");
     CK(hipSetDevice(ctx->dev));
@@ -759,6 +793,7 @@ int omds_apply_update(int K, int n, int H, const float* red, float n_total, floa
 
 int omds_weighted_update(omds_ctx* ctx, float rate, float ker_thr, float* mu_c, float* sigma_c, float* alpha_c,
                          int32_t* mask_out, float* weights_out) {
+    RoctxRange range("shift_policy_means");
     if (!ctx) return OMDS_ERR_INVALID_ARG;
     const int N = ctx->cfg.n_traj, n = ctx->cfg.n_dof, K = ctx->n_kernels, H = ctx->cfg.horizon;
     REQUIRE(K == 0 || (mu_c && sigma_c && alpha_c), OMDS_ERR_INVALID_ARG, "omds_weighted_update: null mean array");

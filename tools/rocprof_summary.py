@@ -29,6 +29,26 @@ def pmc(db):
     return "\n".join(out)
 
 
+def markers(db):
+    """roctx ranges of an OMDS_ROCTX=1 run under --marker-trace: host-side enqueue time per range name (the kernels
+    run asynchronously; the ranges annotate the timeline with the reference's record_function tags)."""
+    import json
+    cur = sqlite3.connect(db).cursor()
+    agg = {}
+    for ext, dur in cur.execute("select extdata, duration from regions where category like 'MARKER%'"):
+        try:
+            name = json.loads(ext).get("message", "?")
+        except Exception:
+            name = "?"
+        a = agg.setdefault(name, [0, 0.0])
+        a[0] += 1
+        a[1] += dur / 1e3
+    out = [f"{'roctx range':60s} {'n':>6s} {'host_us_total':>14s} {'host_us_avg':>12s}"]
+    for name, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        out.append(f"{name[:60]:60s} {n:6d} {tot:14.1f} {tot / n:12.2f}")
+    return "\n".join(out)
+
+
 if __name__ == "__main__":
     mode, db = sys.argv[1], sys.argv[2]
-    print(kernel_stats(db) if mode == "stats" else pmc(db))
+    print({"stats": kernel_stats, "pmc": pmc, "markers": markers}[mode](db))
