@@ -274,7 +274,7 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
     if (ctx->d_dscr) { (void)hipFree(ctx->d_dscr); ctx->d_dscr = nullptr; }
     if (act == OMDS_ACT_TANH) {   // pass 2 keeps 1 - h^2 of every hidden layer for the backward (ReLU uses LDS bit masks)
         const size_t rows = std::max(((size_t)ctx->cfg.n_traj * ctx->cfg.n_closest + 31) / 32 * 32,
-                                     (size_t)omds_tail_workgroups(ctx->cfg.n_traj, ctx->cfg.n_closest) * 32);
+                                     (size_t)omds_tail_scratch_rows(ctx->cfg.n_traj, ctx->cfg.n_closest));
         CK(hipMalloc(&ctx->d_dscr, (size_t)nhid * rows * OMDS_WIDTH * 4));
     }
     const int Wd = OMDS_WIDTH;
@@ -292,6 +292,18 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
                     wb[o] = make_float4(Wl[(k0)*Wd + j], Wl[(k0 + 1) * Wd + j], Wl[(k0 + 2) * Wd + j], Wl[(k0 + 3) * Wd + j]);
                 }
         std::memcpy(&bh[(size_t)l * Wd], b[l + 1], Wd * sizeof(float));
+    }
+    std::vector<float4> wf16(wf.size()), wb16(wf.size());
+    for (int l = 0; l < m.nhh; ++l) {
+        const float* Wl = W[l + 1];
+        for (int cb = 0; cb < 16; ++cb)
+            for (int c = 0; c < 16; ++c)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int j = 16 * cb + (lane & 15), k0 = 16 * c + 4 * (lane >> 4);
+                    const size_t o = (((size_t)l * 16 + cb) * 16 + c) * 64 + lane;
+                    wf16[o] = make_float4(Wl[j * Wd + k0], Wl[j * Wd + k0 + 1], Wl[j * Wd + k0 + 2], Wl[j * Wd + k0 + 3]);
+                    wb16[o] = make_float4(Wl[(k0)*Wd + j], Wl[(k0 + 1) * Wd + j], Wl[(k0 + 2) * Wd + j], Wl[(k0 + 3) * Wd + j]);
+                }
     }
     // last layer: 16x16x4 B-fragments, channels padded to 16
     const float* WL = W[n_linear - 1];
@@ -322,7 +334,20 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
                 for (int mm = 0; mm < 4; ++mm) v[mm] = W[0][(k0 + mm) * F + f];
             w1b[c * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
         }
+    std::vector<float4> w1b16(16 * 2 * 64);
+    for (int c = 0; c < 16; ++c)
+        for (int jb = 0; jb < 2; ++jb)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int f = 16 * jb + (lane & 15), k0 = 16 * c + 4 * (lane >> 4);
+                float v[4] = {0, 0, 0, 0};
+                if (f < F)
+                    for (int mm = 0; mm < 4; ++mm) v[mm] = W[0][(k0 + mm) * F + f];
+                w1b16[(c * 2 + jb) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+            }
     int rc;
+    if ((rc = upload(ctx, wf16, &m.Wf16))) return rc;
+    if ((rc = upload(ctx, wb16, &m.Wb16))) return rc;
+    if ((rc = upload(ctx, w1b16, &m.W1b16))) return rc;
     if ((rc = upload(ctx, wf, &m.Wf))) return rc;
     if ((rc = upload(ctx, wb, &m.Wb))) return rc;
     if ((rc = upload(ctx, bh, &m.bh))) return rc;

@@ -98,6 +98,60 @@ __device__ __forceinline__ void gemm256(const float* __restrict__ Hw, const floa
 // C/D layout of the 32x32 MFMA: lane l, register r -> row (r&3) + 8(r>>2) + 4(l>>5), col l&31.
 __device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// ------------------------------------------------------------------------------------------------
+// [16 x 256] . [256 x 32] on v_mfma_f32_16x16x4_f32 -- the GEMM of the 16-row pass-2 tiles used for small batches,
+// where a tile's chain of dependent GEMMs is the latency of the whole horizon step: half the rows = half the MFMA
+// time per GEMM (3.4 us instead of 6.8 us on the four SIMDs of a CU).
+//   A from LDS: lane l reads H[row = l&15][16c + 4(l>>4) .. +3];  B packed alike (Wf16 / Wb16);
+//   step m of chunk c contracts k = 16c + 4g + m for lane group g = l>>4.  C/D: lane l, reg r -> row 4(l>>4)+r, col l&15.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_chunk16(const float* arow, __amdgpu_buffer_rsrc_t wrsrc, int wvoff, int c, float4& a, float4 (&w)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const omds_f4 v = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, (j * 16 + c) * 64 * 16, 0));
+        w[j] = make_float4(v.x, v.y, v.z, v.w);
+    }
+    a = *reinterpret_cast<const float4*>(arow + 16 * c);
+}
+__device__ __forceinline__ void mfma_chunk16(const float4& a, const float4 (&w)[2], f32x4 (&acc)[2]) {
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[0].x, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[1].x, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[0].y, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[1].y, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[0].z, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[1].z, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[0].w, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[1].w, acc[1], 0, 0, 0);
+}
+// Wp = pack of one layer ([16 colblk16][16 kchunk][64 lane]); wave w produces columns 32w .. 32w+31 (blocks 2w, 2w+1)
+__device__ __forceinline__ void gemm16(const float* __restrict__ Hs, const float4* __restrict__ Wp, int wave, int lane, f32x4 (&acc)[2]) {
+    const float* arow = Hs + (lane & 15) * LDH + 4 * (lane >> 4);
+    const float4* wbase = Wp + (size_t)__builtin_amdgcn_readfirstlane(wave) * (2 * 16 * 64);
+    const __amdgpu_buffer_rsrc_t wp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wbase), 0, 2 * 16 * 64 * 16, 0x00020000);
+    const int wv = lane * 16;
+    float4 a0, a1, w0[2], w1[2];
+    load_chunk16(arow, wp, wv, 0, a0, w0);
+#define OMDS_INTERLEAVE16()                                 \
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);        \
+    __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);       \
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);        \
+    __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);       \
+    __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);        \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      \
+    __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);        \
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) {
+        load_chunk16(arow, wp, wv, c + 1, a1, w1);
+        mfma_chunk16(a0, w0, acc);
+        OMDS_INTERLEAVE16()
+        load_chunk16(arow, wp, wv, (c + 2) & 15, a0, w0);
+        mfma_chunk16(a1, w1, acc);
+        OMDS_INTERLEAVE16()
+    }
+#undef OMDS_INTERLEAVE16
+}
+
 
 template <int MT, int MR, int NR>
 struct Geo {
@@ -342,17 +396,51 @@ struct P2Smem {
     int* rowMin;      // [32] arg-min link of each row
 };
 
-// Body of pass 2 for the 32 rows described by sm.rowT / sm.rowO (already in LDS, barrier done by the
+// Geometry of the per-thread accumulator values of a pass-2 tile: ROWS = 32 uses the 32x32x2 MFMA (16 values per thread,
+// one column), ROWS = 16 the 16x16x4 MFMA (two 16-column blocks -> 8 values per thread, two columns).
+template <int ROWS>
+struct P2Geo {
+    static constexpr int NV = ROWS == 32 ? 16 : 8;
+    static constexpr int NB = ROWS == 32 ? 1 : 2;    // distinct columns per thread
+    static __device__ __forceinline__ int row(int r, int lane) { return ROWS == 32 ? crow(r, lane) : 4 * (lane >> 4) + (r & 3); }
+    static __device__ __forceinline__ int col(int r, int wave, int lane) {
+        return ROWS == 32 ? wave * 32 + (lane & 31) : wave * 32 + 16 * (r >> 2) + (lane & 15);
+    }
+    static __device__ __forceinline__ int blk(int r) { return ROWS == 32 ? 0 : (r >> 2); }
+};
+
+// One [ROWS x 256] . [256 x 256] GEMM of pass 2 (forward pack or transposed pack of layer l); out[r] in P2Geo order.
+template <int ROWS>
+__device__ __forceinline__ void p2_gemm(const float* Hs, const MlpDev& m, int l, bool backward, int wave, int lane,
+                                        float (&out)[P2Geo<ROWS>::NV]) {
+    if constexpr (ROWS == 32) {
+        f32x16 acc[1][1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+        gemm256<1, 1>(Hs, (backward ? m.Wb : m.Wf) + (size_t)l * (OMDS_NCB * 32 * 64), wave, lane, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[r] = acc[0][0][r];
+    } else {
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        gemm16(Hs, (backward ? m.Wb16 : m.Wf16) + (size_t)l * (16 * 16 * 64), wave, lane, acc);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) out[r] = acc[r >> 2][r & 3];
+    }
+}
+
+// Body of pass 2 for the ROWS rows described by sm.rowT / sm.rowO (already in LDS, barrier done by the
 // caller).  R0 = global index of row 0 (tanh scratch, yraw, minidx); outputs go to
 // gradx[(dbase + row) * d + j] and drow[dbase + row] (global memory or LDS).
-template <int ACT, bool LOWREG = false>
+template <int ACT, bool LOWREG = false, int ROWS = 32>
 __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, const float* __restrict__ Apre,
                                            const float* __restrict__ Bpre, const float* __restrict__ radius,
                                            const float* __restrict__ xyzr, int R0, int total_rows,
                                            const float* __restrict__ qT, int ldq, float* gradx, float* drow, int dbase,
                                            float* __restrict__ yraw, int32_t* __restrict__ minidx,
                                            float* __restrict__ dscr, size_t dlayer, int S0, int dbg = 0) {
-    // dbg: timing experiments only (return after a stage).  S0 = first row of this workgroup's private 32-row slot in the tanh scratch
+    // dbg: timing experiments only (return after a stage).  S0 = first row of this workgroup's private slot in the tanh scratch
+    using G = P2Geo<ROWS>;
+    constexpr int NV = G::NV;
     float* Hs = sm.Hs;
     float* P = sm.P;
     float* gf = sm.gf;
@@ -361,23 +449,22 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
     int* rowO = sm.rowO;
     int* rowMin = sm.rowMin;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int col = wave * 32 + (lane & 31);
     constexpr bool relu = ACT == OMDS_ACT_RELU;
 
     // ---- layer 1 in C-layout ------------------------------------------------------------------
     {
         uint32_t bits = 0;
-        float za[16], zb[16];   // all 32 loads in flight before the first use (padding rows read row 0)
+        float za[NV], zb[NV];   // all loads in flight before the first use (padding rows read row 0)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = crow(r, lane);
+        for (int r = 0; r < NV; ++r) {
+            const int row = G::row(r, lane), col = G::col(r, wave, lane);
             const int t = rowT[row];
             za[r] = Apre[(size_t)(t < 0 ? 0 : t) * OMDS_WIDTH + col];
             zb[r] = Bpre[(size_t)rowO[row] * OMDS_WIDTH + col];
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = crow(r, lane);
+        for (int r = 0; r < NV; ++r) {
+            const int row = G::row(r, lane), col = G::col(r, wave, lane);
             const float z = (rowT[row] >= 0) ? za[r] + zb[r] : 0.f;
             bits |= (z > 0.f ? 1u : 0u) << r;
             const float h = actf(z, ACT);
@@ -391,20 +478,21 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
 
     // ---- forward through the hidden -> hidden layers -------------------------------------------
     for (int l = 0; l < m.nhh; ++l) {
-        f32x16 acc[1][1];
+        float bv[G::NB];   // before the GEMM: no L2 round trip at the head of the epilogue
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-        const float bv = m.bh[l * OMDS_WIDTH + col];   // before the GEMM: no L2 round trip at the head of the epilogue
-        gemm256<1, 1>(Hs, m.Wf + (size_t)l * (OMDS_NCB * 32 * 64), wave, lane, acc);
+        for (int jb = 0; jb < G::NB; ++jb) bv[jb] = m.bh[l * OMDS_WIDTH + G::col(4 * jb, wave, lane)];
+        float acc[NV];
+        p2_gemm<ROWS>(Hs, m, l, false, wave, lane, acc);
         __syncthreads();
         uint32_t bits = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float z = acc[0][0][r] + bv;
+        for (int r = 0; r < NV; ++r) {
+            const int row = G::row(r, lane), col = G::col(r, wave, lane);
+            const float z = acc[r] + bv[G::blk(r)];
             bits |= (z > 0.f ? 1u : 0u) << r;
             const float h = actf(z, ACT);
-            Hs[crow(r, lane) * LDH + col] = h;
-            if (!relu) dscr[(l + 1) * dlayer + (size_t)(S0 + crow(r, lane)) * OMDS_WIDTH + col] = 1.f - h * h;
+            Hs[row * LDH + col] = h;
+            if (!relu) dscr[(l + 1) * dlayer + (size_t)(S0 + row) * OMDS_WIDTH + col] = 1.f - h * h;
         }
         maskL[(l + 1) * P2_NT + tid] = (uint16_t)bits;
         __syncthreads();
@@ -412,7 +500,7 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
 
     if (dbg == 11) return;
     // ---- last layer, arg-min over ALL raw outputs (robot_sdf.py:155), distance of that link -------
-    if (wave < P2_MT / 16) {
+    if (wave < ROWS / 16) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* arow = Hs + (wave * 16 + (lane & 15)) * LDH + 4 * (lane >> 4);
         const int j = lane & 15;
@@ -465,8 +553,8 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
     {
         const uint32_t bits = maskL[m.nhh * P2_NT + tid];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = crow(r, lane);
+        for (int r = 0; r < NV; ++r) {
+            const int row = G::row(r, lane), col = G::col(r, wave, lane);
             const float g = m.Wlraw[(size_t)rowMin[row] * OMDS_WIDTH + col];
             const float dv = relu ? (((bits >> r) & 1u) ? 1.f : 0.f)
                                   : dscr[m.nhh * dlayer + (size_t)(S0 + row) * OMDS_WIDTH + col];
@@ -478,24 +566,23 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
 
     // ---- backward through the hidden -> hidden layers ------------------------------------------
     for (int l = m.nhh - 1; l >= 0; --l) {
-        f32x16 acc[1][1];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-        gemm256<1, 1>(Hs, m.Wb + (size_t)l * (OMDS_NCB * 32 * 64), wave, lane, acc);
+        float acc[NV];
+        p2_gemm<ROWS>(Hs, m, l, true, wave, lane, acc);
         __syncthreads();
         const uint32_t bits = maskL[l * P2_NT + tid];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < NV; ++r) {
+            const int row = G::row(r, lane), col = G::col(r, wave, lane);
             const float dv = relu ? (((bits >> r) & 1u) ? 1.f : 0.f)
-                                  : dscr[l * dlayer + (size_t)(S0 + crow(r, lane)) * OMDS_WIDTH + col];
-            Hs[crow(r, lane) * LDH + col] = acc[0][0][r] * dv;
+                                  : dscr[l * dlayer + (size_t)(S0 + row) * OMDS_WIDTH + col];
+            Hs[row * LDH + col] = acc[r] * dv;
         }
         __syncthreads();
     }
 
     if (dbg == 14) return;
     // ---- first layer backward: g_f[row][f] = sum_c Gz1[row][c] W1[c][f], split-K over the 8 waves -------
-    {
+    if constexpr (ROWS == 32) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -512,20 +599,34 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) P[(wave * 32 + crow(r, lane)) * 32 + (lane & 31)] = acc[r];
+    } else {
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const float* arow = Hs + (lane & 15) * LDH + 4 * (lane >> 4);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int c = wave * 2 + cc;
+            const float4 a = *reinterpret_cast<const float4*>(arow + 16 * c);
+            float4 w[2];
+            w[0] = m.W1b16[(c * 2 + 0) * 64 + lane];
+            w[1] = m.W1b16[(c * 2 + 1) * 64 + lane];
+            mfma_chunk16(a, w, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) P[(wave * ROWS + 4 * (lane >> 4) + (r & 3)) * 32 + 16 * (r >> 2) + (lane & 15)] = acc[r >> 2][r & 3];
     }
     __syncthreads();
     if (dbg == 15) return;
-    for (int e = tid; e < 32 * 32; e += P2_NT) {
+    for (int e = tid; e < ROWS * 32; e += P2_NT) {
         const int row = e >> 5, f = e & 31;
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) s += P[(w * 32 + row) * 32 + f];
+        for (int w = 0; w < 8; ++w) s += P[(w * ROWS + row) * 32 + f];
         gf[row * 33 + f] = s;
     }
     __syncthreads();
     // ---- positional-encoding chain rule: d/dx = g[x] + g[sin x] cos x - g[cos x] sin x --------------
     const int d = m.d, n = m.n_dof;
-    if (tid < P2_MT * d) {
+    if (tid < ROWS * d) {
         const int row = tid / d, jj = tid - row * d;
         const int R = R0 + row;
         if (R < total_rows && rowT[row] >= 0) {
@@ -534,4 +635,3 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
         }
     }
 }
-

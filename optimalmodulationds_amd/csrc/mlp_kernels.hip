@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_topk(const float* __restrict__ Dmin, in
 // wave w owns output columns [32w, 32w+32). ReLU masks live in LDS as 16 bits per thread/layer
 // in the MFMA C-layout (the same lane owns the same (row, col) in every layer).
 // ------------------------------------------------------------------------------------------------
-template <int ACT>
+template <int ACT, int ROWS>
 __global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restrict__ Apre,
                                                  const float* __restrict__ Bpre, const float* __restrict__ radius,
                                                  const float* __restrict__ xyzr, const int32_t* __restrict__ idx,
@@ -127,8 +127,8 @@ __global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restri
     sm.rowO = sm.rowT + P2_MT;
     sm.rowMin = sm.rowO + P2_MT;
     const int tid = threadIdx.x;
-    const int R0 = blockIdx.x * P2_MT;
-    if (tid < P2_MT) {
+    const int R0 = blockIdx.x * ROWS;
+    if (tid < ROWS) {
         const int R = R0 + tid;
         int t = -1, o = 0;
         if (R < total_rows) { t = R / k; o = idx[R]; }
@@ -136,8 +136,8 @@ __global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restri
         sm.rowO[tid] = o;
     }
     __syncthreads();
-    pass2_body<ACT>(m, sm, Apre, Bpre, radius, xyzr, R0, total_rows, qT, ldq, gradx, drow, R0, yraw, minidx, dscr,
-               (size_t)gridDim.x * P2_MT * OMDS_WIDTH, R0);
+    pass2_body<ACT, false, ROWS>(m, sm, Apre, Bpre, radius, xyzr, R0, total_rows, qT, ldq, gradx, drow, R0, yraw, minidx, dscr,
+                                 (size_t)gridDim.x * ROWS * OMDS_WIDTH, R0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -259,16 +259,19 @@ void omds_launch_pass2(hipStream_t s, const MlpDev& m, const float* Apre, const 
     const int maxlds = (int)(((size_t)P2_MT * LDH + 8 * 32 * 33 + 32 * 33) * 4 + (size_t)(OMDS_MAX_HIDDEN + 1) * P2_NT * 4 + 3 * P2_MT * 4);
     static std::atomic<uint64_t> configured{0};
     if (omds_first_use_on_device(configured)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<OMDS_ACT_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<OMDS_ACT_TANH>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<OMDS_ACT_RELU, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<OMDS_ACT_TANH, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<OMDS_ACT_RELU, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<OMDS_ACT_TANH, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
     }
-    const dim3 grid((total + P2_MT - 1) / P2_MT);
-    if (m.act == OMDS_ACT_RELU)
-        hipLaunchKernelGGL(k_pass2<OMDS_ACT_RELU>, grid, dim3(P2_NT), lds, s, m, Apre, Bpre, radius, xyzr, idx, total, k, qT, ldq,
-                           gradx, drow, yraw, minidx, dscr);
-    else
-        hipLaunchKernelGGL(k_pass2<OMDS_ACT_TANH>, grid, dim3(P2_NT), lds, s, m, Apre, Bpre, radius, xyzr, idx, total, k, qT, ldq,
-                           gradx, drow, yraw, minidx, dscr);
+    // same tile height as the fused tail would pick for this batch, so that the batch entry points (omds_dist_grad)
+    // reproduce the step path bit for bit
+    const int rows = omds_tail_rows(B, k);
+    const dim3 grid((total + rows - 1) / rows);
+#define OMDS_P2_LAUNCH(A, R) hipLaunchKernelGGL((k_pass2<A, R>), grid, dim3(P2_NT), lds, s, m, Apre, Bpre, radius, xyzr, idx, total, k, qT, ldq, gradx, drow, yraw, minidx, dscr)
+    if (m.act == OMDS_ACT_RELU) { if (rows == 16) OMDS_P2_LAUNCH(OMDS_ACT_RELU, 16); else OMDS_P2_LAUNCH(OMDS_ACT_RELU, 32); }
+    else { if (rows == 16) OMDS_P2_LAUNCH(OMDS_ACT_TANH, 16); else OMDS_P2_LAUNCH(OMDS_ACT_TANH, 32); }
+#undef OMDS_P2_LAUNCH
 }
 
 void omds_launch_blend(hipStream_t s, const float* gradx, const float* drow, int B, int k, int d, int n,

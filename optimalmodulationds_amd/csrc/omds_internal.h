@@ -26,6 +26,11 @@ struct MlpDev {
     const float* W1t;    // [3d][256] first layer transposed
     const float* b1;     // [256]
     const float4* W1b;   // [32 kchunk][64 lane] first layer, backward pack (cols = 3d features, padded to 32)
+    // the same three packs in v_mfma_f32_16x16x4 fragment order, for the 16-row pass-2 tiles of small batches:
+    // lane l of chunk c holds 4 consecutive k = 16c + 4(l>>4) .. +3 of column 16*cb + (l&15)
+    const float4* Wf16;  // [nhh][16 colblk16][16 kchunk][64 lane]
+    const float4* Wb16;  // same shape, transposed
+    const float4* W1b16; // [16 kchunk][2 colblk16][64 lane]
     int nhh;             // number of hidden->hidden layers (= hidden layers - 1)
     int C;               // output channels (links)
     int d;               // raw inputs: n_dof + 3 (obstacle x, y, z), or n_dof + 2 for the toy networks (x, y)
@@ -161,8 +166,8 @@ struct StepArgs {
 void omds_launch_modulate(hipStream_t s, const StepArgs& a);
 // fused per-step tail (tail_kernel.hip): top-k + pass 2 + blend + modulation + next-step layer-1 half
 bool omds_tail_supported(int n_dof, int k);
-int omds_tail_workgroups(int N, int k);
-int omds_tail_rollouts_per_wg(int k);
+int omds_tail_scratch_rows(int N, int k);
+int omds_tail_rows(int N, int k);            // pass-2 tile height (16 | 32) for a batch of N rollouts with k closest obstacles   // rows of the tanh-derivative scratch the tail may touch (either tile height)
 void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
                       const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st, int t_begin, int t_end);
 struct CostArgs {

@@ -2,9 +2,13 @@
 // once the pass-1 min-distance matrix exists -- top-k over the obstacles (MPPI.py:245-247), forward +
 // analytic backward on the k closest rows (robot_sdf.py:153-158), softmax blend, modulation / policy /
 // Euler step (MPPI.py:102-223) and the rollout half of layer 1 for the NEXT step.  A workgroup owns
-// floor(32/k) rollouts (<= 32 network rows), so a horizon step is two launches: k_pass1 + k_tail.
+// floor(ROWS/k) rollouts (<= ROWS network rows), so a horizon step is two launches: k_pass1 + k_tail.  ROWS = 32
+// (v_mfma_f32_32x32x2) for large batches; ROWS = 16 (v_mfma_f32_16x16x4) when the batch has too few rows to fill the
+// CUs with 32-row tiles anyway: the workgroup's chain of dependent GEMMs IS the step latency then, and it halves.
 // The stand-alone kernels (k_topk, k_pass2, k_modulate, k_rollout_layer1) remain for the batch entry
 // points (omds_dist_grad, omds_mlp_forward_vjp) and for n_dof / k combinations not instantiated here.
+#include <algorithm>
+
 #include "mlp_device.h"
 #include "step_device.h"
 
@@ -24,7 +28,7 @@ struct TailArgs {
     StepArgs st;
 };
 
-template <int ND, int ACT>
+template <int ND, int ACT, int ROWS>
 __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const MlpDev& m = a.m;
@@ -41,7 +45,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
     float* feat = dr + 32;                                      // [32][3*ND]: q_next, sin, cos
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.st.N, k = a.st.k, O = a.O;
-    const int RW = P2_MT / k;                 // rollouts per workgroup
+    const int RW = ROWS / k;                  // rollouts per workgroup
     const int t_base = a.t_begin + blockIdx.x * RW;
     const int t_end = a.t_end;
 
@@ -58,8 +62,8 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
 
     // ---- forward + backward on the selected rows; gradients and distances stay in LDS ------------
     const float* qT = a.st.trajT + (size_t)(a.st.step - 1) * ND * N;
-    pass2_body<ACT>(m, sm, a.Apre, a.Bpre, a.radius, a.xyzr, t_base * k, N * k, qT, N, gx, dr, 0, nullptr, nullptr, a.dscr,
-               (size_t)a.n_slots * P2_MT * OMDS_WIDTH, (a.slot0 + (int)blockIdx.x) * P2_MT, a.dbg_stop);
+    pass2_body<ACT, false, ROWS>(m, sm, a.Apre, a.Bpre, a.radius, a.xyzr, t_base * k, N * k, qT, N, gx, dr, 0, nullptr, nullptr,
+                                 a.dscr, (size_t)a.n_slots * ROWS * OMDS_WIDTH, (a.slot0 + (int)blockIdx.x) * ROWS, a.dbg_stop);
     __syncthreads();
     if (a.dbg_stop == 2) return;
 
@@ -109,33 +113,47 @@ static size_t tail_lds_bytes(int nhid) {
            (32 * 12 + 32 + 32 * 3 * OMDS_MAX_DOF) * 4;
 }
 
-template <int ND, int ACT>
+template <int ND, int ACT, int ROWS>
 static void launch_tail_a(hipStream_t s, const TailArgs& a) {
     static std::atomic<uint64_t> configured{0};
     if (omds_first_use_on_device(configured)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<ND, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<ND, ACT, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)tail_lds_bytes(OMDS_MAX_HIDDEN + 1));
     }
-    const int RW = P2_MT / a.st.k;
-    hipLaunchKernelGGL((k_tail<ND, ACT>), dim3((a.t_end - a.t_begin + RW - 1) / RW), dim3(P2_NT), tail_lds_bytes(a.m.nhh + 1), s, a);
+    const int RW = ROWS / a.st.k;
+    hipLaunchKernelGGL((k_tail<ND, ACT, ROWS>), dim3((a.t_end - a.t_begin + RW - 1) / RW), dim3(P2_NT), tail_lds_bytes(a.m.nhh + 1), s, a);
 }
 
-template <int ND>
+template <int ND, int ROWS>
 static void launch_tail_t(hipStream_t s, const TailArgs& a) {
-    if (a.m.act == OMDS_ACT_RELU) launch_tail_a<ND, OMDS_ACT_RELU>(s, a);
-    else launch_tail_a<ND, OMDS_ACT_TANH>(s, a);
+    if (a.m.act == OMDS_ACT_RELU) launch_tail_a<ND, OMDS_ACT_RELU, ROWS>(s, a);
+    else launch_tail_a<ND, OMDS_ACT_TANH, ROWS>(s, a);
 }
 
 bool omds_tail_supported(int n_dof, int k) { return (n_dof == 7 || n_dof == 2) && k >= 1 && k <= P2_MT; }
 
-int omds_tail_workgroups(int N, int k) { const int RW = P2_MT / k; return (N + RW - 1) / RW; }
+// 16-row tiles when 32-row tiles would leave most CUs without a workgroup (OMDS_TAIL_ROWS=16|32 forces one)
+int omds_tail_rows(int N, int k) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("OMDS_TAIL_ROWS"); forced = e ? atoi(e) : 0; }
+    if (k > 16) return 32;
+    if (forced == 16 || forced == 32) return forced;
+    const int RW32 = 32 / k;
+    return (N + RW32 - 1) / RW32 <= 128 ? 16 : 32;
+}
 
-int omds_tail_rollouts_per_wg(int k) { return P2_MT / k; }
+int omds_tail_scratch_rows(int N, int k) {
+    const int RW32 = P2_MT / k;
+    int rows = (N + RW32 - 1) / RW32 * 32;
+    if (k <= 16) { const int RW16 = 16 / k; rows = std::max(rows, (N + RW16 - 1) / RW16 * 16); }
+    return rows;
+}
 
 void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
                       const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st, int t_begin, int t_end) {
     TailArgs a;
-    const int RW = P2_MT / st.k;
+    const int rows = omds_tail_rows(st.N, st.k);
+    const int RW = rows / st.k;
     a.t_begin = t_begin; a.t_end = t_end;          // t_begin must be a multiple of RW
     a.slot0 = t_begin / RW;
     a.n_slots = (st.N + RW - 1) / RW;
@@ -143,6 +161,11 @@ void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const f
     if (stop < 0) { const char* e = getenv("OMDS_TAIL_STOP"); stop = e ? atoi(e) : 0; }
     a.dbg_stop = stop;
     a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Dmin = Dmin; a.Apre = Apre; a.dscr = dscr; a.O = O; a.st = st;
-    if (st.n == 7) launch_tail_t<7>(s, a);
-    else launch_tail_t<2>(s, a);
+    if (rows == 16) {
+        if (st.n == 7) launch_tail_t<7, 16>(s, a);
+        else launch_tail_t<2, 16>(s, a);
+    } else {
+        if (st.n == 7) launch_tail_t<7, 32>(s, a);
+        else launch_tail_t<2, 32>(s, a);
+    }
 }
