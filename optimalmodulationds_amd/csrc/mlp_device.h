@@ -384,11 +384,12 @@ __device__ __forceinline__ void topk_row(const float* __restrict__ row, int O, i
 
 constexpr int P2_MT = 32;
 constexpr int P2_NT = 512;
+constexpr int P2_PSETS = 4;   // split-K partial sets of the first-layer backward kept in sm.P; waves 4-7 park theirs in the (then idle) tile buffer
 
 
 struct P2Smem {
     float* Hs;        // [32][LDH]
-    float* P;         // [8][32][32] split-K partials of the first-layer backward
+    float* P;         // [P2_PSETS][32][33] split-K partials of the first-layer backward (waves 0-3; waves 4-7 use Hs)
     float* gf;        // [32][33] feature gradients
     uint16_t* maskL;  // [nhh+1][512] ReLU masks, 16 bits per thread and layer
     int* rowT;        // [32] rollout of each row (-1: padding row)
@@ -597,8 +598,10 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc, 0, 0, 0);
         }
+        __syncthreads();   // every wave has read its A fragments: the tile buffer may take the partials of waves 4-7
+        float* Pw = wave < P2_PSETS ? P + wave * (32 * 32) : Hs + (wave - P2_PSETS) * (32 * 32);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) P[(wave * 32 + crow(r, lane)) * 32 + (lane & 31)] = acc[r];
+        for (int r = 0; r < 16; ++r) Pw[crow(r, lane) * 32 + (lane & 31)] = acc[r];
     } else {
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         const float* arow = Hs + (lane & 15) * LDH + 4 * (lane >> 4);
@@ -611,8 +614,10 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
             w[1] = m.W1b16[(c * 2 + 1) * 64 + lane];
             mfma_chunk16(a, w, acc);
         }
+        __syncthreads();
+        float* Pw = wave < P2_PSETS ? P + wave * (ROWS * 32) : Hs + (wave - P2_PSETS) * (ROWS * 32);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) P[(wave * ROWS + 4 * (lane >> 4) + (r & 3)) * 32 + 16 * (r >> 2) + (lane & 15)] = acc[r >> 2][r & 3];
+        for (int r = 0; r < 8; ++r) Pw[(4 * (lane >> 4) + (r & 3)) * 32 + 16 * (r >> 2) + (lane & 15)] = acc[r >> 2][r & 3];
     }
     __syncthreads();
     if (dbg == 15) return;
@@ -620,7 +625,7 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
         const int row = e >> 5, f = e & 31;
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) s += P[(w * ROWS + row) * 32 + f];
+        for (int w = 0; w < 8; ++w) s += (w < P2_PSETS ? P + w * (ROWS * 32) : Hs + (w - P2_PSETS) * (ROWS * 32))[row * 32 + f];
         gf[row * 33 + f] = s;
     }
     __syncthreads();

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restri
     P2Smem sm;
     sm.Hs = smem;
     sm.P = sm.Hs + P2_MT * LDH;
-    sm.gf = sm.P + 8 * 32 * 33;
+    sm.gf = sm.P + P2_PSETS * 32 * 33;
     sm.maskL = reinterpret_cast<uint16_t*>(sm.gf + 32 * 33);
     sm.rowT = reinterpret_cast<int*>(sm.maskL + ((m.nhh + 2) / 2 * 2) * P2_NT);
     sm.rowO = sm.rowT + P2_MT;
@@ -255,8 +255,8 @@ void omds_launch_pass2(hipStream_t s, const MlpDev& m, const float* Apre, const 
                        float* drow, float* yraw, int32_t* minidx, float* dscr) {
     const int total = B * k;
     if (total <= 0) return;
-    const size_t lds = ((size_t)P2_MT * LDH + 8 * 32 * 33 + 32 * 33) * 4 + (size_t)(m.nhh + 1) * P2_NT * 4 + 3 * P2_MT * 4;
-    const int maxlds = (int)(((size_t)P2_MT * LDH + 8 * 32 * 33 + 32 * 33) * 4 + (size_t)(OMDS_MAX_HIDDEN + 1) * P2_NT * 4 + 3 * P2_MT * 4);
+    const size_t lds = ((size_t)P2_MT * LDH + P2_PSETS * 32 * 33 + 32 * 33) * 4 + (size_t)(m.nhh + 1) * P2_NT * 4 + 3 * P2_MT * 4;
+    const int maxlds = (int)(((size_t)P2_MT * LDH + P2_PSETS * 32 * 33 + 32 * 33) * 4 + (size_t)(OMDS_MAX_HIDDEN + 1) * P2_NT * 4 + 3 * P2_MT * 4);
     static std::atomic<uint64_t> configured{0};
     if (omds_first_use_on_device(configured)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<OMDS_ACT_RELU, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
