@@ -161,6 +161,11 @@ struct Geo {
     static constexpr int NT = NW * 64;
     static_assert(WM >= 1 && WN >= 1 && WM * 32 * MR == MT && WN * NR == OMDS_NCB, "bad tile geometry");
 };
+// 16-row tile on v_mfma_f32_16x16x4 (gemm16): 8 waves, wave w owns columns 32w .. 32w+31 as two 16-column blocks
+template <>
+struct Geo<16, 1, 1> {
+    static constexpr int WM = 1, WN = 8, NW = 8, NT = 512;
+};
 
 // ------------------------------------------------------------------------------------------------
 // pass 1: all (rollout, obstacle) pairs -> min link distance
@@ -192,9 +197,11 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
 #endif
 
     const int cb0 = wn * NR;
-    float bcur[NR];   // bias of the first hidden->hidden layer: in flight across the whole layer-1 build
+    constexpr int NBIAS = MT == 16 ? 2 : NR;   // distinct output columns per thread
+    auto bias_col = [&](int j) { return MT == 16 ? wave * 32 + 16 * j + (lane & 15) : (cb0 + j) * 32 + (lane & 31); };
+    float bcur[NBIAS];   // bias of the first hidden->hidden layer: in flight across the whole layer-1 build
 #pragma unroll
-    for (int j = 0; j < NR; ++j) bcur[j] = m.nhh > 0 ? m.bh[(cb0 + j) * 32 + (lane & 31)] : 0.f;
+    for (int j = 0; j < NBIAS; ++j) bcur[j] = m.nhh > 0 ? m.bh[bias_col(j)] : 0.f;
 
     // ---- layer 1: H1 = act(Apre[t] + Bpre[o]).  A wave builds one whole row (64 lanes x float4) per step, so the
     //      row bookkeeping (rollout t, obstacle o, bounds) is wave-uniform and stays on the scalar unit, and the two
@@ -254,6 +261,27 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
     // ---- hidden -> hidden layers.  The accumulators start at the bias (fetched one layer ahead), so the epilogue
     //      is activation + LDS write only -----------------------------------------------------------------
     const float* Hw = Hs + (wm * MR * 32) * LDH;
+    if constexpr (MT == 16) {
+        for (int l = 0; l < m.nhh; ++l) {
+            f32x4 acc[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[j][r] = bcur[j];
+            if (l + 1 < m.nhh) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bcur[j] = m.bh[(l + 1) * OMDS_WIDTH + bias_col(j)];
+            }
+            gemm16(Hs, m.Wf16 + (size_t)l * (16 * 16 * 64), wave, lane, acc);
+            __syncthreads();  // every wave has finished reading the tile
+            if (l == 0) OMDS_TL(6);
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                Hs[(4 * (lane >> 4) + (r & 3)) * LDH + wave * 32 + 16 * (r >> 2) + (lane & 15)] = actf(acc[r >> 2][r & 3], ACT);
+            __syncthreads();
+            OMDS_TL(2 + l);
+        }
+    } else
     for (int l = 0; l < m.nhh; ++l) {
         f32x16 acc[MR][NR];
 #pragma unroll

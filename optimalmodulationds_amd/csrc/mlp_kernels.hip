@@ -232,7 +232,9 @@ void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Apre, const 
     // measured on MI355X (profiles/): 64-row tiles (2 workgroups per CU) beat 128-row tiles at N*O = 301k rows
     // (129 vs 123 TFLOP/s: shorter tail) and tie at 1.2M rows (134 TFLOP/s)
     // and ending the launch on one "round" of 32-row tiles (variant 11) shortens the drain: 135 vs 133 TFLOP/s
-    if (v == 0) v = (total >= 64LL * 1024) ? 11 : ((total >= 64LL * 512) ? 3 : 5);
+    // tiny batches (<= 128 32-row tiles: integrator tick, planar toy shapes): 16-row tiles on the 16x16x4 MFMA halve the
+    // chain of dependent GEMMs that is the whole latency of such a launch
+    if (v == 0) v = (total >= 64LL * 1024) ? 11 : ((total >= 64LL * 512) ? 3 : (total <= 32LL * 128 ? 6 : 5));
     if (v >= 10) {   // 10 + r: mixed tiles, the last r "rounds" of 512 workgroups use 32-row tiles
         if (m.act == OMDS_ACT_RELU) launch_pass1_mixed<OMDS_ACT_RELU>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin, v - 10);
         else launch_pass1_mixed<OMDS_ACT_TANH>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin, v - 10);
@@ -241,6 +243,7 @@ void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Apre, const 
     switch (v) {
         case 1: launch_pass1_t<128, 4, 1>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
         case 3: launch_pass1_t<64, 2, 1>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
+        case 6: launch_pass1_t<16, 1, 1>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
         default: launch_pass1_t<32, 1, 1>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
     }
 }
