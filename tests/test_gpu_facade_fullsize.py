@@ -264,10 +264,13 @@ def _mk(N, H, k, obs, m):
     return eng
 
 
-@pytest.mark.parametrize("N,H,k,O", [(1000, 3, 5, 294), (77, 2, 7, 33), (8192, 2, 5, 294), (130, 2, 5, 5), (65, 3, 1, 1)])
+@pytest.mark.parametrize("N,H,k,O", [(1000, 3, 5, 294), (77, 2, 7, 33), (8192, 2, 5, 294), (130, 2, 5, 5), (65, 3, 1, 1),
+                                     # tiny batches: 16-row pass-1 / pass-2 tiles (integrator shape, k = 16 and k = 17 around the
+                                     # 16-row limit, a single pair)
+                                     (1, 2, 5, 294), (1, 1, 1, 1), (3, 2, 2, 2), (17, 2, 16, 40), (9, 2, 17, 40), (40, 3, 5, 294)])
 def test_ragged_and_large_shapes(N, H, k, O):
-    """Sizes that are not multiples of any tile (rows per pass-1 tile 64/32, rollouts per tail workgroup
-    floor(32/k)), O == k, O == 1, and a large N: a 40-rollout sample must match the oracle step by step."""
+    """Sizes that are not multiples of any tile (rows per pass-1 tile 64/32/16, rollouts per tail workgroup
+    floor(32/k) or floor(16/k)), O == k, O == 1, and a large N: a 40-rollout sample must match the oracle step by step."""
     from optimalmodulationds_amd import scenes
     m = orc.Mlp.from_npz(weights_path("franka"))
     obs = scenes.shelf_scene()[np.linspace(0, 293, O).astype(int)]
@@ -282,7 +285,7 @@ def test_ragged_and_large_shapes(N, H, k, O):
     eng.propagate(q0)
     r = eng.get_rollouts()
     assert np.isfinite(r["all_traj"]).all() and np.isfinite(r["closest_dist_all"]).all()
-    sel = np.unique(np.concatenate(([0, 1, N - 2, N - 1], rng.choice(N, 36, replace=False))))
+    sel = np.unique(np.concatenate(([0, min(1, N - 1), max(N - 2, 0), N - 1], rng.choice(N, min(36, N), replace=False))))
     for h in range(H):
         q = r["all_traj"][sel, h]
         d, g, _, idx = orc.distance_repulsion_nn(m, q, obs, k, [0, 1, 2])
