@@ -60,7 +60,7 @@ __device__ __forceinline__ void load_chunk(const float* arow, __amdgpu_buffer_rs
 // with sched_barrier (left alone, hipcc sinks the loads next to their use and waits vmcnt(0) per chunk).
 template <int MR, int NR>
 __device__ __forceinline__ void gemm256(const float* __restrict__ Hw, const float4* __restrict__ Wp, int cb0,
-                                        int lane, f32x16 (&acc)[MR][NR], const bool prio = false) {
+                                        int lane, f32x16 (&acc)[MR][NR]) {
     const float* arow = Hw + (lane & 31) * LDH + 4 * (lane >> 5);
     // cb0 derives from the wave index: wave-uniform, but only readfirstlane makes that provable to the compiler
     const float4* wbase = Wp + (size_t)__builtin_amdgcn_readfirstlane(cb0) * (32 * 64);
@@ -82,7 +82,6 @@ __device__ __forceinline__ void gemm256(const float* __restrict__ Hw, const floa
     }                                                                                 \
     __builtin_amdgcn_sched_group_barrier(0x8, 4 * MR * NR - NR - 2 * MR, 0);          \
     __builtin_amdgcn_sched_barrier(0);
-    (void)prio;   // s_setprio around the loop body bought nothing once the loads were interleaved
 #pragma unroll
     for (int c = 0; c < 32; c += 2) {   // fully unrolled: every LDS / buffer offset is an immediate or an SGPR, no VALU in the loop
         load_chunk<MR, NR>(arow, wp, wv, c + 1, a1, w1);
@@ -182,7 +181,7 @@ struct Geo<16, 1, 1> {
 template <int MT, int MR, int NR, int ACT>
 __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const float* __restrict__ Apre,
                                            const float* __restrict__ Bpre, const float* __restrict__ radius, int O,
-                                           long long total_rows, uint32_t ignored, float* __restrict__ Dmin, int tune,
+                                           long long total_rows, uint32_t ignored, float* __restrict__ Dmin,
                                            const long long row0) {
     using G = Geo<MT, MR, NR>;
     float* Hs = smem;                                           // [MT][LDH]
@@ -294,7 +293,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
 #pragma unroll
             for (int j = 0; j < NR; ++j) bcur[j] = m.bh[(l + 1) * OMDS_WIDTH + (cb0 + j) * 32 + (lane & 31)];
         }
-        gemm256<MR, NR>(Hw, m.Wf + (size_t)l * (OMDS_NCB * 32 * 64), cb0, lane, acc, (tune & 1) != 0);
+        gemm256<MR, NR>(Hw, m.Wf + (size_t)l * (OMDS_NCB * 32 * 64), cb0, lane, acc);
         __syncthreads();  // every wave has finished reading the tile
         if (l == 0) OMDS_TL(6);
 #pragma unroll
@@ -460,7 +459,7 @@ __device__ __forceinline__ void p2_gemm(const float* Hs, const MlpDev& m, int l,
 // Body of pass 2 for the ROWS rows described by sm.rowT / sm.rowO (already in LDS, barrier done by the
 // caller).  R0 = global index of row 0 (tanh scratch, yraw, minidx); outputs go to
 // gradx[(dbase + row) * d + j] and drow[dbase + row] (global memory or LDS).
-template <int ACT, bool LOWREG = false, int ROWS = 32>
+template <int ACT, int ROWS = 32>
 __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, const float* __restrict__ Apre,
                                            const float* __restrict__ Bpre, const float* __restrict__ radius,
                                            const float* __restrict__ xyzr, int R0, int total_rows,
@@ -534,17 +533,14 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
         const float* arow = Hs + (wave * 16 + (lane & 15)) * LDH + 4 * (lane >> 4);
         const int j = lane & 15;
         const float bj = m.bl[j];
-        // weight fragments in flight in batches (all 16 at once unless registers are tight): the chain below is
-        // latency-bound otherwise
-        constexpr int WB = LOWREG ? 4 : 16;
-#pragma unroll 1
-        for (int c0 = 0; c0 < 16; c0 += WB) {
-            float4 wl[WB];
+        // all 16 weight fragments in flight at once: the MFMA chain below is latency-bound otherwise
+        {
+            float4 wl[16];
 #pragma unroll
-            for (int c = 0; c < WB; ++c) wl[c] = m.Wl[(c0 + c) * 64 + lane];
+            for (int c = 0; c < 16; ++c) wl[c] = m.Wl[c * 64 + lane];
 #pragma unroll
-            for (int c = 0; c < WB; ++c) {
-                const float4 a = *reinterpret_cast<const float4*>(arow + 16 * (c0 + c));
+            for (int c = 0; c < 16; ++c) {
+                const float4 a = *reinterpret_cast<const float4*>(arow + 16 * c);
                 const float4 w = wl[c];
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);

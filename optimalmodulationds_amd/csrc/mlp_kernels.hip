@@ -69,9 +69,9 @@ __global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const
                                                                const float* __restrict__ Bpre,
                                                                const float* __restrict__ radius, int O,
                                                                long long total_rows, uint32_t ignored,
-                                                               float* __restrict__ Dmin, int tune) {
+                                                               float* __restrict__ Dmin) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    pass1_tile<MT, MR, NR, ACT>(m, smem, Apre, Bpre, radius, O, total_rows, ignored, Dmin, tune, (long long)blockIdx.x * MT);
+    pass1_tile<MT, MR, NR, ACT>(m, smem, Apre, Bpre, radius, O, total_rows, ignored, Dmin, (long long)blockIdx.x * MT);
 }
 
 // Mixed-granularity launch: the first n_big workgroups take 64-row tiles, the rest cover the remaining rows
@@ -81,13 +81,13 @@ template <int ACT>
 __global__ __launch_bounds__(512) void k_pass1_mixed(MlpDev m, const float* __restrict__ Apre,
                                                      const float* __restrict__ Bpre, const float* __restrict__ radius,
                                                      int O, long long total_rows, uint32_t ignored,
-                                                     float* __restrict__ Dmin, int tune, int n_big) {
+                                                     float* __restrict__ Dmin, int n_big) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     if (b < n_big) {
-        pass1_tile<64, 2, 1, ACT>(m, smem, Apre, Bpre, radius, O, total_rows, ignored, Dmin, tune, (long long)b * 64);
+        pass1_tile<64, 2, 1, ACT>(m, smem, Apre, Bpre, radius, O, total_rows, ignored, Dmin, (long long)b * 64);
     } else {
-        pass1_tile<32, 1, 1, ACT>(m, smem, Apre, Bpre, radius, O, total_rows, ignored, Dmin, tune,
+        pass1_tile<32, 1, 1, ACT>(m, smem, Apre, Bpre, radius, O, total_rows, ignored, Dmin,
                                   (long long)n_big * 64 + (long long)(b - n_big) * 32);
     }
 }
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restri
         sm.rowO[tid] = o;
     }
     __syncthreads();
-    pass2_body<ACT, false, ROWS>(m, sm, Apre, Bpre, radius, xyzr, R0, total_rows, qT, ldq, gradx, drow, R0, yraw, minidx, dscr,
+    pass2_body<ACT, ROWS>(m, sm, Apre, Bpre, radius, xyzr, R0, total_rows, qT, ldq, gradx, drow, R0, yraw, minidx, dscr,
                                  (size_t)gridDim.x * ROWS * OMDS_WIDTH, R0);
 }
 
@@ -184,10 +184,8 @@ static void launch_pass1_a(hipStream_t s, const MlpDev& m, const float* Apre, co
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     const long long tiles = (total + MT - 1) / MT;
-    static int tune = -1;
-    if (tune < 0) { const char* e = getenv("OMDS_TUNE"); tune = e ? atoi(e) : 0; }  // bit 0: s_setprio(1) around the GEMM loop body (no gain once loads are interleaved)
     hipLaunchKernelGGL((k_pass1<MT, MR, NR, ACT>), dim3((unsigned)tiles), dim3(G::NT), lds, s, m, Apre, Bpre, radius, O,
-                       total, ignored, Dmin, tune);
+                       total, ignored, Dmin);
 }
 
 template <int MT, int MR, int NR>
@@ -207,8 +205,6 @@ static void launch_pass1_mixed(hipStream_t s, const MlpDev& m, const float* Apre
     if (omds_first_use_on_device(configured)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1_mixed<ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    static int tune = -1;
-    if (tune < 0) { const char* e = getenv("OMDS_TUNE"); tune = e ? atoi(e) : 0; }
     // keep `small_rounds` x 512 x 64 rows (in units of resident 64-row workgroups) for the 32-row tail tiles
     long long tiles64 = total / 64;
     long long keep = (long long)small_rounds * 512 / 2;   // 64-row tiles' worth of rows given to small tiles
@@ -216,7 +212,7 @@ static void launch_pass1_mixed(hipStream_t s, const MlpDev& m, const float* Apre
     const long long rest = total - n_big * 64;
     const long long n_small = (rest + 31) / 32;
     hipLaunchKernelGGL((k_pass1_mixed<ACT>), dim3((unsigned)(n_big + n_small)), dim3(512), lds, s, m, Apre, Bpre, radius, O,
-                       total, ignored, Dmin, tune, (int)n_big);
+                       total, ignored, Dmin, (int)n_big);
 }
 
 static int g_pass1_variant = -1;  // -1 = auto; set through OMDS_PASS1_VARIANT for experiments

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
 
     // ---- forward + backward on the selected rows; gradients and distances stay in LDS ------------
     const float* qT = a.st.trajT + (size_t)(a.st.step - 1) * ND * N;
-    pass2_body<ACT, false, ROWS>(m, sm, a.Apre, a.Bpre, a.radius, a.xyzr, t_base * k, N * k, qT, N, gx, dr, 0, nullptr, nullptr,
+    pass2_body<ACT, ROWS>(m, sm, a.Apre, a.Bpre, a.radius, a.xyzr, t_base * k, N * k, qT, N, gx, dr, 0, nullptr, nullptr,
                                  a.dscr, (size_t)a.n_slots * ROWS * OMDS_WIDTH, (a.slot0 + (int)blockIdx.x) * ROWS, a.dbg_stop);
     __syncthreads();
     if (a.dbg_stop == 2) return;
