@@ -116,9 +116,10 @@ def pass1_mindist(m: Mlp, q, obs, ignored_links):
     return nn_input, mindist.reshape(obs.shape[0], n_in).T.copy()
 
 
-def distance_repulsion_nn(m: Mlp, q, obs, k, ignored_links):
+def distance_repulsion_nn(m: Mlp, q, obs, k, ignored_links, softmax_k=-10.0):
     """MPPI.distance_repulsion_nn (FN/MPPI.py:227-282): returns (distance [N], nn_grad [N, n]) and
-    the intermediates (min-distance matrix, sorted obstacle indices)."""
+    the intermediates (min-distance matrix, sorted obstacle indices).  softmax_k is the reference's hard-coded -10
+    (:277), a parameter here like in the C-ABI's omds_params."""
     q = np.asarray(q, dtype=F32)
     n_in, n_dof = q.shape
     nn_input, mind = pass1_mindist(m, q, obs, ignored_links)
@@ -131,7 +132,7 @@ def distance_repulsion_nn(m: Mlp, q, obs, k, ignored_links):
     y = y - nn_in2[:, -1:]
     d = y[np.arange(y.shape[0]), min_idx].reshape(n_in, k)                    # :270-272
     g = grad[:, :n_dof].reshape(n_in, k, n_dof)
-    e = np.exp((F32(-10) * d) - (F32(-10) * d).max(axis=1, keepdims=True))    # softmax(-10 d)  :277
+    e = np.exp((F32(softmax_k) * d) - (F32(softmax_k) * d).max(axis=1, keepdims=True))    # softmax(-10 d)  :277
     w = (e / e.sum(axis=1, keepdims=True)).astype(F32)
     nn_grad = (g * w[:, :, None]).sum(axis=1).astype(F32)                     # :278
     return d[:, 0].copy(), nn_grad, mind, sort_idx
@@ -288,7 +289,7 @@ def propagate(m: Mlp, q_cur, qf, obs, *, N, H, dt, k, ignored_links, mu_tmp, sig
     all_traj[:, 0, :] = q_cur
     for i in range(1, H + 1):
         q_prev = all_traj[:, i - 1, :]
-        d_raw, g_raw, _, _ = distance_repulsion_nn(m, q_prev, obs, k, ignored_links)   # :113
+        d_raw, g_raw, _, _ = distance_repulsion_nn(m, q_prev, obs, k, ignored_links, prm.softmax_k)   # :113
         st = modulation_step(q_prev, qf, d_raw, g_raw, mu_tmp, sigma_tmp, alpha_tmp, prm)
         dist_all[:, i - 1] = st["distance"]
         nb_n[:, i - 1] = st["ghat"]

@@ -271,3 +271,70 @@ def test_unfused_step_path_still_passes():
                        env=env, capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "6 passed" in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # (network, n_dof, N, H, k, O, K, rbf_p, params overrides) -- parameter combinations no fixture holds: RBF norm orders
+    # other than 2 (policy.py:41), every constant of the params struct moved off its default at once, n = 2 with k > 1.
+    dict(net="franka", n=7, N=37, H=3, k=4, O=23, K=3, p=1.0, over={}),
+    dict(net="franka", n=7, N=20, H=2, k=6, O=12, K=5, p=3.0, over=dict(goal_act_cut=0.2, norm_clamp=0.3, coll_slow=0.3, coll_repulse=0.2,
+                                                                      softmax_k=-4.0, lvel=(0.1, 0.9, -0.6, 0.1, 20.0),
+                                                                      ln=(0.0, 1.0, 0.02, 0.2, 40.0), ltau=(4.0, 1.5, 0.0, 0.2, 40.0))),
+    dict(net="planar2", n=2, N=45, H=3, k=2, O=5, K=2, p=2.0, over=dict(softmax_k=-20.0)),
+])
+def test_parameter_space_against_oracle(case):
+    """Every horizon step of a free-running device rollout is re-derived by the oracle from the device's own state:
+    distance 1e-5, and (rows without a near-zero ReLU pre-activation) normal, dot product, RBF values, activation and
+    the integrated velocity."""
+    from optimalmodulationds_amd import scenes
+    from optimalmodulationds_amd.engine import Engine
+    n, N, H, k, O, K = (case[x] for x in ("n", "N", "H", "k", "O", "K"))
+    m = orc.Mlp.from_npz(weights_path(case["net"]))
+    rng = np.random.RandomState(N * 7 + k)
+    if n == 7:
+        obs = scenes.shelf_scene()[np.linspace(0, 293, O).astype(int)]
+        q0c, qf, dst_thr, dt, ign = scenes.FRANKA_Q0, scenes.FRANKA_QF, 0.02, 0.5, [0, 1, 2]
+        spread = 0.4
+    else:
+        obs = np.stack([rng.uniform(-6, 6, O), rng.uniform(-6, 6, O), np.zeros(O), np.full(O, 0.5)], axis=1).astype(np.float32)
+        q0c, qf, dst_thr, dt, ign = np.array([-2.0, 0.5], np.float32), np.array([2.5, 0.0], np.float32), 0.25, 0.3, []
+        spread = 0.8
+    prm = dict(dst_thr=dst_thr, p=case["p"], **case["over"])
+    eng = Engine(n, N, H, k, max_obs=max(8, O))
+    eng.set_mlp(m.W, m.b, act=m.act)
+    eng.set_obstacles(obs)
+    P = eng.params
+    P.dt, P.dst_thr, P.rbf_p = dt, dst_thr, case["p"]
+    P.ignored_links = sum(1 << l for l in ign)
+    for key, val in case["over"].items():
+        if isinstance(val, tuple):
+            getattr(P, key)[:] = val
+        else:
+            setattr(P, key, val)
+    eng.push_params()
+    eng.set_ds(qf)
+    q0 = (q0c + spread * rng.standard_normal((N, n))).astype(np.float32)
+    mu = (q0c + spread * rng.standard_normal((N, K, n))).astype(np.float32)
+    sg = rng.uniform(0.3, 1.5, (N, K)).astype(np.float32)
+    al = rng.standard_normal((N, K, n)).astype(np.float32)
+    eng.set_policy_samples(mu, sg, al)
+    eng.propagate(q0)
+    r = eng.get_rollouts()
+    eng.close()
+    oprm = orc.Params(lin_thr=0.015, **{("p" if a == "p" else a): b for a, b in prm.items()})
+    checked = 0
+    for h in range(H):
+        q = r["all_traj"][:, h]
+        d, g, _, idx = orc.distance_repulsion_nn(m, q, obs, k, ign, oprm.softmax_k)
+        assert_close(r["closest_dist_all"][:, h], d - np.float32(dst_thr), RTOL, f"distance h={h}")
+        st = orc.modulation_step(q, qf, d, g, mu, sg, al, oprm)
+        ok = orc.rollout_relu_margin(m, q, obs, idx) >= 5e-6
+        checked += int(ok.sum())
+        assert_close(r["normal"][:, h][ok], st["ghat"][ok], 5e-5, f"normal h={h}")
+        assert_close(r["dot_products"][:, h][ok], st["dot"][ok], 5e-5, f"dot h={h}")
+        assert_close(r["kernel_val_all"][:, h][ok], st["phi"][ok], 2e-5, f"rbf (p={case['p']}) h={h}")
+        assert_close(r["kernel_activations"][:, h][ok], st["act"][ok], 2e-3, f"activation h={h}")   # k=100 sigmoid of a 1e-6 distance difference
+        if h + 1 < H:
+            assert_close((r["all_traj"][:, h + 1] - q)[ok] / np.float32(dt), st["u"][ok], 2e-3, f"velocity h={h}")
+    assert checked > 0.5 * N * H   # the rest sits within rounding of a ReLU kink (k rows per rollout can each flag it)
