@@ -78,10 +78,11 @@ __global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const
 // in 32-row tiles.  Workgroups are dispatched in index order, so the kernel ends on small tiles and the
 // drain phase (slots idling while the last tiles finish) shrinks with the tile size.
 template <int ACT>
-__global__ __launch_bounds__(512) void k_pass1_mixed(MlpDev m, const float* __restrict__ Apre,
-                                                     const float* __restrict__ Bpre, const float* __restrict__ radius,
-                                                     int O, long long total_rows, uint32_t ignored,
-                                                     float* __restrict__ Dmin, int n_big) {
+__global__ __launch_bounds__(512) void k_pass1_mixed(const float* __restrict__ Apre, const float* __restrict__ Bpre,
+                                                     const float* __restrict__ radius, float* __restrict__ Dmin,
+                                                     long long total_rows, int O, uint32_t ignored, int n_big, MlpDev m) {
+    // argument order: the scalars and pointers the layer-1 build needs come first so that they can be preloaded into
+    // SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count); the weight-pack descriptor is fetched behind them
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     if (b < n_big) {
@@ -211,8 +212,8 @@ static void launch_pass1_mixed(hipStream_t s, const MlpDev& m, const float* Apre
     long long n_big = tiles64 > keep ? tiles64 - keep : 0;
     const long long rest = total - n_big * 64;
     const long long n_small = (rest + 31) / 32;
-    hipLaunchKernelGGL((k_pass1_mixed<ACT>), dim3((unsigned)(n_big + n_small)), dim3(512), lds, s, m, Apre, Bpre, radius, O,
-                       total, ignored, Dmin, (int)n_big);
+    hipLaunchKernelGGL((k_pass1_mixed<ACT>), dim3((unsigned)(n_big + n_small)), dim3(512), lds, s, Apre, Bpre, radius, Dmin,
+                       total, O, ignored, (int)n_big, m);
 }
 
 static int g_pass1_variant = -1;  // -1 = auto; set through OMDS_PASS1_VARIANT for experiments
