@@ -178,11 +178,26 @@ struct Geo<16, 1, 1> {
 #define OMDS_TL_WAIT(what) do { } while (0)
 #endif
 
+// n / d for 0 <= n < 2^32 by multiplication (Granlund-Montgomery): q = (mulhi(mul, n) + n) >> shift with
+// shift = ceil(log2 d), mul = floor(2^32 (2^shift - d) / d) + 1; n < 2^31 here, so the sum cannot overflow.
+struct OmdsDivisor {
+    unsigned mul;
+    int shift;
+    __device__ __forceinline__ unsigned div(unsigned n) const { return (__umulhi(mul, n) + n) >> shift; }
+    static OmdsDivisor make(unsigned d) {
+        OmdsDivisor r;
+        r.shift = 0;
+        while ((1ull << r.shift) < d) ++r.shift;
+        r.mul = (unsigned)((((1ull << r.shift) - d) << 32) / d + 1);
+        return r;
+    }
+};
+
 template <int MT, int MR, int NR, int ACT>
 __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const float* __restrict__ Apre,
                                            const float* __restrict__ Bpre, const float* __restrict__ radius, int O,
                                            long long total_rows, uint32_t ignored, float* __restrict__ Dmin,
-                                           const long long row0) {
+                                           const long long row0, const OmdsDivisor odiv) {
     using G = Geo<MT, MR, NR>;
     float* Hs = smem;                                           // [MT][LDH]
     float* rowRad = smem + MT * LDH;                            // [MT] obstacle radius of each row
@@ -212,7 +227,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
         constexpr int IT = MT / G::NW;                          // rows per wave
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         const unsigned row0u = (unsigned)row0;                  // the launcher keeps total_rows below 2^31
-        const unsigned t0 = row0u / (unsigned)O;                // once per workgroup
+        const unsigned t0 = odiv.div(row0u);                    // row0 / O by multiplication (three scalar instructions)
         const int rows_here = (int)((total_rows - row0 < MT) ? (total_rows - row0) : MT);
         const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Apre) + (size_t)t0 * OMDS_WIDTH, 0,
                                                                             0x7fffffff, 0x00020000);

@@ -69,9 +69,9 @@ __global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const
                                                                const float* __restrict__ Bpre,
                                                                const float* __restrict__ radius, int O,
                                                                long long total_rows, uint32_t ignored,
-                                                               float* __restrict__ Dmin) {
+                                                               float* __restrict__ Dmin, OmdsDivisor odiv) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    pass1_tile<MT, MR, NR, ACT>(m, smem, Apre, Bpre, radius, O, total_rows, ignored, Dmin, (long long)blockIdx.x * MT);
+    pass1_tile<MT, MR, NR, ACT>(m, smem, Apre, Bpre, radius, O, total_rows, ignored, Dmin, (long long)blockIdx.x * MT, odiv);
 }
 
 // Mixed-granularity launch: the first n_big workgroups take 64-row tiles, the rest cover the remaining rows
@@ -80,16 +80,17 @@ __global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const
 template <int ACT>
 __global__ __launch_bounds__(512) void k_pass1_mixed(const float* __restrict__ Apre, const float* __restrict__ Bpre,
                                                      const float* __restrict__ radius, float* __restrict__ Dmin,
-                                                     long long total_rows, int O, uint32_t ignored, int n_big, MlpDev m) {
+                                                     long long total_rows, int O, uint32_t ignored, int n_big,
+                                                     OmdsDivisor odiv, MlpDev m) {
     // argument order: the scalars and pointers the layer-1 build needs come first so that they can be preloaded into
     // SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count); the weight-pack descriptor is fetched behind them
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     if (b < n_big) {
-        pass1_tile<64, 2, 1, ACT>(m, smem, Apre, Bpre, radius, O, total_rows, ignored, Dmin, (long long)b * 64);
+        pass1_tile<64, 2, 1, ACT>(m, smem, Apre, Bpre, radius, O, total_rows, ignored, Dmin, (long long)b * 64, odiv);
     } else {
         pass1_tile<32, 1, 1, ACT>(m, smem, Apre, Bpre, radius, O, total_rows, ignored, Dmin,
-                                  (long long)n_big * 64 + (long long)(b - n_big) * 32);
+                                  (long long)n_big * 64 + (long long)(b - n_big) * 32, odiv);
     }
 }
 
@@ -186,7 +187,7 @@ static void launch_pass1_a(hipStream_t s, const MlpDev& m, const float* Apre, co
     }
     const long long tiles = (total + MT - 1) / MT;
     hipLaunchKernelGGL((k_pass1<MT, MR, NR, ACT>), dim3((unsigned)tiles), dim3(G::NT), lds, s, m, Apre, Bpre, radius, O,
-                       total, ignored, Dmin);
+                       total, ignored, Dmin, OmdsDivisor::make((unsigned)O));
 }
 
 template <int MT, int MR, int NR>
@@ -213,7 +214,7 @@ static void launch_pass1_mixed(hipStream_t s, const MlpDev& m, const float* Apre
     const long long rest = total - n_big * 64;
     const long long n_small = (rest + 31) / 32;
     hipLaunchKernelGGL((k_pass1_mixed<ACT>), dim3((unsigned)(n_big + n_small)), dim3(512), lds, s, Apre, Bpre, radius, Dmin,
-                       total, O, ignored, (int)n_big, m);
+                       total, O, ignored, (int)n_big, OmdsDivisor::make((unsigned)O), m);
 }
 
 static int g_pass1_variant = -1;  // -1 = auto; set through OMDS_PASS1_VARIANT for experiments
