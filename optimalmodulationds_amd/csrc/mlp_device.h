@@ -263,7 +263,8 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
             v.z = actf(av[it].z + bv[it].z, ACT);
             v.w = actf(av[it].w + bv[it].w, ACT);
             *reinterpret_cast<float4*>(hrow + it * G::NW * LDH) = v;
-            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(myrad) : "s"(rad[it]), "n"(it));
+            const int rbits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rad[it]));   // wave-uniform: keep it in an SGPR for the asm
+            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(myrad) : "s"(rbits), "n"(it));
         }
         if (lane < IT) rowRad[wv + lane * G::NW] = myrad;
     }
