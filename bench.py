@@ -156,7 +156,10 @@ def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, di
 
     for it in range(warmup):
         iteration(it)
-    eng.prof_enable(prof)     # per-launch HIP events around the dominant kernel (keeps a batch on ONE stream)
+    # HIP events around every launch of the dominant kernel (keeps a batch on ONE stream).  An event record between two
+    # kernels idles the GPU for ~6 us (tools/gap_probe.py); sampling every 8th launch instead (prof_enable(8)) was measured:
+    # same iteration time within noise (back-to-back launches run ~0.7 % slower each), so every launch is timed
+    eng.prof_enable(1 if prof else 0)
     eng.prof_reset()
     barrier()
     t0 = time.perf_counter()

@@ -189,9 +189,10 @@ OMDS_API int omds_apply_update(int n_kernels, int n_dof, int horizon, const floa
                                float ker_thr, uint32_t variant, float* mu_c, float* sigma_c, float* alpha_c,
                                int32_t* mask_out);
 
-/* Measurement: when enabled, every launch of the dominant kernel (mlp_pass1) is bracketed by
- * HIP events on the context stream; omds_prof_read returns the summed elapsed ms and launch
- * count since the last omds_prof_reset.                                                  */
+/* Measurement: when enabled, launches of the dominant kernel (k_pass1) are bracketed by HIP events on the
+ * context stream -- every launch for on == 1, every on-th launch for on > 1 (an event record between two
+ * kernels idles the GPU for ~6 us, so throughput runs sample) -- and omds_prof_read returns the summed elapsed
+ * ms and the number of bracketed launches since the last omds_prof_reset.                                  */
 OMDS_API int omds_prof_enable(omds_ctx* ctx, int on);
 OMDS_API int omds_prof_reset(omds_ctx* ctx);
 OMDS_API int omds_prof_read(omds_ctx* ctx, double* pass1_ms, int64_t* pass1_launches, int64_t* pass1_rows);

@@ -128,6 +128,9 @@ struct omds_ctx {
     float* h_stage = nullptr;
     // profiling
     bool prof_on = false;
+    int prof_stride = 1;         // bracket every prof_stride-th launch of the dominant kernel with events
+    long long prof_seen = 0;     // launches of the dominant kernel since omds_prof_reset
+    bool prof_open = false;      // prof_begin recorded a start event that prof_end has to close
     ProfEvents prof;
 };
 

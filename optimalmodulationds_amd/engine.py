@@ -199,7 +199,8 @@ class Engine:
 
     # ---- measurement --------------------------------------------------------------------------
     def prof_enable(self, on=True):
-        self._ck(self.lib.omds_prof_enable(self.h, 1 if on else 0))
+        """on: False/0 off, True/1 every launch of the dominant kernel, n > 1 every n-th launch."""
+        self._ck(self.lib.omds_prof_enable(self.h, int(on)))
 
     def prof_reset(self):
         self._ck(self.lib.omds_prof_reset(self.h))
