@@ -312,14 +312,16 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
         gemm256<MR, NR>(Hw, m.Wf + (size_t)l * (OMDS_NCB * 32 * 64), cb0, lane, acc);
         __syncthreads();  // every wave has finished reading the tile
         if (l == 0) OMDS_TL(6);
+        // one lane-dependent base address per column block; everything else of (row, col) is a compile-time offset, so the
+        // 16 * MR stores of a block use immediate offsets (hipcc otherwise builds a VGPR address per row: VALU = matrix-pipe time)
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-            const int col = (cb0 + j) * 32 + (lane & 31);
+            float* hb = Hs + (wm * MR * 32 + 4 * (lane >> 5)) * LDH + (cb0 + j) * 32 + (lane & 31);
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    Hs[((wm * MR + i) * 32 + crow(r, lane)) * LDH + col] = actf(acc[i][j][r], ACT);
+                    hb[(i * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = actf(acc[i][j][r], ACT);
         }
         __syncthreads();
         OMDS_TL(2 + l);
