@@ -257,11 +257,12 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
         float myrad = 0.f;                                      // lane it of the wave collects the radius of its row it
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
+            const omds_f4 z = av[it] + bv[it];                  // vector add -> two v_pk_add_f32
             float4 v;                                           // rows past the end were loaded as zeros: act(0) = 0
-            v.x = actf(av[it].x + bv[it].x, ACT);
-            v.y = actf(av[it].y + bv[it].y, ACT);
-            v.z = actf(av[it].z + bv[it].z, ACT);
-            v.w = actf(av[it].w + bv[it].w, ACT);
+            v.x = actf(z.x, ACT);
+            v.y = actf(z.y, ACT);
+            v.z = actf(z.z, ACT);
+            v.w = actf(z.w, ACT);
             *reinterpret_cast<float4*>(hrow + it * G::NW * LDH) = v;
             const int rbits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rad[it]));   // wave-uniform: keep it in an SGPR for the asm
             asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(myrad) : "s"(rbits), "n"(it));
