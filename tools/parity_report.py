@@ -1,0 +1,77 @@
+"""Full-size parity report (BASELINE config 3 shape: Franka shelf, 4096 rollouts x 32 horizon, K = 10): the device rollout
+is re-derived by the oracle (test infrastructure, oracle/) at a random sample of (rollout, step) states, and the cost /
+MPPI weights / policy update are recomputed by the oracle from the device's own rollouts.  Prints max / mean errors.
+usage: python tools/parity_report.py [rollouts] [samples]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from optimalmodulationds_amd import scenes  # noqa: E402
+from optimalmodulationds_amd.cost import FRANKA_Q_MAX, FRANKA_Q_MIN  # noqa: E402
+from optimalmodulationds_amd.engine import Engine  # noqa: E402
+from oracle import omds_oracle as orc  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+H, k, K = 32, 5, 10
+m = orc.Mlp.from_npz(os.path.join(ROOT, "tests", "golden", "weights", "franka.npz"))
+obs, q0, qf, dh = scenes.shelf_scene(), scenes.FRANKA_Q0, scenes.FRANKA_QF, scenes.franka_dh_params()
+qmin, qmax = np.array(FRANKA_Q_MIN, np.float32), np.array(FRANKA_Q_MAX, np.float32)
+eng = Engine(7, N, H, k, max_obs=512)
+eng.set_mlp(m.W, m.b)
+eng.set_obstacles(obs)
+eng.params.dt, eng.params.dst_thr, eng.params.ignored_links = 0.5, 0.01, 0b111
+eng.push_params()
+eng.set_ds(qf)
+eng.set_cost(dh, qmin, qmax)
+rng = np.random.RandomState(7)
+s = (np.arange(K) + 0.5) / K
+mu_c = (q0 + s[:, None] * (qf - q0) + 0.15 * rng.standard_normal((K, 7))).astype(np.float32)
+sg_c = np.ones(K, np.float32)
+al_c = rng.standard_normal((K, 7)).astype(np.float32)
+eng.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 3.0, K, seed=99)
+mu, sg, al = eng.get_policy_samples()
+eng.propagate(q0)
+r = eng.get_rollouts()
+cost = eng.cost()
+nmu, nsg, nal, mask, w = eng.weighted_update(0.1, 0.1, mu_c, sg_c, al_c, want_weights=True)
+eng.close()
+
+t0 = time.time()
+tt = rng.randint(0, N, S)
+hh = rng.randint(0, H, S)
+q = r["all_traj"][tt, hh]
+d, g, _, idx = orc.distance_repulsion_nn(m, q, obs, k, [0, 1, 2])
+st = orc.modulation_step(q, qf, d, g, mu[tt], sg[tt], al[tt], orc.Params(dst_thr=0.01))
+ok = orc.rollout_relu_margin(m, q, obs, idx) >= 5e-6
+
+
+def err(a, b, sel=None, scale=None):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    if sel is not None:
+        a, b = a[sel], b[sel]
+    e = np.abs(a - b) / (scale if scale else max(1.0, np.abs(b).max()))
+    return e.max(), e.mean()
+
+
+print(f"Franka shelf, N={N}, H={H}, O={obs.shape[0]}, k={k}, K={K}; {S} sampled (rollout, step) states re-derived by the oracle "
+      f"({time.time() - t0:.1f} s); {100 * (1 - ok.mean()):.2f} % of them have a ReLU pre-activation within 5e-6 of zero")
+print("quantity                           max rel err   mean rel err")
+print("thresholded distance               %.3e     %.3e" % err(r["closest_dist_all"][tt, hh], d - np.float32(0.01)))
+print("obstacle normal (unflagged)        %.3e     %.3e" % err(r["normal"][tt, hh], st["ghat"], ok))
+print("normal . nominal direction (unfl.) %.3e     %.3e" % err(r["dot_products"][tt, hh], st["dot"], ok))
+print("RBF kernel values                  %.3e     %.3e" % err(r["kernel_val_all"][tt, hh], st["phi"]))
+print("kernel activation (unflagged)      %.3e     %.3e" % err(r["kernel_activations"][tt, hh], st["act"], ok))
+nxt = hh + 1 < H
+vel = (r["all_traj"][tt[nxt], hh[nxt] + 1] - q[nxt]) / np.float32(0.5)
+print("integrated velocity (unflagged)    %.3e     %.3e" % err(vel, st["u"][nxt], ok[nxt]))
+ocost, _ = orc.evaluate_costs(r["all_traj"], r["closest_dist_all"], qf, dh, qmin, qmax)
+print("cost (all rollouts)                %.3e     %.3e" % err(cost, ocost))
+omu, osg, oal, omask, ow = orc.shift_policy_means(cost, r["kernel_val_all"], r["kernel_activations"], mu_c, sg_c, al_c, mu, sg, al, 0.1, 0.1)
+print("MPPI weights                       %.3e     %.3e" % err(w, ow, scale=float(ow.max())))
+print("policy means after update          %.3e     %.3e" % err(np.concatenate([nmu.ravel(), nsg, nal.ravel()]), np.concatenate([omu.ravel(), osg, oal.ravel()])))
+print("update mask identical:", bool(np.array_equal(mask, omask)), " finite outputs:", bool(np.isfinite(r["all_traj"]).all()))
