@@ -1,7 +1,7 @@
 """Full-size parity report (BASELINE config 3 shape: Franka shelf, 4096 rollouts x 32 horizon, K = 10): the device rollout
 is re-derived by the oracle (test infrastructure, oracle/) at a random sample of (rollout, step) states, and the cost /
 MPPI weights / policy update are recomputed by the oracle from the device's own rollouts.  Prints max / mean errors.
-usage: python tools/parity_report.py [rollouts] [samples]"""
+usage: python tests/parity_report.py [rollouts] [samples]"""
 import os
 import sys
 import time
