@@ -10,8 +10,11 @@ the inverse of the reference's "Time per rollout step" (scripts/standalonePlanar
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 10 --warmup 2
 
-Weak scaling: every rank (one process per GPU) owns --rollouts rollouts; the only exchange is
-the cost-weighted update (two tiny all-reduces + one all-gather over RCCL, dist.py).
+Weak scaling: every rank (one process per GPU) owns the workload's rollouts; the only exchange is
+the cost-weighted update: two tiny all-reduces issued by the library itself over RCCL on its own
+stream (csrc/comm.hip).  torch.distributed (gloo) is used for the launcher plumbing only: shipping
+the RCCL id, the barriers around the timed region and the max-over-ranks of the elapsed time.  If
+the RCCL communicator cannot be created the run exits non-zero -- there is no fallback.
 Prints ONE JSON line on rank 0."""
 import argparse
 import json
@@ -108,7 +111,7 @@ def cpu_baseline(w, W, b, obs, q0, qf, K, seed):
 
 def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, dist, torch, time_fetch=False, prof=True):
     """Times `steps` planner iterations of `workload` on this rank's GPU; returns a dict of raw numbers."""
-    from optimalmodulationds_amd.dist import sharded_update
+    from optimalmodulationds_amd.dist import init_native_comm, sharded_update
     from optimalmodulationds_amd.engine import Engine
     w, W, b, obs, q0, qf, dh, qmin, qmax = setup(workload, rank)
     N, H, n, K = w["N"], w["H"], q0.shape[0], args.kernels
@@ -121,6 +124,9 @@ def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, di
     eng.push_params()
     eng.set_ds(qf)
     eng.set_cost(dh, qmin, qmax)
+    native = use_dist and not args.share_gpu
+    if native:   # RCCL communicator owned by the library; raises (-> non-zero exit) if RCCL is unusable
+        init_native_comm(eng)
     # policy means: K kernel centres near the q0 -> qf segment (SURVEY 8d "policy state for timing")
     rng = np.random.RandomState(1234)
     s = (np.arange(K) + 0.5) / max(K, 1)
@@ -143,8 +149,11 @@ def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, di
         eng.propagate(q_cur)
         eng.cost(fetch=False)
         # two tiny all-reduces; the MINLOC gather for get_qdot('best') is not part of a planner iteration
-        mu_c, sg_c, al_c, mask, qd_w, _ = sharded_update(eng.cost_sum, eng.local_sums, K, n, H, 0.1, w["ker_thr"],
-                                                         mu_c, sg_c, al_c, want_best=False)
+        if use_dist and not native:   # --share-gpu: two ranks on ONE GPU cannot form a RCCL communicator; host-mediated gloo
+            mu_c, sg_c, al_c, mask, qd_w, _ = sharded_update(eng.cost_sum, eng.local_sums, K, n, H, 0.1, w["ker_thr"],
+                                                             mu_c, sg_c, al_c, want_best=False)
+        else:                         # library path: RCCL on the context stream (single shard: the same kernels, no collective)
+            mu_c, sg_c, al_c, mask, qd_w, _, _ = eng.weighted_update_sharded(0.1, w["ker_thr"], mu_c, sg_c, al_c)
         q_cur = (q_cur + 0.1 * w["dt"] * qd_w).astype(np.float32)   # drift along the weighted rollout velocity: non-degenerate states
         if w.get("dynamic"):   # Policy.check_traj_for_kernels on the device (policy.py:153-175); only candidates cross PCIe
             eng.kernel_candidates(0.03 - w["dst_thr"], 0.3, -0.9, mu_c, sg_c, K, cap=256)
@@ -169,7 +178,7 @@ def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, di
     barrier()
     el = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([el], device="cuda" if args.dist_backend == "nccl" else "cpu")
+        t = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     p1_ms, p1_launches, p1_rows = eng.prof_read()
@@ -196,9 +205,8 @@ def main():
     ap.add_argument("--kernels", type=int, default=10, help="active RBF navigation kernels K")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short planar7_1024x32 measurement reported under 'also'")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo + --share-gpu lets two ranks share one GPU to exercise the sharded path on a 1-GPU box")
-    ap.add_argument("--share-gpu", action="store_true")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="test mode for a 1-GPU box: all ranks use GPU 0 and exchange through the host (gloo); never a scaling number")
     ap.add_argument("--time-fetch", action="store_true", help="also report the cost of fetching all rollout tensors to the host")
     args = ap.parse_args()
 
@@ -216,21 +224,10 @@ def main():
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # under torchrun, also at N=1
     if use_dist:
+        # launcher plumbing only (RCCL id broadcast, barriers, max over ranks of the elapsed time); the data path's
+        # collectives are the library's own RCCL calls (csrc/comm.hip)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-            try:   # first collective = communicator creation; the payloads here are tiny (<= 3.4 KB per iteration)
-                probe = torch.ones(1, device="cuda")
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-                assert int(probe.item()) == world
-            except Exception as e:   # RCCL unusable on this node: the exchange is latency-bound anyway, use gloo
-                print(f"[bench] RCCL all-reduce failed on rank {rank} ({e}); falling back to gloo", file=sys.stderr)
-                dist.destroy_process_group()
-                args.dist_backend = "gloo"
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     r = measure(args, args.workload, args.steps, args.warmup, rank, world, local_rank, use_dist, dist, torch, args.time_fetch)
     w, W, b, obs, q0, qf, N, H, K, el = (r[k] for k in ("w", "W", "b", "obs", "q0", "qf", "N", "H", "K", "el"))
@@ -250,9 +247,10 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "rollouts_per_gpu": N, "horizon": H, "obstacles": int(obs.shape[0]),
                        "n_closest": w["k"], "active_kernels": K, "network": "x".join(str(x.shape[1]) for x in W) + f"x{W[-1].shape[0]} relu (shipped reference weights)",
-                       "parallelism": f"rollout-sharded x{world}", "collectives": (args.dist_backend if use_dist else "none")},
+                       "parallelism": f"rollout-sharded x{world}", "collectives": (("gloo-host (--share-gpu test mode)" if args.share_gpu else "rccl") if use_dist else "none")},
             "roofline": {"bound": "mfma", "kernel": r["p1_kernel"], "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(args.workload),
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, committed; not re-collected by this run)",
                          "launches": int(p1_launches), "avg_launch_ms": p1_ms / max(p1_launches, 1),
                          "flops_per_launch": r["p1_flops"] / max(p1_launches, 1)},
         }

@@ -169,10 +169,36 @@ OMDS_API int omds_kernel_candidates(omds_ctx* ctx, float thr_dist, float thr_ker
                                     const float* sigma_c, int n_kernels, int cap, float* cand_q, int32_t* cand_th,
                                     int32_t* count);
 
-/* Multi-GPU (new work): rollouts shard across one process per GPU; the only exchange
- * is the cost-weighted update.  The library produces this shard's partial sums in two phases
- * and the host side (optimalmodulationds_amd/dist.py) all-reduces them with torch.distributed
- * (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests):
+/* Multi-GPU (new work; the reference is single-process): rollouts shard across one process per GPU,
+ * every rank holds one context with N_local rollouts, and the only exchange is the cost-weighted update
+ * (MPPI.shift_policy_means / get_qdot, MPPI.py:319-345 + policy.py:88-113).
+ *
+ * Native path (comm.hip): a RCCL communicator per context; the update runs on the context stream on device
+ * buffers -- all-reduce SUM of [sum cost, N_local] (8 bytes) -> global beta; all-reduce SUM of the packed partial
+ * sums (<= 3.4 KB); all-gather of (min cost, qdot of the arg-min) only when qdot_best is asked for.
+ *   omds_comm_unique_id   : rank 0 creates the 128-byte id (ncclGetUniqueId); the launcher ships it to the other
+ *                           ranks by whatever bootstrap it has (bench.py: a gloo broadcast).  No context needed;
+ *                           omds_comm_last_error() holds the message of a failure.
+ *   omds_comm_init_rank   : collective over all ranks (ncclCommInitRank on the context's device).  The shard of
+ *                           rank 0 owns the global rollout 0 (policy.py:74): pass rollout_offset = rank * N_local
+ *                           to omds_sample_policy.
+ *   omds_weighted_update_sharded : collective.  mu_c/sigma_c/alpha_c in/out (identical on every rank afterwards),
+ *                           mask_out [K]; qdot_weighted [n] = get_qdot('weighted') or NULL; qdot_best [n] =
+ *                           get_qdot('best') over all shards or NULL (NULL skips the MINLOC gather);
+ *                           n_total_out = number of rollouts over all shards or NULL.  Without a communicator it
+ *                           is the single-shard update.  Failures of RCCL return OMDS_ERR_RCCL.                  */
+#define OMDS_COMM_ID_BYTES 128
+OMDS_API int omds_comm_unique_id(uint8_t* out128);
+OMDS_API const char* omds_comm_last_error(void);
+OMDS_API int omds_comm_init_rank(omds_ctx* ctx, const uint8_t* id128, int rank, int world);
+OMDS_API int omds_comm_destroy(omds_ctx* ctx);
+OMDS_API int omds_comm_info(const omds_ctx* ctx, int32_t* rank, int32_t* world);
+OMDS_API int omds_weighted_update_sharded(omds_ctx* ctx, float rate, float ker_thr, float* mu_c, float* sigma_c,
+                                          float* alpha_c, int32_t* mask_out, float* qdot_weighted, float* qdot_best,
+                                          float* n_total_out);
+/* Host-mediated form of the same exchange, for launchers without RCCL (tests/test_dist_gloo.py runs it over gloo,
+ * world size 2, on CPU-side reductions): the library produces this shard's partial sums in two phases and the host
+ * (optimalmodulationds_amd/dist.py) all-reduces them:
  *   omds_cost_sum    -> out2 = [sum_t cost, N_local]                 (all-reduce SUM, 8 bytes)
  *   omds_local_sums  -> packed buffer of omds_red_count() floats for the GLOBAL beta:
  *        [0] sum w' | sum w' mu (K*n) | sum w' sigma (K) | sum w' alpha (K*n) |
@@ -196,8 +222,7 @@ OMDS_API int omds_apply_update(int n_kernels, int n_dof, int horizon, const floa
 OMDS_API int omds_prof_enable(omds_ctx* ctx, int on);
 OMDS_API int omds_prof_reset(omds_ctx* ctx);
 OMDS_API int omds_prof_read(omds_ctx* ctx, double* pass1_ms, int64_t* pass1_launches, int64_t* pass1_rows);
-/* Same, for whichever kernel dominated the bracketed launches (k_pass1, or k_horizon when one persistent
- * launch runs the whole horizon): summed ms, launches, algorithmic FLOPs and the kernel's name. */
+/* Same, with the algorithmic FLOPs of the bracketed launches and the kernel's name. */
 OMDS_API int omds_prof_read_ex(omds_ctx* ctx, double* ms, int64_t* launches, double* flops, const char** kernel);
 /* Asynchronous form used by bench loops: propagate + cost + weighted update enqueued without
  * host round trips of rollout data; omds_sync waits for the stream.                       */

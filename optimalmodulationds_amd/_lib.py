@@ -72,6 +72,13 @@ SIGNATURES = {
     "omds_local_sums": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_int, F32P]),
     "omds_apply_update": (C.c_int, [C.c_int, C.c_int, C.c_int, F32P, C.c_float, C.c_float, C.c_float, C.c_uint32,
                                     F32P, F32P, F32P, I32P]),
+    "omds_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "omds_comm_last_error": (C.c_char_p, []),
+    "omds_comm_init_rank": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
+    "omds_comm_destroy": (C.c_int, [C.c_void_p]),
+    "omds_comm_info": (C.c_int, [C.c_void_p, I32P, I32P]),
+    "omds_weighted_update_sharded": (C.c_int, [C.c_void_p, C.c_float, C.c_float, F32P, F32P, F32P, I32P, F32P, F32P,
+                                               F32P]),
     "omds_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "omds_prof_reset": (C.c_int, [C.c_void_p]),
     "omds_prof_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
@@ -83,6 +90,24 @@ SIGNATURES = {
 _lib = None
 
 
+def _autobuild():
+    """`make` in csrc/, serialised across processes (torchrun starts one rank per GPU at once) by an exclusive
+    lock; the Makefile links to a temporary name and renames, so no rank can dlopen a half-written library."""
+    import fcntl
+    import subprocess
+    csrc = os.path.join(_HERE, "csrc")
+    with open(os.path.join(csrc, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if os.path.exists(LIB_PATH):     # another rank built it while this one waited
+                return
+            r = subprocess.run(["make", "-C", csrc, "-j4"], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise OmdsError(f"building {LIB_PATH} failed (make exit {r.returncode}):\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}")
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
 def load():
     """dlopen the in-tree library and bind every entry point.  Fails loudly when it is missing."""
     global _lib
@@ -91,8 +116,7 @@ def load():
     if not os.path.exists(LIB_PATH) and os.environ.get("OMDS_NO_AUTOBUILD") != "1":
         # the library is built in-tree by __graft_entry__.build(); if a checkout arrives without it, build it
         # here (hipcc, gfx950) -- still no fallback of any kind: without the library nothing runs
-        import subprocess
-        subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], check=False)
+        _autobuild()
     if not os.path.exists(LIB_PATH):
         raise OmdsError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         f"or `make -C optimalmodulationds_amd/csrc` (there is no CPU fallback)")

@@ -90,6 +90,7 @@ void omds_default_params(omds_params* p) {
 const char* omds_last_error(const omds_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 static void free_all(omds_ctx* ctx) {
+    omds_comm_release(ctx);
     void* ptrs[] = {ctx->d_obs, ctx->d_Bpre, ctx->d_radius, ctx->d_trajT, ctx->d_distT, ctx->d_dotT, ctx->d_actT,
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
                     ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
@@ -825,21 +826,13 @@ int omds_weighted_update(omds_ctx* ctx, float rate, float ker_thr, float* mu_c, 
                          int32_t* mask_out, float* weights_out) {
     RoctxRange range("shift_policy_means");
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    const int N = ctx->cfg.n_traj, n = ctx->cfg.n_dof, K = ctx->n_kernels, H = ctx->cfg.horizon;
-    REQUIRE(K == 0 || (mu_c && sigma_c && alpha_c), OMDS_ERR_INVALID_ARG, "omds_weighted_update: null mean array");
     int rc;
-    float cs[2];
-    if ((rc = omds_cost_sum(ctx, cs))) return rc;
-    std::vector<float> red(omds_red_size(K, n));
-    if ((rc = omds_local_sums(ctx, cs[0], cs[1], 1, red.data()))) return rc;
-    if ((rc = omds_apply_update(K, n, H, red.data(), cs[1], rate, ker_thr, ctx->prm.variant, mu_c, sigma_c, alpha_c, mask_out))) {
-        ctx->err = "omds_apply_update: invalid argument";
-        return rc;
-    }
+    if ((rc = omds_update_impl(ctx, false, rate, ker_thr, mu_c, sigma_c, alpha_c, mask_out, nullptr, nullptr, nullptr))) return rc;
     if (weights_out) {
+        const int N = ctx->cfg.n_traj;
         std::vector<float> w(N);
         CK(hipMemcpy(w.data(), ctx->d_w, (size_t)N * 4, hipMemcpyDeviceToHost));
-        for (int t = 0; t < N; ++t) weights_out[t] = w[t] / red[0];
+        for (int t = 0; t < N; ++t) weights_out[t] = w[t] / ctx->h_red[0];
     }
     return OMDS_OK;
 }
@@ -847,6 +840,7 @@ int omds_weighted_update(omds_ctx* ctx, float rate, float ker_thr, float* mu_c, 
 int omds_get_qdot(omds_ctx* ctx, int mode, float* out) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
     REQUIRE(out && (mode == 0 || mode == 1), OMDS_ERR_INVALID_ARG, "omds_get_qdot: mode 0 ('best') or 1 ('weighted'), non-null out");
+    // the sums of this shard only (means untouched: rate 0 on null arrays is not allowed, so run the reduction alone)
     int rc;
     float cs[2];
     if ((rc = omds_cost_sum(ctx, cs))) return rc;

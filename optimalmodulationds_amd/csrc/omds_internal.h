@@ -126,6 +126,11 @@ struct omds_ctx {
     float* d_stage = nullptr;    // transposition staging for host copies
     size_t stage_bytes = 0;
     float* h_stage = nullptr;
+    // multi-GPU (comm.hip): RCCL communicator of the rollout shards, nullptr = single shard
+    void* comm = nullptr;        // ncclComm_t
+    int comm_rank = 0, comm_world = 1;
+    float* d_gather = nullptr;   // [world][1+n] (min cost, qdot of the arg-min) of every shard
+    float* h_gather = nullptr;   // pinned mirror
     // profiling
     bool prof_on = false;
     int prof_stride = 1;         // bracket every prof_stride-th launch of the dominant kernel with events
@@ -142,6 +147,12 @@ struct omds_ctx {
             return OMDS_ERR_HIP;                                                          \
         }                                                                                 \
     } while (0)
+
+// comm.hip: releases the communicator and its buffers (called by omds_destroy)
+void omds_comm_release(omds_ctx* ctx);
+// the cost-weighted update on the context stream (one host sync); use_comm = reduce over the communicator's shards
+int omds_update_impl(omds_ctx* ctx, bool use_comm, float rate, float ker_thr, float* mu_c, float* sigma_c, float* alpha_c,
+                     int32_t* mask_out, float* qdot_weighted, float* qdot_best, float* n_total_out);
 
 // ---- launchers implemented in mlp_kernels.hip ------------------------------------------------
 void omds_launch_rollout_layer1(hipStream_t s, const MlpDev& m, const float* qT, int ldq, int B, float* Apre);

@@ -9,8 +9,13 @@ process per GPU) owns a contiguous block of N_local rollouts and nothing is exch
   2. all-reduce SUM of the packed partial sums        (<= 3.4 KB)    -> update of mu/sigma/alpha
      + all-gather of (min cost, qdot of the arg-min)  (for get_qdot('best'))
 
-Both are latency-bound; they go through ``torch.distributed`` so the same code runs over RCCL
-(backend "nccl" on the GPU box, xGMI) and over gloo in the CPU tests.  The final arithmetic is
+Both are latency-bound.  On GPUs the exchange is NATIVE: the library owns a RCCL communicator per
+context and runs the all-reduces on the context stream on device buffers (csrc/comm.hip,
+``omds_weighted_update_sharded``); ``init_native_comm`` below only bootstraps it (the 128-byte id
+travels over whatever process group the launcher has, e.g. gloo under torchrun).
+``sharded_update`` is the host-mediated form of the same exchange (``omds_cost_sum`` /
+``omds_local_sums`` + ``torch.distributed`` all-reduces), kept for launchers without RCCL and for
+the world-size-2 gloo tests; it is never chosen silently.  The final arithmetic is
 ``omds_apply_update`` (host C, no GPU needed)."""
 from __future__ import annotations
 
@@ -19,6 +24,21 @@ import torch
 import torch.distributed as dist
 
 from .engine import apply_update, red_layout
+
+
+def init_native_comm(engine, group=None):
+    """Creates the RCCL communicator of ``engine`` over the ranks of ``group`` (any torch.distributed
+    backend -- it only carries the id).  Raises OmdsError (OMDS_ERR_RCCL) if RCCL cannot be used: there is
+    no fallback.  Without an initialised process group: a single-rank communicator."""
+    if dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        uid = box[0]
+    else:
+        rank, world, uid = 0, 1, engine.comm_unique_id()
+    engine.comm_init(uid, rank, world)
+    return rank, world
 
 
 def _dev_for_backend(group=None):

@@ -183,6 +183,46 @@ class Engine:
                                           L.fptr(red)))
         return red
 
+    # ---- multi-GPU: native RCCL exchange (comm.hip) -------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128-byte RCCL id (rank 0 makes it, the launcher ships it to the other ranks)."""
+        lib = L.load()
+        buf = (C.c_uint8 * 128)()
+        rc = lib.omds_comm_unique_id(buf)
+        if rc != 0:
+            raise L.OmdsError(f"omds_comm_unique_id failed ({rc}): {(lib.omds_comm_last_error() or b'?').decode()}")
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == 128
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._ck(self.lib.omds_comm_init_rank(self.h, buf, int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._ck(self.lib.omds_comm_destroy(self.h))
+
+    def comm_info(self):
+        r, w = C.c_int32(), C.c_int32()
+        self._ck(self.lib.omds_comm_info(self.h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def weighted_update_sharded(self, rate, ker_thr, mu_c, sigma_c, alpha_c, want_best=False):
+        """MPPI.shift_policy_means + get_qdot over all shards of the communicator (all-reduces on the context
+        stream, device buffers).  Returns (mu, sigma, alpha, mask, qdot_weighted, qdot_best | None, n_total)."""
+        K = self.K
+        mu = np.array(np.asarray(mu_c, dtype=np.float32)[:K], dtype=np.float32, order="C", copy=True).reshape(K, self.n)
+        sg = np.array(np.asarray(sigma_c, dtype=np.float32)[:K], dtype=np.float32, order="C", copy=True).reshape(K)
+        al = np.array(np.asarray(alpha_c, dtype=np.float32)[:K], dtype=np.float32, order="C", copy=True).reshape(K, self.n)
+        mask = np.zeros(K, np.int32)
+        qw = np.zeros(self.n, np.float32)
+        qb = np.zeros(self.n, np.float32) if want_best else None
+        nt = C.c_float()
+        self._ck(self.lib.omds_weighted_update_sharded(self.h, float(rate), float(ker_thr), L.fptr(mu), L.fptr(sg),
+                                                       L.fptr(al), L.iptr(mask), L.fptr(qw), L.fptr(qb),
+                                                       C.cast(C.byref(nt), L.F32P)))
+        return mu, sg, al, mask.astype(bool), qw, qb, nt.value
+
     def kernel_candidates(self, thr_dist, thr_kernel, thr_dot, mu_c, sigma_c, K, cap=None):
         """Device-side TensorPolicyMPPI.check_traj_for_kernels: (cand_q [m,n], cand_th [m,2], total)."""
         K = int(K)

@@ -1,0 +1,158 @@
+"""GPU tests of the rollout-sharded update: two device contexts that each hold half of the rollouts must
+reproduce one context holding all of them; the native RCCL path (csrc/comm.hip) runs with a single-rank communicator
+(a 1-GPU box cannot host two RCCL ranks); and BASELINE configs[3]'s per-GPU shard (4096 rollouts x 64 horizon) runs
+and is re-derived by the oracle at sampled states."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import weights_path
+from oracle import omds_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(N, H, k=5, K=6, seed=3, scene="shelf"):
+    from optimalmodulationds_amd import scenes
+    from optimalmodulationds_amd.cost import FRANKA_Q_MAX, FRANKA_Q_MIN
+    from optimalmodulationds_amd.engine import Engine
+    m = orc.Mlp.from_npz(weights_path("franka"))
+    obs = scenes.shelf_scene()
+    q0, qf, dh = scenes.FRANKA_Q0, scenes.FRANKA_QF, scenes.franka_dh_params()
+    qmin, qmax = np.array(FRANKA_Q_MIN, np.float32), np.array(FRANKA_Q_MAX, np.float32)
+
+    def make(n_traj):
+        e = Engine(7, n_traj, H, k, max_obs=512)
+        e.set_mlp(m.W, m.b)
+        e.set_obstacles(obs)
+        e.params.dt, e.params.dst_thr, e.params.ignored_links = 0.5, 0.01, 0b111
+        e.push_params()
+        e.set_ds(qf)
+        e.set_cost(dh, qmin, qmax)
+        return e
+
+    rng = np.random.RandomState(seed)
+    s = (np.arange(K) + 0.5) / max(K, 1)
+    mu_c = (q0 + s[:, None] * (qf - q0) + 0.15 * rng.standard_normal((K, 7))).astype(np.float32)
+    sg_c = np.ones(K, np.float32)
+    al_c = rng.standard_normal((K, 7)).astype(np.float32)
+    return m, obs, q0, qf, dh, qmin, qmax, make, mu_c, sg_c, al_c
+
+
+@pytest.mark.parametrize("N,H,K", [(256, 8, 6), (96, 5, 0), (2048, 4, 50)])
+def test_two_contexts_sum_to_one(N, H, K):
+    """Shards [0, N/2) and [N/2, N) on two contexts of device 0, with the samples of the single N-rollout context split
+    between them (sizes chosen so that both shapes pick the same tile heights, hence bit-identical rollouts): their cost sums and packed partial sums added on the host (what the all-reduce does) must reproduce
+    the single context's update -- identical mask, means to 1e-6 -- and the MINLOC over the shards its best rollout."""
+    from optimalmodulationds_amd.engine import apply_update, red_layout
+    m, obs, q0, qf, dh, qmin, qmax, make, mu_c, sg_c, al_c = _setup(N, H, K=K)
+    one = make(N)
+    one.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 3.0, K, seed=77, rollout_offset=0)
+    mu, sg, al = one.get_policy_samples()
+    one.propagate(q0)
+    c_one = one.cost()
+    ref_mu, ref_sg, ref_al, ref_mask, ref_w = one.weighted_update(0.1, 0.1, mu_c, sg_c, al_c, want_weights=True)
+    qd_w, qd_b = one.get_qdot("weighted"), one.get_qdot("best")
+
+    h = N // 2
+    shards = []
+    for r in range(2):
+        e = make(h)
+        if K:
+            # device-side sampling with the shard's rollout_offset must give exactly the single context's samples
+            e.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 3.0, K, seed=77, rollout_offset=r * h)
+            smu, ssg, sal = e.get_policy_samples()
+            assert np.array_equal(smu, mu[r * h:(r + 1) * h]) and np.array_equal(sal, al[r * h:(r + 1) * h])
+            assert np.array_equal(ssg, sg[r * h:(r + 1) * h])
+        else:
+            e.sample_policy(mu_c, sg_c, al_c, 0, 0, 0, 0, seed=77, rollout_offset=r * h)
+        e.propagate(q0)
+        c = e.cost()
+        assert np.array_equal(c, c_one[r * h:(r + 1) * h])       # rollouts do not depend on which context holds them
+        shards.append(e)
+    cs = sum(e.cost_sum() for e in shards)                        # all-reduce SUM #1
+    assert cs[1] == N
+    reds = [e.local_sums(cs[0], cs[1], include_rollout0=(r == 0)) for r, e in enumerate(shards)]
+    lay = red_layout(K, 7)
+    red = reds[0].copy()
+    red[:lay["n_sum"]] = reds[0][:lay["n_sum"]] + reds[1][:lay["n_sum"]]   # all-reduce SUM #2
+    nmu, nsg, nal, mask = apply_update(K, 7, H, red, float(cs[1]), 0.1, 0.1, mu_c, sg_c, al_c)
+    assert np.array_equal(mask, ref_mask)
+    if K:
+        for a, b, what in ((nmu, ref_mu, "mu"), (nsg, ref_sg, "sigma"), (nal, ref_al, "alpha")):
+            assert np.abs(a - b).max() <= 1e-6 * max(1.0, np.abs(b).max()), what
+    qw = red[lay["qdot"]:lay["qdot"] + 7] / red[0]
+    assert np.abs(qw - qd_w).max() <= 2e-6
+    best = np.stack([r_[lay["n_sum"]:] for r_ in reds])           # all-gather + MINLOC
+    assert np.array_equal(best[int(np.argmin(best[:, 0])), 1:], qd_b)
+    for e in shards + [one]:
+        e.close()
+
+
+def test_native_rccl_single_rank_matches_local_update():
+    """omds_comm_init_rank (world 1) + omds_weighted_update_sharded: the RCCL all-reduces / all-gather run on the
+    context stream on device buffers; with one rank they must leave every number of the local update unchanged."""
+    from optimalmodulationds_amd.engine import Engine
+    N, H, K = 256, 6, 8
+    m, obs, q0, qf, dh, qmin, qmax, make, mu_c, sg_c, al_c = _setup(N, H, K=K)
+    e = make(N)
+    e.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 3.0, K, seed=5)
+    e.propagate(q0)
+    e.cost(fetch=False)
+    ref = e.weighted_update(0.1, 0.1, mu_c, sg_c, al_c)
+    qd_w, qd_b = e.get_qdot("weighted"), e.get_qdot("best")
+    assert e.comm_info() == (0, 1)
+    e.comm_init(Engine.comm_unique_id(), 0, 1)
+    assert e.comm_info() == (0, 1)
+    for _ in range(3):   # repeated collectives on the same communicator
+        mu, sg, al, mask, qw, qb, nt = e.weighted_update_sharded(0.1, 0.1, mu_c, sg_c, al_c, want_best=True)
+        assert nt == N
+        assert np.array_equal(mask, ref[3])
+        assert np.array_equal(mu, ref[0]) and np.array_equal(sg, ref[1]) and np.array_equal(al, ref[2])
+        assert np.array_equal(qw, qd_w) and np.array_equal(qb, qd_b)
+    e.comm_destroy()
+    assert e.comm_info() == (0, 1)
+    mu, sg, al, mask, qw, qb, nt = e.weighted_update_sharded(0.1, 0.1, mu_c, sg_c, al_c, want_best=True)   # no communicator: local
+    assert np.array_equal(mu, ref[0]) and np.array_equal(qb, qd_b)
+    e.close()
+
+
+def test_shard_4096x64_config4():
+    """BASELINE configs[3] per GPU: 4096 rollouts x 64 horizon on the shelf scene (one of 8 shards; rollout_offset of
+    rank 3).  Size-independent checks: finite outputs; H network evaluations; sampled (rollout, step) states re-derived
+    by the oracle; cost / update recomputed by the oracle from the device's rollouts; the sharded-update entry point."""
+    N, H, K, k = 4096, 64, 10, 5
+    m, obs, q0, qf, dh, qmin, qmax, make, mu_c, sg_c, al_c = _setup(N, H, K=K)
+    e = make(N)
+    e.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 3.0, K, seed=11, rollout_offset=3 * N)
+    mu, sg, al = e.get_policy_samples()
+    assert not np.array_equal(al[0], al_c)       # not the owner of global rollout 0: its rollout 0 is noised
+    e.propagate(q0)
+    r = e.get_rollouts()
+    for key, v in r.items():
+        assert np.isfinite(v).all(), key
+    assert r["all_traj"].shape == (N, H, 7) and np.array_equal(r["all_traj"][:, 0], np.broadcast_to(q0, (N, 7)))
+    rng = np.random.RandomState(0)
+    S = 192
+    tt, hh = rng.randint(0, N, S), rng.randint(0, H, S)
+    hh[:16] = H - 1                               # the last evaluation is computed but not integrated (MPPI.py:220)
+    q = r["all_traj"][tt, hh]
+    d, g, _, idx = orc.distance_repulsion_nn(m, q, obs, k, [0, 1, 2])
+    st = orc.modulation_step(q, qf, d, g, mu[tt], sg[tt], al[tt], orc.Params(dst_thr=0.01))
+    assert np.abs(r["closest_dist_all"][tt, hh] - (d - np.float32(0.01))).max() <= 1e-5
+    ok = orc.rollout_relu_margin(m, q, obs, idx) >= 5e-6
+    assert ok.mean() > 0.5
+    assert np.abs(r["kernel_val_all"][tt, hh] - st["phi"]).max() <= 1e-5
+    nxt = (hh + 1 < H) & ok
+    vel = (r["all_traj"][tt[nxt], hh[nxt] + 1] - q[nxt]) / np.float32(0.5)
+    assert np.abs(vel - st["u"][nxt]).max() <= 2e-4
+    cost = e.cost()
+    ocost, _ = orc.evaluate_costs(r["all_traj"], r["closest_dist_all"], qf, dh, qmin, qmax)
+    assert np.abs(cost - ocost).max() <= 1e-5 * max(1.0, np.abs(ocost).max())
+    nmu, nsg, nal, mask, qw, _, nt = e.weighted_update_sharded(0.1, 0.1, mu_c, sg_c, al_c)
+    omu, osg, oal, omask, _ = orc.shift_policy_means(cost, r["kernel_val_all"], r["kernel_activations"], mu_c, sg_c, al_c,
+                                                     mu, sg, al, 0.1, 0.1)
+    assert nt == N and np.array_equal(mask, omask)
+    assert np.abs(nal - oal).max() <= 2e-5 * max(1.0, np.abs(oal).max())
+    e.close()
