@@ -215,6 +215,22 @@ OMDS_API int omds_apply_update(int n_kernels, int n_dof, int horizon, const floa
                                float ker_thr, uint32_t variant, float* mu_c, float* sigma_c, float* alpha_c,
                                int32_t* mask_out);
 
+/* Screening of pass 1 (screen_kernel.hip).  The N*O first-pass evaluations of MPPI.distance_repulsion_nn only feed the
+ * sort that picks the k closest obstacles (MPPI.py:245-253); omds_propagate may therefore evaluate them in fp16 and
+ * re-evaluate in fp32 only the candidates {o : Da(o) <= k-th smallest Da + 2 eps}, which contain the fp32 top-k (ties
+ * included) whenever |Da - D| <= eps.  eps is calibrated per network (4 x the largest error over a calibration batch)
+ * and re-measured on every candidate of every propagate; if the margin ever falls below 2 x the propagate is redone
+ * in fp32.  The distances and gradients a step uses always come from the fp32 pass 2.  omds_dist_grad always uses the
+ * fp32 pass 1.  mode: -1 auto (on for ReLU networks when n_traj * n_obs >= 65536; env OMDS_SCREEN=0|1 overrides),
+ * 0 off, 1 on; eps > 0 fixes the bound, eps = 0 (re)calibrates.
+ * omds_screen_stats: active, eps in use, largest error seen on candidates, mean candidates per (rollout, step) and
+ * fp32 fallbacks since the last omds_prof_reset / creation (NULL = skip).                                           */
+OMDS_API int omds_set_screening(omds_ctx* ctx, int mode, float eps);
+/* Diagnostic: the fp16 screening network alone on q [B,n] -> mindist [B,O] (the values the candidate selection sees). */
+OMDS_API int omds_screen_mindist(omds_ctx* ctx, const float* q, int batch, float* mindist);
+OMDS_API int omds_screen_stats(omds_ctx* ctx, int32_t* active, float* eps, float* max_err_seen,
+                               double* cand_per_rollout_step, int64_t* fallbacks);
+
 /* Measurement: when enabled, launches of the dominant kernel (k_pass1) are bracketed by HIP events on the
  * context stream -- every launch for on == 1, every on-th launch for on > 1 (an event record between two
  * kernels idles the GPU for ~6 us, so throughput runs sample) -- and omds_prof_read returns the summed elapsed

@@ -79,6 +79,9 @@ SIGNATURES = {
     "omds_comm_info": (C.c_int, [C.c_void_p, I32P, I32P]),
     "omds_weighted_update_sharded": (C.c_int, [C.c_void_p, C.c_float, C.c_float, F32P, F32P, F32P, I32P, F32P, F32P,
                                                F32P]),
+    "omds_set_screening": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),
+    "omds_screen_mindist": (C.c_int, [C.c_void_p, F32P, C.c_int, F32P]),
+    "omds_screen_stats": (C.c_int, [C.c_void_p, I32P, F32P, F32P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "omds_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "omds_prof_reset": (C.c_int, [C.c_void_p]),
     "omds_prof_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

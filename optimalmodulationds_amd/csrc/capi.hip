@@ -60,9 +60,31 @@ static int upload(omds_ctx* ctx, const std::vector<T>& h, const T** dptr) {
     return OMDS_OK;
 }
 
+// fp32 -> IEEE binary16 bits, round to nearest even (the screening network's weights, screen_kernel.hip)
+static uint16_t f32_to_f16_bits(float f) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((x > 0x7f800000u) ? 0x200u : 0u));   // inf / nan
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                                        // rounds to >= 65520: inf
+    if (x < 0x38800000u) {                                                                          // subnormal half or zero
+        if (x < 0x33000000u) return (uint16_t)sign;                                                 // < 2^-25: zero
+        const int shift = 126 - (int)(x >> 23);                                                     // 14 .. 24
+        const uint32_t mant = (x & 0x7fffffu) | 0x800000u;
+        const uint32_t q = mant >> shift, rem = mant & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+        return (uint16_t)(sign | (q + ((rem > halfway || (rem == halfway && (q & 1u))) ? 1u : 0u)));
+    }
+    const uint32_t e = (x >> 23) - 112u, mant = x & 0x7fffffu;
+    uint32_t h = (e << 10) | (mant >> 13);
+    const uint32_t rem = mant & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;                                         // may carry into the exponent: correct
+    return (uint16_t)(sign | h);
+}
+
 extern "C" {
 
-int omds_version(void) { return 100; }
+int omds_version(void) { return 200; }
 
 void omds_default_params(omds_params* p) {
     if (!p) return;
@@ -95,7 +117,7 @@ static void free_all(omds_ctx* ctx) {
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
                     ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
                     ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
-                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A};
+                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : ctx->mlp_allocs)
@@ -167,6 +189,9 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
     CKC(hipMalloc(&ctx->d_means, Km * (2 * n + 1) * 4));
     CKC(hipMalloc(&ctx->d_Apre, rows2 * OMDS_WIDTH * 4));
     CKC(hipMalloc(&ctx->d_Dmin, N * Om * 4));
+    CKC(hipMalloc(&ctx->d_rowlist, N * Om * 4));
+    CKC(hipMalloc(&ctx->d_sctotal, (H + 1) * 4));
+    CKC(hipMalloc(&ctx->d_scerr, 4));
     CKC(hipMalloc(&ctx->d_idx, rows2 * 4));
     CKC(hipMalloc(&ctx->d_gradx, rows2 * d * 4));
     CKC(hipMalloc(&ctx->d_drow, rows2 * 4));
@@ -345,7 +370,41 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
                     for (int mm = 0; mm < 4; ++mm) v[mm] = W[0][(k0 + mm) * F + f];
                 w1b16[(c * 2 + jb) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
             }
+    // fp16 screening network: slices of 32 output rows x 256 k in A-fragment order of v_mfma_f32_32x32x16_f16, with the k
+    // order permuted to the C layout of the previous layer (chunk cc, lane-half h, slot j <-> feature 16cc + 8(j>>2) + 4h + (j&3))
+    ctx->screen = ScreenDev{};
+    ctx->screen_ok = false;
+    ctx->screen_cal = false;
+    ctx->screen_eps = 0.f;
+    std::vector<uint16_t> wh;
+    std::vector<float> sbias;
+    if (act == OMDS_ACT_RELU && m.nhh >= 1 && m.nhh <= 4) {
+        const int nsl = m.nhh * 8 + 1;
+        wh.assign((size_t)nsl * 16 * 64 * 8, 0);
+        sbias.assign((size_t)(m.nhh + 1) * Wd, 0.f);
+        for (int sl = 0; sl < nsl; ++sl) {
+            const bool lastl = sl == nsl - 1;
+            const float* Wsrc = lastl ? W[n_linear - 1] : W[sl / 8 + 1];
+            const int fb = lastl ? 0 : sl % 8, rows = lastl ? C : Wd;
+            for (int cc = 0; cc < 16; ++cc)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = 32 * fb + (lane & 31), kk = 16 * cc + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+                        const float v = (r < rows) ? Wsrc[(size_t)r * Wd + kk] : 0.f;
+                        wh[(((size_t)sl * 16 + cc) * 64 + lane) * 8 + j] = f32_to_f16_bits(v);
+                    }
+        }
+        for (int l = 0; l < m.nhh; ++l) std::memcpy(&sbias[(size_t)l * Wd], b[l + 1], Wd * sizeof(float));
+        std::memcpy(&sbias[(size_t)m.nhh * Wd], b[n_linear - 1], C * sizeof(float));
+    }
     int rc;
+    if (!wh.empty()) {
+        const uint16_t* dwh = nullptr;
+        if ((rc = upload(ctx, wh, &dwh))) return rc;
+        if ((rc = upload(ctx, sbias, &ctx->screen.bias))) return rc;
+        ctx->screen.Wh = dwh;
+        ctx->screen_ok = true;
+    }
     if ((rc = upload(ctx, wf16, &m.Wf16))) return rc;
     if ((rc = upload(ctx, wb16, &m.Wb16))) return rc;
     if ((rc = upload(ctx, w1b16, &m.W1b16))) return rc;
@@ -572,6 +631,108 @@ static int check_ready(omds_ctx* ctx, bool need_ds) {
     return OMDS_OK;
 }
 
+// ---- screening (screen_kernel.hip): mode, calibration of eps, the per-step launch sequences ---------------------------------
+static bool screen_wanted(omds_ctx* ctx) {
+    if (!ctx->screen_ok) return false;
+    int mode = ctx->screen_mode;
+    if (mode < 0) {
+        static int env = -2;
+        if (env == -2) { const char* e = getenv("OMDS_SCREEN"); env = e ? atoi(e) : -1; }
+        mode = env;
+    }
+    if (mode == 0) return false;
+    if (mode > 0) return true;
+    // auto: worth it once pass 1 is throughput-bound (below that a step is a chain of latency-bound launches and the
+    // three extra launches cost more than the fp32 pass)
+    return (long long)ctx->cfg.n_traj * ctx->n_obs >= 64LL * 1024 && ctx->n_obs >= 4 * ctx->cfg.n_closest;
+}
+
+// eps = 4 x the largest |screening value - fp32 value| over a calibration batch: states drawn uniformly inside the joint
+// limits (omds_set_cost) or [-pi, pi], against the current obstacle set.  Once per omds_set_mlp; the candidates of every
+// later propagate re-measure the error (d_scerr) and trip the fp32 fallback when the margin shrinks below 2x.
+static int calibrate_screen(omds_ctx* ctx) {
+    ctx->screen_cal = true;
+    if (ctx->screen_eps > 0.f) return OMDS_OK;   // set by the caller (omds_set_screening)
+    const int n = ctx->cfg.n_dof, O = ctx->n_obs;
+    const int B = std::min(ctx->cfg.n_traj, 192);
+    std::vector<float> q((size_t)n * B);          // [n][B]
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    for (int j = 0; j < n; ++j) {
+        const float lo = ctx->have_cost ? ctx->qmin[j] : -3.14159265f, hi = ctx->have_cost ? ctx->qmax[j] : 3.14159265f;
+        for (int t = 0; t < B; ++t) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            q[(size_t)j * B + t] = lo + (hi - lo) * (float)((st >> 40) * (1.0 / 16777216.0));
+        }
+    }
+    CK(hipMemcpyAsync(ctx->d_qstage, q.data(), q.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Apre);
+    std::vector<float> ref((size_t)B * O), apx((size_t)B * O);
+    omds_launch_pass1(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
+    CK(hipMemcpyAsync(ref.data(), ctx->d_Dmin, ref.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
+    CK(hipGetLastError());
+    CK(hipMemcpyAsync(apx.data(), ctx->d_Dmin, apx.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    float worst = 0.f;
+    bool finite = true;
+    for (size_t i = 0; i < ref.size(); ++i) {
+        const float e = std::fabs(apx[i] - ref[i]);
+        if (!(e < 3.0e38f)) { finite = false; break; }
+        worst = std::max(worst, e);
+    }
+    if (!finite) { ctx->screen_ok = false; return OMDS_OK; }   // fp16 range exceeded: this network stays on the fp32 path
+    ctx->screen_eps = std::max(4.f * worst, 1e-12f);
+    return OMDS_OK;
+}
+
+static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) {
+    const int N = a.N, H = a.H, n = a.n;
+    int rc;
+    if (tail) {
+        // two launches per step: k_pass1 over all (rollout, obstacle) pairs, then the rollout-local tail; with screening
+        // k_pass1 becomes k_screen (fp16) + k_select + k_exact (fp32 on the candidates only).
+        // (Measured and rejected: independent rollout groups on separate HIP streams for small batches --
+        // planar7_1024x32 ran 9.0 M rollout-steps/s on one stream, 7.1 / 3.3 / 2.4 M on 2 / 4 / 8 -- and a two-half
+        // ping-pong for large batches with event-chained pass-1 launches so that one half's tail runs under the
+        // other half's pass 1: parity-green, but the half-size launches drain twice per step, 1.00 M vs 1.03 M.)
+        omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, ctx->d_Apre);
+        if (screen) {
+            CK(hipMemsetAsync(ctx->d_sctotal, 0, (size_t)(H + 1) * 4, ctx->stream));
+            CK(hipMemsetAsync(ctx->d_scerr, 0, 4, ctx->stream));
+        }
+        for (int i = 1; i <= H; ++i) {
+            {
+                RoctxRange r1("TAG: evaluate NN_2 (forward pass)");
+                if ((rc = prof_begin(ctx))) return rc;
+                if (screen) {
+                    omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
+                                       ctx->prm.ignored_links, ctx->d_Dmin);
+                    if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs, -1.0, "k_screen"))) return rc;
+                    omds_launch_select(ctx->stream, ctx->d_Dmin, N, ctx->n_obs, a.k, ctx->screen_eps, ctx->d_rowlist, ctx->d_sctotal + (i - 1));
+                    omds_launch_exact(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
+                                      ctx->prm.ignored_links, ctx->d_Dmin, ctx->d_rowlist, ctx->d_sctotal + (i - 1), ctx->d_scerr);
+                } else {
+                    omds_launch_pass1(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
+                                      ctx->prm.ignored_links, ctx->d_Dmin);
+                    if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs))) return rc;
+                }
+            }
+            RoctxRange r2("TAG: evaluate NN_3-5 + Modulation-propagation");
+            a.step = i;
+            omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, ctx->d_Apre,
+                             ctx->d_dscr, ctx->n_obs, a, 0, N);
+        }
+    } else {
+        for (int i = 1; i <= H; ++i) {   // MPPI.py:101: H network evaluations, the last velocity is not integrated
+            if ((rc = enqueue_network(ctx, ctx->d_trajT + (size_t)(i - 1) * n * N, N, N))) return rc;
+            a.step = i;
+            omds_launch_modulate(ctx->stream, a);
+        }
+    }
+    return OMDS_OK;
+}
+
 int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
     RoctxRange range("TAG: general propagation");
     if (!ctx) return OMDS_ERR_INVALID_ARG;
@@ -599,36 +760,32 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
     a.prm = ctx->prm;
     static int fused = -1;   // OMDS_FUSED_TAIL=0 selects the five-kernel step (kept for A/B runs and as the generic path)
     if (fused < 0) { const char* e = getenv("OMDS_FUSED_TAIL"); fused = e ? atoi(e) : 1; }
-    if (fused && omds_tail_supported(n, a.k)) {
-        // two launches per step: k_pass1 over all (rollout, obstacle) pairs, then the rollout-local tail.
-        // (Measured and rejected: independent rollout groups on separate HIP streams for small batches --
-        // planar7_1024x32 ran 9.0 M rollout-steps/s on one stream, 7.1 / 3.3 / 2.4 M on 2 / 4 / 8 -- and a two-half
-        // ping-pong for large batches with event-chained pass-1 launches so that one half's tail runs under the
-        // other half's pass 1: parity-green, but the half-size launches drain twice per step, 1.00 M vs 1.03 M.)
-        omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, ctx->d_Apre);
-        for (int i = 1; i <= H; ++i) {
-            {
-                RoctxRange r1("TAG: evaluate NN_2 (forward pass)");
-                if ((rc = prof_begin(ctx))) return rc;
-                omds_launch_pass1(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
-                                  ctx->prm.ignored_links, ctx->d_Dmin);
-                if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs))) return rc;
-            }
-            RoctxRange r2("TAG: evaluate NN_3-5 + Modulation-propagation");
-            a.step = i;
-            omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, ctx->d_Apre,
-                             ctx->d_dscr, ctx->n_obs, a, 0, N);
+    const bool tail = fused && omds_tail_supported(n, a.k);
+    bool screen = tail && screen_wanted(ctx);
+    if (screen && !ctx->screen_cal && (rc = calibrate_screen(ctx))) return rc;
+    screen = screen && ctx->screen_ok && ctx->screen_eps > 0.f;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if ((rc = enqueue_rollouts(ctx, a, tail, screen))) return rc;
+        CK(hipGetLastError());
+        ctx->have_cost_vals = false;
+        if (screen) {
+            CK(hipMemcpyAsync(ctx->h_red, ctx->d_scerr, 4, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipMemcpyAsync(ctx->h_red + 1, ctx->d_sctotal, (size_t)H * 4, hipMemcpyDeviceToHost, ctx->stream));
         }
-    } else {
-        for (int i = 1; i <= H; ++i) {   // MPPI.py:101: H network evaluations, the last velocity is not integrated
-            if ((rc = enqueue_network(ctx, ctx->d_trajT + (size_t)(i - 1) * n * N, N, N))) return rc;
-            a.step = i;
-            omds_launch_modulate(ctx->stream, a);
-        }
+        CK(hipStreamSynchronize(ctx->stream));
+        if (!screen) break;
+        const float err = ctx->h_red[0];   // max |screening - fp32| over every candidate pair of this propagate
+        if (err > ctx->screen_err_seen || err != err) ctx->screen_err_seen = err;
+        const int32_t* tot = reinterpret_cast<const int32_t*>(ctx->h_red + 1);
+        for (int i = 0; i < H; ++i) ctx->screen_rows += tot[i];
+        ctx->screen_steps += (double)N * H;
+        if (err <= 0.5f * ctx->screen_eps) break;
+        // the calibrated bound lost its 2x margin on live data: this propagate is redone in fp32 and the bound is widened
+        // (or screening is switched off when the error is not even finite -- an fp16 overflow inside the network)
+        ctx->screen_fallbacks++;
+        if (err == err && err < 3.0e38f) ctx->screen_eps = 4.f * err; else ctx->screen_ok = false;
+        screen = false;
     }
-    CK(hipGetLastError());
-    ctx->have_cost_vals = false;
-    CK(hipStreamSynchronize(ctx->stream));
     if (ctx->prof_on && (rc = prof_collect(ctx))) return rc;
     return OMDS_OK;
 }
@@ -889,6 +1046,44 @@ int omds_kernel_candidates(omds_ctx* ctx, float thr_dist, float thr_kernel, floa
     return OMDS_OK;
 }
 
+// ---- screening controls ------------------------------------------------------------------------------
+int omds_set_screening(omds_ctx* ctx, int mode, float eps) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(mode >= -1 && mode <= 1 && !(eps < 0.f), OMDS_ERR_INVALID_ARG, "omds_set_screening: mode in {-1, 0, 1}, eps >= 0");
+    ctx->screen_mode = mode;
+    if (eps > 0.f) { ctx->screen_eps = eps; ctx->screen_cal = true; }
+    else if (ctx->screen_cal) { ctx->screen_cal = false; ctx->screen_eps = 0.f; }   // eps = 0: calibrate again at the next propagate
+    return OMDS_OK;
+}
+// Diagnostic: the screening network alone on a batch (what k_select sees), for tests and for measuring eps.
+int omds_screen_mindist(omds_ctx* ctx, const float* q, int B, float* mindist) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(q && mindist && B >= 1 && B <= ctx->cfg.n_traj, OMDS_ERR_INVALID_ARG, "omds_screen_mindist: need 1 <= batch <= n_traj and non-null arrays");
+    int rc;
+    if ((rc = check_ready(ctx, false))) return rc;
+    REQUIRE(ctx->screen_ok, OMDS_ERR_UNSUPPORTED, "omds_screen_mindist: no screening network for this model (ReLU, 2..5 hidden layers)");
+    CK(hipSetDevice(ctx->dev));
+    const int n = ctx->cfg.n_dof, O = ctx->n_obs;
+    CK(hipMemcpyAsync(ctx->d_stage, q, (size_t)B * n * 4, hipMemcpyHostToDevice, ctx->stream));
+    omds_launch_transpose(ctx->stream, ctx->d_stage, ctx->d_qstage, B, n);
+    omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Apre);
+    omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
+    CK(hipGetLastError());
+    CK(hipMemcpyAsync(mindist, ctx->d_Dmin, (size_t)B * O * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return OMDS_OK;
+}
+int omds_screen_stats(omds_ctx* ctx, int32_t* active, float* eps, float* max_err_seen, double* cand_per_rollout_step,
+                      int64_t* fallbacks) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    if (active) *active = (ctx->screen_ok && screen_wanted(ctx)) ? 1 : 0;
+    if (eps) *eps = ctx->screen_eps;
+    if (max_err_seen) *max_err_seen = ctx->screen_err_seen;
+    if (cand_per_rollout_step) *cand_per_rollout_step = ctx->screen_steps > 0 ? ctx->screen_rows / ctx->screen_steps : 0.0;
+    if (fallbacks) *fallbacks = ctx->screen_fallbacks;
+    return OMDS_OK;
+}
+
 // ---- measurement -------------------------------------------------------------------------------------
 int omds_prof_enable(omds_ctx* ctx, int on) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
@@ -904,6 +1099,8 @@ int omds_prof_reset(omds_ctx* ctx) {
     ctx->prof.rows = 0;
     ctx->prof.flops = 0.0;
     ctx->prof.used = 0;
+    ctx->screen_rows = 0.0;
+    ctx->screen_steps = 0.0;
     return OMDS_OK;
 }
 int omds_prof_read_ex(omds_ctx* ctx, double* ms, int64_t* launches, double* flops, const char** kernel) {

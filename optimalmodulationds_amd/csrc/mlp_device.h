@@ -193,14 +193,20 @@ struct OmdsDivisor {
     }
 };
 
-template <int MT, int MR, int NR, int ACT>
+// LIST = false: the tile covers rows row0 .. row0+MT-1 of the virtual rollout-major pair space (row = t*O + o) and writes
+// Dmin[row].  LIST = true (screening, screen_kernel.hip): the tile covers entries row0 .. of `rowlist`, each naming a pair
+// t*O + o; the result overwrites Dmin[pair] (which holds the screening value) and max |old - new| goes to *maxerr_bits.
+// The arithmetic of a row is the same in both forms and independent of the other rows of the tile: bit-identical results.
+template <int MT, int MR, int NR, int ACT, bool LIST = false>
 __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const float* __restrict__ Apre,
                                            const float* __restrict__ Bpre, const float* __restrict__ radius, int O,
                                            long long total_rows, uint32_t ignored, float* __restrict__ Dmin,
-                                           const long long row0, const OmdsDivisor odiv) {
+                                           const long long row0, const OmdsDivisor odiv,
+                                           const int* __restrict__ rowlist = nullptr, unsigned* maxerr_bits = nullptr) {
     using G = Geo<MT, MR, NR>;
     float* Hs = smem;                                           // [MT][LDH]
     float* rowRad = smem + MT * LDH;                            // [MT] obstacle radius of each row
+    int* rowIdx = reinterpret_cast<int*>(rowRad + MT);          // [MT] LIST: pair index of each row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / G::WN, wn = wave % G::WN;
     OMDS_TL(0);
@@ -233,10 +239,31 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                                                                             0x7fffffff, 0x00020000);
         const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bpre), 0, 0x7fffffff, 0x00020000);
         const int lv = lane * 16;
-        int o = (int)(row0u - t0 * (unsigned)O) + wv, dt = 0;   // row r = wv + it * NW is pair (t0 + dt, o)
-        while (o >= O) { o -= O; ++dt; }
         omds_f4 av[IT], bv[IT];
         float rad[IT];
+        int pidx[IT];
+        if constexpr (LIST) {
+            const __amdgpu_buffer_rsrc_t ar0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Apre), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                if (wv + it * G::NW < rows_here) {
+                    const int idx = __builtin_amdgcn_readfirstlane(rowlist[row0 + wv + it * G::NW]);
+                    const unsigned tt = odiv.div((unsigned)idx);
+                    const int oo = (int)((unsigned)idx - tt * (unsigned)O);
+                    av[it] = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(ar0, lv, (int)(tt * (OMDS_WIDTH * 4)), 0));
+                    bv[it] = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(br, lv, oo * (OMDS_WIDTH * 4), 0));
+                    rad[it] = radius[oo];
+                    pidx[it] = idx;
+                } else {
+                    av[it] = omds_f4{0.f, 0.f, 0.f, 0.f};
+                    bv[it] = av[it];
+                    rad[it] = 0.f;
+                    pidx[it] = 0;
+                }
+            }
+        } else {
+        int o = (int)(row0u - t0 * (unsigned)O) + wv, dt = 0;   // row r = wv + it * NW is pair (t0 + dt, o)
+        while (o >= O) { o -= O; ++dt; }
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             if (wv + it * G::NW < rows_here) {
@@ -251,10 +278,12 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
             o += G::NW;
             while (o >= O) { o -= O; ++dt; }
         }
+        }
         OMDS_TL_WAIT("vmcnt(0)");
         OMDS_TL(8);
         float* hrow = Hs + wv * LDH + 4 * lane;
         float myrad = 0.f;                                      // lane it of the wave collects the radius of its row it
+        int myidx = 0;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const omds_f4 z = av[it] + bv[it];                  // vector add -> two v_pk_add_f32
@@ -266,8 +295,13 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
             *reinterpret_cast<float4*>(hrow + it * G::NW * LDH) = v;
             const int rbits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rad[it]));   // wave-uniform: keep it in an SGPR for the asm
             asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(myrad) : "s"(rbits), "n"(it));
+            if constexpr (LIST) {
+                const int ib = __builtin_amdgcn_readfirstlane(pidx[it]);
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(myidx) : "s"(ib), "n"(it));
+            }
         }
         if (lane < IT) rowRad[wv + lane * G::NW] = myrad;
+        if constexpr (LIST) { if (lane < IT) rowIdx[wv + lane * G::NW] = myidx; }
     }
     OMDS_TL_WAIT("lgkmcnt(0)");
     OMDS_TL(9);
@@ -367,6 +401,21 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
             v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false)));
             y[reg] = v;
         }
+        if constexpr (LIST) {
+            if (j == 0) {
+                float me = 0.f;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    if (row0 + r4 + reg < total_rows) {
+                        float* dst = Dmin + rowIdx[r4 + reg];
+                        const float e = fabsf(*dst - y[reg]);
+                        if (!(e <= me)) me = (e == e) ? e : __builtin_inff();   // a NaN screening value (fp16 overflow) counts as an infinite error
+                        *dst = y[reg];
+                    }
+                }
+                if (me > 0.f) atomicMax(maxerr_bits, __builtin_bit_cast(unsigned, me));   // non-negative floats order like their bits
+            }
+        } else
         if (j == 0) {
             const long long g = row0 + r4;
             if (g + 3 < total_rows) {

@@ -42,6 +42,12 @@ struct MlpDev {
 #endif
 };
 
+// fp16 screening network (screen_kernel.hip): hidden->hidden and last-layer weights as fp16 A-fragment slices
+struct ScreenDev {
+    const void* Wh = nullptr;     // [nhh*8 + 1][16 kchunk][64 lane][8 halfs]
+    const float* bias = nullptr;  // [nhh + 1][256]
+};
+
 // hipFuncSetAttribute applies to the current device only: true the first time a kernel is launched on each device.
 inline bool omds_first_use_on_device(std::atomic<uint64_t>& mask) {
     int dev = 0;
@@ -71,6 +77,19 @@ struct omds_ctx {
     std::vector<void*> mlp_allocs;
     int act = OMDS_ACT_RELU;
     double f_fwd = 0.0, f_bwd = 0.0;   // algorithmic FLOPs of one network forward / backward row
+    // screening (pass 1 in fp16 + exact re-selection, screen_kernel.hip)
+    ScreenDev screen{};
+    bool screen_ok = false;      // packs present (ReLU network)
+    int screen_mode = -1;        // -1 = auto (on for large pair counts), 0 = off, 1 = forced on
+    float screen_eps = 0.f;      // calibrated bound on |screening value - fp32 value|; 0 = not calibrated yet
+    bool screen_cal = false;
+    int* d_rowlist = nullptr;    // [N*max_obs] candidate pairs
+    int* d_sctotal = nullptr;    // [H] candidates listed per horizon step
+    unsigned* d_scerr = nullptr; // max |screening - exact| over the candidates (float bits)
+    double screen_rows = 0.0;    // statistics since the last omds_prof_reset: candidate rows, (rollout, step)s, fallbacks
+    double screen_steps = 0.0;
+    long long screen_fallbacks = 0;
+    float screen_err_seen = 0.f;
     // scene
     int n_obs = 0;
     float* d_obs = nullptr;      // [max_obs][4]
@@ -165,6 +184,14 @@ void omds_launch_pass2(hipStream_t s, const MlpDev& m, const float* Apre, const 
                        float* gradx, float* drow, float* yraw, int32_t* minidx, float* dscr);
 void omds_launch_blend(hipStream_t s, const float* gradx, const float* drow, int B, int k, int d, int n,
                        float softmax_k, float* dist, float* nngrad);
+
+// ---- launchers implemented in screen_kernel.hip -----------------------------------------------
+void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, const float* Apre, const float* Bpre,
+                        const float* radius, int O, int B, uint32_t ignored, float* Dmin);
+bool omds_screen_supported(const MlpDev& m);
+void omds_launch_select(hipStream_t s, float* Dmin, int B, int O, int k, float eps, int* rowlist, int* total);
+void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius, int O,
+                       int B, uint32_t ignored, float* Dmin, const int* rowlist, const int* total, unsigned* maxerr_bits);
 
 // ---- launchers implemented in rollout_kernels.hip ---------------------------------------------
 struct StepArgs {

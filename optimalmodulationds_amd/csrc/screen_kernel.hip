@@ -1,0 +1,365 @@
+// Low-precision SCREENING of pass 1 with exact re-selection (gfx950).
+//
+// Pass 1 of MPPI.distance_repulsion_nn (MPPI.py:233-253) evaluates the distance network on all N*O (rollout, obstacle)
+// pairs, but only feeds the sort that picks the k closest obstacles; the distance and gradient the step uses come from
+// pass 2 on those k rows (MPPI.py:259-280).  So the N*O evaluations need not be fp32 as long as the SELECTED SET is the
+// fp32 one.  Three kernels replace k_pass1 in the horizon step:
+//
+//   k_screen  : the network on all pairs in fp16 (v_mfma_f32_32x32x16_f16, fp32 accumulate) -> approximate min link
+//               distance Da[t][o].
+//   k_select  : per rollout, tau = (k-th smallest Da) + 2 eps; every obstacle with Da <= tau is a CANDIDATE.  If
+//               |Da - D| <= eps for the fp32 value D of every pair, the candidates contain the k smallest D and
+//               everything tied with the k-th (proof in DESIGN.md 4.1b), so the exact top-k over the candidates is the
+//               exact top-k over all obstacles, ties included.  Non-candidates become +inf in the row; candidates go to a
+//               compact row list.
+//   k_exact   : the fp32 pass-1 tile code (pass1_tile, bit-identical arithmetic per row: an MFMA output element is one
+//               k-ordered fmaf chain of its own row) on the listed rows only; writes the exact D over Da and records
+//               max |Da - D| over all candidates (the run-time guard of eps: the host re-runs the propagate without
+//               screening if the observed error ever exceeds the calibrated margin).
+//
+// k_screen design (MI355X-first).  fp16 MFMA is 16x the fp32 rate, so everything the fp32 kernel could hide -- LDS round
+// trips of the activations, weight fragments from L2 -- would dominate.  Hence:
+//   * TRANSPOSED product H'^T = W . H^T: the weights are the A operand, the activations the B operand (column = pair).
+//     A wave owns 32 pairs and ALL 256 features of them, so a layer's output (C layout: lane = pair, registers =
+//     features) IS the next layer's B operand after ReLU + cvt_pk -- the K order inside a dot product is free, the host
+//     packs the weights in the permuted order the C layout produces.  Activations never leave registers: no LDS traffic,
+//     no bank conflicts, no barrier for them.
+//   * weights stream L2 -> LDS by LDS-DMA (buffer/global_load ... lds, 1 KiB = one A fragment per wave instruction) as
+//     16 KB slices (32 output features x 256 k) through a 4-slot ring shared by the 8 waves of the workgroup (256 pairs):
+//     128 KB per layer per 256 pairs instead of per 32, one s_barrier per slice, counted vmcnt, loads two slices ahead.
+//   * layer 1 is the separable sum Apre[t] + Bpre[o] in fp32 (as in k_pass1), rounded to fp16 once.
+#include <algorithm>
+
+#include "mlp_device.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+constexpr int SC_WAVES = 8;
+constexpr int SC_NT = SC_WAVES * 64;
+constexpr int SC_ROWS = SC_WAVES * 32;        // pairs per workgroup
+constexpr int SC_SLICE = 16384;               // bytes: 16 k-chunks x 1 KiB fragment
+constexpr int SC_RING = 4;
+
+struct ScreenArgs {
+    const _Float16* Wh;   // [nhh*8 + 1 slices][16 kchunk][64 lane][8 halfs], fragment order (see omds_pack_screen_weights)
+    const float* bias;    // [nhh + 1][256]: hidden->hidden biases, then the last layer's (padded with zeros)
+    const float* Apre;
+    const float* Bpre;
+    const float* radius;
+    float* Dmin;
+    long long total_rows;
+    int O;
+    uint32_t ignored;
+    OmdsDivisor odiv;
+    int nhh, C;
+    float out_div;
+};
+
+// LDS-DMA: 16 bytes per lane from gsrc (per-lane address) to LDS [lds_dst + 16 * lane] (lds_dst wave-uniform).  Invisible
+// to hipcc's s_waitcnt bookkeeping by design: completion is waited for with counted vmcnt below.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+// counted wait for this wave's LDS-DMA pieces + workgroup barrier; the "memory" clobber keeps hipcc from moving LDS reads
+// of the slice above the barrier
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ h2 relu_pk(float a, float b) {
+    h2 p = {(_Float16)a, (_Float16)b};                 // v_cvt_pk_f16_f32 (round to nearest even)
+    const h2 z = {(_Float16)0, (_Float16)0};
+    return __builtin_elementwise_max(p, z);            // v_pk_max_f16
+}
+
+// A fragments of one group (4 k-chunks) of a slice
+struct AGroup { h8 f[4]; };
+__device__ __forceinline__ AGroup read_group(const unsigned char* slot_lane, int g) {
+    AGroup r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.f[i] = *reinterpret_cast<const h8*>(slot_lane + (4 * g + i) * 1024);
+    return r;
+}
+
+template <int NHH>
+__global__ __launch_bounds__(SC_NT) void k_screen(ScreenArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char* ring = smem_raw;                                   // [SC_RING][SC_SLICE]
+    float* biasL = reinterpret_cast<float*>(smem_raw + SC_RING * SC_SLICE);   // [NHH+1][256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = lane & 31, half = lane >> 5;
+    constexpr int S = NHH * 8 + 1;                                    // slice steps: 8 per hidden->hidden layer + the last layer
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
+
+    // weight slice s -> ring slot s & 3; this wave moves fragments 2w and 2w+1
+    auto issue = [&](int s) {
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.Wh) + (size_t)s * SC_SLICE + (2 * wave) * 1024 + lane * 16;
+        const unsigned dst = ring_lds + (unsigned)((s & (SC_RING - 1)) * SC_SLICE + (2 * wave) * 1024);
+        dma16(src, dst);
+        dma16(src + 1024, dst + 1024);
+    };
+    for (int i = tid; i < (NHH + 1) * OMDS_WIDTH; i += SC_NT) biasL[i] = a.bias[i];
+    __syncthreads();   // bias table visible; nothing of the ring is in flight yet (hipcc's fence would drain it)
+    issue(0);
+    issue(1);
+    issue(2);
+
+    // ---- layer 1: relu(Apre[t] + Bpre[o]) in fp32, rounded to fp16, straight into the B-operand registers.  Chunk cc
+    //      (features 16cc .. 16cc+15): slots 0-3 of lane-half h = features 16cc + 4h .. +3, slots 4-7 = 16cc + 8 + 4h .. +3
+    const long long R0 = (long long)blockIdx.x * SC_ROWS + wave * 32;
+    long long row = R0 + b;
+    const bool valid = row < a.total_rows;
+    if (!valid) row = a.total_rows - 1;
+    const unsigned t = a.odiv.div((unsigned)row);
+    const unsigned o = (unsigned)row - t * (unsigned)a.O;
+    h8 act[16];
+    {
+        const float4* ap = reinterpret_cast<const float4*>(a.Apre + (size_t)t * OMDS_WIDTH) + half;
+        const float4* bp = reinterpret_cast<const float4*>(a.Bpre + (size_t)o * OMDS_WIDTH) + half;
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+            const float4 a0 = ap[4 * cc], a1 = ap[4 * cc + 2], b0 = bp[4 * cc], b1 = bp[4 * cc + 2];
+            const h2 p0 = relu_pk(a0.x + b0.x, a0.y + b0.y), p1 = relu_pk(a0.z + b0.z, a0.w + b0.w);
+            const h2 p2 = relu_pk(a1.x + b1.x, a1.y + b1.y), p3 = relu_pk(a1.z + b1.z, a1.w + b1.w);
+            act[cc] = h8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+        }
+    }
+    const float rad = a.radius[o];
+
+    // ---- the slice pipeline.  Step s multiplies slice s (ring slot s & 3) into the accumulators in 4 groups of 4 k-chunks;
+    //      the A fragments of the next group are read while the current group's MFMAs issue.  In the middle of step s the
+    //      wave waits for ITS pieces of slice s+1 (issued two steps earlier) and meets the others at the barrier: after it
+    //      slice s+1 is complete, and every wave has finished reading slice s-1, whose slot then takes slice s+3.
+    const unsigned char* slot_lane = ring + lane * 16;
+    wait_vm_barrier<4>();   // slice 0 landed (slices 1 and 2 may still be in flight)
+    AGroup cur = read_group(slot_lane, 0);
+    h8 nxt[16];
+    f32x16 acc;
+    float dmin = __builtin_inff();
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int l = s >> 3, fb = s & 7;
+        const bool last = s == S - 1;
+        {   // accumulators start at the bias.  C layout: register r = 4j + i <-> output row 32 fb + 8 j + 4 half + i
+            const float* bl = biasL + l * OMDS_WIDTH + (last ? 0 : 32 * fb) + 4 * half;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 bv = *reinterpret_cast<const float4*>(bl + 8 * j);
+                acc[4 * j] = bv.x; acc[4 * j + 1] = bv.y; acc[4 * j + 2] = bv.z; acc[4 * j + 3] = bv.w;
+            }
+        }
+        const unsigned char* sl = slot_lane + (s & (SC_RING - 1)) * SC_SLICE;
+        const unsigned char* sl_next = slot_lane + ((s + 1) & (SC_RING - 1)) * SC_SLICE;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            AGroup pre = cur;
+            if (g < 3) pre = read_group(sl, g + 1);
+            else if (s + 1 < S) pre = read_group(sl_next, 0);
+            if (g == 1 && s + 1 < S) {
+                if (s + 2 < S) wait_vm_barrier<2>(); else wait_vm_barrier<0>();
+                if (s + 3 < S) issue(s + 3);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[i], act[4 * g + i], acc, 0, 0, 0);
+            cur = pre;
+        }
+        if (!last) {
+            // registers 0-7 are the slots of chunk 2 fb of the next layer, 8-15 of chunk 2 fb + 1
+            const h2 p0 = relu_pk(acc[0], acc[1]), p1 = relu_pk(acc[2], acc[3]), p2 = relu_pk(acc[4], acc[5]), p3 = relu_pk(acc[6], acc[7]);
+            const h2 p4 = relu_pk(acc[8], acc[9]), p5 = relu_pk(acc[10], acc[11]), p6 = relu_pk(acc[12], acc[13]), p7 = relu_pk(acc[14], acc[15]);
+            nxt[2 * fb] = h8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+            nxt[2 * fb + 1] = h8{p4[0], p4[1], p5[0], p5[1], p6[0], p6[1], p7[0], p7[1]};
+            if (fb == 7) {
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) act[cc] = nxt[cc];
+            }
+        } else {
+            // last layer: the links sit on the A rows (rows >= C are zero); min over the valid, un-ignored links
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {   // link = 4 half + (r & 3) + 8 (r >> 2); links >= 16 do not exist (OMDS_CPAD)
+                const int link = 4 * half + (r & 3) + 8 * (r >> 2);
+                float v = acc[r] / a.out_div - rad;
+                v = (link >= a.C) ? __builtin_inff() : (((a.ignored >> link) & 1u) ? 1e6f : v);
+                dmin = fminf(dmin, v);
+            }
+        }
+    }
+    dmin = fminf(dmin, __shfl_xor(dmin, 32));
+    if (half == 0 && valid) a.Dmin[R0 + b] = dmin;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_select: one wave per rollout.  Row of up to 512 approximate distances in registers (longer rows: from memory).
+// ------------------------------------------------------------------------------------------------
+struct SelectArgs {
+    float* Dmin;          // [N][O] in: approximate; out: +inf for non-candidates (candidates keep the approximate value)
+    int* rowlist;         // [N*O] compact list of candidate rows t*O + o
+    int* total;           // number of listed rows (zeroed before the launch)
+    int N, O, k;
+    float two_eps;
+};
+
+__global__ __launch_bounds__(256) void k_select(SelectArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= a.N) return;
+    float* row = a.Dmin + (size_t)t * a.O;
+    const int O = a.O;
+    constexpr int NV = 8;
+    float v[NV];
+    const bool in_regs = O <= 64 * NV;
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { const int o = lane + 64 * i; v[i] = (o < O) ? row[o] : __builtin_inff(); }
+    }
+    // k-th smallest value (multiplicities counted): k rounds of "smallest (value, index) after the previous one".
+    // NaN entries (an fp16 overflow inside the network) never win a round; they are made candidates below.
+    float pv = -__builtin_inff();
+    int pi = -1;
+    for (int j = 0; j < a.k; ++j) {
+        float bv = __builtin_inff();
+        int bi = 0x7fffffff;
+        if (in_regs) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int o = lane + 64 * i;
+                const float x = v[i];
+                const bool after = (x > pv) || (x == pv && o > pi);
+                if (o < O && after && ((x < bv) || (x == bv && o < bi))) { bv = x; bi = o; }
+            }
+        } else {
+            for (int o = lane; o < O; o += 64) {
+                const float x = row[o];
+                const bool after = (x > pv) || (x == pv && o > pi);
+                if (after && ((x < bv) || (x == bv && o < bi))) { bv = x; bi = o; }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            if ((ov < bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        pv = bv;
+        pi = bi;
+    }
+    const float tau = pv + a.two_eps;   // pv = +inf (fewer than k finite values): everything is a candidate
+    // count, reserve a range of the list, write
+    int cnt = 0;
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { const int o = lane + 64 * i; cnt += (o < O && !(v[i] > tau)) ? 1 : 0; }
+    } else {
+        for (int o = lane; o < O; o += 64) cnt += !(row[o] > tau) ? 1 : 0;
+    }
+    int incl = cnt;   // inclusive scan over the lanes
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(incl, off);
+        if (lane >= off) incl += u;
+    }
+    const int wave_total = __shfl(incl, 63);
+    int base = 0;
+    if (lane == 0) base = atomicAdd(a.total, wave_total);
+    base = __shfl(base, 0);
+    int pos = base + incl - cnt;
+    const int rbase = t * O;
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int o = lane + 64 * i;
+            if (o < O) {
+                if (!(v[i] > tau)) a.rowlist[pos++] = rbase + o;
+                else row[o] = __builtin_inff();
+            }
+        }
+    } else {
+        for (int o = lane; o < O; o += 64) {
+            if (!(row[o] > tau)) a.rowlist[pos++] = rbase + o;
+            else row[o] = __builtin_inff();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_exact: fp32 pass-1 tiles over the listed rows (32-row tiles, workgroups stride over the tiles)
+// ------------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(512) void k_exact(MlpDev m, const float* __restrict__ Apre, const float* __restrict__ Bpre,
+                                               const float* __restrict__ radius, int O, uint32_t ignored,
+                                               float* __restrict__ Dmin, OmdsDivisor odiv, const int* __restrict__ rowlist,
+                                               const int* __restrict__ total, unsigned* __restrict__ maxerr_bits) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n = *total;
+    for (int tile = blockIdx.x; tile * 32 < n; tile += gridDim.x) {
+        pass1_tile<32, 1, 1, ACT, true>(m, smem, Apre, Bpre, radius, O, n, ignored, Dmin, (long long)tile * 32, odiv, rowlist,
+                                        maxerr_bits);
+        __syncthreads();   // the tile buffer is reused by the next tile
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+size_t omds_screen_lds_bytes(int nhh) { return (size_t)SC_RING * SC_SLICE + (size_t)(nhh + 1) * OMDS_WIDTH * 4; }
+
+void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, const float* Apre, const float* Bpre,
+                        const float* radius, int O, int B, uint32_t ignored, float* Dmin) {
+    const long long total = (long long)B * O;
+    if (total <= 0) return;
+    ScreenArgs a;
+    a.Wh = reinterpret_cast<const _Float16*>(sd.Wh);
+    a.bias = sd.bias;
+    a.Apre = Apre; a.Bpre = Bpre; a.radius = radius; a.Dmin = Dmin;
+    a.total_rows = total; a.O = O; a.ignored = ignored; a.odiv = OmdsDivisor::make((unsigned)O);
+    a.nhh = m.nhh; a.C = m.C; a.out_div = m.out_div;
+    const size_t lds = omds_screen_lds_bytes(m.nhh);
+    const dim3 grid((unsigned)((total + SC_ROWS - 1) / SC_ROWS));
+#define OMDS_SCREEN_LAUNCH(NHH)                                                                                          \
+    case NHH: {                                                                                                         \
+        static std::atomic<uint64_t> configured{0};                                                                     \
+        if (omds_first_use_on_device(configured))                                                                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_screen<NHH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_screen<NHH>), grid, dim3(SC_NT), lds, s, a);                                             \
+    } break;
+    switch (m.nhh) {
+        OMDS_SCREEN_LAUNCH(1)
+        OMDS_SCREEN_LAUNCH(2)
+        OMDS_SCREEN_LAUNCH(3)
+        OMDS_SCREEN_LAUNCH(4)
+        default: break;   // omds_screen_supported() keeps other depths on the fp32 path
+    }
+#undef OMDS_SCREEN_LAUNCH
+}
+
+bool omds_screen_supported(const MlpDev& m) { return m.act == OMDS_ACT_RELU && m.nhh >= 1 && m.nhh <= 4; }
+
+void omds_launch_select(hipStream_t s, float* Dmin, int B, int O, int k, float eps, int* rowlist, int* total) {
+    if (B <= 0) return;
+    SelectArgs a;
+    a.Dmin = Dmin; a.rowlist = rowlist; a.total = total; a.N = B; a.O = O; a.k = k; a.two_eps = 2.f * eps;
+    hipLaunchKernelGGL(k_select, dim3((B + 3) / 4), dim3(256), 0, s, a);
+}
+
+void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius, int O,
+                       int B, uint32_t ignored, float* Dmin, const int* rowlist, const int* total, unsigned* maxerr_bits) {
+    if (B <= 0) return;
+    const size_t lds = (size_t)32 * LDH * 4 + 32 * 4 + 32 * 4;
+    static std::atomic<uint64_t> configured{0};
+    if (omds_first_use_on_device(configured)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_exact<OMDS_ACT_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_exact<OMDS_ACT_TANH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    // enough workgroups for the typical list (a few candidates per rollout) without striding; longer lists stride
+    const long long tiles_max = ((long long)B * O + 31) / 32;
+    const unsigned grid = (unsigned)std::min<long long>(tiles_max, std::max<long long>(512, ((long long)B * 16 + 31) / 32));
+    const OmdsDivisor od = OmdsDivisor::make((unsigned)O);
+    if (m.act == OMDS_ACT_RELU)
+        hipLaunchKernelGGL((k_exact<OMDS_ACT_RELU>), dim3(grid), dim3(512), lds, s, m, Apre, Bpre, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits);
+    else
+        hipLaunchKernelGGL((k_exact<OMDS_ACT_TANH>), dim3(grid), dim3(512), lds, s, m, Apre, Bpre, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits);
+}

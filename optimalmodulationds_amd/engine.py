@@ -237,6 +237,25 @@ class Engine:
         m = min(cnt.value, cap)
         return q[:m], th[:m], cnt.value
 
+    # ---- screening of pass 1 (fp16 + exact re-selection) ----------------------------------------
+    def set_screening(self, mode=-1, eps=0.0):
+        """mode: -1 auto, 0 off (fp32 pass 1), 1 on; eps > 0 fixes the error bound, 0 = calibrate."""
+        self._ck(self.lib.omds_set_screening(self.h, int(mode), float(eps)))
+
+    def screen_mindist(self, q):
+        q = L.f32(q).reshape(-1, self.n)
+        out = np.zeros((q.shape[0], self.n_obs), np.float32)
+        self._ck(self.lib.omds_screen_mindist(self.h, L.fptr(q), q.shape[0], L.fptr(out)))
+        return out
+
+    def screen_stats(self):
+        act, eps, err = C.c_int32(), C.c_float(), C.c_float()
+        cand, fb = C.c_double(), C.c_int64()
+        self._ck(self.lib.omds_screen_stats(self.h, C.byref(act), C.cast(C.byref(eps), L.F32P), C.cast(C.byref(err), L.F32P),
+                                            C.byref(cand), C.byref(fb)))
+        return dict(active=bool(act.value), eps=eps.value, max_err_seen=err.value, candidates_per_rollout_step=cand.value,
+                    fallbacks=fb.value)
+
     # ---- measurement --------------------------------------------------------------------------
     def prof_enable(self, on=True):
         """on: False/0 off, True/1 every launch of the dominant kernel, n > 1 every n-th launch."""

@@ -1,0 +1,112 @@
+"""GPU tests of the fp16 screening of pass 1 (csrc/screen_kernel.hip): the screening values stay within the calibrated
+bound of the fp32 pass-1 matrix, and a screened propagate is BIT-IDENTICAL to the fp32-pass-1 propagate -- the selected
+obstacle sets are the fp32 ones, so every downstream number is the same -- on more than 10^6 (rollout, step) states."""
+import numpy as np
+import pytest
+
+from helpers import SCENARIOS, load, weights_path
+from oracle import omds_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("all_traj", "closest_dist_all", "kernel_val_all", "dot_products", "kernel_activations", "qdot", "normal")
+
+
+def _engine(N, H, kind="franka", k=5, obs=None):
+    from optimalmodulationds_amd import scenes
+    from optimalmodulationds_amd.engine import Engine
+    m = orc.Mlp.from_npz(weights_path(kind))
+    if kind == "franka":
+        obs = scenes.shelf_scene() if obs is None else obs
+        q0, qf = scenes.FRANKA_Q0, scenes.FRANKA_QF
+        dst_thr, dt, ign = 0.01, 0.5, 0b111
+    else:
+        obs = scenes.planar7_scene() if obs is None else obs
+        q0 = np.zeros(7, np.float32); q0[0] = np.pi / 2
+        qf = np.zeros(7, np.float32); qf[0] = -np.pi / 2
+        dst_thr, dt, ign = 0.25, 0.3, 0
+    e = Engine(7, N, H, k, max_obs=max(64, obs.shape[0]))
+    e.set_mlp(m.W, m.b)
+    e.set_obstacles(obs)
+    e.params.dt, e.params.dst_thr, e.params.ignored_links = dt, dst_thr, ign
+    e.push_params()
+    e.set_ds(qf)
+    return e, m, obs, q0, qf
+
+
+def test_screening_values_within_calibrated_bound():
+    e, m, obs, q0, qf = _engine(512, 4)
+    rng = np.random.RandomState(1)
+    q = (q0 + (qf - q0) * rng.rand(512, 1) + 0.3 * rng.standard_normal((512, 7))).astype(np.float32)
+    _, _, ref, _ = e.dist_grad(q, want_mindist=True)          # fp32 pass 1
+    apx = e.screen_mindist(q)
+    err = np.abs(apx - ref)
+    assert np.isfinite(apx).all()
+    assert err.max() < 5e-3, err.max()                        # fp16 network, fp32 accumulation: ~1e-3 m on the shelf scene
+    # calibration happens at the first screened propagate
+    e.set_screening(1)
+    e.sample_policy(None, None, None, 0, 0, 0, 0, seed=1)
+    e.propagate(q0)
+    st = e.screen_stats()
+    assert st["active"] and st["fallbacks"] == 0
+    assert err.max() <= st["eps"], (err.max(), st)            # eps = 4 x calibration maximum covers an independent batch
+    assert st["max_err_seen"] <= 0.5 * st["eps"]
+    assert 5.0 <= st["candidates_per_rollout_step"] <= 64.0, st
+    e.close()
+
+
+def _run(e, q, mode, K, mu_c, sg_c, al_c, seed):
+    e.set_screening(mode)
+    e.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 3.0, K, seed=seed)
+    e.propagate(q)
+    return e.get_rollouts()
+
+
+@pytest.mark.parametrize("N,H,iters", [(1024, 32, 32), (4096, 32, 8), (256, 6, 4)])
+def test_screened_propagate_is_bit_identical(N, H, iters):
+    """>= 10^6 (rollout, step) states per full-size shape: the screened propagate reproduces the fp32-pass-1 propagate bit
+    for bit (free-running rollouts from moving start states, K = 10 sampled kernels)."""
+    e, m, obs, q0, qf = _engine(N, H)
+    K = 10
+    rng = np.random.RandomState(5)
+    s = (np.arange(K) + 0.5) / K
+    mu_c = (q0 + s[:, None] * (qf - q0) + 0.15 * rng.standard_normal((K, 7))).astype(np.float32)
+    sg_c = np.ones(K, np.float32)
+    al_c = rng.standard_normal((K, 7)).astype(np.float32)
+    q = q0.copy()
+    states = 0
+    for it in range(iters):
+        a = _run(e, q, 0, K, mu_c, sg_c, al_c, seed=100 + it)
+        b = _run(e, q, 1, K, mu_c, sg_c, al_c, seed=100 + it)
+        for key in KEYS:
+            assert np.array_equal(a[key], b[key]), (it, key, float(np.abs(a[key] - b[key]).max()))
+        states += N * H
+        q = (q + 0.04 * (qf - q0) + 0.02 * rng.standard_normal(7)).astype(np.float32)
+    st = e.screen_stats()
+    assert st["fallbacks"] == 0 and st["max_err_seen"] <= 0.5 * st["eps"], st
+    assert iters < 8 or states >= 10 ** 6
+    e.close()
+
+
+def test_screened_teacher_forced_fixture():
+    """The reference-captured Franka shelf fixture through the screened path (per-rollout start states)."""
+    fx = load("franka_shelf_K6")
+    from optimalmodulationds_amd.engine import Engine
+    m = orc.Mlp.from_npz(weights_path("franka"))
+    N, H, K = int(fx["N"]), int(fx["H"]), int(fx["K"])
+    outs = []
+    for mode in (0, 1):
+        e = Engine(7, N, H, int(fx["k"]), max_obs=512)
+        e.set_mlp(m.W, m.b)
+        e.set_obstacles(fx["obs"])
+        e.params.dt, e.params.dst_thr = float(fx["dt"]), float(fx["dst_thr"])
+        e.params.ignored_links = sum(1 << int(l) for l in fx["ignored_links"])
+        e.push_params()
+        e.set_ds(fx["qf"])
+        e.set_screening(mode)
+        e.set_policy_samples(fx["it0_mu_tmp"][:, :K], fx["it0_sigma_tmp"][:, :K], fx["it0_alpha_tmp"][:, :K])
+        e.propagate(fx["it0_q_cur"])
+        outs.append(e.get_rollouts())
+        e.close()
+    for key in KEYS:
+        assert np.array_equal(outs[0][key], outs[1][key]), key
