@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libomds_hip.so")
+# OMDS_LIB: another build of the same library (diagnostic / experiment builds under csrc/), never a different backend
+LIB_PATH = os.environ.get("OMDS_LIB") or os.path.join(_HERE, "csrc", "libomds_hip.so")
 
 OMDS_MAX_DOF = 7
 F32P = C.POINTER(C.c_float)

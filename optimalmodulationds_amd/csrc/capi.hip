@@ -117,7 +117,7 @@ static void free_all(omds_ctx* ctx) {
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
                     ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
                     ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
-                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr};
+                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_BpreH, ctx->d_ApreH};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : ctx->mlp_allocs)
@@ -173,6 +173,8 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
     CKC(hipMalloc(&ctx->d_A, OMDS_MAX_DOF * OMDS_MAX_DOF * 4));
     CKC(hipMalloc(&ctx->d_Bpre, std::max(Om, rows2) * OMDS_WIDTH * 4));
     CKC(hipMalloc(&ctx->d_radius, std::max(Om, rows2) * 4));
+    CKC(hipMalloc(&ctx->d_BpreH, Om * OMDS_WIDTH * 2));
+    CKC(hipMalloc(&ctx->d_ApreH, N * OMDS_WIDTH * 2));
     CKC(hipMalloc(&ctx->d_trajT, H * n * N * 4));
     CKC(hipMalloc(&ctx->d_distT, H * N * 4));
     CKC(hipMalloc(&ctx->d_dotT, H * N * 4));
@@ -432,7 +434,7 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
     ctx->f_bwd = ctx->f_fwd - 2.0 * true_dims[n_linear - 1] * true_dims[n_linear];   // no weight-gradient, no last-layer GEMM
     ctx->have_mlp = true;
     if (ctx->n_obs > 0) {  // re-derive the obstacle half of layer 1 for the new weights
-        omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, ctx->n_obs, ctx->d_Bpre, ctx->d_radius);
+        omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, ctx->n_obs, ctx->d_Bpre, ctx->d_radius, ctx->d_BpreH);
         CK(hipGetLastError());
         CK(hipStreamSynchronize(ctx->stream));
     }
@@ -448,7 +450,7 @@ int omds_set_obstacles(omds_ctx* ctx, const float* xyzr, int n_obs) {
     CK(hipMemcpyAsync(ctx->d_obs, xyzr, (size_t)n_obs * 16, hipMemcpyHostToDevice, ctx->stream));
     ctx->n_obs = n_obs;
     if (ctx->have_mlp) {
-        omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, n_obs, ctx->d_Bpre, ctx->d_radius);
+        omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, n_obs, ctx->d_Bpre, ctx->d_radius, ctx->d_BpreH);
         CK(hipGetLastError());
     }
     CK(hipStreamSynchronize(ctx->stream));
@@ -665,12 +667,12 @@ static int calibrate_screen(omds_ctx* ctx) {
         }
     }
     CK(hipMemcpyAsync(ctx->d_qstage, q.data(), q.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Apre);
+    omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Apre, ctx->d_ApreH);
     std::vector<float> ref((size_t)B * O), apx((size_t)B * O);
     omds_launch_pass1(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
     CK(hipMemcpyAsync(ref.data(), ctx->d_Dmin, ref.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
-    omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
+    omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_ApreH, ctx->d_BpreH, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
     CK(hipGetLastError());
     CK(hipMemcpyAsync(apx.data(), ctx->d_Dmin, apx.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
@@ -681,6 +683,7 @@ static int calibrate_screen(omds_ctx* ctx) {
         if (!(e < 3.0e38f)) { finite = false; break; }
         worst = std::max(worst, e);
     }
+    if (!finite && getenv("OMDS_SCREEN_NOGUARD")) { ctx->screen_eps = 1e-3f; return OMDS_OK; }   // timing experiments only
     if (!finite) { ctx->screen_ok = false; return OMDS_OK; }   // fp16 range exceeded: this network stays on the fp32 path
     ctx->screen_eps = std::max(4.f * worst, 1e-12f);
     return OMDS_OK;
@@ -696,7 +699,7 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
         // planar7_1024x32 ran 9.0 M rollout-steps/s on one stream, 7.1 / 3.3 / 2.4 M on 2 / 4 / 8 -- and a two-half
         // ping-pong for large batches with event-chained pass-1 launches so that one half's tail runs under the
         // other half's pass 1: parity-green, but the half-size launches drain twice per step, 1.00 M vs 1.03 M.)
-        omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, ctx->d_Apre);
+        omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, ctx->d_Apre, screen ? ctx->d_ApreH : nullptr);
         if (screen) {
             CK(hipMemsetAsync(ctx->d_sctotal, 0, (size_t)(H + 1) * 4, ctx->stream));
             CK(hipMemsetAsync(ctx->d_scerr, 0, 4, ctx->stream));
@@ -706,7 +709,7 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
                 RoctxRange r1("TAG: evaluate NN_2 (forward pass)");
                 if ((rc = prof_begin(ctx))) return rc;
                 if (screen) {
-                    omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
+                    omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_ApreH, ctx->d_BpreH, ctx->d_radius, ctx->n_obs, N,
                                        ctx->prm.ignored_links, ctx->d_Dmin);
                     if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs, -1.0, "k_screen"))) return rc;
                     omds_launch_select(ctx->stream, ctx->d_Dmin, N, ctx->n_obs, a.k, ctx->screen_eps, ctx->d_rowlist, ctx->d_sctotal + (i - 1));
@@ -721,7 +724,7 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
             RoctxRange r2("TAG: evaluate NN_3-5 + Modulation-propagation");
             a.step = i;
             omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, ctx->d_Apre,
-                             ctx->d_dscr, ctx->n_obs, a, 0, N);
+                             ctx->d_dscr, ctx->n_obs, a, 0, N, screen ? ctx->d_ApreH : nullptr);
         }
     } else {
         for (int i = 1; i <= H; ++i) {   // MPPI.py:101: H network evaluations, the last velocity is not integrated
@@ -779,7 +782,9 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
         const int32_t* tot = reinterpret_cast<const int32_t*>(ctx->h_red + 1);
         for (int i = 0; i < H; ++i) ctx->screen_rows += tot[i];
         ctx->screen_steps += (double)N * H;
-        if (err <= 0.5f * ctx->screen_eps) break;
+        static int noguard = -1;   // OMDS_SCREEN_NOGUARD=1: timing experiments with deliberately broken screening kernels only
+        if (noguard < 0) { const char* e = getenv("OMDS_SCREEN_NOGUARD"); noguard = e ? atoi(e) : 0; }
+        if (err <= 0.5f * ctx->screen_eps || noguard) break;
         // the calibrated bound lost its 2x margin on live data: this propagate is redone in fp32 and the bound is widened
         // (or screening is switched off when the error is not even finite -- an fp16 overflow inside the network)
         ctx->screen_fallbacks++;
@@ -1066,8 +1071,8 @@ int omds_screen_mindist(omds_ctx* ctx, const float* q, int B, float* mindist) {
     const int n = ctx->cfg.n_dof, O = ctx->n_obs;
     CK(hipMemcpyAsync(ctx->d_stage, q, (size_t)B * n * 4, hipMemcpyHostToDevice, ctx->stream));
     omds_launch_transpose(ctx->stream, ctx->d_stage, ctx->d_qstage, B, n);
-    omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Apre);
-    omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
+    omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Apre, ctx->d_ApreH);
+    omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_ApreH, ctx->d_BpreH, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
     CK(hipGetLastError());
     CK(hipMemcpyAsync(mindist, ctx->d_Dmin, (size_t)B * O * 4, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));

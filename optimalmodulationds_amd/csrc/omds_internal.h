@@ -48,6 +48,11 @@ struct ScreenDev {
     const float* bias = nullptr;  // [nhh + 1][256]
 };
 
+// element index of feature c of row t in the fp16 layer-1 tables: chunk c/16, lane-half (c>>2)&1, slot (c&3) + 4((c>>3)&1)
+__host__ __device__ inline size_t omds_screen_hidx(int c, int t, int stride) {
+    return ((size_t)(((c >> 4) * 2 + ((c >> 2) & 1))) * stride + t) * 8 + ((c & 3) + 4 * ((c >> 3) & 1));
+}
+
 // hipFuncSetAttribute applies to the current device only: true the first time a kernel is launched on each device.
 inline bool omds_first_use_on_device(std::atomic<uint64_t>& mask) {
     int dev = 0;
@@ -94,6 +99,8 @@ struct omds_ctx {
     int n_obs = 0;
     float* d_obs = nullptr;      // [max_obs][4]
     float* d_Bpre = nullptr;     // [max_obs][256] obstacle part of layer 1
+    uint16_t* d_BpreH = nullptr; // the same as fp16 in the screening kernel's operand order (stride n_obs)
+    uint16_t* d_ApreH = nullptr; // rollout part likewise (stride = batch)
     float* d_radius = nullptr;   // [max_obs]
     // DS / cost
     bool have_ds = false, have_cost = false;
@@ -174,8 +181,10 @@ int omds_update_impl(omds_ctx* ctx, bool use_comm, float rate, float ker_thr, fl
                      int32_t* mask_out, float* qdot_weighted, float* qdot_best, float* n_total_out);
 
 // ---- launchers implemented in mlp_kernels.hip ------------------------------------------------
-void omds_launch_rollout_layer1(hipStream_t s, const MlpDev& m, const float* qT, int ldq, int B, float* Apre);
-void omds_launch_obstacle_layer1(hipStream_t s, const MlpDev& m, const float* xyzr, int O, float* Bpre, float* radius);
+// ApreH / BpreH (optional): the same layer-1 halves as fp16 in the screening kernel's operand order,
+// [16 chunk][2 lane-half][rows][8 slots] (omds_screen_hidx), row stride = B / O
+void omds_launch_rollout_layer1(hipStream_t s, const MlpDev& m, const float* qT, int ldq, int B, float* Apre, uint16_t* ApreH = nullptr);
+void omds_launch_obstacle_layer1(hipStream_t s, const MlpDev& m, const float* xyzr, int O, float* Bpre, float* radius, uint16_t* BpreH = nullptr);
 void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
                        int O, int B, uint32_t ignored_links, float* Dmin);
 void omds_launch_topk(hipStream_t s, const float* Dmin, int B, int O, int k, int32_t* idx);
@@ -186,7 +195,7 @@ void omds_launch_blend(hipStream_t s, const float* gradx, const float* drow, int
                        float softmax_k, float* dist, float* nngrad);
 
 // ---- launchers implemented in screen_kernel.hip -----------------------------------------------
-void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, const float* Apre, const float* Bpre,
+void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, const uint16_t* ApreH, const uint16_t* BpreH,
                         const float* radius, int O, int B, uint32_t ignored, float* Dmin);
 bool omds_screen_supported(const MlpDev& m);
 void omds_launch_select(hipStream_t s, float* Dmin, int B, int O, int k, float eps, int* rowlist, int* total);
@@ -210,7 +219,8 @@ bool omds_tail_supported(int n_dof, int k);
 int omds_tail_scratch_rows(int N, int k);
 int omds_tail_rows(int N, int k);            // pass-2 tile height (16 | 32) for a batch of N rollouts with k closest obstacles   // rows of the tanh-derivative scratch the tail may touch (either tile height)
 void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
-                      const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st, int t_begin, int t_end);
+                      const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st, int t_begin, int t_end,
+                      uint16_t* ApreH = nullptr);
 struct CostArgs {
     int N, H, n;
     uint32_t terms;   // OMDS_COST_* bits

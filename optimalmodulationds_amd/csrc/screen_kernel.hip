@@ -27,7 +27,9 @@
 //   * weights stream L2 -> LDS by LDS-DMA (buffer/global_load ... lds, 1 KiB = one A fragment per wave instruction) as
 //     16 KB slices (32 output features x 256 k) through a 4-slot ring shared by the 8 waves of the workgroup (256 pairs):
 //     128 KB per layer per 256 pairs instead of per 32, one s_barrier per slice, counted vmcnt, loads two slices ahead.
-//   * layer 1 is the separable sum Apre[t] + Bpre[o] in fp32 (as in k_pass1), rounded to fp16 once.
+//   * layer 1 is the separable sum Apre[t] + Bpre[o] (as in k_pass1) of fp16 copies of the two halves, stored in the
+//     B-operand order so that a lane fetches its 8 slots of a chunk with one 16-byte load and a wave's loads are contiguous
+//     (reading the fp32 rows cost 36 % of the kernel: 64 scattered 16-byte loads per lane).
 #include <algorithm>
 
 #include "mlp_device.h"
@@ -35,25 +37,36 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
-constexpr int SC_WAVES = 8;
+#ifndef OMDS_SC_WAVES
+#define OMDS_SC_WAVES 8
+#endif
+#ifndef OMDS_SC_RING
+#define OMDS_SC_RING 4
+#define OMDS_SC_DIST 3
+#endif
+constexpr int SC_WAVES = OMDS_SC_WAVES;
 constexpr int SC_NT = SC_WAVES * 64;
 constexpr int SC_ROWS = SC_WAVES * 32;        // pairs per workgroup
 constexpr int SC_SLICE = 16384;               // bytes: 16 k-chunks x 1 KiB fragment
-constexpr int SC_RING = 4;
+constexpr int SC_RING = OMDS_SC_RING;         // ring slots of 16 KB (a power of two)
+constexpr int SC_DIST = OMDS_SC_DIST;         // slices in flight ahead of the one being multiplied (<= RING - 1)
+constexpr int SC_PW = 16 / SC_WAVES;          // LDS-DMA pieces (1 KiB fragments) per wave and slice
 
 struct ScreenArgs {
-    const _Float16* Wh;   // [nhh*8 + 1 slices][16 kchunk][64 lane][8 halfs], fragment order (see omds_pack_screen_weights)
-    const float* bias;    // [nhh + 1][256]: hidden->hidden biases, then the last layer's (padded with zeros)
-    const float* Apre;
-    const float* Bpre;
+    const _Float16* Wh;      // [nhh*8 + 1 slices][16 kchunk][64 lane][8 halfs], fragment order (packed by omds_set_mlp)
+    const float* bias;       // [nhh + 1][256]: hidden->hidden biases, then the last layer's (padded with zeros)
+    const _Float16* ApreH;   // [16 chunk][2 lane-half][B rows][8 slots]: fp16 rollout half of layer 1 (omds_screen_hidx)
+    const _Float16* BpreH;   // [16][2][O][8]: obstacle half
     const float* radius;
     float* Dmin;
     long long total_rows;
-    int O;
+    int B, O;
     uint32_t ignored;
     OmdsDivisor odiv;
     int nhh, C;
     float out_div;
+    int dbg;                 // timing experiments only (OMDS_SCREEN_DBG): 1 = no weight streaming after the prologue,
+                             // 2 = no layer-1 loads, 4 = no per-slice wait + barrier
 };
 
 // LDS-DMA: 16 bytes per lane from gsrc (per-lane address) to LDS [lds_dst + 16 * lane] (lds_dst wave-uniform).  Invisible
@@ -68,7 +81,22 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
 // counted wait for this wave's LDS-DMA pieces + workgroup barrier; the "memory" clobber keeps hipcc from moving LDS reads
 // of the slice above the barrier
 template <int N>
-__device__ __forceinline__ void wait_vm_barrier() { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vm_barrier_n() { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory"); }
+// n = LDS-DMA pieces of this wave that may stay in flight (a compile-time constant once the slice loop is unrolled)
+__device__ __forceinline__ void wait_vm_barrier(int n) {
+    switch (n) {
+        case 0: wait_vm_barrier_n<0>(); break;
+        case 2: wait_vm_barrier_n<2>(); break;
+        case 4: wait_vm_barrier_n<4>(); break;
+        case 6: wait_vm_barrier_n<6>(); break;
+        case 8: wait_vm_barrier_n<8>(); break;
+        case 10: wait_vm_barrier_n<10>(); break;
+        case 12: wait_vm_barrier_n<12>(); break;
+        case 16: wait_vm_barrier_n<16>(); break;
+        case 20: wait_vm_barrier_n<20>(); break;
+        default: wait_vm_barrier_n<0>(); break;
+    }
+}
 
 __device__ __forceinline__ h2 relu_pk(float a, float b) {
     h2 p = {(_Float16)a, (_Float16)b};                 // v_cvt_pk_f16_f32 (round to nearest even)
@@ -86,7 +114,7 @@ __device__ __forceinline__ AGroup read_group(const unsigned char* slot_lane, int
 }
 
 template <int NHH>
-__global__ __launch_bounds__(SC_NT) void k_screen(ScreenArgs a) {
+__global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char* ring = smem_raw;                                   // [SC_RING][SC_SLICE]
     float* biasL = reinterpret_cast<float*>(smem_raw + SC_RING * SC_SLICE);   // [NHH+1][256]
@@ -95,21 +123,22 @@ __global__ __launch_bounds__(SC_NT) void k_screen(ScreenArgs a) {
     constexpr int S = NHH * 8 + 1;                                    // slice steps: 8 per hidden->hidden layer + the last layer
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
 
-    // weight slice s -> ring slot s & 3; this wave moves fragments 2w and 2w+1
+    // weight slice s -> ring slot s % RING; this wave moves fragments PW*w .. PW*w + PW-1
     auto issue = [&](int s) {
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.Wh) + (size_t)s * SC_SLICE + (2 * wave) * 1024 + lane * 16;
-        const unsigned dst = ring_lds + (unsigned)((s & (SC_RING - 1)) * SC_SLICE + (2 * wave) * 1024);
-        dma16(src, dst);
-        dma16(src + 1024, dst + 1024);
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.Wh) + (size_t)s * SC_SLICE + (SC_PW * wave) * 1024 + lane * 16;
+        const unsigned dst = ring_lds + (unsigned)((s & (SC_RING - 1)) * SC_SLICE + (SC_PW * wave) * 1024);
+#pragma unroll
+        for (int i = 0; i < SC_PW; ++i) dma16(src + i * 1024, dst + i * 1024);
     };
     for (int i = tid; i < (NHH + 1) * OMDS_WIDTH; i += SC_NT) biasL[i] = a.bias[i];
     __syncthreads();   // bias table visible; nothing of the ring is in flight yet (hipcc's fence would drain it)
-    issue(0);
-    issue(1);
-    issue(2);
+#pragma unroll
+    for (int s0 = 0; s0 < SC_DIST && s0 < S; ++s0) issue(s0);
 
-    // ---- layer 1: relu(Apre[t] + Bpre[o]) in fp32, rounded to fp16, straight into the B-operand registers.  Chunk cc
-    //      (features 16cc .. 16cc+15): slots 0-3 of lane-half h = features 16cc + 4h .. +3, slots 4-7 = 16cc + 8 + 4h .. +3
+    // ---- layer 1: relu(ApreH[t] + BpreH[o]) (fp16 copies of the separable halves, already in B-operand order: chunk cc,
+    //      lane-half h, slot j <-> feature 16cc + 8(j>>2) + 4h + (j&3)).  One 16-byte load per operand and chunk: lane
+    //      (b, half) reads exactly its 8 slots; consecutive lanes = consecutive obstacles (and mostly one rollout), so the
+    //      wave's loads are contiguous
     const long long R0 = (long long)blockIdx.x * SC_ROWS + wave * 32;
     long long row = R0 + b;
     const bool valid = row < a.total_rows;
@@ -118,53 +147,78 @@ __global__ __launch_bounds__(SC_NT) void k_screen(ScreenArgs a) {
     const unsigned o = (unsigned)row - t * (unsigned)a.O;
     h8 act[16];
     {
-        const float4* ap = reinterpret_cast<const float4*>(a.Apre + (size_t)t * OMDS_WIDTH) + half;
-        const float4* bp = reinterpret_cast<const float4*>(a.Bpre + (size_t)o * OMDS_WIDTH) + half;
+        const h8* ap = reinterpret_cast<const h8*>(a.ApreH) + (size_t)half * a.B + t;
+        const h8* bp = reinterpret_cast<const h8*>(a.BpreH) + (size_t)half * a.O + o;
+        const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc) {
-            const float4 a0 = ap[4 * cc], a1 = ap[4 * cc + 2], b0 = bp[4 * cc], b1 = bp[4 * cc + 2];
-            const h2 p0 = relu_pk(a0.x + b0.x, a0.y + b0.y), p1 = relu_pk(a0.z + b0.z, a0.w + b0.w);
-            const h2 p2 = relu_pk(a1.x + b1.x, a1.y + b1.y), p3 = relu_pk(a1.z + b1.z, a1.w + b1.w);
-            act[cc] = h8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+            h8 av, bv;
+            if (a.dbg & 2) { av = z; bv = z + (_Float16)0.25f; }
+            else { av = ap[(size_t)cc * 2 * a.B]; bv = bp[(size_t)cc * 2 * a.O]; }
+            act[cc] = __builtin_elementwise_max(av + bv, z);
         }
     }
     const float rad = a.radius[o];
 
-    // ---- the slice pipeline.  Step s multiplies slice s (ring slot s & 3) into the accumulators in 4 groups of 4 k-chunks;
+    // ---- the slice pipeline.  Step s multiplies slice s (ring slot s % RING) into the accumulators in 4 groups of 4 k-chunks;
     //      the A fragments of the next group are read while the current group's MFMAs issue.  In the middle of step s the
-    //      wave waits for ITS pieces of slice s+1 (issued two steps earlier) and meets the others at the barrier: after it
-    //      slice s+1 is complete, and every wave has finished reading slice s-1, whose slot then takes slice s+3.
+    //      wave waits for ITS pieces of slice s+1 (issued DIST-1 steps earlier) and meets the others at the barrier: after it
+    //      slice s+1 is complete, and every wave has finished reading slice s-1, so slice s+DIST may overwrite a slot that
+    //      held slice s+DIST-RING <= s-1.
     const unsigned char* slot_lane = ring + lane * 16;
-    wait_vm_barrier<4>();   // slice 0 landed (slices 1 and 2 may still be in flight)
+    wait_vm_barrier(SC_PW * ((SC_DIST < S ? SC_DIST : S) - 1));   // slice 0 landed (the later ones may still be in flight)
     AGroup cur = read_group(slot_lane, 0);
     h8 nxt[16];
-    f32x16 acc;
     float dmin = __builtin_inff();
+    // accumulators start at the bias, read one step ahead.  C layout: register r = 4j + i <-> output row 32 fb + 8 j + 4 half + i
+    auto read_bias = [&](int s) {
+        f32x16 r;
+        const float* bl = biasL + (s >> 3) * OMDS_WIDTH + ((s == S - 1) ? 0 : 32 * (s & 7)) + 4 * half;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 bv = *reinterpret_cast<const float4*>(bl + 8 * j);
+            r[4 * j] = bv.x; r[4 * j + 1] = bv.y; r[4 * j + 2] = bv.z; r[4 * j + 3] = bv.w;
+        }
+        return r;
+    };
+    f32x16 acc = read_bias(0);
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        const int l = s >> 3, fb = s & 7;
+        const int fb = s & 7;
         const bool last = s == S - 1;
-        {   // accumulators start at the bias.  C layout: register r = 4j + i <-> output row 32 fb + 8 j + 4 half + i
-            const float* bl = biasL + l * OMDS_WIDTH + (last ? 0 : 32 * fb) + 4 * half;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 bv = *reinterpret_cast<const float4*>(bl + 8 * j);
-                acc[4 * j] = bv.x; acc[4 * j + 1] = bv.y; acc[4 * j + 2] = bv.z; acc[4 * j + 3] = bv.w;
-            }
-        }
         const unsigned char* sl = slot_lane + (s & (SC_RING - 1)) * SC_SLICE;
         const unsigned char* sl_next = slot_lane + ((s + 1) & (SC_RING - 1)) * SC_SLICE;
+        f32x16 acc_next = acc;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            if (g == 1 && s + 1 < S) {
+                // this wave's pieces of slice s+1 are the oldest in flight; slices s+2 .. s+DIST-1 may stay in flight
+                const int hi = (s + SC_DIST - 1 < S - 1) ? s + SC_DIST - 1 : S - 1;
+                if (!(a.dbg & 4)) wait_vm_barrier(SC_PW * (hi - (s + 1)));
+                if (s + SC_DIST < S && !(a.dbg & 1)) issue(s + SC_DIST);   // into the slot of slice s + DIST - RING <= s - 1: free since this barrier
+            }
             AGroup pre = cur;
             if (g < 3) pre = read_group(sl, g + 1);
             else if (s + 1 < S) pre = read_group(sl_next, 0);
-            if (g == 1 && s + 1 < S) {
-                if (s + 2 < S) wait_vm_barrier<2>(); else wait_vm_barrier<0>();
-                if (s + 3 < S) issue(s + 3);
-            }
+            if (g == 2 && s + 1 < S) acc_next = read_bias(s + 1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[i], act[4 * g + i], acc, 0, 0, 0);
+            // issue order inside the group: one fragment read of the NEXT group ahead of each MFMA (4 MFMAs = 128+ cycles of
+            // lead for the LDS latency; group 2 also carries the four bias reads of the next step); everything else (the
+            // previous step's epilogue VALU) fills in behind
+            if (g == 2 && s + 1 < S) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+            }
             cur = pre;
         }
         if (!last) {
@@ -187,6 +241,7 @@ __global__ __launch_bounds__(SC_NT) void k_screen(ScreenArgs a) {
                 dmin = fminf(dmin, v);
             }
         }
+        acc = acc_next;
     }
     dmin = fminf(dmin, __shfl_xor(dmin, 32));
     if (half == 0 && valid) a.Dmin[R0 + b] = dmin;
@@ -307,16 +362,20 @@ __global__ __launch_bounds__(512) void k_exact(MlpDev m, const float* __restrict
 // ------------------------------------------------------------------------------------------------
 size_t omds_screen_lds_bytes(int nhh) { return (size_t)SC_RING * SC_SLICE + (size_t)(nhh + 1) * OMDS_WIDTH * 4; }
 
-void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, const float* Apre, const float* Bpre,
+void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, const uint16_t* ApreH, const uint16_t* BpreH,
                         const float* radius, int O, int B, uint32_t ignored, float* Dmin) {
     const long long total = (long long)B * O;
     if (total <= 0) return;
     ScreenArgs a;
     a.Wh = reinterpret_cast<const _Float16*>(sd.Wh);
     a.bias = sd.bias;
-    a.Apre = Apre; a.Bpre = Bpre; a.radius = radius; a.Dmin = Dmin;
+    a.ApreH = reinterpret_cast<const _Float16*>(ApreH); a.BpreH = reinterpret_cast<const _Float16*>(BpreH);
+    a.radius = radius; a.Dmin = Dmin; a.B = B;
     a.total_rows = total; a.O = O; a.ignored = ignored; a.odiv = OmdsDivisor::make((unsigned)O);
     a.nhh = m.nhh; a.C = m.C; a.out_div = m.out_div;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("OMDS_SCREEN_DBG"); dbg = e ? atoi(e) : 0; }
+    a.dbg = dbg;
     const size_t lds = omds_screen_lds_bytes(m.nhh);
     const dim3 grid((unsigned)((total + SC_ROWS - 1) / SC_ROWS));
 #define OMDS_SCREEN_LAUNCH(NHH)                                                                                          \

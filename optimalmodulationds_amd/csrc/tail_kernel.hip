@@ -19,6 +19,7 @@ struct TailArgs {
     const float* xyzr;
     const float* Dmin;   // [N][O]
     float* Apre;         // [N][256] in: this step, out: next step (rows of the workgroup's own rollouts)
+    _Float16* ApreH;     // next step's rows again as fp16 in the screening kernel's operand order (nullptr: not screening)
     float* dscr;         // tanh derivative scratch
     int O;
     int t_begin, t_end;  // rollout range of this launch (a group of the rollouts; the whole batch = [0, N))
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
 #pragma unroll
             for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)(2 * d + j) * OMDS_WIDTH + c], f[2 * ND + j], acc);
             a.Apre[(size_t)t * OMDS_WIDTH + c] = acc;
+            if (a.ApreH) a.ApreH[omds_screen_hidx(c, t, N)] = (_Float16)acc;
         }
     }
 }
@@ -150,8 +152,9 @@ int omds_tail_scratch_rows(int N, int k) {
 }
 
 void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
-                      const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st, int t_begin, int t_end) {
+                      const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st, int t_begin, int t_end, uint16_t* ApreH) {
     TailArgs a;
+    a.ApreH = reinterpret_cast<_Float16*>(ApreH);
     const int rows = omds_tail_rows(st.N, st.k);
     const int RW = rows / st.k;
     a.t_begin = t_begin; a.t_end = t_end;          // t_begin must be a multiple of RW
