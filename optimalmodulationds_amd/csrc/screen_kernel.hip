@@ -31,6 +31,8 @@
 //     B-operand order so that a lane fetches its 8 slots of a chunk with one 16-byte load and a wave's loads are contiguous
 //     (reading the fp32 rows cost 36 % of the kernel: 64 scattered 16-byte loads per lane).
 #include <algorithm>
+#include <cstdio>
+#include <vector>
 
 #include "mlp_device.h"
 
@@ -65,6 +67,7 @@ struct ScreenArgs {
     OmdsDivisor odiv;
     int nhh, C;
     float out_div;
+    unsigned long long* tl;  // diagnostic (OMDS_SCREEN_TL=1): [workgroup][8] s_memtime stamps, nullptr otherwise
     int dbg;                 // timing experiments only (OMDS_SCREEN_DBG): 1 = no weight streaming after the prologue,
                              // 2 = no layer-1 loads, 4 = no per-slice wait + barrier
 };
@@ -113,9 +116,12 @@ __device__ __forceinline__ AGroup read_group(const unsigned char* slot_lane, int
     return r;
 }
 
+#define SC_TL(i) do { if (a.tl && threadIdx.x == 0) a.tl[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+
 template <int NHH>
 __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    SC_TL(0);
     unsigned char* ring = smem_raw;                                   // [SC_RING][SC_SLICE]
     float* biasL = reinterpret_cast<float*>(smem_raw + SC_RING * SC_SLICE);   // [NHH+1][256]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -132,6 +138,7 @@ __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
     };
     for (int i = tid; i < (NHH + 1) * OMDS_WIDTH; i += SC_NT) biasL[i] = a.bias[i];
     __syncthreads();   // bias table visible; nothing of the ring is in flight yet (hipcc's fence would drain it)
+    SC_TL(1);
 #pragma unroll
     for (int s0 = 0; s0 < SC_DIST && s0 < S; ++s0) issue(s0);
 
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
         }
     }
     const float rad = a.radius[o];
+    if (a.tl) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SC_TL(2); }
 
     // ---- the slice pipeline.  Step s multiplies slice s (ring slot s % RING) into the accumulators in 4 groups of 4 k-chunks;
     //      the A fragments of the next group are read while the current group's MFMAs issue.  In the middle of step s the
@@ -167,6 +175,7 @@ __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
     //      held slice s+DIST-RING <= s-1.
     const unsigned char* slot_lane = ring + lane * 16;
     wait_vm_barrier(SC_PW * ((SC_DIST < S ? SC_DIST : S) - 1));   // slice 0 landed (the later ones may still be in flight)
+    SC_TL(3);
     AGroup cur = read_group(slot_lane, 0);
     h8 nxt[16];
     float dmin = __builtin_inff();
@@ -242,9 +251,12 @@ __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
             }
         }
         acc = acc_next;
+        if (s == 7) SC_TL(4);
+        if (s == S - 2) SC_TL(5);
     }
     dmin = fminf(dmin, __shfl_xor(dmin, 32));
     if (half == 0 && valid) a.Dmin[R0 + b] = dmin;
+    SC_TL(6);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -378,6 +390,16 @@ void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, con
     a.dbg = dbg;
     const size_t lds = omds_screen_lds_bytes(m.nhh);
     const dim3 grid((unsigned)((total + SC_ROWS - 1) / SC_ROWS));
+    // diagnostic timeline (OMDS_SCREEN_TL=1): per-workgroup phase stamps of every launch, summarised on stderr
+    static int tl_on = -1;
+    static unsigned long long* tl_buf = nullptr;
+    if (tl_on < 0) { const char* e = getenv("OMDS_SCREEN_TL"); tl_on = e ? atoi(e) : 0; }
+    a.tl = nullptr;
+    if (tl_on && grid.x <= 65536) {
+        if (!tl_buf) (void)hipMalloc(&tl_buf, (size_t)65536 * 8 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(tl_buf, 0, (size_t)grid.x * 8 * sizeof(unsigned long long), s);
+        a.tl = tl_buf;
+    }
 #define OMDS_SCREEN_LAUNCH(NHH)                                                                                          \
     case NHH: {                                                                                                         \
         static std::atomic<uint64_t> configured{0};                                                                     \
@@ -393,6 +415,21 @@ void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, con
         default: break;   // omds_screen_supported() keeps other depths on the fp32 path
     }
 #undef OMDS_SCREEN_LAUNCH
+    if (a.tl) {
+        std::vector<unsigned long long> h((size_t)grid.x * 8);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), tl_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        double seg[6] = {0, 0, 0, 0, 0, 0};
+        for (unsigned w = 0; w < grid.x; ++w) {
+            const unsigned long long* r = &h[(size_t)w * 8];
+            t0 = std::min(t0, r[0]); t1 = std::max(t1, r[6]);
+            for (int i = 0; i < 6; ++i) seg[i] += (double)(r[i + 1] - r[i]);
+        }
+        fprintf(stderr, "[k_screen timeline] %u workgroups, span %.1f kcycles (cycle counter units); mean per workgroup: bias+sync %.0f, "
+                        "dma issue + layer-1 loads %.0f, first slice wait %.0f, layer A (8 steps) %.0f, other layers %.0f, last layer + store %.0f\n",
+                grid.x, (t1 - t0) / 1e3, seg[0] / grid.x, seg[1] / grid.x, seg[2] / grid.x, seg[3] / grid.x, seg[4] / grid.x, seg[5] / grid.x);
+    }
 }
 
 bool omds_screen_supported(const MlpDev& m) { return m.act == OMDS_ACT_RELU && m.nhh >= 1 && m.nhh <= 4; }
