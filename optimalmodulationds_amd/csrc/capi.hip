@@ -117,7 +117,7 @@ static void free_all(omds_ctx* ctx) {
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
                     ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
                     ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
-                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_BpreH, ctx->d_ApreH};
+                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : ctx->mlp_allocs)
@@ -173,8 +173,10 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
     CKC(hipMalloc(&ctx->d_A, OMDS_MAX_DOF * OMDS_MAX_DOF * 4));
     CKC(hipMalloc(&ctx->d_Bpre, std::max(Om, rows2) * OMDS_WIDTH * 4));
     CKC(hipMalloc(&ctx->d_radius, std::max(Om, rows2) * 4));
-    CKC(hipMalloc(&ctx->d_BpreH, Om * OMDS_WIDTH * 2));
-    CKC(hipMalloc(&ctx->d_ApreH, N * OMDS_WIDTH * 2));
+    CKC(hipMalloc(&ctx->d_FpH, Om * 32 * 2));
+    CKC(hipMalloc(&ctx->d_FqH, N * 32 * 2));
+    CKC(hipMemsetAsync(ctx->d_FpH, 0, Om * 32 * 2, ctx->stream));
+    CKC(hipMemsetAsync(ctx->d_FqH, 0, N * 32 * 2, ctx->stream));
     CKC(hipMalloc(&ctx->d_trajT, H * n * N * 4));
     CKC(hipMalloc(&ctx->d_distT, H * N * 4));
     CKC(hipMalloc(&ctx->d_dotT, H * N * 4));
@@ -375,19 +377,31 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
     // fp16 screening network: slices of 32 output rows x 256 k in A-fragment order of v_mfma_f32_32x32x16_f16, with the k
     // order permuted to the C layout of the previous layer (chunk cc, lane-half h, slot j <-> feature 16cc + 8(j>>2) + 4h + (j&3))
     ctx->screen = ScreenDev{};
+    // the input tables keep zeros in the slots the other operand owns; the slot assignment depends on the network's d
+    CK(hipMemsetAsync(ctx->d_FpH, 0, (size_t)ctx->cfg.max_obs * 32 * 2, ctx->stream));
+    CK(hipMemsetAsync(ctx->d_FqH, 0, (size_t)ctx->cfg.n_traj * 32 * 2, ctx->stream));
     ctx->screen_ok = false;
     ctx->screen_cal = false;
     ctx->screen_eps = 0.f;
     std::vector<uint16_t> wh;
     std::vector<float> sbias;
     if (act == OMDS_ACT_RELU && m.nhh >= 1 && m.nhh <= 4) {
-        const int nsl = m.nhh * 8 + 1;
+        const int nsl = m.nhh * 8 + 2;
         wh.assign((size_t)nsl * 16 * 64 * 8, 0);
-        sbias.assign((size_t)(m.nhh + 1) * Wd, 0.f);
-        for (int sl = 0; sl < nsl; ++sl) {
+        sbias.assign((size_t)(m.nhh + 2) * Wd, 0.f);
+        // slice 0: layer 1, fragment 2 fb + cc = rows 32 fb .. +31 x inputs 16 cc .. +15 (slot j of lane-half h = input 16cc + 8h + j)
+        for (int fb = 0; fb < 8; ++fb)
+            for (int cc = 0; cc < 2; ++cc)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = 32 * fb + (lane & 31), kk = 16 * cc + 8 * (lane >> 5) + j;
+                        const float v = (kk < F) ? W[0][(size_t)r * F + kk] : 0.f;
+                        wh[(((size_t)(2 * fb + cc)) * 64 + lane) * 8 + j] = f32_to_f16_bits(v);
+                    }
+        for (int sl = 1; sl < nsl; ++sl) {
             const bool lastl = sl == nsl - 1;
-            const float* Wsrc = lastl ? W[n_linear - 1] : W[sl / 8 + 1];
-            const int fb = lastl ? 0 : sl % 8, rows = lastl ? C : Wd;
+            const float* Wsrc = lastl ? W[n_linear - 1] : W[(sl - 1) / 8 + 1];
+            const int fb = lastl ? 0 : (sl - 1) % 8, rows = lastl ? C : Wd;
             for (int cc = 0; cc < 16; ++cc)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
@@ -396,8 +410,9 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
                         wh[(((size_t)sl * 16 + cc) * 64 + lane) * 8 + j] = f32_to_f16_bits(v);
                     }
         }
-        for (int l = 0; l < m.nhh; ++l) std::memcpy(&sbias[(size_t)l * Wd], b[l + 1], Wd * sizeof(float));
-        std::memcpy(&sbias[(size_t)m.nhh * Wd], b[n_linear - 1], C * sizeof(float));
+        std::memcpy(&sbias[0], b[0], Wd * sizeof(float));
+        for (int l = 0; l < m.nhh; ++l) std::memcpy(&sbias[(size_t)(l + 1) * Wd], b[l + 1], Wd * sizeof(float));
+        std::memcpy(&sbias[(size_t)(m.nhh + 1) * Wd], b[n_linear - 1], C * sizeof(float));
     }
     int rc;
     if (!wh.empty()) {
@@ -434,7 +449,7 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
     ctx->f_bwd = ctx->f_fwd - 2.0 * true_dims[n_linear - 1] * true_dims[n_linear];   // no weight-gradient, no last-layer GEMM
     ctx->have_mlp = true;
     if (ctx->n_obs > 0) {  // re-derive the obstacle half of layer 1 for the new weights
-        omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, ctx->n_obs, ctx->d_Bpre, ctx->d_radius, ctx->d_BpreH);
+        omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, ctx->n_obs, ctx->d_Bpre, ctx->d_radius, ctx->d_FpH, ctx->cfg.max_obs);
         CK(hipGetLastError());
         CK(hipStreamSynchronize(ctx->stream));
     }
@@ -450,7 +465,7 @@ int omds_set_obstacles(omds_ctx* ctx, const float* xyzr, int n_obs) {
     CK(hipMemcpyAsync(ctx->d_obs, xyzr, (size_t)n_obs * 16, hipMemcpyHostToDevice, ctx->stream));
     ctx->n_obs = n_obs;
     if (ctx->have_mlp) {
-        omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, n_obs, ctx->d_Bpre, ctx->d_radius, ctx->d_BpreH);
+        omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, n_obs, ctx->d_Bpre, ctx->d_radius, ctx->d_FpH, ctx->cfg.max_obs);
         CK(hipGetLastError());
     }
     CK(hipStreamSynchronize(ctx->stream));
@@ -667,12 +682,12 @@ static int calibrate_screen(omds_ctx* ctx) {
         }
     }
     CK(hipMemcpyAsync(ctx->d_qstage, q.data(), q.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Apre, ctx->d_ApreH);
+    omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Apre, ctx->d_FqH, ctx->cfg.n_traj);
     std::vector<float> ref((size_t)B * O), apx((size_t)B * O);
     omds_launch_pass1(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
     CK(hipMemcpyAsync(ref.data(), ctx->d_Dmin, ref.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
-    omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_ApreH, ctx->d_BpreH, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
+    omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_FqH, ctx->cfg.n_traj, ctx->d_FpH, ctx->cfg.max_obs, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
     CK(hipGetLastError());
     CK(hipMemcpyAsync(apx.data(), ctx->d_Dmin, apx.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
@@ -699,7 +714,7 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
         // planar7_1024x32 ran 9.0 M rollout-steps/s on one stream, 7.1 / 3.3 / 2.4 M on 2 / 4 / 8 -- and a two-half
         // ping-pong for large batches with event-chained pass-1 launches so that one half's tail runs under the
         // other half's pass 1: parity-green, but the half-size launches drain twice per step, 1.00 M vs 1.03 M.)
-        omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, ctx->d_Apre, screen ? ctx->d_ApreH : nullptr);
+        omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, ctx->d_Apre, screen ? ctx->d_FqH : nullptr, N);
         if (screen) {
             CK(hipMemsetAsync(ctx->d_sctotal, 0, (size_t)(H + 1) * 4, ctx->stream));
             CK(hipMemsetAsync(ctx->d_scerr, 0, 4, ctx->stream));
@@ -709,7 +724,7 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
                 RoctxRange r1("TAG: evaluate NN_2 (forward pass)");
                 if ((rc = prof_begin(ctx))) return rc;
                 if (screen) {
-                    omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_ApreH, ctx->d_BpreH, ctx->d_radius, ctx->n_obs, N,
+                    omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_FqH, ctx->cfg.n_traj, ctx->d_FpH, ctx->cfg.max_obs, ctx->d_radius, ctx->n_obs, N,
                                        ctx->prm.ignored_links, ctx->d_Dmin);
                     if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs, -1.0, "k_screen"))) return rc;
                     omds_launch_select(ctx->stream, ctx->d_Dmin, N, ctx->n_obs, a.k, ctx->screen_eps, ctx->d_rowlist, ctx->d_sctotal + (i - 1));
@@ -724,7 +739,7 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
             RoctxRange r2("TAG: evaluate NN_3-5 + Modulation-propagation");
             a.step = i;
             omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, ctx->d_Apre,
-                             ctx->d_dscr, ctx->n_obs, a, 0, N, screen ? ctx->d_ApreH : nullptr);
+                             ctx->d_dscr, ctx->n_obs, a, 0, N, screen ? ctx->d_FqH : nullptr, N);
         }
     } else {
         for (int i = 1; i <= H; ++i) {   // MPPI.py:101: H network evaluations, the last velocity is not integrated
@@ -1071,8 +1086,8 @@ int omds_screen_mindist(omds_ctx* ctx, const float* q, int B, float* mindist) {
     const int n = ctx->cfg.n_dof, O = ctx->n_obs;
     CK(hipMemcpyAsync(ctx->d_stage, q, (size_t)B * n * 4, hipMemcpyHostToDevice, ctx->stream));
     omds_launch_transpose(ctx->stream, ctx->d_stage, ctx->d_qstage, B, n);
-    omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Apre, ctx->d_ApreH);
-    omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_ApreH, ctx->d_BpreH, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
+    omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Apre, ctx->d_FqH, ctx->cfg.n_traj);
+    omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_FqH, ctx->cfg.n_traj, ctx->d_FpH, ctx->cfg.max_obs, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
     CK(hipGetLastError());
     CK(hipMemcpyAsync(mindist, ctx->d_Dmin, (size_t)B * O * 4, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));

@@ -28,7 +28,7 @@
 // layer-1 halves
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rollout_layer1(MlpDev m, const float* __restrict__ qT, int ldq, int B,
-                                                        float* __restrict__ Apre, _Float16* __restrict__ ApreH) {
+                                                        float* __restrict__ Apre, _Float16* __restrict__ FqH, int ldF) {
     __shared__ float f[3 * OMDS_MAX_DOF];
     const int t = blockIdx.x, c = threadIdx.x, n = m.n_dof, d = m.d;
     if (c < n) {
@@ -36,6 +36,11 @@ __global__ __launch_bounds__(256) void k_rollout_layer1(MlpDev m, const float* _
         f[c] = q;
         f[n + c] = sinf(q);
         f[2 * n + c] = cosf(q);
+        if (FqH) {   // the screening kernel's input row of this rollout (the other slots stay zero)
+            FqH[omds_screen_fidx(c, t, ldF)] = (_Float16)q;
+            FqH[omds_screen_fidx(d + c, t, ldF)] = (_Float16)f[n + c];
+            FqH[omds_screen_fidx(2 * d + c, t, ldF)] = (_Float16)f[2 * n + c];
+        }
     }
     __syncthreads();
     float acc = m.b1[c];
@@ -43,12 +48,11 @@ __global__ __launch_bounds__(256) void k_rollout_layer1(MlpDev m, const float* _
     for (int j = 0; j < n; ++j) acc = fmaf(m.W1t[(size_t)(d + j) * OMDS_WIDTH + c], f[n + j], acc);
     for (int j = 0; j < n; ++j) acc = fmaf(m.W1t[(size_t)(2 * d + j) * OMDS_WIDTH + c], f[2 * n + j], acc);
     Apre[(size_t)t * OMDS_WIDTH + c] = acc;
-    if (ApreH) ApreH[omds_screen_hidx(c, t, B)] = (_Float16)acc;
 }
 
 __global__ __launch_bounds__(256) void k_obstacle_layer1(MlpDev m, const float* __restrict__ xyzr, int O,
                                                          float* __restrict__ Bpre, float* __restrict__ radius,
-                                                         _Float16* __restrict__ BpreH) {
+                                                         _Float16* __restrict__ FpH, int ldF) {
     __shared__ float f[9];
     const int o = blockIdx.x, c = threadIdx.x, n = m.n_dof, d = m.d, po = d - n;   // po = 3 (x, y, z) or 2 (toy networks)
     if (c < po) {
@@ -56,6 +60,11 @@ __global__ __launch_bounds__(256) void k_obstacle_layer1(MlpDev m, const float* 
         f[c] = p;
         f[3 + c] = sinf(p);
         f[6 + c] = cosf(p);
+        if (FpH) {
+            FpH[omds_screen_fidx(n + c, o, ldF)] = (_Float16)p;
+            FpH[omds_screen_fidx(d + n + c, o, ldF)] = (_Float16)f[3 + c];
+            FpH[omds_screen_fidx(2 * d + n + c, o, ldF)] = (_Float16)f[6 + c];
+        }
     }
     if (c == 3) radius[o] = xyzr[o * 4 + 3];
     __syncthreads();
@@ -64,7 +73,6 @@ __global__ __launch_bounds__(256) void k_obstacle_layer1(MlpDev m, const float* 
     for (int j = 0; j < po; ++j) acc = fmaf(m.W1t[(size_t)(d + n + j) * OMDS_WIDTH + c], f[3 + j], acc);
     for (int j = 0; j < po; ++j) acc = fmaf(m.W1t[(size_t)(2 * d + n + j) * OMDS_WIDTH + c], f[6 + j], acc);
     Bpre[(size_t)o * OMDS_WIDTH + c] = acc;
-    if (BpreH) BpreH[omds_screen_hidx(c, o, O)] = (_Float16)acc;
 }
 
 template <int MT, int MR, int NR, int ACT>
@@ -168,14 +176,14 @@ __global__ __launch_bounds__(256) void k_blend(const float* __restrict__ gradx, 
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-void omds_launch_rollout_layer1(hipStream_t s, const MlpDev& m, const float* qT, int ldq, int B, float* Apre, uint16_t* ApreH) {
+void omds_launch_rollout_layer1(hipStream_t s, const MlpDev& m, const float* qT, int ldq, int B, float* Apre, uint16_t* FqH, int ldF) {
     if (B <= 0) return;
-    hipLaunchKernelGGL(k_rollout_layer1, dim3(B), dim3(256), 0, s, m, qT, ldq, B, Apre, reinterpret_cast<_Float16*>(ApreH));
+    hipLaunchKernelGGL(k_rollout_layer1, dim3(B), dim3(256), 0, s, m, qT, ldq, B, Apre, reinterpret_cast<_Float16*>(FqH), ldF);
 }
 
-void omds_launch_obstacle_layer1(hipStream_t s, const MlpDev& m, const float* xyzr, int O, float* Bpre, float* radius, uint16_t* BpreH) {
+void omds_launch_obstacle_layer1(hipStream_t s, const MlpDev& m, const float* xyzr, int O, float* Bpre, float* radius, uint16_t* FpH, int ldF) {
     if (O <= 0) return;
-    hipLaunchKernelGGL(k_obstacle_layer1, dim3(O), dim3(256), 0, s, m, xyzr, O, Bpre, radius, reinterpret_cast<_Float16*>(BpreH));
+    hipLaunchKernelGGL(k_obstacle_layer1, dim3(O), dim3(256), 0, s, m, xyzr, O, Bpre, radius, reinterpret_cast<_Float16*>(FpH), ldF);
 }
 
 template <int MT, int MR, int NR, int ACT>

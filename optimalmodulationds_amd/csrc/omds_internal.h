@@ -44,13 +44,14 @@ struct MlpDev {
 
 // fp16 screening network (screen_kernel.hip): hidden->hidden and last-layer weights as fp16 A-fragment slices
 struct ScreenDev {
-    const void* Wh = nullptr;     // [nhh*8 + 1][16 kchunk][64 lane][8 halfs]
-    const float* bias = nullptr;  // [nhh + 1][256]
+    const void* Wh = nullptr;     // [nhh*8 + 2 slices][16 fragments][64 lane][8 halfs]: layer 1, hidden->hidden, last layer
+    const float* bias = nullptr;  // [nhh + 2][256]
 };
 
-// element index of feature c of row t in the fp16 layer-1 tables: chunk c/16, lane-half (c>>2)&1, slot (c&3) + 4((c>>3)&1)
-__host__ __device__ inline size_t omds_screen_hidx(int c, int t, int stride) {
-    return ((size_t)(((c >> 4) * 2 + ((c >> 2) & 1))) * stride + t) * 8 + ((c & 3) + 4 * ((c >> 3) & 1));
+// element index of network input feature kappa (of [x, sin x, cos x], < 32) of row t in the fp16 input tables of the
+// screening kernel: 16-byte piece kappa / 8 (= k-chunk kappa / 16, lane-half (kappa / 8) & 1), slot kappa % 8
+__host__ __device__ inline size_t omds_screen_fidx(int kappa, int t, int stride) {
+    return ((size_t)(kappa >> 3) * stride + t) * 8 + (kappa & 7);
 }
 
 // hipFuncSetAttribute applies to the current device only: true the first time a kernel is launched on each device.
@@ -99,8 +100,8 @@ struct omds_ctx {
     int n_obs = 0;
     float* d_obs = nullptr;      // [max_obs][4]
     float* d_Bpre = nullptr;     // [max_obs][256] obstacle part of layer 1
-    uint16_t* d_BpreH = nullptr; // the same as fp16 in the screening kernel's operand order (stride n_obs)
-    uint16_t* d_ApreH = nullptr; // rollout part likewise (stride = batch)
+    uint16_t* d_FpH = nullptr;   // [4][n_obs][8] fp16 network inputs of the obstacle points for the screening kernel
+    uint16_t* d_FqH = nullptr;   // [4][batch][8] rollout states likewise
     float* d_radius = nullptr;   // [max_obs]
     // DS / cost
     bool have_ds = false, have_cost = false;
@@ -181,10 +182,12 @@ int omds_update_impl(omds_ctx* ctx, bool use_comm, float rate, float ker_thr, fl
                      int32_t* mask_out, float* qdot_weighted, float* qdot_best, float* n_total_out);
 
 // ---- launchers implemented in mlp_kernels.hip ------------------------------------------------
-// ApreH / BpreH (optional): the same layer-1 halves as fp16 in the screening kernel's operand order,
-// [16 chunk][2 lane-half][rows][8 slots] (omds_screen_hidx), row stride = B / O
-void omds_launch_rollout_layer1(hipStream_t s, const MlpDev& m, const float* qT, int ldq, int B, float* Apre, uint16_t* ApreH = nullptr);
-void omds_launch_obstacle_layer1(hipStream_t s, const MlpDev& m, const float* xyzr, int O, float* Bpre, float* radius, uint16_t* BpreH = nullptr);
+// FqH / FpH (optional): the network inputs (q, sin q, cos q / the obstacle point likewise) as fp16 at their feature slots
+// of the screening kernel's input tables, [4 pieces][ldF rows][8] (omds_screen_fidx).  ldF is the table's CAPACITY
+// (n_traj / max_obs), never the batch: the slots the other operand owns must stay zero, and a batch-dependent stride would
+// alias them with data of an earlier call
+void omds_launch_rollout_layer1(hipStream_t s, const MlpDev& m, const float* qT, int ldq, int B, float* Apre, uint16_t* FqH = nullptr, int ldF = 0);
+void omds_launch_obstacle_layer1(hipStream_t s, const MlpDev& m, const float* xyzr, int O, float* Bpre, float* radius, uint16_t* FpH = nullptr, int ldF = 0);
 void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
                        int O, int B, uint32_t ignored_links, float* Dmin);
 void omds_launch_topk(hipStream_t s, const float* Dmin, int B, int O, int k, int32_t* idx);
@@ -195,8 +198,8 @@ void omds_launch_blend(hipStream_t s, const float* gradx, const float* drow, int
                        float softmax_k, float* dist, float* nngrad);
 
 // ---- launchers implemented in screen_kernel.hip -----------------------------------------------
-void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, const uint16_t* ApreH, const uint16_t* BpreH,
-                        const float* radius, int O, int B, uint32_t ignored, float* Dmin);
+void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, const uint16_t* FqH, int ldFq, const uint16_t* FpH,
+                        int ldFp, const float* radius, int O, int B, uint32_t ignored, float* Dmin);
 bool omds_screen_supported(const MlpDev& m);
 void omds_launch_select(hipStream_t s, float* Dmin, int B, int O, int k, float eps, int* rowlist, int* total);
 void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius, int O,
@@ -220,7 +223,7 @@ int omds_tail_scratch_rows(int N, int k);
 int omds_tail_rows(int N, int k);            // pass-2 tile height (16 | 32) for a batch of N rollouts with k closest obstacles   // rows of the tanh-derivative scratch the tail may touch (either tile height)
 void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
                       const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st, int t_begin, int t_end,
-                      uint16_t* ApreH = nullptr);
+                      uint16_t* FqH = nullptr, int ldF = 0);
 struct CostArgs {
     int N, H, n;
     uint32_t terms;   // OMDS_COST_* bits

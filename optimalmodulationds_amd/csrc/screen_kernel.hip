@@ -27,9 +27,10 @@
 //   * weights stream L2 -> LDS by LDS-DMA (buffer/global_load ... lds, 1 KiB = one A fragment per wave instruction) as
 //     16 KB slices (32 output features x 256 k) through a 4-slot ring shared by the 8 waves of the workgroup (256 pairs):
 //     128 KB per layer per 256 pairs instead of per 32, one s_barrier per slice, counted vmcnt, loads two slices ahead.
-//   * layer 1 is the separable sum Apre[t] + Bpre[o] (as in k_pass1) of fp16 copies of the two halves, stored in the
-//     B-operand order so that a lane fetches its 8 slots of a chunk with one 16-byte load and a wave's loads are contiguous
-//     (reading the fp32 rows cost 36 % of the kernel: 64 scattered 16-byte loads per lane).
+//   * layer 1 runs on the matrix pipe too: its 3(n+3) <= 32 inputs are two k-chunks, fetched as fp16 from a 64-byte row per
+//     rollout and per obstacle (four 16-byte loads per lane and tile; reading the separable fp32 halves Apre[t] + Bpre[o]
+//     like k_pass1 does cost 36 % of the kernel, their fp16 copies still 25 %), W1 is one more slice of the ring.
+//   * persistent workgroups (one per CU) loop over their tiles: the ring never drains, no refill gap between tiles.
 #include <algorithm>
 #include <cstdio>
 #include <vector>
@@ -53,12 +54,14 @@ constexpr int SC_SLICE = 16384;               // bytes: 16 k-chunks x 1 KiB frag
 constexpr int SC_RING = OMDS_SC_RING;         // ring slots of 16 KB (a power of two)
 constexpr int SC_DIST = OMDS_SC_DIST;         // slices in flight ahead of the one being multiplied (<= RING - 1)
 constexpr int SC_PW = 16 / SC_WAVES;          // LDS-DMA pieces (1 KiB fragments) per wave and slice
+constexpr int SC_MAX_TILES = 20;              // tiles per workgroup whose results fit the LDS next to the ring
 
 struct ScreenArgs {
-    const _Float16* Wh;      // [nhh*8 + 1 slices][16 kchunk][64 lane][8 halfs], fragment order (packed by omds_set_mlp)
-    const float* bias;       // [nhh + 1][256]: hidden->hidden biases, then the last layer's (padded with zeros)
-    const _Float16* ApreH;   // [16 chunk][2 lane-half][B rows][8 slots]: fp16 rollout half of layer 1 (omds_screen_hidx)
-    const _Float16* BpreH;   // [16][2][O][8]: obstacle half
+    const _Float16* Wh;      // [nhh*8 + 2 slices][16 fragments][64 lane][8 halfs], fragment order (packed by omds_set_mlp)
+    const float* bias;       // [nhh + 2][256]: layer 1, hidden->hidden, the last layer's (padded with zeros)
+    const _Float16* FqH;     // [4 pieces][ldFq rows][8]: fp16 network inputs of the rollouts (q, sin q, cos q at their feature slots)
+    const _Float16* FpH;     // [4][ldFp][8]: obstacle points likewise (omds_screen_fidx)
+    int ldFq, ldFp;          // row capacities of the two tables
     const float* radius;
     float* Dmin;
     long long total_rows;
@@ -74,11 +77,14 @@ struct ScreenArgs {
 
 // LDS-DMA: 16 bytes per lane from gsrc (per-lane address) to LDS [lds_dst + 16 * lane] (lds_dst wave-uniform).  Invisible
 // to hipcc's s_waitcnt bookkeeping by design: completion is waited for with counted vmcnt below.
-__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+// The source is a wave-uniform base (SGPR pair) + a per-lane 32-bit byte offset + an immediate: per-lane 64-bit
+// pointers would be loop-invariant VGPR pairs, one per slice, that hipcc hoists out of the tile loop and spills.
+template <int IMM>
+__device__ __forceinline__ void dma16(const void* gbase_uniform, unsigned voff, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
+                 : "v"(voff), "s"(gbase_uniform), "s"(lds_dst), "n"(IMM)
                  : "memory");
 }
 // counted wait for this wave's LDS-DMA pieces + workgroup barrier; the "memory" clobber keeps hipcc from moving LDS reads
@@ -116,73 +122,79 @@ __device__ __forceinline__ AGroup read_group(const unsigned char* slot_lane, int
     return r;
 }
 
-#define SC_TL(i) do { if (a.tl && threadIdx.x == 0) a.tl[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define SC_TL(i) do { if (a.tl && threadIdx.x == 0 && it == 0) a.tl[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+
+struct TileRow { unsigned t, o; bool valid; };
+__device__ __forceinline__ TileRow tile_row(const ScreenArgs& a, long long tile, int wave, int b) {
+    long long row = tile * SC_ROWS + wave * 32 + b;
+    TileRow r;
+    r.valid = row < a.total_rows;
+    if (!r.valid) row = a.total_rows - 1;   // tiles past the end (prefetch of a non-existent next tile) clamp too
+    r.t = a.odiv.div((unsigned)row);
+    r.o = (unsigned)row - r.t * (unsigned)a.O;
+    return r;
+}
+
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 template <int NHH>
 __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
+    // PERSISTENT: workgroup w multiplies tiles w, w + G, w + 2G, ... (G = gridDim.x = one workgroup per CU).  The weight
+    // slices keep streaming through the ring across tile boundaries (the slice sequence is periodic), the bias table is
+    // loaded once, and the results wait in LDS until the end -- a store in flight would perturb the counted vmcnt waits of
+    // the LDS-DMA pieces (stores and loads retire out of order with respect to each other).  Measured on the one-tile-per-
+    // workgroup form (OMDS_SCREEN_TL): of 57 kcycles per tile slot 14 were the refill gap between two workgroups of a CU,
+    // 12 the layer-1 operand loads and first-slice latency, and only 29 the slice loop.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    SC_TL(0);
-    unsigned char* ring = smem_raw;                                   // [SC_RING][SC_SLICE]
-    float* biasL = reinterpret_cast<float*>(smem_raw + SC_RING * SC_SLICE);   // [NHH+1][256]
+    unsigned char* ring = smem_raw;                                            // [SC_RING][SC_SLICE]
+    float* biasL = reinterpret_cast<float*>(smem_raw + SC_RING * SC_SLICE);    // [NHH+2][256]: layer 1, hidden->hidden, last
+    float* resL = biasL + (NHH + 2) * OMDS_WIDTH;                              // [tiles of this workgroup][SC_ROWS]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = lane & 31, half = lane >> 5;
-    constexpr int S = NHH * 8 + 1;                                    // slice steps: 8 per hidden->hidden layer + the last layer
+    constexpr int S = NHH * 8 + 2;                 // slice steps of a tile: layer 1, 8 per hidden->hidden layer, the last layer
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
+    const long long ntiles = (a.total_rows + SC_ROWS - 1) / SC_ROWS;
+    const int my_tiles = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);   // >= 1: the grid never exceeds ntiles
 
-    // weight slice s -> ring slot s % RING; this wave moves fragments PW*w .. PW*w + PW-1
-    auto issue = [&](int s) {
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.Wh) + (size_t)s * SC_SLICE + (SC_PW * wave) * 1024 + lane * 16;
-        const unsigned dst = ring_lds + (unsigned)((s & (SC_RING - 1)) * SC_SLICE + (SC_PW * wave) * 1024);
-#pragma unroll
-        for (int i = 0; i < SC_PW; ++i) dma16(src + i * 1024, dst + i * 1024);
+    // slice `sl` of the network -> ring slot `slot`; this wave moves fragments PW*w .. PW*w + PW-1
+    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.Wh) + (SC_PW * wave) * 1024;   // wave-uniform
+    const unsigned lane16 = lane * 16;
+    auto issue = [&](int sl, int slot) {
+        const unsigned char* src = wbase + (size_t)sl * SC_SLICE;
+        const unsigned dst = ring_lds + (unsigned)(slot * SC_SLICE + (SC_PW * wave) * 1024);
+        // the instruction offset advances the global AND the LDS address
+        dma16<0>(src, lane16, dst);
+        if (SC_PW > 1) dma16<1024>(src, lane16, dst);
+        if (SC_PW > 2) { dma16<2048>(src, lane16, dst); dma16<3072>(src, lane16, dst); }
     };
-    for (int i = tid; i < (NHH + 1) * OMDS_WIDTH; i += SC_NT) biasL[i] = a.bias[i];
+    for (int i = tid; i < (NHH + 2) * OMDS_WIDTH; i += SC_NT) biasL[i] = a.bias[i];
     __syncthreads();   // bias table visible; nothing of the ring is in flight yet (hipcc's fence would drain it)
-    SC_TL(1);
 #pragma unroll
-    for (int s0 = 0; s0 < SC_DIST && s0 < S; ++s0) issue(s0);
+    for (int s0 = 0; s0 < SC_DIST; ++s0) issue(s0 % S, s0 % SC_RING);
 
-    // ---- layer 1: relu(ApreH[t] + BpreH[o]) (fp16 copies of the separable halves, already in B-operand order: chunk cc,
-    //      lane-half h, slot j <-> feature 16cc + 8(j>>2) + 4h + (j&3)).  One 16-byte load per operand and chunk: lane
-    //      (b, half) reads exactly its 8 slots; consecutive lanes = consecutive obstacles (and mostly one rollout), so the
-    //      wave's loads are contiguous
-    const long long R0 = (long long)blockIdx.x * SC_ROWS + wave * 32;
-    long long row = R0 + b;
-    const bool valid = row < a.total_rows;
-    if (!valid) row = a.total_rows - 1;
-    const unsigned t = a.odiv.div((unsigned)row);
-    const unsigned o = (unsigned)row - t * (unsigned)a.O;
-    h8 act[16];
-    {
-        const h8* ap = reinterpret_cast<const h8*>(a.ApreH) + (size_t)half * a.B + t;
-        const h8* bp = reinterpret_cast<const h8*>(a.BpreH) + (size_t)half * a.O + o;
-        const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) {
-            h8 av, bv;
-            if (a.dbg & 2) { av = z; bv = z + (_Float16)0.25f; }
-            else { av = ap[(size_t)cc * 2 * a.B]; bv = bp[(size_t)cc * 2 * a.O]; }
-            act[cc] = __builtin_elementwise_max(av + bv, z);
-        }
-    }
-    const float rad = a.radius[o];
-    if (a.tl) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SC_TL(2); }
+    // network inputs of a pair as fp16 B operands: chunk cc, lane-half h, slot j <-> feature 16 cc + 8 h + j of
+    // [x, sin x, cos x] (x = q then the obstacle point).  The rollout table holds the q features (zeros elsewhere), the
+    // obstacle table the point features: two 16-byte loads per chunk and a bitwise OR
+    // (buffer loads: SGPR descriptor + 32-bit lane offset + scalar piece offset -- no 64-bit per-lane pointers to keep alive)
+    const __amdgpu_buffer_rsrc_t fq_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.FqH), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t fp_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.FpH), 0, 0x7fffffff, 0x00020000);
+    auto load_inputs = [&](const TileRow& r, u4 (&raw)[4]) {
+        const int vq = (int)((half * (unsigned)a.ldFq + r.t) * 16u), vp = (int)((half * (unsigned)a.ldFp + r.o) * 16u);
+        raw[0] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(fq_rs, vq, 0, 0));
+        raw[1] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(fp_rs, vp, 0, 0));
+        raw[2] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(fq_rs, vq, a.ldFq * 32, 0));
+        raw[3] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(fp_rs, vp, a.ldFp * 32, 0));
+    };
+    TileRow row = tile_row(a, blockIdx.x, wave, b);
+    u4 raw[4];
+    load_inputs(row, raw);
+    float rad = a.radius[row.o];
 
-    // ---- the slice pipeline.  Step s multiplies slice s (ring slot s % RING) into the accumulators in 4 groups of 4 k-chunks;
-    //      the A fragments of the next group are read while the current group's MFMAs issue.  In the middle of step s the
-    //      wave waits for ITS pieces of slice s+1 (issued DIST-1 steps earlier) and meets the others at the barrier: after it
-    //      slice s+1 is complete, and every wave has finished reading slice s-1, so slice s+DIST may overwrite a slot that
-    //      held slice s+DIST-RING <= s-1.
-    const unsigned char* slot_lane = ring + lane * 16;
-    wait_vm_barrier(SC_PW * ((SC_DIST < S ? SC_DIST : S) - 1));   // slice 0 landed (the later ones may still be in flight)
-    SC_TL(3);
-    AGroup cur = read_group(slot_lane, 0);
-    h8 nxt[16];
-    float dmin = __builtin_inff();
-    // accumulators start at the bias, read one step ahead.  C layout: register r = 4j + i <-> output row 32 fb + 8 j + 4 half + i
-    auto read_bias = [&](int s) {
+    const unsigned char* ring_lane = ring + lane * 16;
+    // accumulators start at the bias.  C layout: register r = 4j + i <-> output row 32 fb + 8 j + 4 half + i
+    auto read_bias = [&](int layer, int fb) {
         f32x16 r;
-        const float* bl = biasL + (s >> 3) * OMDS_WIDTH + ((s == S - 1) ? 0 : 32 * (s & 7)) + 4 * half;
+        const float* bl = biasL + layer * OMDS_WIDTH + 32 * fb + 4 * half;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float4 bv = *reinterpret_cast<const float4*>(bl + 8 * j);
@@ -190,73 +202,139 @@ __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
         }
         return r;
     };
-    f32x16 acc = read_bias(0);
+    auto to_act = [&](const f32x16& acc, h8& lo, h8& hi) {   // registers 0-7 are the slots of chunk 2 fb of the next layer, 8-15 of 2 fb + 1
+        const h2 p0 = relu_pk(acc[0], acc[1]), p1 = relu_pk(acc[2], acc[3]), p2 = relu_pk(acc[4], acc[5]), p3 = relu_pk(acc[6], acc[7]);
+        const h2 p4 = relu_pk(acc[8], acc[9]), p5 = relu_pk(acc[10], acc[11]), p6 = relu_pk(acc[12], acc[13]), p7 = relu_pk(acc[14], acc[15]);
+        lo = h8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+        hi = h8{p4[0], p4[1], p5[0], p5[1], p6[0], p6[1], p7[0], p7[1]};
+    };
+
+    // ---- the slice pipeline.  Global step sigma = it * S + s multiplies slice s (ring slot sigma % RING) in 4 groups of 4
+    //      fragments; the A fragments of the next group are read while the current group's MFMAs issue.  In the middle of a
+    //      step the wave waits for ITS pieces of the next slice (issued DIST-1 steps earlier) and meets the others at the
+    //      barrier: after it that slice is complete and every wave has finished reading the previous one, so the slice DIST
+    //      steps ahead may overwrite a slot last read RING - DIST >= 1 steps ago.  Slices keep being issued past the last
+    //      tile (into free slots, never read), so the counted wait is one constant.
+    wait_vm_barrier(SC_PW * (SC_DIST - 1));   // slice 0 landed (the later ones may still be in flight)
+    AGroup cur = read_group(ring_lane, 0);
+    int sigma0 = 0;
+    for (int it = 0; it < my_tiles; ++it, sigma0 += S) {
+        SC_TL(0);
+        auto sync_and_issue = [&](int s) {
+            wait_vm_barrier(SC_PW * (SC_DIST - 2));
+            issue((s + SC_DIST) % S, (sigma0 + s + SC_DIST) & (SC_RING - 1));
+        };
+        auto slot_ptr = [&](int s) { return ring_lane + ((sigma0 + s) & (SC_RING - 1)) * SC_SLICE; };
+        const bool valid = row.valid;
+        h8 in[2];
+        {
+            const u4 i0 = raw[0] | raw[1], i1 = raw[2] | raw[3];
+            in[0] = __builtin_bit_cast(h8, i0);
+            in[1] = __builtin_bit_cast(h8, i1);
+        }
+        h8 act[16];
+        // ---- step 0: layer 1 on the matrix pipe.  Slice 0 = W1 as 8 row blocks x 2 k-chunks (fragment 2 fb + cc)
+        {
+            const unsigned char* sl = slot_ptr(0);
+            const unsigned char* sl_next = slot_ptr(1);
+            // group g = row blocks 2g, 2g+1 (two MFMAs each); their ReLU + conversion runs one group later, under the next
+            // group's MFMAs; the scheduling barriers keep hipcc from batching all 16 MFMAs first (8 live accumulators spill)
+            f32x16 pa, pb;
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const int fb = s & 7;
-        const bool last = s == S - 1;
-        const unsigned char* sl = slot_lane + (s & (SC_RING - 1)) * SC_SLICE;
-        const unsigned char* sl_next = slot_lane + ((s + 1) & (SC_RING - 1)) * SC_SLICE;
-        f32x16 acc_next = acc;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (g == 1 && s + 1 < S) {
-                // this wave's pieces of slice s+1 are the oldest in flight; slices s+2 .. s+DIST-1 may stay in flight
-                const int hi = (s + SC_DIST - 1 < S - 1) ? s + SC_DIST - 1 : S - 1;
-                if (!(a.dbg & 4)) wait_vm_barrier(SC_PW * (hi - (s + 1)));
-                if (s + SC_DIST < S && !(a.dbg & 1)) issue(s + SC_DIST);   // into the slot of slice s + DIST - RING <= s - 1: free since this barrier
-            }
-            AGroup pre = cur;
-            if (g < 3) pre = read_group(sl, g + 1);
-            else if (s + 1 < S) pre = read_group(sl_next, 0);
-            if (g == 2 && s + 1 < S) acc_next = read_bias(s + 1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[i], act[4 * g + i], acc, 0, 0, 0);
-            // issue order inside the group: one fragment read of the NEXT group ahead of each MFMA (4 MFMAs = 128+ cycles of
-            // lead for the LDS latency; group 2 also carries the four bias reads of the next step); everything else (the
-            // previous step's epilogue VALU) fills in behind
-            if (g == 2 && s + 1 < S) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            for (int g = 0; g < 4; ++g) {
+                if (g == 1) sync_and_issue(0);
+                const AGroup pre = (g < 3) ? read_group(sl, g + 1) : read_group(sl_next, 0);
+                f32x16 ca = read_bias(0, 2 * g), cb = read_bias(0, 2 * g + 1);
+                ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[0], in[0], ca, 0, 0, 0);
+                cb = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[2], in[0], cb, 0, 0, 0);
+                ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[1], in[1], ca, 0, 0, 0);
+                cb = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[3], in[1], cb, 0, 0, 0);
+                if (g > 0) {
+                    to_act(pa, act[4 * g - 4], act[4 * g - 3]);
+                    to_act(pb, act[4 * g - 2], act[4 * g - 1]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                pa = ca; pb = cb;
+                cur = pre;
+            }
+            to_act(pa, act[12], act[13]);
+            to_act(pb, act[14], act[15]);
+        }
+        SC_TL(1);
+        // ---- steps 1 .. S-1: hidden->hidden layers and the last layer
+        h8 nxt[16];
+        float dmin = __builtin_inff();
+        f32x16 acc = read_bias(1, 0);
+        TileRow nrow = row;
+#pragma unroll
+        for (int s = 1; s < S; ++s) {
+            const int l = (s - 1) >> 3, fb = (s - 1) & 7;      // hidden->hidden layer l (bias row l + 1), output row block fb
+            const bool last = s == S - 1;
+            const unsigned char* sl = slot_ptr(s);
+            const unsigned char* sl_next = slot_ptr(s + 1);
+            f32x16 acc_next = acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g == 1) sync_and_issue(s);
+                const AGroup pre = (g < 3) ? read_group(sl, g + 1) : read_group(sl_next, 0);
+                if (g == 2 && !last) acc_next = (s + 1 == S - 1) ? read_bias(NHH + 1, 0) : read_bias(((s) >> 3) + 1, s & 7);
+                if (s == S - 2 && g == 2) {   // the next tile's inputs, fetched under the last two steps of this one
+                    nrow = tile_row(a, blockIdx.x + (long long)(it + 1) * gridDim.x, wave, b);
+                    load_inputs(nrow, raw);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[i], act[4 * g + i], acc, 0, 0, 0);
+                // issue order inside the group: one fragment read of the NEXT group ahead of each MFMA (4 MFMAs = 128+ cycles
+                // of lead for the LDS latency; group 2 also carries the four bias reads of the next step); everything else
+                // (the previous step's epilogue VALU) fills in behind
+                if (g == 2 && !last) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+                }
+                cur = pre;
+            }
+            if (!last) {
+                to_act(acc, nxt[2 * fb], nxt[2 * fb + 1]);
+                if (fb == 7) {
+#pragma unroll
+                    for (int cc = 0; cc < 16; ++cc) act[cc] = nxt[cc];
+                }
+                (void)l;
             } else {
+                // last layer: the links sit on the A rows (rows >= C are zero); min over the valid, un-ignored links
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                for (int r = 0; r < 8; ++r) {   // link = 4 half + (r & 3) + 8 (r >> 2); links >= 16 do not exist (OMDS_CPAD)
+                    const int link = 4 * half + (r & 3) + 8 * (r >> 2);
+                    float v = acc[r] / a.out_div - rad;
+                    v = (link >= a.C) ? __builtin_inff() : (((a.ignored >> link) & 1u) ? 1e6f : v);
+                    dmin = fminf(dmin, v);
                 }
             }
-            cur = pre;
+            acc = acc_next;
+            if (s == 8) SC_TL(2);
         }
-        if (!last) {
-            // registers 0-7 are the slots of chunk 2 fb of the next layer, 8-15 of chunk 2 fb + 1
-            const h2 p0 = relu_pk(acc[0], acc[1]), p1 = relu_pk(acc[2], acc[3]), p2 = relu_pk(acc[4], acc[5]), p3 = relu_pk(acc[6], acc[7]);
-            const h2 p4 = relu_pk(acc[8], acc[9]), p5 = relu_pk(acc[10], acc[11]), p6 = relu_pk(acc[12], acc[13]), p7 = relu_pk(acc[14], acc[15]);
-            nxt[2 * fb] = h8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
-            nxt[2 * fb + 1] = h8{p4[0], p4[1], p5[0], p5[1], p6[0], p6[1], p7[0], p7[1]};
-            if (fb == 7) {
-#pragma unroll
-                for (int cc = 0; cc < 16; ++cc) act[cc] = nxt[cc];
-            }
-        } else {
-            // last layer: the links sit on the A rows (rows >= C are zero); min over the valid, un-ignored links
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {   // link = 4 half + (r & 3) + 8 (r >> 2); links >= 16 do not exist (OMDS_CPAD)
-                const int link = 4 * half + (r & 3) + 8 * (r >> 2);
-                float v = acc[r] / a.out_div - rad;
-                v = (link >= a.C) ? __builtin_inff() : (((a.ignored >> link) & 1u) ? 1e6f : v);
-                dmin = fminf(dmin, v);
-            }
-        }
-        acc = acc_next;
-        if (s == 7) SC_TL(4);
-        if (s == S - 2) SC_TL(5);
+        SC_TL(3);
+        dmin = fminf(dmin, __shfl_xor(dmin, 32));
+        if (half == 0) resL[it * SC_ROWS + wave * 32 + b] = valid ? dmin : 0.f;
+        row = nrow;
+        rad = a.radius[row.o];
     }
-    dmin = fminf(dmin, __shfl_xor(dmin, 32));
-    if (half == 0 && valid) a.Dmin[R0 + b] = dmin;
-    SC_TL(6);
+    // ---- drain the ring (pieces issued past the last tile still target this workgroup's LDS), then flush the results
+    wait_vm_barrier(0);
+    __syncthreads();
+    for (int i = tid; i < my_tiles * SC_ROWS; i += SC_NT) {
+        const long long r = ((long long)blockIdx.x + (long long)(i / SC_ROWS) * gridDim.x) * SC_ROWS + (i % SC_ROWS);
+        if (r < a.total_rows) a.Dmin[r] = resL[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -372,25 +450,42 @@ __global__ __launch_bounds__(512) void k_exact(MlpDev m, const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-size_t omds_screen_lds_bytes(int nhh) { return (size_t)SC_RING * SC_SLICE + (size_t)(nhh + 1) * OMDS_WIDTH * 4; }
+size_t omds_screen_lds_bytes(int nhh) { return (size_t)SC_RING * SC_SLICE + (size_t)(nhh + 2) * OMDS_WIDTH * 4; }
 
-void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, const uint16_t* ApreH, const uint16_t* BpreH,
-                        const float* radius, int O, int B, uint32_t ignored, float* Dmin) {
+void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, const uint16_t* FqH, int ldFq, const uint16_t* FpH,
+                        int ldFp, const float* radius, int O, int B, uint32_t ignored, float* Dmin) {
     const long long total = (long long)B * O;
     if (total <= 0) return;
     ScreenArgs a;
     a.Wh = reinterpret_cast<const _Float16*>(sd.Wh);
     a.bias = sd.bias;
-    a.ApreH = reinterpret_cast<const _Float16*>(ApreH); a.BpreH = reinterpret_cast<const _Float16*>(BpreH);
+    a.FqH = reinterpret_cast<const _Float16*>(FqH); a.FpH = reinterpret_cast<const _Float16*>(FpH);
+    a.ldFq = ldFq; a.ldFp = ldFp;
     a.radius = radius; a.Dmin = Dmin; a.B = B;
     a.total_rows = total; a.O = O; a.ignored = ignored; a.odiv = OmdsDivisor::make((unsigned)O);
     a.nhh = m.nhh; a.C = m.C; a.out_div = m.out_div;
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("OMDS_SCREEN_DBG"); dbg = e ? atoi(e) : 0; }
     a.dbg = dbg;
-    const size_t lds = omds_screen_lds_bytes(m.nhh);
-    const dim3 grid((unsigned)((total + SC_ROWS - 1) / SC_ROWS));
-    // diagnostic timeline (OMDS_SCREEN_TL=1): per-workgroup phase stamps of every launch, summarised on stderr
+    // persistent: one workgroup per CU (256 on MI355X; more only when a workgroup's result buffer would overflow its LDS)
+    const long long ntiles = (total + SC_ROWS - 1) / SC_ROWS;
+    static std::atomic<int> ncu_of[64];   // CUs per device, asked once
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int ncu = ncu_of[dev & 63].load();
+    if (ncu == 0) {
+        ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (ncu <= 0) ncu = 256;
+        ncu_of[dev & 63].store(ncu);
+    }
+    long long gl = std::min<long long>(ntiles, ncu);
+    gl = std::max<long long>(gl, (ntiles + SC_MAX_TILES - 1) / SC_MAX_TILES);
+    const dim3 grid((unsigned)gl);
+    const int tiles_per_wg = (int)((ntiles + gl - 1) / gl);
+    const size_t lds = omds_screen_lds_bytes(m.nhh) + (size_t)tiles_per_wg * SC_ROWS * 4;
+    const size_t lds_max = omds_screen_lds_bytes(4) + (size_t)SC_MAX_TILES * SC_ROWS * 4;
+    // diagnostic timeline (OMDS_SCREEN_TL=1): phase stamps of every workgroup's FIRST tile, summarised on stderr
     static int tl_on = -1;
     static unsigned long long* tl_buf = nullptr;
     if (tl_on < 0) { const char* e = getenv("OMDS_SCREEN_TL"); tl_on = e ? atoi(e) : 0; }
@@ -404,7 +499,7 @@ void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, con
     case NHH: {                                                                                                         \
         static std::atomic<uint64_t> configured{0};                                                                     \
         if (omds_first_use_on_device(configured))                                                                       \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_screen<NHH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_screen<NHH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); \
         hipLaunchKernelGGL((k_screen<NHH>), grid, dim3(SC_NT), lds, s, a);                                             \
     } break;
     switch (m.nhh) {
@@ -419,16 +514,13 @@ void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, con
         std::vector<unsigned long long> h((size_t)grid.x * 8);
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h.data(), tl_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        unsigned long long t0 = ~0ull, t1 = 0;
-        double seg[6] = {0, 0, 0, 0, 0, 0};
+        double seg[3] = {0, 0, 0};
         for (unsigned w = 0; w < grid.x; ++w) {
             const unsigned long long* r = &h[(size_t)w * 8];
-            t0 = std::min(t0, r[0]); t1 = std::max(t1, r[6]);
-            for (int i = 0; i < 6; ++i) seg[i] += (double)(r[i + 1] - r[i]);
+            for (int i = 0; i < 3; ++i) seg[i] += (double)(r[i + 1] - r[i]);
         }
-        fprintf(stderr, "[k_screen timeline] %u workgroups, span %.1f kcycles (cycle counter units); mean per workgroup: bias+sync %.0f, "
-                        "dma issue + layer-1 loads %.0f, first slice wait %.0f, layer A (8 steps) %.0f, other layers %.0f, last layer + store %.0f\n",
-                grid.x, (t1 - t0) / 1e3, seg[0] / grid.x, seg[1] / grid.x, seg[2] / grid.x, seg[3] / grid.x, seg[4] / grid.x, seg[5] / grid.x);
+        fprintf(stderr, "[k_screen timeline] %u workgroups x %d tiles; first tile, mean cycles: layer-1 step %.0f, first hidden layer %.0f, "
+                        "remaining layers %.0f\n", grid.x, tiles_per_wg, seg[0] / grid.x, seg[1] / grid.x, seg[2] / grid.x);
     }
 }
 

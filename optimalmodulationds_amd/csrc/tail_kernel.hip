@@ -19,7 +19,8 @@ struct TailArgs {
     const float* xyzr;
     const float* Dmin;   // [N][O]
     float* Apre;         // [N][256] in: this step, out: next step (rows of the workgroup's own rollouts)
-    _Float16* ApreH;     // next step's rows again as fp16 in the screening kernel's operand order (nullptr: not screening)
+    _Float16* FqH;       // next step's states as fp16 network inputs for the screening kernel (nullptr: not screening)
+    int ldF;             // row capacity of FqH
     float* dscr;         // tanh derivative scratch
     int O;
     int t_begin, t_end;  // rollout range of this launch (a group of the rollouts; the whole batch = [0, N))
@@ -84,6 +85,12 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
                 feat[rl * 3 * ND + sub] = v;
                 feat[rl * 3 * ND + ND + sub] = sinf(v);
                 feat[rl * 3 * ND + 2 * ND + sub] = cosf(v);
+                if (a.FqH && a.st.step < a.st.H) {
+                    const int d = m.d;
+                    a.FqH[omds_screen_fidx(sub, t, a.ldF)] = (_Float16)v;
+                    a.FqH[omds_screen_fidx(d + sub, t, a.ldF)] = (_Float16)feat[rl * 3 * ND + ND + sub];
+                    a.FqH[omds_screen_fidx(2 * d + sub, t, a.ldF)] = (_Float16)feat[rl * 3 * ND + 2 * ND + sub];
+                }
             }
         }
     }
@@ -105,7 +112,6 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
 #pragma unroll
             for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)(2 * d + j) * OMDS_WIDTH + c], f[2 * ND + j], acc);
             a.Apre[(size_t)t * OMDS_WIDTH + c] = acc;
-            if (a.ApreH) a.ApreH[omds_screen_hidx(c, t, N)] = (_Float16)acc;
         }
     }
 }
@@ -152,9 +158,10 @@ int omds_tail_scratch_rows(int N, int k) {
 }
 
 void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
-                      const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st, int t_begin, int t_end, uint16_t* ApreH) {
+                      const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st, int t_begin, int t_end, uint16_t* FqH, int ldF) {
     TailArgs a;
-    a.ApreH = reinterpret_cast<_Float16*>(ApreH);
+    a.FqH = reinterpret_cast<_Float16*>(FqH);
+    a.ldF = ldF;
     const int rows = omds_tail_rows(st.N, st.k);
     const int RW = rows / st.k;
     a.t_begin = t_begin; a.t_end = t_end;          // t_begin must be a multiple of RW
