@@ -221,8 +221,13 @@ __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
     for (int it = 0; it < my_tiles; ++it, sigma0 += S) {
         SC_TL(0);
         auto sync_and_issue = [&](int s) {
+#ifdef OMDS_SC_EXPERIMENT   // timing experiments only (variant builds): OMDS_SCREEN_DBG 4 = no wait + barrier, 1 = no weight streaming
+            if (!(a.dbg & 4)) wait_vm_barrier(SC_PW * (SC_DIST - 2));
+            if (!(a.dbg & 1)) issue((s + SC_DIST) % S, (sigma0 + s + SC_DIST) & (SC_RING - 1));
+#else
             wait_vm_barrier(SC_PW * (SC_DIST - 2));
             issue((s + SC_DIST) % S, (sigma0 + s + SC_DIST) & (SC_RING - 1));
+#endif
         };
         auto slot_ptr = [&](int s) { return ring_lane + ((sigma0 + s) & (SC_RING - 1)) * SC_SLICE; };
         const bool valid = row.valid;
@@ -273,6 +278,11 @@ __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
             const unsigned char* sl = slot_ptr(s);
             const unsigned char* sl_next = slot_ptr(s + 1);
             f32x16 acc_next = acc;
+#ifdef OMDS_SC_TWOACC
+            f32x16 acc2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#endif
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (g == 1) sync_and_issue(s);
@@ -282,8 +292,15 @@ __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
                     nrow = tile_row(a, blockIdx.x + (long long)(it + 1) * gridDim.x, wave, b);
                     load_inputs(nrow, raw);
                 }
+#ifdef OMDS_SC_TWOACC
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[0], act[4 * g + 0], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[1], act[4 * g + 1], acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[2], act[4 * g + 2], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[3], act[4 * g + 3], acc2, 0, 0, 0);
+#else
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[i], act[4 * g + i], acc, 0, 0, 0);
+#endif
                 // issue order inside the group: one fragment read of the NEXT group ahead of each MFMA (4 MFMAs = 128+ cycles
                 // of lead for the LDS latency; group 2 also carries the four bias reads of the next step); everything else
                 // (the previous step's epilogue VALU) fills in behind
@@ -302,6 +319,9 @@ __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
                 }
                 cur = pre;
             }
+#ifdef OMDS_SC_TWOACC
+            acc = acc + acc2;
+#endif
             if (!last) {
                 to_act(acc, nxt[2 * fb], nxt[2 * fb + 1]);
                 if (fb == 7) {
