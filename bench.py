@@ -191,8 +191,9 @@ def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, di
             eng.get_rollouts()
         fetch_ms = (time.perf_counter() - tf) / 5 * 1e3
 
+    scr = eng.screen_stats()
     eng.close()
-    return dict(w=w, W=W, b=b, obs=obs, q0=q0, qf=qf, N=N, H=H, K=K, el=el, p1_ms=p1_ms, p1_launches=p1_launches,
+    return dict(scr=scr, w=w, W=W, b=b, obs=obs, q0=q0, qf=qf, N=N, H=H, K=K, el=el, p1_ms=p1_ms, p1_launches=p1_launches,
                 p1_rows=p1_rows, p1_flops=p1_flops, p1_kernel=p1_kernel, fetch_ms=fetch_ms)
 
 
@@ -254,6 +255,7 @@ def main():
                          "launches": int(p1_launches), "avg_launch_ms": p1_ms / max(p1_launches, 1),
                          "flops_per_launch": r["p1_flops"] / max(p1_launches, 1)},
         }
+        out["screening"] = r["scr"]   # fp16 screening of pass 1 + exact fp32 re-selection; inactive = fp32 pass 1
         if fetch_ms is not None:
             out["fetch_all_rollouts_ms"] = fetch_ms
         if also is not None:

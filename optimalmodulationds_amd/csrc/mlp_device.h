@@ -506,18 +506,20 @@ struct P2Geo {
 };
 
 // One [ROWS x 256] . [256 x 256] GEMM of pass 2 (forward pack or transposed pack of layer l); out[r] in P2Geo order.
+// init[jb] = start value of the accumulators of column block jb: the bias in the forward pass -- the same start as in
+// pass1_tile, so that the forward of a row is bit-identical in pass 1 and pass 2 (32-row tiles) -- and 0 in the backward.
 template <int ROWS>
 __device__ __forceinline__ void p2_gemm(const float* Hs, const MlpDev& m, int l, bool backward, int wave, int lane,
-                                        float (&out)[P2Geo<ROWS>::NV]) {
+                                        float (&out)[P2Geo<ROWS>::NV], const float (&init)[P2Geo<ROWS>::NB]) {
     if constexpr (ROWS == 32) {
         f32x16 acc[1][1];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[0][0][r] = init[0];
         gemm256<1, 1>(Hs, (backward ? m.Wb : m.Wf) + (size_t)l * (OMDS_NCB * 32 * 64), wave, lane, acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[r] = acc[0][0][r];
     } else {
-        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x4 acc[2] = {{init[0], init[0], init[0], init[0]}, {init[1], init[1], init[1], init[1]}};
         gemm16(Hs, (backward ? m.Wb16 : m.Wf16) + (size_t)l * (16 * 16 * 64), wave, lane, acc);
 #pragma unroll
         for (int r = 0; r < 8; ++r) out[r] = acc[r >> 2][r & 3];
@@ -533,7 +535,10 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
                                            const float* __restrict__ xyzr, int R0, int total_rows,
                                            const float* __restrict__ qT, int ldq, float* gradx, float* drow, int dbase,
                                            float* __restrict__ yraw, int32_t* __restrict__ minidx,
-                                           float* __restrict__ dscr, size_t dlayer, int S0, int dbg = 0) {
+                                           float* __restrict__ dscr, size_t dlayer, int S0, int dbg = 0,
+                                           float* d1row = nullptr, uint32_t ignored = 0) {
+    // d1row (optional, [ROWS]): the pass-1 value of each row, min over the un-ignored links of y / out_div - radius
+    // (MPPI.py:236-242), computed from the same last-layer outputs -- bit-identical to pass1_tile's Dmin for 32-row tiles
     // dbg: timing experiments only (return after a stage).  S0 = first row of this workgroup's private slot in the tanh scratch
     using G = P2Geo<ROWS>;
     constexpr int NV = G::NV;
@@ -547,6 +552,9 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr bool relu = ACT == OMDS_ACT_RELU;
 
+    float bnext[G::NB];   // bias of the first hidden -> hidden layer: in flight across the layer-1 build
+#pragma unroll
+    for (int jb = 0; jb < G::NB; ++jb) bnext[jb] = m.nhh > 0 ? m.bh[G::col(4 * jb, wave, lane)] : 0.f;
     // ---- layer 1 in C-layout ------------------------------------------------------------------
     {
         uint32_t bits = 0;
@@ -574,17 +582,21 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
 
     // ---- forward through the hidden -> hidden layers -------------------------------------------
     for (int l = 0; l < m.nhh; ++l) {
-        float bv[G::NB];   // before the GEMM: no L2 round trip at the head of the epilogue
+        float bv[G::NB];   // the accumulators start at the bias, fetched one layer ahead (no L2 round trip in front of the GEMM)
 #pragma unroll
-        for (int jb = 0; jb < G::NB; ++jb) bv[jb] = m.bh[l * OMDS_WIDTH + G::col(4 * jb, wave, lane)];
+        for (int jb = 0; jb < G::NB; ++jb) bv[jb] = bnext[jb];
+        if (l + 1 < m.nhh) {
+#pragma unroll
+            for (int jb = 0; jb < G::NB; ++jb) bnext[jb] = m.bh[(l + 1) * OMDS_WIDTH + G::col(4 * jb, wave, lane)];
+        }
         float acc[NV];
-        p2_gemm<ROWS>(Hs, m, l, false, wave, lane, acc);
+        p2_gemm<ROWS>(Hs, m, l, false, wave, lane, acc, bv);
         __syncthreads();
         uint32_t bits = 0;
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
             const int row = G::row(r, lane), col = G::col(r, wave, lane);
-            const float z = acc[r] + bv[G::blk(r)];
+            const float z = acc[r];
             bits |= (z > 0.f ? 1u : 0u) << r;
             const float h = actf(z, ACT);
             Hs[row * LDH + col] = h;
@@ -630,6 +642,13 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
                 const int oi = __shfl_xor(bi, off);
                 if ((ov < bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
             }
+            if (d1row != nullptr) {
+                float v = y / m.out_div - radius[rowO[r]];
+                v = (j >= m.C) ? __builtin_inff() : (((ignored >> j) & 1u) ? 1e6f : v);
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) v = fminf(v, __shfl_xor(v, off));
+                if (j == 0) d1row[r] = v;
+            }
             if (j == 0) {
                 rowMin[r] = bi;
                 if (R < total_rows) {
@@ -660,7 +679,8 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
     // ---- backward through the hidden -> hidden layers ------------------------------------------
     for (int l = m.nhh - 1; l >= 0; --l) {
         float acc[NV];
-        p2_gemm<ROWS>(Hs, m, l, true, wave, lane, acc);
+        const float zinit[G::NB] = {};
+        p2_gemm<ROWS>(Hs, m, l, true, wave, lane, acc, zinit);
         __syncthreads();
         const uint32_t bits = maskL[l * P2_NT + tid];
 #pragma unroll

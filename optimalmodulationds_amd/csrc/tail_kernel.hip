@@ -116,6 +116,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
     }
 }
 
+
 static size_t tail_lds_bytes(int nhid) {
     return ((size_t)P2_MT * LDH + P2_PSETS * 32 * 33 + 32 * 33) * 4 + (size_t)nhid * P2_NT * 4 + 3 * P2_MT * 4 +
            (32 * 12 + 32 + 32 * 3 * OMDS_MAX_DOF) * 4;
