@@ -664,21 +664,30 @@ static bool screen_wanted(omds_ctx* ctx) {
     return (long long)ctx->cfg.n_traj * ctx->n_obs >= 64LL * 1024 && ctx->n_obs >= 4 * ctx->cfg.n_closest;
 }
 
-// eps = 4 x the largest |screening value - fp32 value| over a calibration batch: states drawn uniformly inside the joint
-// limits (omds_set_cost) or [-pi, pi], against the current obstacle set.  Once per omds_set_mlp; the candidates of every
-// later propagate re-measure the error (d_scerr) and trip the fp32 fallback when the margin shrinks below 2x.
-static int calibrate_screen(omds_ctx* ctx) {
+// eps = 4 x the largest |screening value - fp32 value| over a calibration batch of up to 1024 states x all obstacles
+// (~3e5 pairs: about what one propagate evaluates per step): half of them uniform inside the joint limits (omds_set_cost) or
+// [-pi, pi], half scattered around the current start state (sigma 0.6 rad, where rollouts live), against the current
+// obstacle set.  Once per omds_set_mlp; the candidates of every later propagate re-measure the error (d_scerr) and trip the
+// fp32 fallback when the margin shrinks below 2x.
+static int calibrate_screen(omds_ctx* ctx, const float* q_center) {
     ctx->screen_cal = true;
     if (ctx->screen_eps > 0.f) return OMDS_OK;   // set by the caller (omds_set_screening)
     const int n = ctx->cfg.n_dof, O = ctx->n_obs;
-    const int B = std::min(ctx->cfg.n_traj, 192);
+    const int B = std::min(ctx->cfg.n_traj, 1024);
     std::vector<float> q((size_t)n * B);          // [n][B]
     uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto uni = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (float)(((st >> 40) + 0.5) * (1.0 / 16777216.0)); };
     for (int j = 0; j < n; ++j) {
         const float lo = ctx->have_cost ? ctx->qmin[j] : -3.14159265f, hi = ctx->have_cost ? ctx->qmax[j] : 3.14159265f;
         for (int t = 0; t < B; ++t) {
-            st = st * 6364136223846793005ull + 1442695040888963407ull;
-            q[(size_t)j * B + t] = lo + (hi - lo) * (float)((st >> 40) * (1.0 / 16777216.0));
+            float v;
+            if (t & 1) {
+                const float g = std::sqrt(-2.f * std::log(uni())) * std::cos(6.2831853f * uni());   // Box-Muller
+                v = std::min(hi, std::max(lo, q_center[j] + 0.6f * g));
+            } else {
+                v = lo + (hi - lo) * uni();
+            }
+            q[(size_t)j * B + t] = v;
         }
     }
     CK(hipMemcpyAsync(ctx->d_qstage, q.data(), q.size() * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -780,7 +789,7 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
     if (fused < 0) { const char* e = getenv("OMDS_FUSED_TAIL"); fused = e ? atoi(e) : 1; }
     const bool tail = fused && omds_tail_supported(n, a.k);
     bool screen = tail && screen_wanted(ctx);
-    if (screen && !ctx->screen_cal && (rc = calibrate_screen(ctx))) return rc;
+    if (screen && !ctx->screen_cal && (rc = calibrate_screen(ctx, q_cur))) return rc;
     screen = screen && ctx->screen_ok && ctx->screen_eps > 0.f;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if ((rc = enqueue_rollouts(ctx, a, tail, screen))) return rc;

@@ -332,6 +332,58 @@ def rollout_relu_margin(m: Mlp, q, obs, sort_idx):
     return relu_margin(m, x).reshape(N, k).min(axis=1)
 
 
+def blended_gradient_alternatives(m: Mlp, q_row, obs, idx_row, margin, softmax_k=-10.0, max_units=10):
+    """All blended gradients (FN/MPPI.py:270-278) one rollout can legitimately have under fp32 rounding of the forward pass.
+
+    The vjp of a ReLU network multiplies by the masks 1[z > 0]; a hidden pre-activation within ``margin`` (relative to the
+    layer's largest |z|) of zero may come out on either side of it depending on the summation order of the dot product --
+    the reference's BLAS, the numpy oracle and an MFMA chain all round differently -- and each choice is a valid fp32
+    evaluation of the same network.  This enumerates every assignment of those ambiguous units over the rollout's k rows
+    (``idx_row`` = the k closest obstacles, ascending) and returns the list of resulting blended gradients [n_alt, n];
+    entry 0 is the oracle's own.  Rows with more than ``max_units`` ambiguous units in total return only entry 0."""
+    q_row = np.asarray(q_row, dtype=F32).reshape(1, -1)
+    n_dof = q_row.shape[1]
+    k = len(idx_row)
+    x = np.concatenate((np.repeat(q_row, k, axis=0), np.asarray(obs, dtype=F32)[np.asarray(idx_row), :3]), axis=1)
+    d = x.shape[1]
+    feats = positional_encoding(x)
+    hs, zs = [feats], []
+    for i in range(len(m.W) - 1):
+        z = hs[-1] @ m.W[i].T + m.b[i]
+        zs.append(z)
+        hs.append(_act(z, m.act))
+    y = (hs[-1] @ m.W[-1].T + m.b[-1]).astype(F32)
+    min_idx = np.argmin(y, axis=1)
+    yd = y / F32(100) if m.out_channels == 9 else y
+    dist = (yd - np.asarray(obs, dtype=F32)[np.asarray(idx_row), 3:4])[np.arange(k), min_idx]
+    e = np.exp(F32(softmax_k) * dist - (F32(softmax_k) * dist).max())
+    w = (e / e.sum()).astype(F32)
+    amb = []                                     # (row, layer, unit)
+    if m.act == "relu":
+        for i, z in enumerate(zs):
+            az = np.abs(z)
+            r, j = np.nonzero(az < F32(margin) * az.max(axis=1, keepdims=True))
+            amb += [(int(a), i, int(b)) for a, b in zip(r, j)]
+    masks0 = [_dact(zs[i], hs[i + 1], m.act) for i in range(len(zs))]
+
+    def grad_with(masks):
+        g = m.W[-1][min_idx]
+        for i in range(len(m.W) - 2, -1, -1):
+            g = (g * masks[i]) @ m.W[i]
+        gx = g[:, :d] + g[:, d:2 * d] * np.cos(x) - g[:, 2 * d:] * np.sin(x)
+        return (gx[:, :n_dof].astype(F32) * w[:, None]).sum(axis=0).astype(F32)
+
+    out = [grad_with(masks0)]
+    if 0 < len(amb) <= max_units:
+        for code in range(1, 1 << len(amb)):
+            masks = [mk.copy() for mk in masks0]
+            for bit, (r, i, j) in enumerate(amb):
+                if (code >> bit) & 1:
+                    masks[i][r, j] = F32(1) - masks[i][r, j]
+            out.append(grad_with(masks))
+    return np.stack(out)
+
+
 # ---------------------------------------------------------------------------------------------
 # cost (FN/cost.py) and forward kinematics (FN/fk_num.py)
 # ---------------------------------------------------------------------------------------------

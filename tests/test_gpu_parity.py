@@ -66,26 +66,41 @@ def test_dist_grad_stages(name):
     eng.close()
 
 
-MARGIN = 5e-6       # relative ReLU margin below which a mask may flip under fp32 rounding
-E2E_TOL = 2e-4      # end-to-end vs the reference: 1e-6-class distance errors x sigmoid slope 100
+MARGIN = 5e-6       # relative ReLU margin below which a mask may come out either way under fp32 rounding
+# The reference's own fp32 forward pass differs from exact arithmetic by up to ~3e-7 of the output scale on these networks,
+# the same size as an MFMA fmaf chain's error (tools/accuracy_study.py, profiles/r02_distance_accuracy.txt), so two correct
+# fp32 evaluations of the distance differ by that much -- and MPPI.py:149-155 feeds the distance to sigmoids of slope 100.
+DIST_ULP = 5e-7     # x max(1, largest network distance of the step): admissible difference between two fp32 evaluations
+
+
+def _velocity_envelope(q, qf, d_raw, grads, mu, sg, al, prm, delta):
+    """Per component [lo, hi] of the modulated velocity when the network distance moves within +-delta, for each of the
+    given blended gradients (the oracle's and the GPU's: equal to 2e-5 by stage A)."""
+    us = [orc.modulation_step(q, qf, (d_raw + np.float32(s * delta)).astype(np.float32), g, mu, sg, al, prm)["u"]
+          for s in (-1.0, -0.5, 0.0, 0.5, 1.0) for g in grads]
+    us = np.stack(us)
+    return us.min(axis=0), us.max(axis=0)
 
 
 @pytest.mark.parametrize("name", SCENARIOS)
 def test_teacher_forced_steps(name):
     """Every horizon step restarted from the reference's own state (H=1, per-rollout starts) and
-    checked in three stages:
-      A  network:    distance / blended gradient vs the oracle              (1e-5 / 2e-5)
-      B  modulation: GPU step outputs vs oracle.modulation_step fed the GPU's own
-                     (distance, gradient) -- isolates k_modulate             (1e-5)
-      C  end to end: next state / qdot vs the reference's golden rollouts   (E2E_TOL; rollouts whose
-                     ReLU margin is below MARGIN are only held to a loose bound: a flipped mask
-                     changes the gradient discretely, in the reference's own BLAS as much as here)"""
+    checked in three stages, every row at north_star's 1e-5 (2e-5 for gradients):
+      A  network:    distance vs the oracle (1e-5); blended gradient vs the oracle (2e-5) -- for a row with a hidden
+                     pre-activation within MARGIN of zero: vs the oracle gradient under SOME assignment of the ambiguous
+                     ReLU masks (oracle.blended_gradient_alternatives), still at 2e-5
+      B  modulation: GPU step outputs vs oracle.modulation_step fed the GPU's own (distance, gradient) -- isolates the
+                     per-rollout kernel                                        (1e-5)
+      C  end to end: qdot / next state vs the reference's golden rollouts: inside the envelope the oracle's modulation
+                     spans when the reference's distance moves by +-DIST_ULP, widened by 1e-5 (rows whose gradient took
+                     another admissible mask assignment than the oracle's are covered by A + B only: which assignment
+                     the reference's BLAS happened to take is not recorded in its outputs)"""
     fx = load(name)
     eng, m = _engine(fx, H=1)
     H, k, N = int(fx["H"]), int(fx["k"]), int(fx["N"])
     dt = np.float32(fx["dt"])
     prm = orc.Params(dst_thr=float(fx["dst_thr"]), lin_thr=float(fx["lin_thr"]), p=int(fx["p"]))
-    n_flag = n_tot = 0
+    n_alt_rows = n_rows = 0
     for it in range(int(fx["n_iter"])):
         pre = f"it{it}_"
         ref = fx[pre + "all_traj"]
@@ -96,17 +111,26 @@ def test_teacher_forced_steps(name):
             eng.propagate(q)
             r = eng.get_rollouts()
             d_gpu, g_gpu, _, idx = eng.dist_grad(q, want_idx=True)
-            d_orc, g_orc, _, oidx = orc.distance_repulsion_nn(m, q, fx["obs"], k, fx["ignored_links"])
-            ok = orc.rollout_relu_margin(m, q, fx["obs"], oidx) >= MARGIN
-            ok &= (idx == oidx).all(axis=1)
-            _, first = np.unique(q, axis=0, return_index=True)      # count distinct states only
-            n_flag += int((~ok[first]).sum()); n_tot += len(first)
+            d_orc, g_orc, mind_orc, oidx = orc.distance_repulsion_nn(m, q, fx["obs"], k, fx["ignored_links"])
+            same_idx = (idx == oidx).all(axis=1)
+            # identical dummy obstacles may swap places in the sort: harmless, identical rows
+            assert same_idx.all() or np.allclose(fx["obs"][idx[~same_idx]], fx["obs"][oidx[~same_idx]]), "closest obstacles differ"
+            clear = orc.rollout_relu_margin(m, q, fx["obs"], oidx) >= MARGIN
             gscale = float(np.abs(g_orc).max())
             # --- A: network -------------------------------------------------------------------
             assert_close(d_gpu, d_orc, RTOL, f"A distance, step {i}")
-            if ok.any():
-                assert_close(g_gpu[ok], g_orc[ok], 2e-5, f"A gradient, step {i}", floor=gscale)
-            assert rel_err(g_gpu, g_orc, floor=gscale) < 0.2, "A gradient (flagged rows, loose)"
+            own = np.ones(N, bool)      # rows whose gradient is the oracle's own mask assignment
+            for t in range(N):
+                e0 = np.abs(g_gpu[t] - g_orc[t]).max() / gscale
+                if e0 <= 2e-5:
+                    continue
+                assert not clear[t], f"A gradient, step {i}, rollout {t}: {e0:.2e} with a clear ReLU margin"
+                alts = orc.blended_gradient_alternatives(m, q[t], fx["obs"], oidx[t], MARGIN)
+                e_alt = np.abs(alts - g_gpu[t]).max(axis=1) / gscale
+                assert e_alt.min() <= 2e-5, (f"A gradient, step {i}, rollout {t}: no admissible ReLU mask assignment "
+                                              f"reproduces the GPU gradient ({len(alts)} tried, best {e_alt.min():.2e})")
+                own[t] = False
+            n_alt_rows += int((~own).sum()); n_rows += N
             # --- B: modulation kernel on identical inputs ----------------------------------------
             st = orc.modulation_step(q, fx["qf"], d_gpu, g_gpu, mu, sg, al, prm)
             edge = (np.abs(st["unorm"] - prm.norm_clamp) < 1e-5) | (np.abs(st["distance"]) < 1e-6) | \
@@ -120,17 +144,27 @@ def test_teacher_forced_steps(name):
             assert_close(r["kernel_val_all"][keep, 0], st["phi"][keep], RTOL, f"B rbf {i}")
             assert_close(r["qdot"][keep], st["u"][keep], RTOL, f"B modulated velocity {i}")
             # --- C: end to end vs the reference ---------------------------------------------------
-            okc = ok & keep
-            if i < H and okc.any():
-                assert_close((q + dt * r["qdot"])[okc], ref[okc, i, :], E2E_TOL, f"C next state, step {i}")
-            if i == 1 and okc.any():
-                assert_close(r["qdot"][okc], fx[pre + "qdot"][okc], E2E_TOL, "C qdot vs reference")
+            okc = own & keep
+            d_ref_raw = (fx[pre + "closest_dist_all"][:, i - 1] + np.float32(prm.dst_thr)).astype(np.float32)
+            delta = DIST_ULP * max(1.0, float(np.abs(mind_orc[mind_orc < 1e5]).max()))   # rounding scales with the network's outputs
+            lo, hi = _velocity_envelope(q, fx["qf"], d_ref_raw, (g_orc, g_gpu), mu, sg, al, prm, delta)
+            uscale = max(1.0, float(np.abs(hi).max()))
+            if okc.any():
+                u = r["qdot"][okc]
+                assert (u >= lo[okc] - RTOL * uscale).all() and (u <= hi[okc] + RTOL * uscale).all(), \
+                    f"C modulated velocity outside the reference's +-{delta:.1e} distance envelope, step {i}"
+                if i < H:      # the reference's own next state lies in the same envelope
+                    u_ref = (ref[okc, i, :] - q[okc]) / dt
+                    pad = 4e-6 * max(1.0, float(np.abs(ref).max())) / float(dt) + RTOL * uscale   # (q_next - q) / dt loses bits
+                    assert (u_ref >= lo[okc] - pad).all() and (u_ref <= hi[okc] + pad).all(), f"C reference outside its own envelope, step {i}"
+                if i == 1:
+                    uq = fx[pre + "qdot"][okc]
+                    assert (uq >= lo[okc] - RTOL * uscale).all() and (uq <= hi[okc] + RTOL * uscale).all(), "C reference qdot outside its envelope"
             assert_close(r["closest_dist_all"][:, 0], fx[pre + "closest_dist_all"][:, i - 1], RTOL, f"C distance {i}")
             if okc.any():
                 assert_close(r["normal"][okc, 0], fx[pre + "norm_basis_n"][okc, i - 1], 5e-5, f"C normal {i}")
                 assert_close(r["dot_products"][okc, 0], fx[pre + "dot_products"][okc, i - 1], 5e-5, f"C dot {i}")
             assert_close(r["kernel_val_all"][:, 0], fx[pre + "kernel_val_all"][:, i - 1], RTOL, f"C rbf {i}")
-    assert n_flag <= max(8, 0.25 * n_tot), f"too many flagged rollouts: {n_flag}/{n_tot}"
     eng.close()
 
 
