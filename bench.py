@@ -79,34 +79,50 @@ def flops_per_row(W):
     return 2 * sum(int(w.shape[0]) * int(w.shape[1]) for w in W)
 
 
-def cpu_baseline(w, W, b, obs, q0, qf, K, seed):
-    """The numpy oracle (a port of the reference's unfused op sequence) timed on a bounded sample of
-    the same workload on this box's host cores."""
+def cpu_baseline(w, W, b, obs, q0, qf, dh, qmin, qmax, K, H_full):
+    """The reference's path as unfused torch-CPU ops (oracle/torch_baseline.py, pinned to the numpy oracle and through it
+    to the reference's own outputs), timed on this box's host cores on a bounded sample of the same workload: 256 rollouts
+    x 4 steps x all obstacles, full planner iteration (sample + propagate + cost + update), 3 warm-up + 5 timed iterations,
+    median, at T = 8 threads (the setting of the survey's measurement of the reference itself) and
+    at T = all physical cores.  propagate is linear in the horizon and the rest independent of it, so the full-horizon
+    figure is N*H_full / (H_full/4 * t_propagate + t_rest)."""
+    import platform
+    import torch
     from oracle import omds_oracle as orc
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
+    from oracle.torch_baseline import TorchPlanner, time_iterations
     m = orc.Mlp([x.astype(np.float32) for x in W], [x.astype(np.float32) for x in b])
-    Ns, Hs = 128, 4
-    rng = np.random.RandomState(seed)
-    n = q0.shape[0]
-    mu = (q0 + (qf - q0) * rng.rand(Ns, K, 1) + 0.1 * rng.standard_normal((Ns, K, n))).astype(np.float32)
-    sg = np.full((Ns, K), w["sigma"], np.float32)
-    al = (w["alpha_s"] * rng.standard_normal((Ns, K, n))).astype(np.float32)
+    Ns, Hs = 256, 4
     prm = orc.Params(dst_thr=w["dst_thr"])
-    t0 = time.time()
-    reps = 0
-    while True:
-        orc.propagate(m, q0, qf, obs, N=Ns, H=Hs, dt=w["dt"], k=w["k"], ignored_links=w["ignored"], mu_tmp=mu,
-                      sigma_tmp=sg, alpha_tmp=al, prm=prm)
-        reps += 1
-        if time.time() - t0 > 10.0 or reps >= 20:
-            break
-    el = time.time() - t0
-    return {"value": Ns * Hs * reps / el, "unit": "rollout-steps/s", "cores": int(threads), "kind": "port",
-            "sample": f"numpy oracle propagate, {Ns} rollouts x {Hs} steps x {obs.shape[0]} obstacles, {reps} reps in {el:.1f}s"}
+    pl = TorchPlanner(m, obs, qf, dh, qmin, qmax, dt=w["dt"], k=w["k"], ignored_links=w["ignored"], prm=prm)
+    rng = np.random.RandomState(1234)
+    n = q0.shape[0]
+    s = (np.arange(K) + 0.5) / max(K, 1)
+    mu_c = (q0 + s[:, None] * (qf - q0) + 0.15 * rng.standard_normal((K, n))).astype(np.float32)
+    sg_c = np.full(K, w["sigma"], np.float32)
+    al_c = rng.standard_normal((K, n)).astype(np.float32)
+    cpu = platform.processor() or ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
+    except Exception:
+        pass
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except Exception:
+        phys = os.cpu_count() or 1
+    out = {"unit": "rollout-steps/s", "kind": "port", "cpu": cpu,
+           "sample": f"torch {torch.__version__} CPU, unfused op sequence of the reference, {Ns} rollouts x {Hs} steps x "
+                     f"{obs.shape[0]} obstacles, K = {K}, full iteration, 3 warm-up + 5 timed, median; H = {H_full} figure = "
+                     f"N*H / (H/{Hs} * t_propagate + t_rest)"}
+    for label, T in (("t8", min(8, phys)), ("tall", phys)):
+        tp, tr = time_iterations(pl, Ns, Hs, q0, mu_c, sg_c, al_c, w["alpha_s"], w["ker_thr"], T)
+        out[label] = {"threads": int(T), "propagate_only": Ns * Hs / tp, "full_iteration": Ns * Hs / (tp + tr),
+                      "full_iteration_at_workload_horizon": Ns * H_full / (H_full / Hs * tp + tr),
+                      "t_propagate_s": tp, "t_rest_s": tr}
+    out["value"] = out["tall"]["full_iteration_at_workload_horizon"]
+    out["cores"] = out["tall"]["threads"]
+    return out
 
 
 def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, dist, torch, time_fetch=False, prof=True):
@@ -193,7 +209,7 @@ def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, di
 
     scr = eng.screen_stats()
     eng.close()
-    return dict(scr=scr, w=w, W=W, b=b, obs=obs, q0=q0, qf=qf, N=N, H=H, K=K, el=el, p1_ms=p1_ms, p1_launches=p1_launches,
+    return dict(scr=scr, dh=dh, qmin=qmin, qmax=qmax, w=w, W=W, b=b, obs=obs, q0=q0, qf=qf, N=N, H=H, K=K, el=el, p1_ms=p1_ms, p1_launches=p1_launches,
                 p1_rows=p1_rows, p1_flops=p1_flops, p1_kernel=p1_kernel, fetch_ms=fetch_ms)
 
 
@@ -261,7 +277,7 @@ def main():
         if also is not None:
             out["also"] = also
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(w, W, b, obs, q0, qf, K, 7)
+            out["cpu_baseline"] = cpu_baseline(w, W, b, obs, q0, qf, r["dh"], r["qmin"], r["qmax"], K, H)
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -147,3 +147,34 @@ def test_kernel_candidates_and_add_kernel(name):
         assert P.n_kernels == int(fx["add_n_kernels"]) == K + 1
         assert np.array_equal(P.mu_c[:K + 1].numpy(), fx["add_mu_c"]) and np.array_equal(P.alpha_c[:K + 1].numpy(), fx["add_alpha_c"])
         assert np.array_equal(P.sigma_c[:K + 1].numpy(), fx["add_sigma_c"]) and np.array_equal(P.kernel_gammas[:K + 1].numpy(), fx["add_gammas"])
+
+
+def test_torch_baseline_matches_the_numpy_oracle():
+    """bench.py's CPU baseline (oracle/torch_baseline.py, the reference's unfused op sequence in torch-CPU) reproduces the
+    numpy oracle -- which the tests above pin to the reference's own outputs -- on a fixture's inputs: rollouts, cost, update."""
+    import torch
+    from oracle.torch_baseline import TorchPlanner, _t
+    fx = load("franka_sub40_K4")
+    m = orc.Mlp.from_npz(weights_path("franka"))
+    N, H, k, K = int(fx["N"]), int(fx["H"]), int(fx["k"]), int(fx["K"])
+    prm = orc.Params(dst_thr=float(fx["dst_thr"]), lin_thr=float(fx["lin_thr"]), p=int(fx["p"]))
+    pl = TorchPlanner(m, fx["obs"], fx["qf"], fx["dh_params"], fx["cost_q_min"], fx["cost_q_max"], dt=float(fx["dt"]), k=k,
+                      ignored_links=[int(l) for l in fx["ignored_links"]], prm=prm)
+    mu, sg, al = fx["it0_mu_tmp"][:, :K], fx["it0_sigma_tmp"][:, :K], fx["it0_alpha_tmp"][:, :K]
+    torch.set_num_threads(4)
+    with torch.no_grad():
+        traj, dist, kval, acts, qdot = pl.propagate(_t(fx["it0_q_cur"]), H, _t(mu), _t(sg), _t(al))
+        cost = pl.evaluate_costs(traj, dist)
+        mu_n, sg_n, al_n, w = pl.shift_policy_means(cost, kval, acts, _t(fx["it0_mu_c"][:K]), _t(fx["it0_sigma_c"][:K]),
+                                                    _t(fx["it0_alpha_c"][:K]), _t(mu), _t(sg), _t(al), 0.1, float(fx["ker_thr"]))
+    o = orc.propagate(m, fx["it0_q_cur"], fx["qf"], fx["obs"], N=N, H=H, dt=float(fx["dt"]), k=k,
+                      ignored_links=fx["ignored_links"], mu_tmp=mu, sigma_tmp=sg, alpha_tmp=al, prm=prm)
+    assert_close(qdot.numpy(), o.qdot, 2e-5, "qdot")
+    assert_close(dist.numpy()[:, 0], o.closest_dist_all[:, 0], RTOL, "distance")
+    assert_close(traj.numpy(), o.all_traj, 1e-2, "free-running rollouts")
+    oc, _ = orc.evaluate_costs(traj.numpy(), dist.numpy(), fx["qf"], fx["dh_params"], fx["cost_q_min"], fx["cost_q_max"])
+    assert_close(cost.numpy(), oc, 2e-5, "cost")
+    omu, osg, oal, omask, ow = orc.shift_policy_means(cost.numpy(), kval.numpy(), acts.numpy(), fx["it0_mu_c"][:K],
+                                                      fx["it0_sigma_c"][:K], fx["it0_alpha_c"][:K], mu, sg, al, 0.1, float(fx["ker_thr"]))
+    assert_close(w.numpy(), ow, 1e-5, "weights", floor=float(ow.max()))
+    assert_close(al_n.numpy(), oal, 2e-5, "alpha_c")
