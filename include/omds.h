@@ -150,6 +150,11 @@ OMDS_API int omds_mlp_forward_vjp(omds_ctx* ctx, const float* x, int batch, floa
 
 /* MPPI.get_cost -> Cost.evaluate_costs (MPPI.py:315-317, cost.py:13-22). cost_out [N] or NULL. */
 OMDS_API int omds_cost(omds_ctx* ctx, float* cost_out);
+/* Cost.evaluate_costs on caller-supplied tensors (cost.py:13-22 evaluates exactly what it is given): all_traj
+ * [B,H,n], closest_dist_all [B,H], B <= n_traj; cost_out [B].  Evaluated on the device; the context's own rollouts and
+ * their cost stay untouched.                                                                                   */
+OMDS_API int omds_cost_eval(omds_ctx* ctx, const float* all_traj, const float* closest_dist_all, int batch,
+                            float* cost_out);
 /* MPPI.shift_policy_means + TensorPolicyMPPI.update_policy (MPPI.py:331-345,
  * policy.py:88-113), single-shard form.  mu_c/sigma_c/alpha_c: in/out host means of the first K
  * kernels; mask_out [K] (1 = updated); weights_out [N] (normalised MPPI weights) or NULL.   */

@@ -28,8 +28,18 @@ class Cost:
         self._owner = owner
 
     def evaluate_costs(self, all_traj=None, closest_dist_all=None):
-        """Cost of the owner's CURRENT rollouts (cost.py:13-22), evaluated on the device.  The
-        tensor arguments are accepted for signature compatibility; the device copies are used."""
+        """cost.py:13-22, on the device.  Called the way MPPI.get_cost does -- with the owner's own rollout tensors (or no
+        arguments) -- it evaluates the device-resident rollouts in place; any other tensors (a subset, edited
+        trajectories, another planner's rollouts) are uploaded and evaluated as given, like the reference does."""
         if self._owner is None:
-            raise RuntimeError("Cost.evaluate_costs needs an owning MPPI (device-resident rollouts)")
-        return self._owner.get_cost()
+            raise RuntimeError("Cost.evaluate_costs needs an owning MPPI (its device context evaluates the cost)")
+        o = self._owner
+        own = (all_traj is None and closest_dist_all is None) or \
+              (all_traj is o.all_traj and closest_dist_all is o.closest_dist_all and bool(o._cache))
+        if own:
+            return o.get_cost()
+        tr = torch.as_tensor(all_traj, dtype=torch.float32)
+        if tr.ndim != 3 or tr.shape[1] != o.dt_H or tr.shape[2] != o.n_dof:
+            raise ValueError(f"all_traj must be [B, {o.dt_H}, {o.n_dof}], got {tuple(tr.shape)}")
+        o._push()
+        return torch.from_numpy(o._engine.cost_eval(tr.numpy(), torch.as_tensor(closest_dist_all, dtype=torch.float32).numpy()))

@@ -117,7 +117,7 @@ static void free_all(omds_ctx* ctx) {
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
                     ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
                     ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
-                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH};
+                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : ctx->mlp_allocs)
@@ -884,11 +884,14 @@ int omds_mlp_forward_vjp(omds_ctx* ctx, const float* x, int B, float* y, float* 
         for (int j = 0; j < d - n; ++j) xyzr[(size_t)r * 4 + j] = x[(size_t)r * d + n + j];
         ident[r] = r;
     }
-    float *d_xyzr = nullptr, *d_B = nullptr, *d_rad = nullptr;
-    CK(hipMalloc(&d_xyzr, (size_t)B * 16));
-    CK(hipMalloc(&d_B, (size_t)B * OMDS_WIDTH * 4));
-    CK(hipMalloc(&d_rad, (size_t)B * 4));
-    auto cleanup = [&]() { (void)hipFree(d_xyzr); (void)hipFree(d_B); (void)hipFree(d_rad); };
+    // per-row "obstacle" buffers of this entry point, allocated on first use for the context's capacity and kept
+    if (!ctx->d_vjp_xyzr) {
+        CK(hipMalloc(&ctx->d_vjp_xyzr, (size_t)cap * 16));
+        CK(hipMalloc(&ctx->d_vjp_B, (size_t)cap * OMDS_WIDTH * 4));
+        CK(hipMalloc(&ctx->d_vjp_rad, (size_t)cap * 4));
+    }
+    float *d_xyzr = ctx->d_vjp_xyzr, *d_B = ctx->d_vjp_B, *d_rad = ctx->d_vjp_rad;
+    auto cleanup = [&]() {};
     hipError_t e;
 #define CKL(expr) do { e = (expr); if (e != hipSuccess) { cleanup(); ctx->err = std::string(#expr) + ": " + hipGetErrorString(e); return OMDS_ERR_HIP; } } while (0)
     CKL(hipMemcpyAsync(d_xyzr, xyzr.data(), (size_t)B * 16, hipMemcpyHostToDevice, ctx->stream));
@@ -942,6 +945,41 @@ int omds_cost(omds_ctx* ctx, float* cost_out) {
         CK(hipMemcpyAsync(cost_out, ctx->d_cost, (size_t)ctx->cfg.n_traj * 4, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
     }
+    return OMDS_OK;
+}
+
+// Cost.evaluate_costs on caller-supplied tensors (cost.py:13-22 evaluates exactly its arguments): all_traj [B,H,n],
+// closest_dist_all [B,H] in the reference layout, B <= n_traj.  The device rollouts of the context are not touched.
+int omds_cost_eval(omds_ctx* ctx, const float* all_traj, const float* closest_dist_all, int B, float* cost_out) {
+    RoctxRange range("TAG: cost calculation");
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(all_traj && closest_dist_all && cost_out && B >= 1 && B <= ctx->cfg.n_traj, OMDS_ERR_INVALID_ARG,
+            "omds_cost_eval: need 1 <= batch <= n_traj and non-null arrays");
+    REQUIRE(ctx->have_ds && ctx->have_cost, OMDS_ERR_NOT_INITIALISED, "omds_cost_eval: call omds_set_ds and omds_set_cost first");
+    CK(hipSetDevice(ctx->dev));
+    const size_t H = ctx->cfg.horizon, n = ctx->cfg.n_dof, N = ctx->cfg.n_traj;
+    if (!ctx->d_evalT) CK(hipMalloc(&ctx->d_evalT, (H * n * N + H * N + N) * 4));
+    float* trajT = ctx->d_evalT;                 // [H][n][B]
+    float* distT = trajT + H * n * N;            // [H][B]
+    float* costv = distT + H * N;                // [B]
+    CK(hipMemcpyAsync(ctx->d_stage, all_traj, (size_t)B * H * n * 4, hipMemcpyHostToDevice, ctx->stream));
+    omds_launch_transpose(ctx->stream, ctx->d_stage, trajT, B, (int)(H * n));
+    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipMemcpyAsync(ctx->d_stage, closest_dist_all, (size_t)B * H * 4, hipMemcpyHostToDevice, ctx->stream));
+    omds_launch_transpose(ctx->stream, ctx->d_stage, distT, B, (int)H);
+    CostArgs a{};
+    a.N = B; a.H = (int)H; a.n = (int)n;
+    a.trajT = trajT; a.distT = distT; a.cost = costv;
+    a.terms = ctx->prm.cost_terms;
+    std::memcpy(a.qf, ctx->qf, sizeof(a.qf));
+    std::memcpy(a.qmin, ctx->qmin, sizeof(a.qmin));
+    std::memcpy(a.qmax, ctx->qmax, sizeof(a.qmax));
+    std::memcpy(a.dh, ctx->dh, sizeof(a.dh));
+    std::memcpy(a.goal_fk, ctx->goal_fk, sizeof(a.goal_fk));
+    omds_launch_cost(ctx->stream, a);
+    CK(hipGetLastError());
+    CK(hipMemcpyAsync(cost_out, costv, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
     return OMDS_OK;
 }
 

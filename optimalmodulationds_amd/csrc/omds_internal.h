@@ -139,6 +139,10 @@ struct omds_ctx {
     float* d_dscr = nullptr;     // tanh only: [hidden layers][N*k padded to 32][256] activation derivatives
     float* d_dist = nullptr;     // [N]
     float* d_nngrad = nullptr;   // [N][n]
+    float* d_evalT = nullptr;    // omds_cost_eval scratch (first use): caller tensors in SoA + their cost
+    float* d_vjp_xyzr = nullptr; // omds_mlp_forward_vjp scratch (first use): per-row points, their layer-1 halves, zero radii
+    float* d_vjp_B = nullptr;
+    float* d_vjp_rad = nullptr;
     // cost / reduction
     float* d_cost = nullptr;     // [N]
     float* d_w = nullptr;        // [N] unnormalised weights

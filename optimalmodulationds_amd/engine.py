@@ -155,6 +155,16 @@ class Engine:
         self._ck(self.lib.omds_cost(self.h, L.fptr(c)))
         return c
 
+    def cost_eval(self, all_traj, closest_dist_all):
+        """Cost.evaluate_costs on arbitrary [B,H,n] / [B,H] tensors (device evaluation, any B: chunks of N)."""
+        tr = L.f32(all_traj).reshape(-1, self.H, self.n)
+        di = L.f32(closest_dist_all).reshape(-1, self.H)
+        out = np.zeros(tr.shape[0], np.float32)
+        for s in range(0, tr.shape[0], self.N):
+            a, b, o = np.ascontiguousarray(tr[s:s + self.N]), np.ascontiguousarray(di[s:s + self.N]), out[s:s + self.N]
+            self._ck(self.lib.omds_cost_eval(self.h, L.fptr(a), L.fptr(b), a.shape[0], L.fptr(o)))
+        return out
+
     def weighted_update(self, rate, ker_thr, mu_c, sigma_c, alpha_c, want_weights=False):
         K = self.K
         # copies: the C function updates the means in place and must not alias the caller's arrays

@@ -120,10 +120,28 @@ class MPPI:
         self.obs = torch.as_tensor(_np(obs)).reshape(-1, 4)
         self.n_obs = self.obs.shape[0]
         if self.n_obs > self._max_obs:
-            raise ValueError(f"{self.n_obs} obstacles exceed the context capacity {self._max_obs}; "
-                             f"construct MPPI with max_obs >= {self.n_obs}")
+            self._grow_obstacle_capacity(self.n_obs)       # the reference takes any obstacle count at any time
         self._engine.set_obstacles(self.obs.numpy())
         return 0
+
+    def _grow_obstacle_capacity(self, n_obs):
+        """A larger device context (obstacle buffers are sized at creation) carrying over the network, the parameters
+        and the current policy samples; device rollouts of the old context are dropped (the next propagate refills them)."""
+        old = self._engine
+        samples = old.get_policy_samples() if old.K else None
+        self._max_obs = int(max(2 * n_obs, 64))
+        new = Engine(self.n_dof, self.N_traj, self.dt_H, self.n_closest_obs, self._max_obs, device=self._device)
+        m = self.nn_model.model
+        new.set_mlp(m.W, m.b, m.act)
+        new.params = old.params
+        new.push_params()
+        if samples is not None:
+            new.set_policy_samples(*samples)
+        self._engine = new
+        self.Policy._engine = new
+        self._cache = {}
+        self.cur_cost = None
+        old.close()
 
     # ---- parameters -> device ----------------------------------------------------------------------
     def _push(self):

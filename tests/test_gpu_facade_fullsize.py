@@ -313,3 +313,144 @@ def test_example_drivers_run():
     mppi2, n_iter = mods["standalone_planar2d"].main(max_iter=60, quiet=True)
     d0 = float(torch.norm(torch.tensor([-3.14, 0.0]) - torch.tensor([3.14, 0.0])))
     assert float(torch.norm(mppi2.q_cur - torch.tensor([3.14, 0.0]))) < d0        # it moves towards the goal
+
+
+def test_planner_payload_round_trip_into_the_integrator():
+    """frankaPlanner.py:166-179 -> (pickle) -> frankaIntegratorSwitching.py:102-117: the policy dictionary a planner on
+    this package publishes is consumed by an N = 1, H = 2 integrator MPPI; its tick equals the oracle's step under the same
+    policy, and the state dictionary has the reference's keys."""
+    import pickle
+    from optimalmodulationds_amd import MPPI, LinDS, RobotSdfCollisionNet, scenes
+    from optimalmodulationds_amd.payloads import integrator_tick, kernel_fk, planner_payload
+    mppi, nn_model = _franka_mppi(N=64, H=6)
+    # a planner iteration with two kernels installed the way add_kernel does it
+    all_kernel_fk = []
+    for c in (0.3, 0.6):
+        q_k = mppi.q0 + c * (mppi.qf - mppi.q0)
+        d, g = mppi.distance_repulsion_nn(q_k[None])
+        E = torch.linalg.qr(torch.cat((g.reshape(-1, 1), torch.eye(7)[:, 1:]), dim=1))[0]
+        mppi.Policy.add_kernel(q_k, d[0], E)
+        all_kernel_fk.append(kernel_fk(q_k, mppi.dh_params))
+    mppi.Policy.sample_policy()
+    mppi.propagate()
+    cost = mppi.get_cost()
+    mppi.shift_policy_means()
+    data = pickle.loads(pickle.dumps(planner_payload(mppi, cost, all_kernel_fk)))       # the wire format is a pickle
+    K = mppi.Policy.n_kernels
+    assert set(data) == {'n_kernels', 'mu_c', 'alpha_c', 'sigma_c', 'norm_basis', 'kernel_fk', 'best_traj_fk'}
+    assert data['n_kernels'] == K == 2 and data['mu_c'].shape == (K, 7) and data['norm_basis'].shape == (K, 7, 7)
+    assert data['best_traj_fk'].shape == (1, 14, 3) and data['kernel_fk'][0].shape == (12, 3)
+    best = int(torch.argmin(cost))
+    from optimalmodulationds_amd.fk_num import numeric_fk_model
+    assert torch.allclose(data['best_traj_fk'][0], numeric_fk_model(mppi.all_traj[best, -1], mppi.dh_params, 2)[0].reshape(-1, 3), atol=1e-6)
+    # integrator side
+    dh = mppi.dh_params
+    step = MPPI(mppi.q0, mppi.qf, dh, mppi.obs, 0.01, 2, 1, [LinDS(mppi.qf), LinDS(mppi.q0)], dh[:, 2], nn_model, 5)
+    step.dst_thr = 0.03
+    step.Policy.alpha_s *= 0
+    step.Policy.p = mppi.Policy.p
+    q_before = step.q_cur.clone()
+    state = integrator_tick(step, data, mppi.obs, 0.01)
+    assert set(state) == {'q', 'dq', 'ds_idx'} and state['q'].shape == (7,) and state['dq'].shape == (7,) and state['ds_idx'] == 0
+    assert step.Policy.n_kernels == K and torch.equal(step.Policy.mu_c[:K], data['mu_c'])
+    assert torch.equal(step.Policy.kernel_obstacle_bases[:K], data['norm_basis'])
+    m = orc.Mlp.from_npz(weights_path("franka"))
+    o = orc.propagate(m, q_before.numpy(), mppi.qf.numpy(), mppi.obs.numpy(), N=1, H=2, dt=0.01, k=5, ignored_links=[0, 1, 2],
+                      mu_tmp=data['mu_c'].numpy()[None], sigma_tmp=data['sigma_c'].numpy()[None], alpha_tmp=data['alpha_c'].numpy()[None],
+                      prm=orc.Params(dst_thr=0.03))
+    assert_close(state['dq'].numpy(), o.qdot[0], 2e-4, "integrator dq vs oracle")
+    assert torch.allclose(state['q'], torch.clamp(q_before + state['dq'] * 0.01, step.Cost.q_min, step.Cost.q_max))
+
+
+def test_cost_of_foreign_tensors_and_obstacle_growth():
+    """Cost.evaluate_costs evaluates the tensors it is given (cost.py:13-22), not only the owner's rollouts; and
+    update_obstacles accepts a set larger than anything seen so far (MPPI.py:347-350, frankaPlanner.py:126)."""
+    from optimalmodulationds_amd import scenes
+    small = scenes.shelf_scene()[:20]
+    mppi, _ = _franka_mppi(N=64, H=6, obs=small)
+    assert mppi._max_obs < 294
+    mppi.Policy.sample_policy()
+    all_traj, dist_all, *_ = mppi.propagate()
+    c_own = mppi.Cost.evaluate_costs(all_traj, dist_all)
+    oc, _ = orc.evaluate_costs(all_traj.numpy(), dist_all.numpy(), mppi.qf.numpy(), mppi.dh_params.numpy(),
+                               mppi.Cost.q_min.numpy(), mppi.Cost.q_max.numpy())
+    assert_close(c_own.numpy(), oc, RTOL, "own rollouts")
+    # edited trajectories / a subset: evaluated as given
+    traj2 = all_traj[5:40].clone()
+    traj2[:, -1, :] += 0.05
+    dist2 = dist_all[5:40].clone()
+    dist2[::3, 2] = -0.01
+    c2 = mppi.Cost.evaluate_costs(traj2, dist2)
+    oc2, _ = orc.evaluate_costs(traj2.numpy(), dist2.numpy(), mppi.qf.numpy(), mppi.dh_params.numpy(),
+                                mppi.Cost.q_min.numpy(), mppi.Cost.q_max.numpy())
+    assert c2.shape == (35,)
+    assert_close(c2.numpy(), oc2, RTOL, "foreign tensors")
+    assert torch.equal(mppi.Cost.evaluate_costs(all_traj, dist_all), c_own)        # the device rollouts were not disturbed
+    # a much larger obstacle set arrives mid-loop
+    big_obs = torch.tensor(scenes.shelf_scene())
+    mu, sg, al = (x.clone() for x in (mppi.Policy.mu_tmp, mppi.Policy.sigma_tmp, mppi.Policy.alpha_tmp))
+    mppi.update_obstacles(big_obs)
+    assert mppi._max_obs >= 294 and mppi.n_obs == 294
+    all_traj, dist_all, *_ = mppi.propagate()
+    m = orc.Mlp.from_npz(weights_path("franka"))
+    K = mppi.Policy.n_kernels
+    o = orc.propagate(m, mppi.q_cur.numpy(), mppi.qf.numpy(), big_obs.numpy(), N=64, H=6, dt=0.5, k=5, ignored_links=[0, 1, 2],
+                      mu_tmp=mu[:, :K].numpy(), sigma_tmp=sg[:, :K].numpy(), alpha_tmp=al[:, :K].numpy(), prm=orc.Params(dst_thr=0.01))
+    assert_close(mppi.qdot.numpy(), o.qdot, 2e-4, "qdot after the capacity grew")
+
+
+def _basis_tol(ghat0):
+    """QR of [g, e_2 .. e_n] is a Householder reflection built from g + sign(g_0) |g| e_1: its tangent columns move by
+    ~ delta(g) / (1 + |g_0|/|g|) -- benign -- except through the sign choice at g_0 = 0; column 0 is overwritten by g."""
+    return np.minimum(2e-2, 5e-5 * (1.0 + 1.0 / np.maximum(np.abs(ghat0), 1e-6)))
+
+
+@pytest.mark.parametrize("name", ["franka_shelf_K6", "franka_sub40_K4", "planar7_K4", "planar2_c1_K3"])
+def test_norm_basis_matches_the_reference_qr(name):
+    """MPPI.norm_basis (MPPI.py:122-127): the facade's lazily completed basis vs the reference's own [N,H,n,n] tensor,
+    every horizon step restarted from the reference's state (so that the normals are comparable entry by entry)."""
+    from optimalmodulationds_amd.mppi import _qr_complete
+    from test_gpu_parity import _engine
+    fx = load(name)
+    if "it0_norm_basis" not in fx:
+        pytest.skip("fixture without the full basis")
+    eng, m = _engine(fx, H=1)
+    ref_nb, ref_traj = fx["it0_norm_basis"], fx["it0_all_traj"]
+    K = int(fx["K"])
+    eng.set_policy_samples(fx["it0_mu_tmp"][:, :K], fx["it0_sigma_tmp"][:, :K], fx["it0_alpha_tmp"][:, :K])
+    worst = 0.0
+    for h in range(int(fx["H"])):
+        eng.propagate(np.ascontiguousarray(ref_traj[:, h, :]))
+        normal = eng.get_rollouts(want=("normal",))["normal"][:, 0]            # [N, n]
+        E = _qr_complete(normal).numpy()
+        R = ref_nb[:, h]
+        finite = np.isfinite(R).all(axis=(1, 2)) & np.isfinite(E).all(axis=(1, 2))
+        assert finite.mean() > 0.9
+        assert np.abs(E[finite][:, :, 0] - R[finite][:, :, 0]).max() <= 5e-5, "column 0 = the obstacle normal"
+        tol = _basis_tol(R[finite][:, 0, 0])
+        err = np.abs(E[finite] - R[finite]).max(axis=(1, 2))
+        assert (err <= tol).all(), (h, float(err.max()), float(tol[np.argmax(err - tol)]))
+        worst = max(worst, float(err.max()))
+        eye = np.einsum('tij,til->tjl', E[finite], E[finite])
+        assert np.abs(eye - np.eye(E.shape[-1])).max() < 2e-4
+    eng.close()
+
+
+def test_update_kernel_normal_bases_matches_the_reference():
+    """MPPI.update_kernel_normal_bases (MPPI.py:284-304) after the obstacles moved: Policy.kernel_obstacle_bases vs the
+    tensor the reference produced for the same kernel centres and obstacles (tests/golden/bases_franka.npz,
+    tools/make_golden_bases.py)."""
+    fx = load("bases_franka")
+    mppi, _ = _franka_mppi(N=8, H=2)
+    K = int(fx["K"])
+    mppi.Policy.n_kernels = K
+    mppi.Policy.mu_c[:K] = torch.tensor(fx["mu_c"])
+    mppi.update_obstacles(torch.tensor(fx["obs"]))
+    mppi.update_kernel_normal_bases()
+    B = mppi.Policy.kernel_obstacle_bases[:K].numpy()
+    d, g = mppi.distance_repulsion_nn(mppi.Policy.mu_c[:K])
+    assert_close(d.numpy(), fx["distance"], RTOL, "distance at the kernel centres")
+    assert_close(g.numpy(), fx["nn_grad"], 1e-4, "gradient at the kernel centres", floor=float(np.abs(fx["nn_grad"]).max()))
+    assert np.abs(B[:, :, 0] - fx["bases"][:, :, 0]).max() <= 5e-5
+    err = np.abs(B - fx["bases"]).max(axis=(1, 2))
+    assert (err <= _basis_tol(fx["bases"][:, 0, 0])).all(), err
