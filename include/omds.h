@@ -52,8 +52,12 @@ typedef struct {
     int32_t max_obs;       /* capacity of the obstacle buffer                              */
     int32_t n_closest;     /* k: n_closest_obs                                             */
     int32_t device;        /* HIP device ordinal                                           */
-    int32_t flags;         /* reserved, 0                                                  */
+    int32_t flags;         /* OMDS_FLAG_* bits, 0 = defaults                               */
 } omds_config;
+
+/* omds_config.flags: the generic step of omds_propagate -- five launches (k_pass1, k_topk, k_pass2, k_modulate,
+ * k_rollout_layer1), the only one for n_dof other than 2 and 7 -- instead of the two-launch k_pass1 + k_tail step. */
+#define OMDS_FLAG_UNFUSED_STEP 1
 
 /* The constants the reference hard-codes inside propagate() (MPPI.py:117-217,277) and
  * LinDS (LinDS.py:9), as parameters; omds_default_params() fills the reference values.   */

@@ -32,6 +32,7 @@ class OmdsParams(C.Structure):
                 ("variant", C.c_uint32), ("cost_terms", C.c_uint32)]
 
 
+FLAG_UNFUSED_STEP = 1   # omds_config.flags
 # omds_params.variant / cost_terms bits (include/omds.h)
 VARIANT_KVAL_TIMES_ACT = 1
 VARIANT_NO_BASE_MASK = 2

@@ -11,11 +11,11 @@ from . import _lib as L
 
 
 class Engine:
-    def __init__(self, n_dof, n_traj, horizon, n_closest, max_obs, n_kernel_max=50, device=0):
+    def __init__(self, n_dof, n_traj, horizon, n_closest, max_obs, n_kernel_max=50, device=0, flags=0):
         self.lib = L.load()
         self.n, self.N, self.H, self.k = int(n_dof), int(n_traj), int(horizon), int(n_closest)
         self.max_obs, self.Kmax, self.device = int(max_obs), int(n_kernel_max), int(device)
-        cfg = L.OmdsConfig(self.n, self.N, self.H, self.Kmax, self.max_obs, self.k, self.device, 0)
+        cfg = L.OmdsConfig(self.n, self.N, self.H, self.Kmax, self.max_obs, self.k, self.device, int(flags))
         h = C.c_void_p()
         rc = self.lib.omds_create(C.byref(cfg), C.byref(h))
         if rc != 0:

@@ -13,11 +13,11 @@ from oracle import omds_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def _engine(fx, H=None, N=None):
+def _engine(fx, H=None, N=None, flags=0):
     from optimalmodulationds_amd.engine import Engine
     m = orc.Mlp.from_npz(weights_path(str(fx["kind"])))
     n = int(fx["q0"].shape[0])
-    eng = Engine(n, int(N or fx["N"]), int(H or fx["H"]), int(fx["k"]), max_obs=max(64, 2 * fx["obs"].shape[0]))
+    eng = Engine(n, int(N or fx["N"]), int(H or fx["H"]), int(fx["k"]), max_obs=max(64, 2 * fx["obs"].shape[0]), flags=flags)
     eng.set_mlp(m.W, m.b, act=m.act)
     eng.set_obstacles(fx["obs"])
     p = eng.params
@@ -84,6 +84,10 @@ def _velocity_envelope(q, qf, d_raw, grads, mu, sg, al, prm, delta):
 
 @pytest.mark.parametrize("name", SCENARIOS)
 def test_teacher_forced_steps(name):
+    _check_teacher_forced(name, 0)
+
+
+def _check_teacher_forced(name, flags):
     """Every horizon step restarted from the reference's own state (H=1, per-rollout starts) and
     checked in three stages, every row at north_star's 1e-5 (2e-5 for gradients):
       A  network:    distance vs the oracle (1e-5); blended gradient vs the oracle (2e-5) -- for a row with a hidden
@@ -96,7 +100,7 @@ def test_teacher_forced_steps(name):
                      another admissible mask assignment than the oracle's are covered by A + B only: which assignment
                      the reference's BLAS happened to take is not recorded in its outputs)"""
     fx = load(name)
-    eng, m = _engine(fx, H=1)
+    eng, m = _engine(fx, H=1, flags=flags)
     H, k, N = int(fx["H"]), int(fx["k"]), int(fx["N"])
     dt = np.float32(fx["dt"])
     prm = orc.Params(dst_thr=float(fx["dst_thr"]), lin_thr=float(fx["lin_thr"]), p=int(fx["p"]))
@@ -170,8 +174,12 @@ def test_teacher_forced_steps(name):
 
 @pytest.mark.parametrize("name", SCENARIOS)
 def test_free_running_cost_update(name):
+    _check_free_running(name, 0)
+
+
+def _check_free_running(name, flags):
     fx = load(name)
-    eng, m = _engine(fx)
+    eng, m = _engine(fx, flags=flags)
     N, H, K = int(fx["N"]), int(fx["H"]), int(fx["K"])
     for it in range(int(fx["n_iter"])):
         pre = f"it{it}_"
@@ -292,19 +300,13 @@ def test_error_paths():
     eng.close()
 
 
-def test_unfused_step_path_still_passes():
-    """The five-kernel step (k_topk / k_pass2 / k_modulate / k_rollout_layer1; the generic path for n_dof
-    other than 2 and 7) is selected with OMDS_FUSED_TAIL=0 and must pass the same staged parity tests."""
-    import os
-    import subprocess
-    import sys
-    from helpers import ROOT
-    env = dict(os.environ, OMDS_FUSED_TAIL="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu",
-                        "-k", "(teacher_forced or free_running) and (franka_shelf_K6 or planar2_c1_K3 or franka_tanh)"],
-                       env=env, capture_output=True, text=True, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "6 passed" in r.stdout, r.stdout[-500:]
+@pytest.mark.parametrize("name", ["franka_shelf_K6", "planar2_c1_K3", "franka_tanh_shelf_K4"])
+def test_unfused_step_path(name):
+    """The five-kernel step (k_pass1 / k_topk / k_pass2 / k_modulate / k_rollout_layer1; the generic path for n_dof other
+    than 2 and 7), selected per context with OMDS_FLAG_UNFUSED_STEP, passes the same staged parity checks."""
+    from optimalmodulationds_amd._lib import FLAG_UNFUSED_STEP
+    _check_teacher_forced(name, FLAG_UNFUSED_STEP)
+    _check_free_running(name, FLAG_UNFUSED_STEP)
 
 
 @pytest.mark.gpu
