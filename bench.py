@@ -41,6 +41,8 @@ WORKLOADS = {
                                    sigma=1.0, ignored=[0, 1, 2], dynamic=True),
 }
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 FLOP/clk
+MFMA_F16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (v_mfma_f32_32x32x16_f16), never the 2:1-sparsity figure
+PEAK_OF = {"k_pass1": ("f32 MFMA", MFMA_F32_PEAK_TFLOPS), "k_screen": ("f16 MFMA, f32 accumulate", MFMA_F16_PEAK_TFLOPS)}
 
 
 def setup(wl, rank):
@@ -64,12 +66,12 @@ def setup(wl, rank):
     return w, W, b, obs, q0, qf, dh, qmin, qmax
 
 
-def pmc_traffic(workload):
-    """HBM bytes per k_pass1 launch from the committed rocprofv3 PMC summary of this workload
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this workload
     (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)[workload]["k_pass1"]["traffic_bytes"]
+            return json.load(f)[workload][kernel]["traffic_bytes"]
     except Exception:
         return None
 
@@ -120,8 +122,9 @@ def cpu_baseline(w, W, b, obs, q0, qf, dh, qmin, qmax, K, H_full):
         out[label] = {"threads": int(T), "propagate_only": Ns * Hs / tp, "full_iteration": Ns * Hs / (tp + tr),
                       "full_iteration_at_workload_horizon": Ns * H_full / (H_full / Hs * tp + tr),
                       "t_propagate_s": tp, "t_rest_s": tr}
-    out["value"] = out["tall"]["full_iteration_at_workload_horizon"]
-    out["cores"] = out["tall"]["threads"]
+    best = max(("t8", "tall"), key=lambda l: out[l]["full_iteration_at_workload_horizon"])   # more threads are not always faster here
+    out["value"] = out[best]["full_iteration_at_workload_horizon"]
+    out["cores"] = out[best]["threads"]
     return out
 
 
@@ -257,6 +260,7 @@ def main():
                 "ms_per_step": 1e3 * r2["el"] / 5}
     if rank == 0:
         ach = r["p1_flops"] / (p1_ms * 1e-3) / 1e12 if p1_ms > 0 else 0.0
+        pipe, peak = PEAK_OF.get(r["p1_kernel"], PEAK_OF["k_pass1"])
         out = {
             "metric": "modulated rollout-steps/sec", "value": world * N * H * args.steps / el,
             "unit": "rollout-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -265,8 +269,8 @@ def main():
             "config": {"workload": args.workload, "rollouts_per_gpu": N, "horizon": H, "obstacles": int(obs.shape[0]),
                        "n_closest": w["k"], "active_kernels": K, "network": "x".join(str(x.shape[1]) for x in W) + f"x{W[-1].shape[0]} relu (shipped reference weights)",
                        "parallelism": f"rollout-sharded x{world}", "collectives": (("gloo-host (--share-gpu test mode)" if args.share_gpu else "rccl") if use_dist else "none")},
-            "roofline": {"bound": "mfma", "kernel": r["p1_kernel"], "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(args.workload),
+            "roofline": {"bound": "mfma", "kernel": r["p1_kernel"], "pipe": pipe, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                         "frac": ach / peak, "traffic": pmc_traffic(args.workload, r["p1_kernel"]),
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, committed; not re-collected by this run)",
                          "launches": int(p1_launches), "avg_launch_ms": p1_ms / max(p1_launches, 1),
                          "flops_per_launch": r["p1_flops"] / max(p1_launches, 1)},

@@ -227,7 +227,7 @@ OMDS_API int omds_apply_update(int n_kernels, int n_dof, int horizon, const floa
 /* Screening of pass 1 (screen_kernel.hip).  The N*O first-pass evaluations of MPPI.distance_repulsion_nn only feed the
  * sort that picks the k closest obstacles (MPPI.py:245-253); omds_propagate may therefore evaluate them in fp16 and
  * re-evaluate in fp32 only the candidates {o : Da(o) <= k-th smallest Da + 2 eps}, which contain the fp32 top-k (ties
- * included) whenever |Da - D| <= eps.  eps is calibrated per network (4 x the largest error over a calibration batch)
+ * included) whenever |Da - D| <= eps.  eps is calibrated per network (8 x the largest error over a calibration batch)
  * and re-measured on every candidate of every propagate; if the margin ever falls below 2 x the propagate is redone
  * in fp32.  The distances and gradients a step uses always come from the fp32 pass 2.  omds_dist_grad always uses the
  * fp32 pass 1.  mode: -1 auto (on for ReLU networks when n_traj * n_obs >= 65536; env OMDS_SCREEN=0|1 overrides),

@@ -70,6 +70,7 @@ struct ScreenArgs {
     OmdsDivisor odiv;
     int nhh, C;
     float out_div;
+    int res_tiles;           // tiles per workgroup (capacity of the result buffer in LDS)
     unsigned long long* tl;  // diagnostic (OMDS_SCREEN_TL=1): [workgroup][8] s_memtime stamps, nullptr otherwise
     int dbg;                 // timing experiments only (OMDS_SCREEN_DBG): 1 = no weight streaming after the prologue,
                              // 2 = no layer-1 loads, 4 = no per-slice wait + barrier
@@ -124,15 +125,15 @@ __device__ __forceinline__ AGroup read_group(const unsigned char* slot_lane, int
 
 #define SC_TL(i) do { if (a.tl && threadIdx.x == 0 && it == 0) a.tl[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 
-struct TileRow { unsigned t, o; bool valid; };
-__device__ __forceinline__ TileRow tile_row(const ScreenArgs& a, long long tile, int wave, int b) {
+// pair (rollout t, obstacle o) of this lane in a tile; rows past the end (also: the prefetch of a non-existent next tile)
+// clamp to the last pair and are not stored.  Plain scalars on purpose: a struct carried around the tile loop went through
+// scratch memory
+__device__ __forceinline__ void tile_row(const ScreenArgs& a, long long tile, int wave, int b, unsigned& t, unsigned& o, bool& valid) {
     long long row = tile * SC_ROWS + wave * 32 + b;
-    TileRow r;
-    r.valid = row < a.total_rows;
-    if (!r.valid) row = a.total_rows - 1;   // tiles past the end (prefetch of a non-existent next tile) clamp too
-    r.t = a.odiv.div((unsigned)row);
-    r.o = (unsigned)row - r.t * (unsigned)a.O;
-    return r;
+    valid = row < a.total_rows;
+    if (!valid) row = a.total_rows - 1;
+    t = a.odiv.div((unsigned)row);
+    o = (unsigned)row - t * (unsigned)a.O;
 }
 
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
@@ -146,9 +147,11 @@ __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
     // workgroup form (OMDS_SCREEN_TL): of 57 kcycles per tile slot 14 were the refill gap between two workgroups of a CU,
     // 12 the layer-1 operand loads and first-slice latency, and only 29 the slice loop.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned char* ring = smem_raw;                                            // [SC_RING][SC_SLICE]
-    float* biasL = reinterpret_cast<float*>(smem_raw + SC_RING * SC_SLICE);    // [NHH+2][256]: layer 1, hidden->hidden, last
-    float* resL = biasL + (NHH + 2) * OMDS_WIDTH;                              // [tiles of this workgroup][SC_ROWS]
+    // the small tables first: their ds_read offsets then fit the 16-bit immediate from ONE base register (behind the 64 KB
+    // ring hipcc kept a base VGPR per 256-byte window alive across the tile loop, and spilled them)
+    float* biasL = reinterpret_cast<float*>(smem_raw);                         // [NHH+2][256]: layer 1, hidden->hidden, last
+    float* resL = biasL + (NHH + 2) * OMDS_WIDTH;                              // [a.res_tiles][SC_ROWS]
+    unsigned char* ring = reinterpret_cast<unsigned char*>(resL + a.res_tiles * SC_ROWS);   // [SC_RING][SC_SLICE]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = lane & 31, half = lane >> 5;
     constexpr int S = NHH * 8 + 2;                 // slice steps of a tile: layer 1, 8 per hidden->hidden layer, the last layer
@@ -168,6 +171,7 @@ __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
         if (SC_PW > 2) { dma16<2048>(src, lane16, dst); dma16<3072>(src, lane16, dst); }
     };
     for (int i = tid; i < (NHH + 2) * OMDS_WIDTH; i += SC_NT) biasL[i] = a.bias[i];
+    for (int i = tid; i < my_tiles * SC_ROWS; i += SC_NT) resL[i] = __builtin_inff();   // the two lane-halves of a pair min into it
     __syncthreads();   // bias table visible; nothing of the ring is in flight yet (hipcc's fence would drain it)
 #pragma unroll
     for (int s0 = 0; s0 < SC_DIST; ++s0) issue(s0 % S, s0 % SC_RING);
@@ -178,17 +182,21 @@ __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
     // (buffer loads: SGPR descriptor + 32-bit lane offset + scalar piece offset -- no 64-bit per-lane pointers to keep alive)
     const __amdgpu_buffer_rsrc_t fq_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.FqH), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t fp_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.FpH), 0, 0x7fffffff, 0x00020000);
-    auto load_inputs = [&](const TileRow& r, u4 (&raw)[4]) {
-        const int vq = (int)((half * (unsigned)a.ldFq + r.t) * 16u), vp = (int)((half * (unsigned)a.ldFp + r.o) * 16u);
+    auto load_inputs = [&](unsigned rt, unsigned ro, u4 (&raw)[4]) {
+        unsigned hh = (unsigned)half;
+        asm volatile("" : "+v"(hh));   // opaque: keeps hipcc from hoisting half * ld out of the tile loop into VGPRs it then spills
+        const int vq = (int)((hh * (unsigned)a.ldFq + rt) * 16u), vp = (int)((hh * (unsigned)a.ldFp + ro) * 16u);
         raw[0] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(fq_rs, vq, 0, 0));
         raw[1] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(fp_rs, vp, 0, 0));
         raw[2] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(fq_rs, vq, a.ldFq * 32, 0));
         raw[3] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(fp_rs, vp, a.ldFp * 32, 0));
     };
-    TileRow row = tile_row(a, blockIdx.x, wave, b);
+    unsigned row_t, row_o;
+    bool row_valid;
+    tile_row(a, blockIdx.x, wave, b, row_t, row_o, row_valid);
     u4 raw[4];
-    load_inputs(row, raw);
-    float rad = a.radius[row.o];
+    load_inputs(row_t, row_o, raw);
+    float rad = a.radius[row_o];
 
     const unsigned char* ring_lane = ring + lane * 16;
     // accumulators start at the bias.  C layout: register r = 4j + i <-> output row 32 fb + 8 j + 4 half + i
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
 #endif
         };
         auto slot_ptr = [&](int s) { return ring_lane + ((sigma0 + s) & (SC_RING - 1)) * SC_SLICE; };
-        const bool valid = row.valid;
+        const bool valid = row_valid;
         h8 in[2];
         {
             const u4 i0 = raw[0] | raw[1], i1 = raw[2] | raw[3];
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
         h8 nxt[16];
         float dmin = __builtin_inff();
         f32x16 acc = read_bias(1, 0);
-        TileRow nrow = row;
+        unsigned nrow_o = row_o;
 #pragma unroll
         for (int s = 1; s < S; ++s) {
             const int l = (s - 1) >> 3, fb = (s - 1) & 7;      // hidden->hidden layer l (bias row l + 1), output row block fb
@@ -289,8 +297,9 @@ __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
                 const AGroup pre = (g < 3) ? read_group(sl, g + 1) : read_group(sl_next, 0);
                 if (g == 2 && !last) acc_next = (s + 1 == S - 1) ? read_bias(NHH + 1, 0) : read_bias(((s) >> 3) + 1, s & 7);
                 if (s == S - 2 && g == 2) {   // the next tile's inputs, fetched under the last two steps of this one
-                    nrow = tile_row(a, blockIdx.x + (long long)(it + 1) * gridDim.x, wave, b);
-                    load_inputs(nrow, raw);
+                    unsigned nt;
+                    tile_row(a, blockIdx.x + (long long)(it + 1) * gridDim.x, wave, b, nt, nrow_o, row_valid);
+                    load_inputs(nt, nrow_o, raw);
                 }
 #ifdef OMDS_SC_TWOACC
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[0], act[4 * g + 0], acc, 0, 0, 0);
@@ -343,10 +352,12 @@ __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
             if (s == 8) SC_TL(2);
         }
         SC_TL(3);
-        dmin = fminf(dmin, __shfl_xor(dmin, 32));
-        if (half == 0) resL[it * SC_ROWS + wave * 32 + b] = valid ? dmin : 0.f;
-        row = nrow;
-        rad = a.radius[row.o];
+        // links 0-3, 8-11 sit in lane-half 0, the others in half 1: both min into the pair's LDS slot (ds_min_f32; a cross-lane
+        // exchange would keep a lane-index VGPR alive across the whole tile loop)
+        (void)valid;
+        __hip_atomic_fetch_min(&resL[it * SC_ROWS + wave * 32 + b], dmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        row_o = nrow_o;
+        rad = a.radius[row_o];
     }
     // ---- drain the ring (pieces issued past the last tile still target this workgroup's LDS), then flush the results
     wait_vm_barrier(0);
@@ -504,6 +515,7 @@ void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, con
     const dim3 grid((unsigned)gl);
     const int tiles_per_wg = (int)((ntiles + gl - 1) / gl);
     const size_t lds = omds_screen_lds_bytes(m.nhh) + (size_t)tiles_per_wg * SC_ROWS * 4;
+    a.res_tiles = tiles_per_wg;
     const size_t lds_max = omds_screen_lds_bytes(4) + (size_t)SC_MAX_TILES * SC_ROWS * 4;
     // diagnostic timeline (OMDS_SCREEN_TL=1): phase stamps of every workgroup's FIRST tile, summarised on stderr
     static int tl_on = -1;

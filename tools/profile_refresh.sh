@@ -2,7 +2,7 @@
 # Regenerates the rocprofv3 summaries committed under profiles/ (run on the GPU box through gpurun from the repo root).
 # Every rocprofv3 call has python3 directly after "--"; counters are collected in their own passes.
 set -u
-R=${1:-r01}
+R=${1:-r02}
 OUT=$PWD/gpurun_out/prof_$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -24,4 +24,28 @@ done
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA -d "$OUT/pmc_sq" -- python3 $P > "$OUT/pmc_sq.log" 2>&1
 python3 tools/rocprof_summary.py pmc "$(finddb "$OUT/pmc_sq")" > "$OUT/pmc_sq.txt"
 rm -rf "$OUT/pmc_sq"
+# HBM bytes per launch of each workload's kernels -> profiles/pmc_traffic.json (read by bench.py for roofline.traffic)
+python3 - "$OUT" <<'PY'
+import json, re, sys
+out = sys.argv[1]
+def table(path):
+    t = {}
+    for line in open(path):
+        m = re.match(r"^(.{40}) (\S+)\s+(\d+)\s+([0-9.]+)", line)
+        if m and m.group(2) in ("FETCH_SIZE", "WRITE_SIZE"):
+            t[m.group(1).strip()] = float(m.group(4))
+    return t
+f, w = table(out + "/pmc_FETCH_SIZE.txt"), table(out + "/pmc_WRITE_SIZE.txt")
+res = {"_doc": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024 from separate rocprofv3 --pmc passes of "
+               "bench.py --workload franka_shelf_1024x32 (FETCH_SIZE doubled: gfx950 correction of MI355X_MICROARCH.md)",
+       "franka_shelf_1024x32": {}}
+for name in f:
+    short = "k_screen" if "k_screen" in name else "k_tail" if "k_tail" in name else "k_exact" if "k_exact" in name else \
+            "k_select" if "k_select" in name else "k_pass1" if "k_pass1" in name else None
+    if short and name in w:
+        res["franka_shelf_1024x32"][short] = {"fetch_kb": f[name], "write_kb": w[name], "traffic_bytes": int((2 * f[name] + w[name]) * 1024)}
+json.dump(res, open(out + "/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY
+python3 tests/parity_report.py 4096 1024 > "$OUT/parity_fullsize.txt" 2>&1
 ls -la "$OUT"
