@@ -117,7 +117,7 @@ static void free_all(omds_ctx* ctx) {
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
                     ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
                     ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
-                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad};
+                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : ctx->mlp_allocs)
@@ -194,6 +194,12 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
     CKC(hipMalloc(&ctx->d_Apre, rows2 * OMDS_WIDTH * 4));
     CKC(hipMalloc(&ctx->d_Dmin, N * Om * 4));
     CKC(hipMalloc(&ctx->d_rowlist, N * Om * 4));
+    CKC(hipMalloc(&ctx->d_range, N * 2 * 4));
+    ctx->ex_cap = (int)std::min<size_t>(N * Om, N * 32);   // 32 candidates per rollout on average; longer lists -> fp32 fallback
+    CKC(hipMalloc(&ctx->d_exD, (size_t)ctx->ex_cap * 4));
+    CKC(hipMalloc(&ctx->d_exDr, (size_t)ctx->ex_cap * 4));
+    CKC(hipMalloc(&ctx->d_exMin, (size_t)ctx->ex_cap * 4));
+    CKC(hipMalloc(&ctx->d_exMask, (size_t)ctx->ex_cap * (OMDS_MAX_HIDDEN + 1) * 8 * 4));
     CKC(hipMalloc(&ctx->d_sctotal, (H + 1) * 4));
     CKC(hipMalloc(&ctx->d_scerr, 4));
     CKC(hipMalloc(&ctx->d_idx, rows2 * 4));
@@ -719,6 +725,7 @@ static int calibrate_screen(omds_ctx* ctx, const float* q_center) {
 static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) {
     const int N = a.N, H = a.H, n = a.n;
     int rc;
+    ExactOut ex{ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->ex_cap};
     if (tail) {
         // two launches per step: k_pass1 over all (rollout, obstacle) pairs, then the rollout-local tail; with screening
         // k_pass1 becomes k_screen (fp16) + k_select + k_exact (fp32 on the candidates only).
@@ -739,9 +746,10 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
                     omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_FqH, ctx->cfg.n_traj, ctx->d_FpH, ctx->cfg.max_obs, ctx->d_radius, ctx->n_obs, N,
                                        ctx->prm.ignored_links, ctx->d_Dmin);
                     if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs, -1.0, "k_screen"))) return rc;
-                    omds_launch_select(ctx->stream, ctx->d_Dmin, N, ctx->n_obs, a.k, ctx->screen_eps, ctx->d_rowlist, ctx->d_sctotal + (i - 1));
+                    omds_launch_select(ctx->stream, ctx->d_Dmin, N, ctx->n_obs, a.k, ctx->screen_eps, ctx->d_rowlist, ctx->d_range,
+                                       ctx->d_sctotal + (i - 1));
                     omds_launch_exact(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
-                                      ctx->prm.ignored_links, ctx->d_Dmin, ctx->d_rowlist, ctx->d_sctotal + (i - 1), ctx->d_scerr);
+                                      ctx->prm.ignored_links, ctx->d_Dmin, ctx->d_rowlist, ctx->d_sctotal + (i - 1), ctx->d_scerr, ex);
                 } else {
                     omds_launch_pass1(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
                                       ctx->prm.ignored_links, ctx->d_Dmin);
@@ -750,8 +758,12 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
             }
             RoctxRange r2("TAG: evaluate NN_3-5 + Modulation-propagation");
             a.step = i;
-            omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, ctx->d_Apre,
-                             ctx->d_dscr, ctx->n_obs, a, 0, N, screen ? ctx->d_FqH : nullptr, N);
+            if (screen)
+                omds_launch_tail_sel(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Apre, ctx->n_obs, a,
+                                     ctx->d_rowlist, ctx->d_range, ex, ctx->d_FqH, N);
+            else
+                omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, ctx->d_Apre,
+                                 ctx->d_dscr, ctx->n_obs, a, 0, N);
         }
     } else {
         for (int i = 1; i <= H; ++i) {   // MPPI.py:101: H network evaluations, the last velocity is not integrated
@@ -807,11 +819,19 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
         const float err = ctx->h_red[0];   // max |screening - fp32| over every candidate pair of this propagate
         if (err > ctx->screen_err_seen || err != err) ctx->screen_err_seen = err;
         const int32_t* tot = reinterpret_cast<const int32_t*>(ctx->h_red + 1);
-        for (int i = 0; i < H; ++i) ctx->screen_rows += tot[i];
+        bool overflow = false;   // a step listed more candidates than k_exact's per-entry outputs hold: redo in fp32
+        for (int i = 0; i < H; ++i) { ctx->screen_rows += tot[i]; overflow = overflow || tot[i] > ctx->ex_cap; }
         ctx->screen_steps += (double)N * H;
+        if (overflow) { ctx->screen_fallbacks++; screen = false; continue; }
         static int noguard = -1;   // OMDS_SCREEN_NOGUARD=1: timing experiments with deliberately broken screening kernels only
         if (noguard < 0) { const char* e = getenv("OMDS_SCREEN_NOGUARD"); noguard = e ? atoi(e) : 0; }
-        if (err <= 0.5f * ctx->screen_eps || noguard) break;
+        if (err <= 0.5f * ctx->screen_eps || noguard) {
+            // accepted (the bound kept a 2x margin over everything seen).  Keep it at >= 4x the largest error seen so far, so
+            // that states drifting into regions where the fp16 network is less accurate widen the bound gradually instead
+            // of tripping the fallback
+            if (!noguard && 4.f * err > ctx->screen_eps) ctx->screen_eps = 4.f * err;
+            break;
+        }
         // the calibrated bound lost its 2x margin on live data: this propagate is redone in fp32 and the bound is widened
         // (or screening is switched off when the error is not even finite -- an fp16 overflow inside the network)
         ctx->screen_fallbacks++;

@@ -202,11 +202,14 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                                            const float* __restrict__ Bpre, const float* __restrict__ radius, int O,
                                            long long total_rows, uint32_t ignored, float* __restrict__ Dmin,
                                            const long long row0, const OmdsDivisor odiv,
-                                           const int* __restrict__ rowlist = nullptr, unsigned* maxerr_bits = nullptr) {
+                                           const int* __restrict__ rowlist = nullptr, unsigned* maxerr_bits = nullptr,
+                                           const ExactOut* ex = nullptr) {
     using G = Geo<MT, MR, NR>;
     float* Hs = smem;                                           // [MT][LDH]
     float* rowRad = smem + MT * LDH;                            // [MT] obstacle radius of each row
     int* rowIdx = reinterpret_cast<int*>(rowRad + MT);          // [MT] LIST: pair index of each row
+    uint32_t* maskS = reinterpret_cast<uint32_t*>(rowIdx + MT); // [MT][nhid][8] LIST: ReLU masks of the tile's rows
+    const int nhid = m.nhh + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / G::WN, wn = wave % G::WN;
     OMDS_TL(0);
@@ -287,6 +290,14 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const omds_f4 z = av[it] + bv[it];                  // vector add -> two v_pk_add_f32
+            if constexpr (LIST) {                               // layer-1 masks of this row: four ballots, written by lane 0
+                const unsigned long long b0 = __ballot(z.x > 0.f), b1 = __ballot(z.y > 0.f), b2 = __ballot(z.z > 0.f), b3 = __ballot(z.w > 0.f);
+                if (lane == 0) {
+                    uint32_t* ms = maskS + (size_t)(wv + it * G::NW) * nhid * 8;
+                    ms[0] = (uint32_t)b0; ms[1] = (uint32_t)(b0 >> 32); ms[2] = (uint32_t)b1; ms[3] = (uint32_t)(b1 >> 32);
+                    ms[4] = (uint32_t)b2; ms[5] = (uint32_t)(b2 >> 32); ms[6] = (uint32_t)b3; ms[7] = (uint32_t)(b3 >> 32);
+                }
+            }
             float4 v;                                           // rows past the end were loaded as zeros: act(0) = 0
             v.x = actf(z.x, ACT);
             v.y = actf(z.y, ACT);
@@ -355,8 +366,17 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
+                for (int r = 0; r < 16; ++r) {
                     hb[(i * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = actf(acc[i][j][r], ACT);
+                    if constexpr (LIST) {   // lanes 0-31 hold row (r&3) + 8(r>>2) of this 32-column block, lanes 32-63 that row + 4
+                        const unsigned long long bal = __ballot(acc[i][j][r] > 0.f);
+                        if (lane == 0) {
+                            const int rr = wm * MR * 32 + i * 32 + (r & 3) + 8 * (r >> 2);
+                            maskS[((size_t)rr * nhid + (l + 1)) * 8 + cb0 + j] = (uint32_t)bal;
+                            maskS[((size_t)(rr + 4) * nhid + (l + 1)) * 8 + cb0 + j] = (uint32_t)(bal >> 32);
+                        }
+                    }
+                }
         }
         __syncthreads();
         OMDS_TL(2 + l);
@@ -390,8 +410,22 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
         const float4 rr = *reinterpret_cast<const float4*>(rowRad + r4);
         const float rad[4] = {rr.x, rr.y, rr.z, rr.w};
         float y[4];
+        [[maybe_unused]] float ydr[4];
+        [[maybe_unused]] int yam[4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
+            if constexpr (LIST) {   // pass 2's arg-min over ALL raw outputs (robot_sdf.py:155) and the distance of that link
+                float bv = pad ? __builtin_inff() : acc[reg] + bj;
+                int bi = j;
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    const float ov = __shfl_xor(bv, off);
+                    const int oi = __shfl_xor(bi, off);
+                    if ((ov < bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                ydr[reg] = bv / m.out_div - rad[reg];
+                yam[reg] = bi;
+            }
             float v = (acc[reg] + bj) / m.out_div - rad[reg];
             v = pad ? __builtin_inff() : (ign ? 1e6f : v);
             // min over the 16 lanes of the row group: xor 1, xor 2 inside the quad, then mirror within 8 and within 16
@@ -406,11 +440,11 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                 float me = 0.f;
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    if (row0 + r4 + reg < total_rows) {
-                        float* dst = Dmin + rowIdx[r4 + reg];
-                        const float e = fabsf(*dst - y[reg]);
+                    const long long e_idx = row0 + r4 + reg;
+                    if (e_idx < total_rows) {
+                        const float e = fabsf(Dmin[rowIdx[r4 + reg]] - y[reg]);   // Dmin holds the screening value of the pair
                         if (!(e <= me)) me = (e == e) ? e : __builtin_inff();   // a NaN screening value (fp16 overflow) counts as an infinite error
-                        *dst = y[reg];
+                        if (e_idx < ex->cap) { ex->D[e_idx] = y[reg]; ex->dr[e_idx] = ydr[reg]; ex->amin[e_idx] = yam[reg]; }
                     }
                 }
                 if (me > 0.f) atomicMax(maxerr_bits, __builtin_bit_cast(unsigned, me));   // non-negative floats order like their bits
@@ -425,6 +459,14 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                 for (int reg = 0; reg < 4; ++reg)
                     if (g + reg < total_rows) Dmin[g + reg] = y[reg];
             }
+        }
+    }
+    if constexpr (LIST) {   // the tile's rows are consecutive list entries: one contiguous block of masks
+        __syncthreads();
+        const long long words = (long long)((total_rows - row0 < MT) ? (total_rows - row0) : MT) * nhid * 8;
+        for (int i = tid; i < words; i += G::NT) {
+            const long long e_idx = row0 + i / (nhid * 8);
+            if (e_idx < ex->cap) ex->mask[(size_t)row0 * nhid * 8 + i] = maskS[i];
         }
     }
 #ifdef OMDS_TIMELINE
@@ -526,6 +568,11 @@ __device__ __forceinline__ void p2_gemm(const float* Hs, const MlpDev& m, int l,
     }
 }
 
+template <int ACT, int ROWS>
+__device__ __forceinline__ void pass2_backward(const MlpDev& m, const P2Smem& sm, const float* __restrict__ xyzr, int R0,
+                                               int total_rows, const float* __restrict__ qT, int ldq, float* gradx, int dbase,
+                                               float* __restrict__ dscr, size_t dlayer, int S0, int dbg = 0);
+
 // Body of pass 2 for the ROWS rows described by sm.rowT / sm.rowO (already in LDS, barrier done by the
 // caller).  R0 = global index of row 0 (tanh scratch, yraw, minidx); outputs go to
 // gradx[(dbase + row) * d + j] and drow[dbase + row] (global memory or LDS).
@@ -543,8 +590,6 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
     using G = P2Geo<ROWS>;
     constexpr int NV = G::NV;
     float* Hs = sm.Hs;
-    float* P = sm.P;
-    float* gf = sm.gf;
     uint16_t* maskL = sm.maskL;
     int* rowT = sm.rowT;
     int* rowO = sm.rowO;
@@ -660,6 +705,28 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
     }
     __syncthreads();
     if (dbg == 12) return;
+    pass2_backward<ACT, ROWS>(m, sm, xyzr, R0, total_rows, qT, ldq, gradx, dbase, dscr, dlayer, S0, dbg);
+}
+
+// The backward half of pass 2: from sm.rowMin (arg-min link of each row), the activation derivatives -- sm.maskL (ReLU:
+// 16 bits per thread and layer in the MFMA C layout) or dscr (tanh) -- and sm.rowT / sm.rowO to the input gradients
+// gradx[(dbase + row) * d + j].  pass2_body runs it behind its own forward; the screened step (k_tail_sel) runs it on masks
+// that k_exact produced when it evaluated the candidates.
+template <int ACT, int ROWS>
+__device__ __forceinline__ void pass2_backward(const MlpDev& m, const P2Smem& sm, const float* __restrict__ xyzr, int R0,
+                                               int total_rows, const float* __restrict__ qT, int ldq, float* gradx, int dbase,
+                                               float* __restrict__ dscr, size_t dlayer, int S0, int dbg) {
+    using G = P2Geo<ROWS>;
+    constexpr int NV = G::NV;
+    float* Hs = sm.Hs;
+    float* P = sm.P;
+    float* gf = sm.gf;
+    uint16_t* maskL = sm.maskL;
+    int* rowT = sm.rowT;
+    int* rowO = sm.rowO;
+    int* rowMin = sm.rowMin;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr bool relu = ACT == OMDS_ACT_RELU;
 
     // ---- backward seed: dy[minIdx]/dH_last = Wlast[minIdx], masked by the last hidden layer ---------
     {

@@ -90,6 +90,12 @@ struct omds_ctx {
     float screen_eps = 0.f;      // calibrated bound on |screening value - fp32 value|; 0 = not calibrated yet
     bool screen_cal = false;
     int* d_rowlist = nullptr;    // [N*max_obs] candidate pairs
+    int* d_range = nullptr;      // [N][2] each rollout's range of the list
+    int ex_cap = 0;              // entries the k_exact output arrays hold (N * 32)
+    float* d_exD = nullptr;      // [ex_cap] pass-1 value / pass-2 distance / arg-min link / ReLU masks of each list entry
+    float* d_exDr = nullptr;
+    int* d_exMin = nullptr;
+    uint32_t* d_exMask = nullptr;
     int* d_sctotal = nullptr;    // [H] candidates listed per horizon step
     unsigned* d_scerr = nullptr; // max |screening - exact| over the candidates (float bits)
     double screen_rows = 0.0;    // statistics since the last omds_prof_reset: candidate rows, (rollout, step)s, fallbacks
@@ -205,9 +211,23 @@ void omds_launch_blend(hipStream_t s, const float* gradx, const float* drow, int
 void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, const uint16_t* FqH, int ldFq, const uint16_t* FpH,
                         int ldFp, const float* radius, int O, int B, uint32_t ignored, float* Dmin);
 bool omds_screen_supported(const MlpDev& m);
-void omds_launch_select(hipStream_t s, float* Dmin, int B, int O, int k, float eps, int* rowlist, int* total);
+// What k_exact leaves behind for the screened step's tail (k_tail_sel), per entry of the candidate list: the pass-1 value,
+// and everything pass 2's forward would produce for that row -- its arithmetic is the same bit for bit -- so that the tail
+// only runs the backward: the pass-2 distance, the arg-min link, and the ReLU masks of every hidden layer.  mask layout per
+// entry: [hidden layer][8 words]; layer 0 (the separable layer 1, built one row per wave) holds the four 64-lane ballots of
+// the lanes' float4 components (column 4 l + c = bit l of ballot c), layers >= 1 hold bit (col & 31) of word col >> 5.
+struct ExactOut {
+    float* D;          // [cap] pass-1 value
+    float* dr;         // [cap] pass-2 distance y[argmin] / out_div - radius
+    int* amin;         // [cap] arg-min link over all raw outputs
+    uint32_t* mask;    // [cap][nhid][8]
+    int cap;           // entries the arrays hold (the list may be longer: the host then redoes the propagate in fp32)
+};
+
+void omds_launch_select(hipStream_t s, const float* Dmin, int B, int O, int k, float eps, int* rowlist, int* range, int* total);
 void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius, int O,
-                       int B, uint32_t ignored, float* Dmin, const int* rowlist, const int* total, unsigned* maxerr_bits);
+                       int B, uint32_t ignored, float* Dmin, const int* rowlist, const int* total, unsigned* maxerr_bits,
+                       const ExactOut& ex);
 
 // ---- launchers implemented in rollout_kernels.hip ---------------------------------------------
 struct StepArgs {
@@ -228,6 +248,11 @@ int omds_tail_rows(int N, int k);            // pass-2 tile height (16 | 32) for
 void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
                       const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st, int t_begin, int t_end,
                       uint16_t* FqH = nullptr, int ldF = 0);
+// screened step's tail: top-k over the candidates k_exact evaluated + pass-2 backward on its masks + the rest of k_tail
+bool omds_tail_sel_supported(int n_dof, int k);
+void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
+                          float* Apre, int O, const StepArgs& st, const int* rowlist, const int* range, const ExactOut& ex,
+                          uint16_t* FqH, int ldF);
 struct CostArgs {
     int N, H, n;
     uint32_t terms;   // OMDS_COST_* bits

@@ -10,10 +10,12 @@
 //   k_select  : per rollout, tau = (k-th smallest Da) + 2 eps; every obstacle with Da <= tau is a CANDIDATE.  If
 //               |Da - D| <= eps for the fp32 value D of every pair, the candidates contain the k smallest D and
 //               everything tied with the k-th (proof in DESIGN.md 4.1b), so the exact top-k over the candidates is the
-//               exact top-k over all obstacles, ties included.  Non-candidates become +inf in the row; candidates go to a
-//               compact row list.
+//               exact top-k over all obstacles, ties included.  The candidates of a rollout take a contiguous range of a
+//               compact list (range start and length per rollout).
 //   k_exact   : the fp32 pass-1 tile code (pass1_tile, bit-identical arithmetic per row: an MFMA output element is one
-//               k-ordered fmaf chain of its own row) on the listed rows only; writes the exact D over Da and records
+//               k-ordered fmaf chain of its own row) on the listed rows only.  Per entry it leaves the exact D and what
+//               pass 2's forward would compute for the row (same arithmetic): pass-2 distance, arg-min link, ReLU masks --
+//               k_tail_sel then picks the top-k by (D, obstacle) and runs only the backward.  It also records
 //               max |Da - D| over all candidates (the run-time guard of eps: the host re-runs the propagate without
 //               screening if the observed error ever exceeds the calibrated margin).
 //
@@ -372,8 +374,9 @@ __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
 // k_select: one wave per rollout.  Row of up to 512 approximate distances in registers (longer rows: from memory).
 // ------------------------------------------------------------------------------------------------
 struct SelectArgs {
-    float* Dmin;          // [N][O] in: approximate; out: +inf for non-candidates (candidates keep the approximate value)
+    const float* Dmin;    // [N][O] screening values
     int* rowlist;         // [N*O] compact list of candidate rows t*O + o
+    int* range;           // [N][2] start and length of each rollout's entries in the list
     int* total;           // number of listed rows (zeroed before the launch)
     int N, O, k;
     float two_eps;
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= a.N) return;
-    float* row = a.Dmin + (size_t)t * a.O;
+    const float* row = a.Dmin + (size_t)t * a.O;
     const int O = a.O;
     constexpr int NV = 8;
     float v[NV];
@@ -440,7 +443,11 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a) {
     }
     const int wave_total = __shfl(incl, 63);
     int base = 0;
-    if (lane == 0) base = atomicAdd(a.total, wave_total);
+    if (lane == 0) {
+        base = atomicAdd(a.total, wave_total);
+        a.range[2 * t] = base;
+        a.range[2 * t + 1] = wave_total;
+    }
     base = __shfl(base, 0);
     int pos = base + incl - cnt;
     const int rbase = t * O;
@@ -448,16 +455,11 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int o = lane + 64 * i;
-            if (o < O) {
-                if (!(v[i] > tau)) a.rowlist[pos++] = rbase + o;
-                else row[o] = __builtin_inff();
-            }
+            if (o < O && !(v[i] > tau)) a.rowlist[pos++] = rbase + o;
         }
     } else {
-        for (int o = lane; o < O; o += 64) {
+        for (int o = lane; o < O; o += 64)
             if (!(row[o] > tau)) a.rowlist[pos++] = rbase + o;
-            else row[o] = __builtin_inff();
-        }
     }
 }
 
@@ -468,12 +470,12 @@ template <int ACT>
 __global__ __launch_bounds__(512) void k_exact(MlpDev m, const float* __restrict__ Apre, const float* __restrict__ Bpre,
                                                const float* __restrict__ radius, int O, uint32_t ignored,
                                                float* __restrict__ Dmin, OmdsDivisor odiv, const int* __restrict__ rowlist,
-                                               const int* __restrict__ total, unsigned* __restrict__ maxerr_bits) {
+                                               const int* __restrict__ total, unsigned* __restrict__ maxerr_bits, ExactOut ex) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = *total;
     for (int tile = blockIdx.x; tile * 32 < n; tile += gridDim.x) {
         pass1_tile<32, 1, 1, ACT, true>(m, smem, Apre, Bpre, radius, O, n, ignored, Dmin, (long long)tile * 32, odiv, rowlist,
-                                        maxerr_bits);
+                                        maxerr_bits, &ex);
         __syncthreads();   // the tile buffer is reused by the next tile
     }
 }
@@ -558,17 +560,18 @@ void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, con
 
 bool omds_screen_supported(const MlpDev& m) { return m.act == OMDS_ACT_RELU && m.nhh >= 1 && m.nhh <= 4; }
 
-void omds_launch_select(hipStream_t s, float* Dmin, int B, int O, int k, float eps, int* rowlist, int* total) {
+void omds_launch_select(hipStream_t s, const float* Dmin, int B, int O, int k, float eps, int* rowlist, int* range, int* total) {
     if (B <= 0) return;
     SelectArgs a;
-    a.Dmin = Dmin; a.rowlist = rowlist; a.total = total; a.N = B; a.O = O; a.k = k; a.two_eps = 2.f * eps;
+    a.Dmin = Dmin; a.rowlist = rowlist; a.range = range; a.total = total; a.N = B; a.O = O; a.k = k; a.two_eps = 2.f * eps;
     hipLaunchKernelGGL(k_select, dim3((B + 3) / 4), dim3(256), 0, s, a);
 }
 
 void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius, int O,
-                       int B, uint32_t ignored, float* Dmin, const int* rowlist, const int* total, unsigned* maxerr_bits) {
+                       int B, uint32_t ignored, float* Dmin, const int* rowlist, const int* total, unsigned* maxerr_bits,
+                       const ExactOut& ex) {
     if (B <= 0) return;
-    const size_t lds = (size_t)32 * LDH * 4 + 32 * 4 + 32 * 4;
+    const size_t lds = (size_t)32 * LDH * 4 + 32 * 4 + 32 * 4 + (size_t)32 * (OMDS_MAX_HIDDEN + 1) * 8 * 4;
     static std::atomic<uint64_t> configured{0};
     if (omds_first_use_on_device(configured)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_exact<OMDS_ACT_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -579,7 +582,7 @@ void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const 
     const unsigned grid = (unsigned)std::min<long long>(tiles_max, std::max<long long>(512, ((long long)B * 16 + 31) / 32));
     const OmdsDivisor od = OmdsDivisor::make((unsigned)O);
     if (m.act == OMDS_ACT_RELU)
-        hipLaunchKernelGGL((k_exact<OMDS_ACT_RELU>), dim3(grid), dim3(512), lds, s, m, Apre, Bpre, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits);
+        hipLaunchKernelGGL((k_exact<OMDS_ACT_RELU>), dim3(grid), dim3(512), lds, s, m, Apre, Bpre, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits, ex);
     else
-        hipLaunchKernelGGL((k_exact<OMDS_ACT_TANH>), dim3(grid), dim3(512), lds, s, m, Apre, Bpre, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits);
+        hipLaunchKernelGGL((k_exact<OMDS_ACT_TANH>), dim3(grid), dim3(512), lds, s, m, Apre, Bpre, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits, ex);
 }

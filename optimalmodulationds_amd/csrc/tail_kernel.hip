@@ -27,6 +27,10 @@ struct TailArgs {
     int slot0;           // first 32-row slot of this launch in the tanh scratch
     int n_slots;         // slots of the whole batch (scratch stride between layers)
     int dbg_stop;        // timing experiments only (OMDS_TAIL_STOP): return after phase 1 / 2 / 3
+    // screened step (k_tail_sel): the candidate list of k_select and what k_exact computed for its entries
+    const int* rowlist;  // [entries] pair t*O + o
+    const int* range;    // [N][2] start, length of each rollout's entries
+    ExactOut ex;
     StepArgs st;
 };
 
@@ -117,6 +121,182 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
 }
 
 
+static size_t tail_lds_bytes(int nhid);
+
+// ------------------------------------------------------------------------------------------------
+// Screened step: k_screen -> k_select -> k_exact -> k_tail_sel.  k_exact has evaluated every candidate row in fp32 with
+// pass 1's arithmetic, which is also pass 2's forward (same start value, same k order), and left the pass-1 value D, the
+// pass-2 distance, the arg-min link and the ReLU masks per list entry.  This tail therefore needs no forward at all: top-k
+// by (D, obstacle index) over each rollout's few candidates, masks of the selected entries gathered into the MFMA C layout,
+// the pass-2 backward, then blend / modulation / Euler step / next-step layer 1 exactly as in k_tail.
+// ------------------------------------------------------------------------------------------------
+template <int ND>
+__global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
+    constexpr int ACT = OMDS_ACT_RELU, ROWS = 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const MlpDev& m = a.m;
+    P2Smem sm;
+    sm.Hs = smem;
+    sm.P = sm.Hs + P2_MT * LDH;
+    sm.gf = sm.P + P2_PSETS * 32 * 33;
+    sm.maskL = reinterpret_cast<uint16_t*>(sm.gf + 32 * 33);
+    sm.rowT = reinterpret_cast<int*>(sm.maskL + ((m.nhh + 2) / 2 * 2) * P2_NT);
+    sm.rowO = sm.rowT + P2_MT;
+    sm.rowMin = sm.rowO + P2_MT;
+    float* gx = reinterpret_cast<float*>(sm.rowMin + P2_MT);   // [32][d]
+    float* dr = gx + 32 * 12;                                   // [32]
+    float* feat = dr + 32;                                      // [32][3*ND]: q_next, sin, cos
+    int* sel = reinterpret_cast<int*>(feat + 32 * 3 * OMDS_MAX_DOF);   // [32] list entry of each backward row (-1: padding)
+    uint32_t* maskRow = reinterpret_cast<uint32_t*>(sm.Hs);     // [32][nhid][8] gathered masks; the tile buffer is idle until the seed
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = a.st.N, k = a.st.k, O = a.O, nhid = m.nhh + 1;
+    const int RW = ROWS / k;                  // rollouts per workgroup
+    const int t_base = a.t_begin + blockIdx.x * RW;
+    const int t_end = a.t_end;
+
+    // ---- top-k of each rollout's candidates by (D, obstacle index): k rounds of "smallest after the previous one" ----
+    if (tid < P2_MT) { sm.rowT[tid] = -1; sm.rowO[tid] = 0; sm.rowMin[tid] = 0; sel[tid] = -1; dr[tid] = 0.f; }
+    __syncthreads();
+    for (int rl = wave; rl < RW; rl += 8) {
+        const int t = t_base + rl;
+        if (t >= t_end) break;
+        const int base = a.range[2 * t], cnt = a.range[2 * t + 1];
+        float pv = -__builtin_inff();
+        int po = -1;
+        for (int j = 0; j < k; ++j) {
+            float bv = __builtin_inff();
+            int bo = 0x7fffffff, be = -1;
+            for (int i = lane; i < cnt; i += 64) {
+                const int e = base + i;
+                if (e >= a.ex.cap) break;   // list longer than k_exact's outputs: the host sees the count and redoes the propagate in fp32
+                const float x = a.ex.D[e];
+                const int o = a.rowlist[e] - t * O;
+                const bool after = (x > pv) || (x == pv && o > po);
+                if (after && ((x < bv) || (x == bv && o < bo))) { bv = x; bo = o; be = e; }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ov = __shfl_xor(bv, off);
+                const int oo = __shfl_xor(bo, off);
+                const int oe = __shfl_xor(be, off);
+                if ((ov < bv) || (ov == bv && oo < bo)) { bv = ov; bo = oo; be = oe; }
+            }
+            pv = bv;
+            po = bo;
+            if (lane == 0 && be >= 0) {
+                const int r = rl * k + j;
+                sm.rowT[r] = t;
+                sm.rowO[r] = bo;
+                sm.rowMin[r] = a.ex.amin[be];
+                dr[r] = a.ex.dr[be];
+                sel[r] = be;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the selected entries' masks -> LDS -> 16 bits per thread and layer in the MFMA C layout (what pass 2's forward
+    //      would have left in sm.maskL): thread (wave = 32-column block, lane) owns column wave*32 + (lane&31) of rows crow(r, lane)
+    for (int i = tid; i < 32 * nhid * 8; i += P2_NT) {
+        const int r = i / (nhid * 8);
+        maskRow[i] = sel[r] >= 0 ? a.ex.mask[(size_t)sel[r] * nhid * 8 + (i - r * nhid * 8)] : 0u;
+    }
+    __syncthreads();
+    {
+        const int col = wave * 32 + (lane & 31);
+        const int w1 = (col & 3) * 2 + (col >> 7), b1 = (col >> 2) & 31;     // layer 1: ballot of component col&3, lane col>>2
+        for (int l = 0; l < nhid; ++l) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t* mr = maskRow + ((size_t)crow(r, lane) * nhid + l) * 8;
+                const uint32_t bit = (l == 0) ? ((mr[w1] >> b1) & 1u) : ((mr[wave] >> (lane & 31)) & 1u);
+                bits |= bit << r;
+            }
+            sm.maskL[l * P2_NT + tid] = (uint16_t)bits;
+        }
+    }
+    __syncthreads();
+
+    // ---- backward on the selected rows; gradients stay in LDS -----------------------------------------
+    const float* qT = a.st.trajT + (size_t)(a.st.step - 1) * ND * N;
+    pass2_backward<ACT, ROWS>(m, sm, a.xyzr, t_base * k, N * k, qT, N, gx, 0, nullptr, 0, 0);
+    __syncthreads();
+
+    // ---- modulation / policy / Euler step: 16 lanes per rollout -------------------------------------
+    {
+        const int rl = tid >> 4, sub = tid & 15;
+        const int t = t_base + rl;
+        if (rl < RW && t < t_end) {
+            float q[ND], qn[ND];
+#pragma unroll
+            for (int j = 0; j < ND; ++j) q[j] = qT[(size_t)j * N + t];
+            modulate_core<ND, 16>(a.st, a.st.step, t, sub, gx, dr, rl * k, q, qn);
+            if (sub < ND) {
+                float v = qn[0];
+#pragma unroll
+                for (int j = 1; j < ND; ++j) v = (sub == j) ? qn[j] : v;
+                feat[rl * 3 * ND + sub] = v;
+                feat[rl * 3 * ND + ND + sub] = sinf(v);
+                feat[rl * 3 * ND + 2 * ND + sub] = cosf(v);
+                if (a.FqH && a.st.step < a.st.H) {
+                    const int d = m.d;
+                    a.FqH[omds_screen_fidx(sub, t, a.ldF)] = (_Float16)v;
+                    a.FqH[omds_screen_fidx(d + sub, t, a.ldF)] = (_Float16)feat[rl * 3 * ND + ND + sub];
+                    a.FqH[omds_screen_fidx(2 * d + sub, t, a.ldF)] = (_Float16)feat[rl * 3 * ND + 2 * ND + sub];
+                }
+            }
+        }
+    }
+    if (a.st.step >= a.st.H) return;   // last step: nothing is integrated, no next network evaluation
+    __syncthreads();
+
+    // ---- rollout half of layer 1 for the next step (same arithmetic order as k_rollout_layer1) --------
+    {
+        const int c = tid & 255, d = m.d;
+        for (int rl = tid >> 8; rl < RW; rl += 2) {
+            const int t = t_base + rl;
+            if (t >= t_end) break;
+            const float* f = feat + rl * 3 * ND;
+            float acc = m.b1[c];
+#pragma unroll
+            for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)j * OMDS_WIDTH + c], f[j], acc);
+#pragma unroll
+            for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)(d + j) * OMDS_WIDTH + c], f[ND + j], acc);
+#pragma unroll
+            for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)(2 * d + j) * OMDS_WIDTH + c], f[2 * ND + j], acc);
+            a.Apre[(size_t)t * OMDS_WIDTH + c] = acc;
+        }
+    }
+}
+
+template <int ND>
+static void launch_tail_sel_t(hipStream_t s, const TailArgs& a) {
+    static std::atomic<uint64_t> configured{0};
+    const size_t extra = 32 * 4;   // sel
+    if (omds_first_use_on_device(configured)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail_sel<ND>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(tail_lds_bytes(OMDS_MAX_HIDDEN + 1) + extra));
+    }
+    const int RW = 32 / a.st.k;
+    hipLaunchKernelGGL((k_tail_sel<ND>), dim3((a.t_end - a.t_begin + RW - 1) / RW), dim3(P2_NT), tail_lds_bytes(a.m.nhh + 1) + extra, s, a);
+}
+
+bool omds_tail_sel_supported(int n_dof, int k) { return (n_dof == 7 || n_dof == 2) && k >= 1 && k <= 32; }
+
+void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
+                          float* Apre, int O, const StepArgs& st, const int* rowlist, const int* range, const ExactOut& ex,
+                          uint16_t* FqH, int ldF) {
+    TailArgs a;
+    a.FqH = reinterpret_cast<_Float16*>(FqH);
+    a.ldF = ldF;
+    a.t_begin = 0; a.t_end = st.N;
+    a.slot0 = 0; a.n_slots = 0; a.dbg_stop = 0;
+    a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Dmin = nullptr; a.Apre = Apre; a.dscr = nullptr; a.O = O; a.st = st;
+    a.rowlist = rowlist; a.range = range; a.ex = ex;
+    if (st.n == 7) launch_tail_sel_t<7>(s, a);
+    else launch_tail_sel_t<2>(s, a);
+}
+
 static size_t tail_lds_bytes(int nhid) {
     return ((size_t)P2_MT * LDH + P2_PSETS * 32 * 33 + 32 * 33) * 4 + (size_t)nhid * P2_NT * 4 + 3 * P2_MT * 4 +
            (32 * 12 + 32 + 32 * 3 * OMDS_MAX_DOF) * 4;
@@ -171,6 +351,7 @@ void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const f
     static int stop = -1;
     if (stop < 0) { const char* e = getenv("OMDS_TAIL_STOP"); stop = e ? atoi(e) : 0; }
     a.dbg_stop = stop;
+    a.rowlist = nullptr; a.range = nullptr; a.ex = ExactOut{};
     a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Dmin = Dmin; a.Apre = Apre; a.dscr = dscr; a.O = O; a.st = st;
     if (rows == 16) {
         if (st.n == 7) launch_tail_t<7, 16>(s, a);

