@@ -63,6 +63,17 @@ print(f"Franka shelf, N={N}, H={H}, O={obs.shape[0]}, k={k}, K={K}; {S} sampled 
 print("quantity                           max rel err   mean rel err")
 print("thresholded distance               %.3e     %.3e" % err(r["closest_dist_all"][tt, hh], d - np.float32(0.01)))
 print("obstacle normal (unflagged)        %.3e     %.3e" % err(r["normal"][tt, hh], st["ghat"], ok))
+# rows with a hidden pre-activation within 5e-6 of zero: the normal must be the oracle's under SOME admissible assignment of
+# the ambiguous ReLU masks (oracle.blended_gradient_alternatives), at the same tolerance as every other row
+gn = r["normal"][tt, hh]
+worst_alt, n_unmatched = 0.0, 0
+for i in np.nonzero(~ok)[0]:
+    alts = orc.blended_gradient_alternatives(m, q[i], obs, idx[i], 5e-6)
+    alts = alts / np.linalg.norm(alts, axis=1, keepdims=True)
+    e_best = float(np.abs(alts - gn[i]).max(axis=1).min())
+    worst_alt = max(worst_alt, e_best)
+    n_unmatched += e_best > 2e-5
+print("obstacle normal (flagged rows, best admissible mask assignment)  max err %.3e, rows above 2e-5: %d of %d" % (worst_alt, n_unmatched, int((~ok).sum())))
 print("normal . nominal direction (unfl.) %.3e     %.3e" % err(r["dot_products"][tt, hh], st["dot"], ok))
 print("RBF kernel values                  %.3e     %.3e" % err(r["kernel_val_all"][tt, hh], st["phi"]))
 print("kernel activation (unflagged)      %.3e     %.3e" % err(r["kernel_activations"][tt, hh], st["act"], ok))
