@@ -107,6 +107,16 @@ OMDS_API const char* omds_last_error(const omds_ctx* ctx);
  * scripts/standaloneToy2d.py:33); the z column of the obstacle array is then ignored.    */
 OMDS_API int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* const* W,
                           const float* const* b, int act, float out_div);
+/* The same for MLPRegression(..., skips=[...]) (network_macros_mod.py:113-146): behind the activations of
+ * the Linear layers named in skip_after[n_skips] (indices into the flat sequence of Linear layers, 0 ..
+ * n_linear-2) the encoded input [x, sin x, cos x] is concatenated, so the next Linear layer is 3(n+3)
+ * wider than the previous one's output: W[i] is [out_dims[i], in_dims[i]] with in_dims[0] = 3(n+3) and
+ * in_dims[i] = out_dims[i-1] (+ 3(n+3) behind a concatenation, its columns last, as torch.cat((y, x_nerf))
+ * orders them).  out_dims[i] + 3(n+3) <= 256 for those layers (the reference narrows them by 3(n+3) itself).
+ * n_skips = 0 is omds_set_mlp.  Skip-connection networks run the all-fp32 step (no fp16 screening).      */
+OMDS_API int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const int32_t* out_dims,
+                             const float* const* W, const float* const* b, int act, float out_div,
+                             int n_skips, const int32_t* skip_after);
 
 /* MPPI.update_obstacles (MPPI.py:347-350): xyzr is [O,4] spheres (x,y,z,r). */
 OMDS_API int omds_set_obstacles(omds_ctx* ctx, const float* xyzr, int n_obs);

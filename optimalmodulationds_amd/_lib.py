@@ -51,6 +51,8 @@ SIGNATURES = {
     "omds_destroy": (None, [C.c_void_p]),
     "omds_last_error": (C.c_char_p, [C.c_void_p]),
     "omds_set_mlp": (C.c_int, [C.c_void_p, C.c_int, I32P, C.POINTER(F32P), C.POINTER(F32P), C.c_int, C.c_float]),
+    "omds_set_mlp_ex": (C.c_int, [C.c_void_p, C.c_int, I32P, I32P, C.POINTER(F32P), C.POINTER(F32P), C.c_int, C.c_float,
+                                  C.c_int, I32P]),
     "omds_set_obstacles": (C.c_int, [C.c_void_p, F32P, C.c_int]),
     "omds_set_ds": (C.c_int, [C.c_void_p, F32P]),
     "omds_set_ds_matrix": (C.c_int, [C.c_void_p, F32P, F32P]),

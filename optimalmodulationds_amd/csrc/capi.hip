@@ -117,7 +117,7 @@ static void free_all(omds_ctx* ctx) {
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
                     ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
                     ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
-                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask};
+                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : ctx->mlp_allocs)
@@ -258,30 +258,47 @@ extern "C" OMDS_API int omds_timeline_fetch(omds_ctx* ctx, unsigned long long* h
 int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* const* W, const float* const* b, int act,
                  float out_div) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    REQUIRE(dims && W && b && n_linear >= 2, OMDS_ERR_INVALID_ARG, "omds_set_mlp: null argument or fewer than 2 Linear layers");
+    REQUIRE(dims && n_linear >= 2, OMDS_ERR_INVALID_ARG, "omds_set_mlp: null argument or fewer than 2 Linear layers");
+    return omds_set_mlp_ex(ctx, n_linear, dims, dims + 1, W, b, act, out_div, 0, nullptr);
+}
+
+int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const int32_t* out_dims, const float* const* W,
+                    const float* const* b, int act, float out_div, int n_skips, const int32_t* skip_after) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(in_dims && out_dims && W && b && n_linear >= 2, OMDS_ERR_INVALID_ARG, "omds_set_mlp: null argument or fewer than 2 Linear layers");
+    REQUIRE(n_skips == 0 || skip_after, OMDS_ERR_INVALID_ARG, "omds_set_mlp_ex: n_skips > 0 needs skip_after");
     const int n = ctx->cfg.n_dof;
-    REQUIRE(dims[0] == 3 * (n + 3) || dims[0] == 3 * (n + 2), OMDS_ERR_INVALID_ARG,
+    REQUIRE(in_dims[0] == 3 * (n + 3) || in_dims[0] == 3 * (n + 2), OMDS_ERR_INVALID_ARG,
             "omds_set_mlp: dims[0] must be 3*(n_dof+3), or 3*(n_dof+2) for planar obstacle points (NeRF encoding [x, sin x, cos x])");
-    const int d = dims[0] / 3;
+    const int d = in_dims[0] / 3;
     REQUIRE(3 * d <= 32, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: 3*(n_dof+3) > 32 not supported");
     const int nhid = n_linear - 1;
     REQUIRE(nhid <= OMDS_MAX_HIDDEN, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: too many hidden layers");
-    for (int i = 1; i <= nhid; ++i)
-        REQUIRE(dims[i] >= 1 && dims[i] <= OMDS_WIDTH, OMDS_ERR_UNSUPPORTED,
-                "omds_set_mlp: hidden widths above 256 are not supported by the MFMA kernels (narrower layers are zero-padded to width 256)");
-    const int C = dims[n_linear];
+    uint32_t skip_mask = 0;   // bit i: the encoded input is concatenated behind the activations of Linear i (network_macros_mod.py:142-146)
+    for (int s = 0; s < n_skips; ++s) {
+        REQUIRE(skip_after[s] >= 0 && skip_after[s] < nhid, OMDS_ERR_INVALID_ARG,
+                "omds_set_mlp_ex: skip_after entries must name a hidden Linear layer (0 .. n_linear-2)");
+        skip_mask |= 1u << skip_after[s];
+    }
+    for (int i = 0; i < nhid; ++i)
+        REQUIRE(out_dims[i] >= 1 && out_dims[i] + (((skip_mask >> i) & 1u) ? 3 * d : 0) <= OMDS_WIDTH, OMDS_ERR_UNSUPPORTED,
+                "omds_set_mlp: hidden widths (plus a concatenated input) above 256 are not supported by the MFMA kernels (narrower layers are zero-padded to width 256)");
+    for (int i = 1; i < n_linear; ++i)
+        REQUIRE(in_dims[i] == out_dims[i - 1] + (((skip_mask >> (i - 1)) & 1u) ? 3 * d : 0), OMDS_ERR_INVALID_ARG,
+                "omds_set_mlp: the input width of a Linear layer must be the previous output width (+ 3*(n_dof+3) behind a skip concatenation)");
+    const int C = out_dims[n_linear - 1];
     REQUIRE(C >= 1 && C <= OMDS_CPAD, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: 1 <= out_channels <= 16 required");
     REQUIRE(act == OMDS_ACT_RELU || act == OMDS_ACT_TANH, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: act must be OMDS_ACT_RELU or OMDS_ACT_TANH");
     REQUIRE(out_div != 0.f, OMDS_ERR_INVALID_ARG, "omds_set_mlp: out_div must be non-zero");
     // Narrower hidden layers (the reference also ships 128-wide nets) are zero-padded to the kernels' width:
     // padded units have zero weights and biases on both sides, so relu/tanh(0) = 0 feeds nothing forward and
     // receives no gradient -- outputs and gradients are unchanged (the padded MFMA work is wasted, not wrong).
+    // A concatenated input keeps its place: its columns follow the (narrower) layer's own outputs in the padded row.
     std::vector<std::vector<float>> Wpad(n_linear), bpad(n_linear);
     std::vector<const float*> Wp(n_linear), bp(n_linear);
-    std::vector<int32_t> pdims(dims, dims + n_linear + 1);
-    for (int i = 1; i <= nhid; ++i) pdims[i] = OMDS_WIDTH;
     for (int i = 0; i < n_linear; ++i) {
-        const int in = dims[i], out = dims[i + 1], pin = pdims[i], pout = pdims[i + 1];
+        const int in = in_dims[i], out = out_dims[i];
+        const int pin = i == 0 ? in : OMDS_WIDTH, pout = i == n_linear - 1 ? out : OMDS_WIDTH;
         Wpad[i].assign((size_t)pout * pin, 0.f);
         bpad[i].assign((size_t)pout, 0.f);
         for (int o = 0; o < out; ++o) {
@@ -291,8 +308,6 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
         Wp[i] = Wpad[i].data();
         bp[i] = bpad[i].data();
     }
-    const int32_t* true_dims = dims;
-    dims = pdims.data();
     W = Wp.data();
     b = bp.data();
     CK(hipSetDevice(ctx->dev));
@@ -307,6 +322,17 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
     m.n_dof = n;
     m.out_div = out_div;
     m.act = act;
+    m.skip_mask = skip_mask;
+    for (int i = 0; i < nhid; ++i) m.skip_col[i] = (uint8_t)(((skip_mask >> i) & 1u) ? out_dims[i] : 0);
+    if (skip_mask) {   // encoded-input tables beside Apre / Bpre, written by the layer-1 kernels (zero in the other operand's slots)
+        const size_t rowsA = (size_t)ctx->cfg.n_traj * ctx->cfg.n_closest, rowsB = (size_t)ctx->cfg.max_obs;
+        if (!ctx->d_featQ) CK(hipMalloc(&ctx->d_featQ, rowsA * 32 * 4));
+        if (!ctx->d_featP) CK(hipMalloc(&ctx->d_featP, rowsB * 32 * 4));
+        CK(hipMemsetAsync(ctx->d_featQ, 0, rowsA * 32 * 4, ctx->stream));
+        CK(hipMemsetAsync(ctx->d_featP, 0, rowsB * 32 * 4, ctx->stream));
+        m.featQ = ctx->d_featQ;
+        m.featP = ctx->d_featP;
+    }
     if (ctx->d_dscr) { (void)hipFree(ctx->d_dscr); ctx->d_dscr = nullptr; }
     if (act == OMDS_ACT_TANH) {   // pass 2 keeps 1 - h^2 of every hidden layer for the backward (ReLU uses LDS bit masks)
         const size_t rows = std::max(((size_t)ctx->cfg.n_traj * ctx->cfg.n_closest + 31) / 32 * 32,
@@ -391,7 +417,7 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
     ctx->screen_eps = 0.f;
     std::vector<uint16_t> wh;
     std::vector<float> sbias;
-    if (act == OMDS_ACT_RELU && m.nhh >= 1 && m.nhh <= 4) {
+    if (act == OMDS_ACT_RELU && m.nhh >= 1 && m.nhh <= 4 && !skip_mask) {   // skip-connection networks run the fp32 step
         const int nsl = m.nhh * 8 + 2;
         wh.assign((size_t)nsl * 16 * 64 * 8, 0);
         sbias.assign((size_t)(m.nhh + 2) * Wd, 0.f);
@@ -451,11 +477,11 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
     ctx->mlp = m;
     ctx->act = act;
     ctx->f_fwd = 0.0;
-    for (int i = 0; i < n_linear; ++i) ctx->f_fwd += 2.0 * true_dims[i] * true_dims[i + 1];   // algorithmic: un-padded
-    ctx->f_bwd = ctx->f_fwd - 2.0 * true_dims[n_linear - 1] * true_dims[n_linear];   // no weight-gradient, no last-layer GEMM
+    for (int i = 0; i < n_linear; ++i) ctx->f_fwd += 2.0 * in_dims[i] * out_dims[i];   // algorithmic: un-padded
+    ctx->f_bwd = ctx->f_fwd - 2.0 * in_dims[n_linear - 1] * out_dims[n_linear - 1];   // no weight-gradient, no last-layer GEMM
     ctx->have_mlp = true;
     if (ctx->n_obs > 0) {  // re-derive the obstacle half of layer 1 for the new weights
-        omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, ctx->n_obs, ctx->d_Bpre, ctx->d_radius, ctx->d_FpH, ctx->cfg.max_obs);
+        omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, ctx->n_obs, ctx->d_Bpre, ctx->d_radius, ctx->d_FpH, ctx->cfg.max_obs, ctx->mlp.featP);
         CK(hipGetLastError());
         CK(hipStreamSynchronize(ctx->stream));
     }
@@ -471,7 +497,7 @@ int omds_set_obstacles(omds_ctx* ctx, const float* xyzr, int n_obs) {
     CK(hipMemcpyAsync(ctx->d_obs, xyzr, (size_t)n_obs * 16, hipMemcpyHostToDevice, ctx->stream));
     ctx->n_obs = n_obs;
     if (ctx->have_mlp) {
-        omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, n_obs, ctx->d_Bpre, ctx->d_radius, ctx->d_FpH, ctx->cfg.max_obs);
+        omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, n_obs, ctx->d_Bpre, ctx->d_radius, ctx->d_FpH, ctx->cfg.max_obs, ctx->mlp.featP);
         CK(hipGetLastError());
     }
     CK(hipStreamSynchronize(ctx->stream));

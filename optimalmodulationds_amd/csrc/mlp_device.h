@@ -318,6 +318,26 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
     OMDS_TL(9);
     __syncthreads();
     OMDS_TL(1);
+    // skip-connection networks: the encoded input of each row goes behind the activations of `level` (MlpDev::skip_mask)
+    auto inject = [&](int level) {
+        const int c0 = m.skip_col[level], F = 3 * m.d;
+        for (int e = tid; e < MT * 32; e += G::NT) {
+            const int r = e >> 5, f = e & 31;
+            if (f < F) {
+                float v = 0.f;
+                if (row0 + r < total_rows) {
+                    unsigned pair;
+                    if constexpr (LIST) pair = (unsigned)rowIdx[r];
+                    else pair = (unsigned)row0 + (unsigned)r;
+                    const unsigned t = odiv.div(pair), o = pair - t * (unsigned)O;
+                    v = m.featQ[(size_t)t * 32 + f] + m.featP[(size_t)o * 32 + f];
+                }
+                Hs[r * LDH + c0 + f] = v;
+            }
+        }
+        __syncthreads();
+    };
+    if (m.skip_mask & 1u) inject(0);
 
     // ---- hidden -> hidden layers.  The accumulators start at the bias (fetched one layer ahead), so the epilogue
     //      is activation + LDS write only -----------------------------------------------------------------
@@ -340,6 +360,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
             for (int r = 0; r < 8; ++r)
                 Hs[(4 * (lane >> 4) + (r & 3)) * LDH + wave * 32 + 16 * (r >> 2) + (lane & 15)] = actf(acc[r >> 2][r & 3], ACT);
             __syncthreads();
+            if ((m.skip_mask >> (l + 1)) & 1u) inject(l + 1);
             OMDS_TL(2 + l);
         }
     } else
@@ -379,6 +400,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                 }
         }
         __syncthreads();
+        if ((m.skip_mask >> (l + 1)) & 1u) inject(l + 1);
         OMDS_TL(2 + l);
     }
 
@@ -624,6 +646,26 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
     }
     __syncthreads();
     if (dbg == 10) return;
+    // skip-connection networks: [x, sin x, cos x] of each row behind the activations of `level` (MlpDev::skip_mask); the same
+    // sinf / cosf as the layer-1 kernels, so pass 1 (tables) and pass 2 see the same values
+    auto inject = [&](int level) {
+        const int c0 = m.skip_col[level], d = m.d, n = m.n_dof, F = 3 * d;
+        for (int e = tid; e < ROWS * 32; e += P2_NT) {
+            const int r = e >> 5, f = e & 31;
+            if (f < F) {
+                float v = 0.f;
+                const int t = rowT[r];
+                if (t >= 0) {
+                    const int part = f / d, jj = f - part * d;
+                    const float x = (jj < n) ? qT[(size_t)jj * ldq + t] : xyzr[rowO[r] * 4 + (jj - n)];
+                    v = part == 0 ? x : (part == 1 ? sinf(x) : cosf(x));
+                }
+                Hs[r * LDH + c0 + f] = v;
+            }
+        }
+        __syncthreads();
+    };
+    if (m.skip_mask & 1u) inject(0);
 
     // ---- forward through the hidden -> hidden layers -------------------------------------------
     for (int l = 0; l < m.nhh; ++l) {
@@ -649,6 +691,7 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
         }
         maskL[(l + 1) * P2_NT + tid] = (uint16_t)bits;
         __syncthreads();
+        if ((m.skip_mask >> (l + 1)) & 1u) inject(l + 1);
     }
 
     if (dbg == 11) return;
@@ -728,13 +771,23 @@ __device__ __forceinline__ void pass2_backward(const MlpDev& m, const P2Smem& sm
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr bool relu = ACT == OMDS_ACT_RELU;
 
+    // skip-connection networks: the gradient that arrives at the concatenated input columns of a level is a direct
+    // contribution to the feature gradient; it is collected in gf (one owner thread per element and level)
+    const int F3 = 3 * m.d;
+    if (m.skip_mask) {
+        for (int e = tid; e < ROWS * 33; e += P2_NT) gf[e] = 0.f;
+        __syncthreads();
+    }
     // ---- backward seed: dy[minIdx]/dH_last = Wlast[minIdx], masked by the last hidden layer ---------
     {
         const uint32_t bits = maskL[m.nhh * P2_NT + tid];
+        const bool cap = (m.skip_mask >> m.nhh) & 1u;
+        const int c0 = m.skip_col[m.nhh];
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
             const int row = G::row(r, lane), col = G::col(r, wave, lane);
             const float g = m.Wlraw[(size_t)rowMin[row] * OMDS_WIDTH + col];
+            if (cap && col >= c0 && col < c0 + F3) gf[row * 33 + col - c0] += g;
             const float dv = relu ? (((bits >> r) & 1u) ? 1.f : 0.f)
                                   : dscr[m.nhh * dlayer + (size_t)(S0 + row) * OMDS_WIDTH + col];
             Hs[row * LDH + col] = g * dv;
@@ -750,11 +803,14 @@ __device__ __forceinline__ void pass2_backward(const MlpDev& m, const P2Smem& sm
         p2_gemm<ROWS>(Hs, m, l, true, wave, lane, acc, zinit);
         __syncthreads();
         const uint32_t bits = maskL[l * P2_NT + tid];
+        const bool cap = (m.skip_mask >> l) & 1u;
+        const int c0 = m.skip_col[l];
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
             const int row = G::row(r, lane), col = G::col(r, wave, lane);
             const float dv = relu ? (((bits >> r) & 1u) ? 1.f : 0.f)
                                   : dscr[l * dlayer + (size_t)(S0 + row) * OMDS_WIDTH + col];
+            if (cap && col >= c0 && col < c0 + F3) gf[row * 33 + col - c0] += acc[r];
             Hs[row * LDH + col] = acc[r] * dv;
         }
         __syncthreads();
@@ -805,7 +861,7 @@ __device__ __forceinline__ void pass2_backward(const MlpDev& m, const P2Smem& sm
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) s += (w < P2_PSETS ? P + w * (ROWS * 32) : Hs + (w - P2_PSETS) * (ROWS * 32))[row * 32 + f];
-        gf[row * 33 + f] = s;
+        gf[row * 33 + f] = m.skip_mask ? s + gf[row * 33 + f] : s;
     }
     __syncthreads();
     // ---- positional-encoding chain rule: d/dx = g[x] + g[sin x] cos x - g[cos x] sin x --------------

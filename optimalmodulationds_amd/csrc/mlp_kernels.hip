@@ -41,6 +41,11 @@ __global__ __launch_bounds__(256) void k_rollout_layer1(MlpDev m, const float* _
             FqH[omds_screen_fidx(d + c, t, ldF)] = (_Float16)f[n + c];
             FqH[omds_screen_fidx(2 * d + c, t, ldF)] = (_Float16)f[2 * n + c];
         }
+        if (m.featQ) {   // skip-connection networks: the encoded input itself, concatenated behind a hidden layer
+            m.featQ[(size_t)t * 32 + c] = q;
+            m.featQ[(size_t)t * 32 + d + c] = f[n + c];
+            m.featQ[(size_t)t * 32 + 2 * d + c] = f[2 * n + c];
+        }
     }
     __syncthreads();
     float acc = m.b1[c];
@@ -52,7 +57,7 @@ __global__ __launch_bounds__(256) void k_rollout_layer1(MlpDev m, const float* _
 
 __global__ __launch_bounds__(256) void k_obstacle_layer1(MlpDev m, const float* __restrict__ xyzr, int O,
                                                          float* __restrict__ Bpre, float* __restrict__ radius,
-                                                         _Float16* __restrict__ FpH, int ldF) {
+                                                         _Float16* __restrict__ FpH, int ldF, float* __restrict__ featP) {
     __shared__ float f[9];
     const int o = blockIdx.x, c = threadIdx.x, n = m.n_dof, d = m.d, po = d - n;   // po = 3 (x, y, z) or 2 (toy networks)
     if (c < po) {
@@ -64,6 +69,11 @@ __global__ __launch_bounds__(256) void k_obstacle_layer1(MlpDev m, const float* 
             FpH[omds_screen_fidx(n + c, o, ldF)] = (_Float16)p;
             FpH[omds_screen_fidx(d + n + c, o, ldF)] = (_Float16)f[3 + c];
             FpH[omds_screen_fidx(2 * d + n + c, o, ldF)] = (_Float16)f[6 + c];
+        }
+        if (featP) {
+            featP[(size_t)o * 32 + n + c] = p;
+            featP[(size_t)o * 32 + d + n + c] = f[3 + c];
+            featP[(size_t)o * 32 + 2 * d + n + c] = f[6 + c];
         }
     }
     if (c == 3) radius[o] = xyzr[o * 4 + 3];
@@ -181,9 +191,10 @@ void omds_launch_rollout_layer1(hipStream_t s, const MlpDev& m, const float* qT,
     hipLaunchKernelGGL(k_rollout_layer1, dim3(B), dim3(256), 0, s, m, qT, ldq, B, Apre, reinterpret_cast<_Float16*>(FqH), ldF);
 }
 
-void omds_launch_obstacle_layer1(hipStream_t s, const MlpDev& m, const float* xyzr, int O, float* Bpre, float* radius, uint16_t* FpH, int ldF) {
+void omds_launch_obstacle_layer1(hipStream_t s, const MlpDev& m, const float* xyzr, int O, float* Bpre, float* radius, uint16_t* FpH, int ldF,
+                                 float* featP) {
     if (O <= 0) return;
-    hipLaunchKernelGGL(k_obstacle_layer1, dim3(O), dim3(256), 0, s, m, xyzr, O, Bpre, radius, reinterpret_cast<_Float16*>(FpH), ldF);
+    hipLaunchKernelGGL(k_obstacle_layer1, dim3(O), dim3(256), 0, s, m, xyzr, O, Bpre, radius, reinterpret_cast<_Float16*>(FpH), ldF, featP);
 }
 
 template <int MT, int MR, int NR, int ACT>

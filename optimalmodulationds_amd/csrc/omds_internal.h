@@ -37,6 +37,14 @@ struct MlpDev {
     int n_dof;
     float out_div;
     int act;             // OMDS_ACT_RELU | OMDS_ACT_TANH
+    // Skip-connection networks (network_macros_mod.py:117-146: the encoded input is concatenated behind the activations of a
+    // hidden layer).  Level 0 = output of layer 1, level l + 1 = output of hidden->hidden layer l.  The layer in front of a
+    // concatenation is narrower by 3d, so the concatenated vector still has <= 256 columns: the encoded input is written into
+    // columns skip_col[L] .. +3d-1 of the activation tile, whose padded units are zero there.
+    uint32_t skip_mask;  // bit L: concatenation behind level L
+    uint8_t skip_col[OMDS_MAX_HIDDEN + 1];
+    float* featQ;        // [Apre rows][32] joint part of the encoded input of each Apre row (others 0); null without skips
+    float* featP;        // [max_obs][32] obstacle part of each Bpre row
 #ifdef OMDS_TIMELINE
     unsigned long long* tl;   // diagnostic build only (make TIMELINE=1): [workgroup][8] phase timestamps of k_pass1
 #endif
@@ -107,6 +115,8 @@ struct omds_ctx {
     float* d_obs = nullptr;      // [max_obs][4]
     float* d_Bpre = nullptr;     // [max_obs][256] obstacle part of layer 1
     uint16_t* d_FpH = nullptr;   // [4][n_obs][8] fp16 network inputs of the obstacle points for the screening kernel
+    float* d_featQ = nullptr;    // [n_traj*n_closest][32] / [max_obs][32] encoded inputs (skip-connection networks, MlpDev::featQ/featP)
+    float* d_featP = nullptr;
     uint16_t* d_FqH = nullptr;   // [4][batch][8] rollout states likewise
     float* d_radius = nullptr;   // [max_obs]
     // DS / cost
@@ -197,7 +207,8 @@ int omds_update_impl(omds_ctx* ctx, bool use_comm, float rate, float ker_thr, fl
 // (n_traj / max_obs), never the batch: the slots the other operand owns must stay zero, and a batch-dependent stride would
 // alias them with data of an earlier call
 void omds_launch_rollout_layer1(hipStream_t s, const MlpDev& m, const float* qT, int ldq, int B, float* Apre, uint16_t* FqH = nullptr, int ldF = 0);
-void omds_launch_obstacle_layer1(hipStream_t s, const MlpDev& m, const float* xyzr, int O, float* Bpre, float* radius, uint16_t* FpH = nullptr, int ldF = 0);
+void omds_launch_obstacle_layer1(hipStream_t s, const MlpDev& m, const float* xyzr, int O, float* Bpre, float* radius, uint16_t* FpH = nullptr, int ldF = 0,
+                                 float* featP = nullptr);
 void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
                        int O, int B, uint32_t ignored_links, float* Dmin);
 void omds_launch_topk(hipStream_t s, const float* Dmin, int B, int O, int k, int32_t* idx);

@@ -117,6 +117,11 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
             for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)(2 * d + j) * OMDS_WIDTH + c], f[2 * ND + j], acc);
             a.Apre[(size_t)t * OMDS_WIDTH + c] = acc;
         }
+        if (m.featQ)   // skip-connection networks: the encoded joint inputs of the next step (as k_rollout_layer1 writes them)
+            for (int e = tid; e < RW * 3 * ND; e += P2_NT) {
+                const int rl = e / (3 * ND), cc = e - rl * (3 * ND), part = cc / ND, t = t_base + rl;
+                if (t < t_end) m.featQ[(size_t)t * 32 + part * d + (cc - part * ND)] = feat[e];
+            }
     }
 }
 
@@ -266,6 +271,11 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
             for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)(2 * d + j) * OMDS_WIDTH + c], f[2 * ND + j], acc);
             a.Apre[(size_t)t * OMDS_WIDTH + c] = acc;
         }
+        if (m.featQ)   // skip-connection networks: the encoded joint inputs of the next step (as k_rollout_layer1 writes them)
+            for (int e = tid; e < RW * 3 * ND; e += P2_NT) {
+                const int rl = e / (3 * ND), cc = e - rl * (3 * ND), part = cc / ND, t = t_base + rl;
+                if (t < t_end) m.featQ[(size_t)t * 32 + part * d + (cc - part * ND)] = feat[e];
+            }
     }
 }
 

@@ -41,18 +41,27 @@ class Engine:
         L.check(self.h, rc)
 
     # ---- configuration ------------------------------------------------------------------------
-    def set_mlp(self, weights, biases, act="relu", out_div=None):
+    def set_mlp(self, weights, biases, act="relu", out_div=None, skip_after=()):
+        """``skip_after``: indices of the Linear layers behind whose activations the encoded input is concatenated
+        (MLPRegression skips, network_macros_mod.py:142-146); empty for the plain sequential network."""
         Ws = [L.f32(w) for w in weights]
         bs = [L.f32(b) for b in biases]
-        dims = np.array([Ws[0].shape[1]] + [w.shape[0] for w in Ws], dtype=np.int32)
+        ins = np.array([w.shape[1] for w in Ws], dtype=np.int32)
+        outs = np.array([w.shape[0] for w in Ws], dtype=np.int32)
         nl = len(Ws)
         Wp = (L.F32P * nl)(*[L.fptr(w) for w in Ws])
         bp = (L.F32P * nl)(*[L.fptr(b) for b in bs])
-        self.C = int(dims[-1])
-        self.d = int(dims[0]) // 3                      # raw network inputs: n + 3, or n + 2 for the toy networks
+        self.C = int(outs[-1])
+        self.d = int(ins[0]) // 3                       # raw network inputs: n + 3, or n + 2 for the toy networks
         if out_div is None:
             out_div = 100.0 if self.C == 9 else 1.0     # MPPI.py:236-237
-        self._ck(self.lib.omds_set_mlp(self.h, nl, L.iptr(dims), Wp, bp, 0 if act == "relu" else 1, float(out_div)))
+        a = 0 if act == "relu" else 1
+        sk = np.asarray(list(skip_after), dtype=np.int32)
+        if sk.size or (ins[1:] != outs[:-1]).any():   # the explicit form also validates every layer's input width
+            self._ck(self.lib.omds_set_mlp_ex(self.h, nl, L.iptr(ins), L.iptr(outs), Wp, bp, a, float(out_div), int(sk.size), L.iptr(sk)))
+        else:
+            dims = np.concatenate((ins[:1], outs)).astype(np.int32)
+            self._ck(self.lib.omds_set_mlp(self.h, nl, L.iptr(dims), Wp, bp, a, float(out_div)))
 
     def set_obstacles(self, obs):
         obs = L.f32(obs).reshape(-1, 4)

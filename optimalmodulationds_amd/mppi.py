@@ -87,7 +87,7 @@ class MPPI:
         self._device = device
         self._max_obs = int(max_obs or max(64, 2 * self.n_obs))
         self._engine = Engine(self.n_dof, N_traj, dt_H, n_closest_obs, self._max_obs, device=device)
-        self._engine.set_mlp(nn_model.model.W, nn_model.model.b, nn_model.model.act)
+        self._engine.set_mlp(nn_model.model.W, nn_model.model.b, nn_model.model.act, skip_after=getattr(nn_model.model, 'skip_after', ()))
         self._engine.set_obstacles(self.obs.numpy())
         self.Policy = TensorPolicyMPPI(N_traj, self.n_dof, self.tensor_args, engine=self._engine, seed=seed,
                                        rollout_offset=rollout_offset)
@@ -132,7 +132,7 @@ class MPPI:
         self._max_obs = int(max(2 * n_obs, 64))
         new = Engine(self.n_dof, self.N_traj, self.dt_H, self.n_closest_obs, self._max_obs, device=self._device)
         m = self.nn_model.model
-        new.set_mlp(m.W, m.b, m.act)
+        new.set_mlp(m.W, m.b, m.act, skip_after=getattr(m, 'skip_after', ()))
         new.params = old.params
         new.push_params()
         if samples is not None:

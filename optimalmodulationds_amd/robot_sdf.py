@@ -10,13 +10,36 @@ import torch
 from .engine import Engine
 
 
+def linear_plan(in_features, out_channels, layers, skips):
+    """The flat sequence of Linear layers MLPRegression builds from (mlp_layers, skips), network_macros_mod.py:113-133:
+    the layer list is cut at the skip positions into modules; the last layer of every module but the final one is
+    narrowed by the encoded input width (the concatenation restores it), and the first entry of every later module only
+    names the width of that concatenated vector.  Returns ([(in, out)], state-dict key stems, skip_after) with
+    skip_after = indices of the Linear layers followed by a concatenation."""
+    layers = [int(v) for v in layers]
+    cuts = [0] + [int(s) for s in skips] + [len(layers)]
+    groups = [layers[cuts[i]:cuts[i + 1]] for i in range(len(cuts) - 1)]
+    for g in groups[:-1]:
+        g[-1] -= in_features
+    groups[0] = [in_features] + groups[0]
+    groups[-1] = groups[-1] + [out_channels]
+    shapes, stems, skip_after = [], [], []
+    for gi, g in enumerate(groups):
+        for i in range(1, len(g)):
+            shapes.append((g[i - 1], g[i]))
+            stems.append(f"layers.{gi}.{i - 1}.0")
+        if gi < len(groups) - 1:
+            skip_after.append(len(shapes) - 1)
+    return shapes, stems, skip_after
+
+
 class _WeightBag:
     """Stands in for ``nn_model.model``: holds W[i] ([out, in] like nn.Linear) and b[i]."""
 
-    def __init__(self, in_channels, out_channels, layers):
-        dims = [3 * in_channels] + list(layers) + [out_channels]
-        self.W = [np.zeros((dims[i + 1], dims[i]), np.float32) for i in range(len(dims) - 1)]
-        self.b = [np.zeros(dims[i + 1], np.float32) for i in range(len(dims) - 1)]
+    def __init__(self, in_channels, out_channels, layers, skips=()):
+        shapes, self.stems, self.skip_after = linear_plan(3 * in_channels, out_channels, layers, skips)
+        self.W = [np.zeros((o, i), np.float32) for i, o in shapes]
+        self.b = [np.zeros(o, np.float32) for _, o in shapes]
         self.act = "relu"
 
     def to(self, *a, **k):
@@ -28,11 +51,9 @@ class _WeightBag:
 
 class RobotSdfCollisionNet:
     def __init__(self, in_channels, out_channels, skips, layers):
-        if len(skips) > 0:
-            raise NotImplementedError("skip connections are not supported (every reference driver uses skips=[])")
         self.in_channels = in_channels
         self.out_channels = out_channels
-        self.model = _WeightBag(in_channels, out_channels, layers)
+        self.model = _WeightBag(in_channels, out_channels, layers, skips)
         self.model_jit = self          # drivers call nn_model.model_jit.forward(x)
         self.order = list(range(out_channels))
         self.norm_dict = None
@@ -57,11 +78,11 @@ class RobotSdfCollisionNet:
             chk = torch.load(f_name, map_location=torch.device("cpu"), weights_only=False)
             sd = chk["model_state_dict"]
             self.norm_dict = chk.get("norm")
-            W, b, i = [], [], 0
-            while f"layers.0.{i}.0.weight" in sd:
-                W.append(sd[f"layers.0.{i}.0.weight"].numpy().astype(np.float32))
-                b.append(sd[f"layers.0.{i}.0.bias"].numpy().astype(np.float32))
-                i += 1
+            missing = [st for st in self.model.stems if st + ".weight" not in sd]
+            if missing:
+                raise ValueError(f"checkpoint has no {missing[0]}.weight: it was not saved from a network with these layers / skips")
+            W = [sd[st + ".weight"].numpy().astype(np.float32) for st in self.model.stems]
+            b = [sd[st + ".bias"].numpy().astype(np.float32) for st in self.model.stems]
         if [w.shape for w in W] != [w.shape for w in self.model.W]:
             raise ValueError(f"checkpoint shapes {[w.shape for w in W]} do not match the declared network "
                              f"{[w.shape for w in self.model.W]}")
@@ -84,7 +105,7 @@ class RobotSdfCollisionNet:
             cap = max(256, int(batch))
             n = self.in_channels - 3
             self._engine = Engine(n, cap, 1, 1, 1, device=self.device)
-            self._engine.set_mlp(self.model.W, self.model.b, self.model.act)
+            self._engine.set_mlp(self.model.W, self.model.b, self.model.act, skip_after=self.model.skip_after)
             self._engine_cap = cap
         return self._engine
 

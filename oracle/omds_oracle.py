@@ -36,6 +36,8 @@ class Mlp:
     W: list
     b: list
     act: str = "relu"
+    skip_after: tuple = ()   # indices of the Linear layers behind whose activations the encoded input is concatenated
+                             # (MLPRegression skips, ML/network_macros_mod.py:113-146: y = layer(cat(y, x_nerf)))
 
     @property
     def out_channels(self):
@@ -46,7 +48,8 @@ class Mlp:
         z = np.load(path)
         n = len([k for k in z.files if k.startswith("W")])
         act = str(z["act"]) if "act" in z.files else "relu"
-        return Mlp([z[f"W{i}"].astype(F32) for i in range(n)], [z[f"b{i}"].astype(F32) for i in range(n)], act)
+        skip = tuple(int(v) for v in z["skip_after"]) if "skip_after" in z.files else ()
+        return Mlp([z[f"W{i}"].astype(F32) for i in range(n)], [z[f"b{i}"].astype(F32) for i in range(n)], act, skip)
 
 
 def _act(z, act):
@@ -64,10 +67,14 @@ def positional_encoding(x):
 
 
 def mlp_forward(m: Mlp, x):
-    """MLPRegression.forward with skips=[] (ML/network_macros_mod.py:137-146)."""
-    h = positional_encoding(np.asarray(x, dtype=F32))
+    """MLPRegression.forward (ML/network_macros_mod.py:137-146); with skips the encoded input is concatenated behind
+    the output of each module (``torch.cat((y, x_nerf), dim=1)``)."""
+    feats = positional_encoding(np.asarray(x, dtype=F32))
+    h = feats
     for i in range(len(m.W) - 1):
         h = _act(h @ m.W[i].T + m.b[i], m.act)
+        if i in m.skip_after:
+            h = np.concatenate((h, feats), axis=1)
     return (h @ m.W[-1].T + m.b[-1]).astype(F32)
 
 
@@ -78,16 +85,23 @@ def mlp_vjp_argmin(m: Mlp, x):
     x = np.asarray(x, dtype=F32)
     d = x.shape[1]
     feats = positional_encoding(x)
-    hs, zs = [feats], []
+    hs, zs, cur = [feats], [], feats
     for i in range(len(m.W) - 1):
-        z = hs[-1] @ m.W[i].T + m.b[i]
+        z = cur @ m.W[i].T + m.b[i]
         zs.append(z)
         hs.append(_act(z, m.act))
-    y = (hs[-1] @ m.W[-1].T + m.b[-1]).astype(F32)
+        cur = np.concatenate((hs[-1], feats), axis=1) if i in m.skip_after else hs[-1]
+    y = (cur @ m.W[-1].T + m.b[-1]).astype(F32)
     min_idx = np.argmin(y, axis=1)
-    g = m.W[-1][min_idx]                                     # dy/dh_last  [B, width]
+    g = m.W[-1][min_idx]                                     # dy/d(input of the last layer)  [B, width]
+    g_feat = np.zeros_like(feats)                            # direct paths into the encoded input (skip concatenations)
     for i in range(len(m.W) - 2, -1, -1):
+        if i in m.skip_after:                                # g is w.r.t. cat(h_i, feats): split it
+            w = hs[i + 1].shape[1]
+            g_feat = g_feat + g[:, w:]
+            g = g[:, :w]
         g = (g * _dact(zs[i], hs[i + 1], m.act)) @ m.W[i]    # -> grad wrt layer i input
+    g = g + g_feat
     grad = g[:, :d] + g[:, d:2 * d] * np.cos(x) - g[:, 2 * d:] * np.sin(x)
     return y, grad.astype(F32), min_idx
 
@@ -316,11 +330,14 @@ def relu_margin(m: Mlp, x):
     marg = np.full(h.shape[0], np.inf, dtype=F32)
     if m.act != "relu":
         return marg                      # smooth activation: no masks to flip
+    feats = h
     for i in range(len(m.W) - 1):
         z = h @ m.W[i].T + m.b[i]
         az = np.abs(z)
         marg = np.minimum(marg, az.min(axis=1) / np.maximum(az.max(axis=1), F32(1e-30)))
         h = _act(z, m.act)
+        if i in m.skip_after:
+            h = np.concatenate((h, feats), axis=1)
     return marg
 
 
@@ -347,12 +364,13 @@ def blended_gradient_alternatives(m: Mlp, q_row, obs, idx_row, margin, softmax_k
     x = np.concatenate((np.repeat(q_row, k, axis=0), np.asarray(obs, dtype=F32)[np.asarray(idx_row), :3]), axis=1)
     d = x.shape[1]
     feats = positional_encoding(x)
-    hs, zs = [feats], []
+    hs, zs, cur = [feats], [], feats
     for i in range(len(m.W) - 1):
-        z = hs[-1] @ m.W[i].T + m.b[i]
+        z = cur @ m.W[i].T + m.b[i]
         zs.append(z)
         hs.append(_act(z, m.act))
-    y = (hs[-1] @ m.W[-1].T + m.b[-1]).astype(F32)
+        cur = np.concatenate((hs[-1], feats), axis=1) if i in m.skip_after else hs[-1]
+    y = (cur @ m.W[-1].T + m.b[-1]).astype(F32)
     min_idx = np.argmin(y, axis=1)
     yd = y / F32(100) if m.out_channels == 9 else y
     dist = (yd - np.asarray(obs, dtype=F32)[np.asarray(idx_row), 3:4])[np.arange(k), min_idx]
@@ -368,8 +386,13 @@ def blended_gradient_alternatives(m: Mlp, q_row, obs, idx_row, margin, softmax_k
 
     def grad_with(masks):
         g = m.W[-1][min_idx]
+        g_feat = np.zeros_like(feats)
         for i in range(len(m.W) - 2, -1, -1):
+            if i in m.skip_after:
+                g_feat = g_feat + g[:, hs[i + 1].shape[1]:]
+                g = g[:, :hs[i + 1].shape[1]]
             g = (g * masks[i]) @ m.W[i]
+        g = g + g_feat
         gx = g[:, :d] + g[:, d:2 * d] * np.cos(x) - g[:, 2 * d:] * np.sin(x)
         return (gx[:, :n_dof].astype(F32) * w[:, None]).sum(axis=0).astype(F32)
 

@@ -9,7 +9,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 _ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(p).startswith(("mlp_", "fk_", "bases_")))
 SCENARIOS = [s for s in _ALL if not s.startswith("toy")]          # MPPI.py fixtures (tools/make_golden.py)
 TOY_SCENARIOS = [s for s in _ALL if s.startswith("toy")]          # MPPI_toy.py fixtures (tools/make_golden_toy.py)
-MLP_KINDS = ["franka", "planar7", "planar2", "franka_tanh", "planar7_128"]
+MLP_KINDS = ["franka", "planar7", "planar2", "franka_tanh", "planar7_128", "franka_skip"]
 # tolerance named by BASELINE.json's north_star: 1e-5 relative fp32 on modulated velocities
 RTOL = 1e-5
 

@@ -256,7 +256,7 @@ def _mk(N, H, k, obs, m):
     from optimalmodulationds_amd import scenes
     from optimalmodulationds_amd.engine import Engine
     eng = Engine(7, N, H, k, max_obs=max(8, obs.shape[0]))
-    eng.set_mlp(m.W, m.b, act=m.act)
+    eng.set_mlp(m.W, m.b, act=m.act, skip_after=m.skip_after)
     eng.set_obstacles(obs)
     eng.params.dt = 0.5; eng.params.dst_thr = 0.01; eng.params.ignored_links = 0b111
     eng.push_params()

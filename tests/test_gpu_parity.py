@@ -18,7 +18,7 @@ def _engine(fx, H=None, N=None, flags=0):
     m = orc.Mlp.from_npz(weights_path(str(fx["kind"])))
     n = int(fx["q0"].shape[0])
     eng = Engine(n, int(N or fx["N"]), int(H or fx["H"]), int(fx["k"]), max_obs=max(64, 2 * fx["obs"].shape[0]), flags=flags)
-    eng.set_mlp(m.W, m.b, act=m.act)
+    eng.set_mlp(m.W, m.b, act=m.act, skip_after=m.skip_after)
     eng.set_obstacles(fx["obs"])
     p = eng.params
     p.dt = float(fx["dt"]); p.dst_thr = float(fx["dst_thr"]); p.lin_thr = float(fx["lin_thr"]); p.rbf_p = float(fx["p"])
@@ -39,7 +39,7 @@ def test_mlp_forward_and_vjp(kind):
     m = orc.Mlp.from_npz(weights_path(kind))
     n = fx["x"].shape[1] - 3
     eng = Engine(n, 128, 1, 1, max_obs=8)
-    eng.set_mlp(m.W, m.b, act=m.act)
+    eng.set_mlp(m.W, m.b, act=m.act, skip_after=m.skip_after)
     y, g, mi = eng.mlp_forward_vjp(fx["x"])
     assert_close(y, fx["y"], RTOL, "mlp forward vs reference")
     assert (mi == fx["min_idx"]).all()
@@ -338,7 +338,7 @@ def test_parameter_space_against_oracle(case):
         spread = 0.8
     prm = dict(dst_thr=dst_thr, p=case["p"], **case["over"])
     eng = Engine(n, N, H, k, max_obs=max(8, O))
-    eng.set_mlp(m.W, m.b, act=m.act)
+    eng.set_mlp(m.W, m.b, act=m.act, skip_after=m.skip_after)
     eng.set_obstacles(obs)
     P = eng.params
     P.dt, P.dst_thr, P.rbf_p = dt, dst_thr, case["p"]

@@ -48,6 +48,9 @@ MODELS = {
     "franka_tanh": (None, 7, 9),
     # the reference's narrower shipped net (30-128-128-7): exercises the zero-padding of hidden layers to width 256
     "planar7_128": ("7dof_sdf_128x3_mesh.pt", 7, 7),
+    # skip-connection layout (MLPRegression(..., skips=[2]), network_macros_mod.py:113-146): no such weights ship either;
+    # the reference's own class with seeded synthetic weights pins the concatenation arithmetic, forward and backward
+    "franka_skip": (None, 7, 9),
 }
 
 
@@ -57,6 +60,22 @@ def quiet():
 
 def load_model(kind):
     fname, dof, out = MODELS[kind]
+    if kind == "franka_skip":
+        torch.manual_seed(20241)
+        nn_model = RobotSdfCollisionNet(in_channels=dof + 3, out_channels=out, layers=[256] * 4, skips=[2])
+        with torch.no_grad():
+            last = nn_model.model.layers[-1][-1][0]
+            last.weight.mul_(40.0)          # outputs are read as centimetres (C == 9): spread them
+            last.bias.add_(12.0)
+        nn_model.model.eval()
+        nn_model.model.to(**PARAMS)
+        try:
+            nn_model.model_jit = torch.jit.optimize_for_inference(torch.jit.script(nn_model.model))
+        except Exception as e:   # the drivers script the model (frankaPlanner.py:47); eager is the same arithmetic
+            print("franka_skip: torch.jit.script failed (%s); eager model used" % type(e).__name__)
+            nn_model.model_jit = nn_model.model
+        nn_model.aot_lambda = nn_model.functorch_vjp
+        return nn_model
     if fname is None:
         from sdf.network_macros_mod import MLPRegression
         from torch.nn import Tanh
@@ -85,11 +104,19 @@ def load_model(kind):
 def export_weights(kind, nn_model):
     sd = nn_model.model.state_dict()
     arrs = {}
-    i = 0
-    while f"layers.0.{i}.0.weight" in sd:
-        arrs[f"W{i}"] = sd[f"layers.0.{i}.0.weight"].numpy().astype(np.float32)
-        arrs[f"b{i}"] = sd[f"layers.0.{i}.0.bias"].numpy().astype(np.float32)
-        i += 1
+    i, g, skip_after = 0, 0, []
+    while f"layers.{g}.0.0.weight" in sd:      # modules in order; the encoded input is concatenated between modules
+        j = 0
+        while f"layers.{g}.{j}.0.weight" in sd:
+            arrs[f"W{i}"] = sd[f"layers.{g}.{j}.0.weight"].numpy().astype(np.float32)
+            arrs[f"b{i}"] = sd[f"layers.{g}.{j}.0.bias"].numpy().astype(np.float32)
+            i += 1
+            j += 1
+        g += 1
+        if f"layers.{g}.0.0.weight" in sd:
+            skip_after.append(i - 1)
+    if skip_after:
+        arrs["skip_after"] = np.asarray(skip_after, np.int32)
     arrs["act"] = np.array("tanh" if kind.endswith("tanh") else "relu")
     os.makedirs(os.path.join(OUT, "weights"), exist_ok=True)
     np.savez(os.path.join(OUT, "weights", kind + ".npz"), **arrs)
@@ -259,11 +286,14 @@ def mlp_vectors(kind, nn_model, seed):
     feats = torch.cat((x, torch.sin(x), torch.cos(x)), dim=-1)
     zmin = torch.full((B,), 1e9)
     hcur = feats
-    seq = nn_model.model.layers[0]
-    for li in range(len(seq) - 1):
-        z = seq[li][0](hcur)
-        zmin = torch.minimum(zmin, z.abs().min(dim=1)[0].detach())
-        hcur = seq[li][1](z)
+    mods = list(nn_model.model.layers)
+    for gi, seq in enumerate(mods):
+        if gi > 0:
+            hcur = torch.cat((hcur, feats), dim=1)
+        for li in range(len(seq) - (1 if gi == len(mods) - 1 else 0)):
+            z = seq[li][0](hcur)
+            zmin = torch.minimum(zmin, z.abs().min(dim=1)[0].detach())
+            hcur = seq[li][1](z)
     np.savez_compressed(os.path.join(OUT, f"mlp_{kind}.npz"), x=t2n(x), y=t2n(y), y_vjp=t2n(y2), grad=t2n(g),
                         min_idx=t2n(mi).astype(np.int32), min_abs_preact=t2n(zmin))
     print(f"mlp_{kind}: y range [{float(y.min()):.3f}, {float(y.max()):.3f}]  min|z|={float(zmin.min()):.2e}")
@@ -290,6 +320,13 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if "--only-fk" in sys.argv:
         return fk_vectors()
+    if "--only-skip" in sys.argv:   # added after the other fixtures were committed: generate this network's files only
+        m = load_model("franka_skip")
+        export_weights("franka_skip", m)
+        mlp_vectors("franka_skip", m, seed=11)
+        run_scenario("franka_skip_shelf_K4", N=48, H=6, obs=scenes.shelf_scene(), k=5, K=4, seed=17, kind="franka_skip", nn_model=m,
+                     dt=0.5, q0=scenes.FRANKA_Q0, qf=scenes.FRANKA_QF, dst_thr=0.01, ker_thr=0.1, alpha_s=3.0, sigma_nom=1.0)
+        return
     fk_vectors()
     models = {k: load_model(k) for k in MODELS}
     for k, m in models.items():
@@ -331,6 +368,8 @@ def main():
     # tanh 256x3 network (synthetic weights) on the shelf scene
     run_scenario("franka_tanh_shelf_K4", N=48, H=6, obs=shelf, k=5, K=4, seed=15, **{**fr, "kind": "franka_tanh",
                                                                                       "nn_model": models["franka_tanh"]})
+    run_scenario("franka_skip_shelf_K4", N=48, H=6, obs=shelf, k=5, K=4, seed=17, **{**fr, "kind": "franka_skip",
+                                                                                      "nn_model": models["franka_skip"]})
 
 
 if __name__ == "__main__":
