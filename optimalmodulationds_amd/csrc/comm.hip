@@ -7,8 +7,8 @@
 //   d_red[n_sum : n_sum+1+n] = (min cost, its qdot)    ncclAllGather (only for 'best')  -> MINLOC on the host
 //
 // then ONE D2H copy + stream sync and the O(K n) host arithmetic of omds_apply_update.  RCCL (xGMI on the box) is
-// dlopen'ed the first time a communicator is asked for: single-GPU processes never load it, and a process that already
-// has an RCCL (e.g. PyTorch's) shares that copy instead of mapping a second one.
+// dlopen'ed the first time a communicator is asked for: single-GPU processes never load it.  The copy beside the loaded
+// HIP runtime is used (in a process that imported PyTorch first that is PyTorch's own, already mapped).
 #include <cstring>
 #include <new>
 
@@ -29,15 +29,32 @@ struct Rccl {
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     Rccl() {
-        const char* names[] = {"librccl.so.1", "librccl.so"};
-        for (const char* nm : names) {   // a copy that is already mapped wins (RTLD_NOLOAD), then the ROCm install
-            handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-            if (handle) break;
+        // The RCCL that belongs to the HIP runtime THIS library is bound to comes first: the one in the directory of the
+        // loaded libamdhip64 (a PyTorch wheel bundles its own HIP + HSA + RCCL; which HIP a process ends up with depends
+        // on whether torch or this library was loaded first, and an RCCL from the other set opens a second, uninitialised
+        // HSA runtime: "no ROCm-capable device is detected" at ncclCommInitRank).  If that is the copy the process already
+        // has mapped, dlopen returns the same handle -- no second RCCL.
+        Dl_info info{};
+        if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                for (const char* nm : {"librccl.so.1", "librccl.so"}) {
+                    handle = dlopen((dir + nm).c_str(), RTLD_NOW | RTLD_LOCAL);
+                    if (handle) break;
+                }
+            }
+        }
+        if (!handle) {   // then a copy that is already mapped (RTLD_NOLOAD), then the default search and the ROCm install
+            for (const char* nm : {"librccl.so.1", "librccl.so"}) {
+                handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
+                if (handle) break;
+            }
         }
         if (!handle) {
-            const char* paths[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
-            for (const char* nm : paths) {
-                handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+            for (const char* nm : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+                handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
                 if (handle) break;
             }
         }

@@ -42,16 +42,26 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
+// Geometry: SC_WAVES waves per workgroup, each owning SC_RB blocks of 32 pairs; every A fragment (1 KiB of weights) a wave
+// reads from the ring feeds SC_RB MFMAs.  Default 8 waves x 1 block (two waves per SIMD, 241 registers).  The alternative
+// 4 waves x 2 blocks (one wave per SIMD with the 512-register budget: half the LDS reads per MFMA; make variant V=rb2
+// VFLAGS="-DOMDS_SC_WAVES=4 -DOMDS_SC_RB=2") is bit-identical and measured 104 vs 99 us per launch: the LDS port is not the
+// limit (tools/ubench/mfma_f16_issue.hip: one fragment read per MFMA sustains 83-87 % of the fp16 MFMA peak at two waves
+// per SIMD, 63-65 % at one), a single wave per SIMD hides less.
 #ifndef OMDS_SC_WAVES
 #define OMDS_SC_WAVES 8
+#endif
+#ifndef OMDS_SC_RB
+#define OMDS_SC_RB 1
 #endif
 #ifndef OMDS_SC_RING
 #define OMDS_SC_RING 4
 #define OMDS_SC_DIST 3
 #endif
 constexpr int SC_WAVES = OMDS_SC_WAVES;
+constexpr int SC_RB = OMDS_SC_RB;             // 32-pair blocks per wave
 constexpr int SC_NT = SC_WAVES * 64;
-constexpr int SC_ROWS = SC_WAVES * 32;        // pairs per workgroup
+constexpr int SC_ROWS = SC_WAVES * SC_RB * 32; // pairs per workgroup
 constexpr int SC_SLICE = 16384;               // bytes: 16 k-chunks x 1 KiB fragment
 constexpr int SC_RING = OMDS_SC_RING;         // ring slots of 16 KB (a power of two)
 constexpr int SC_DIST = OMDS_SC_DIST;         // slices in flight ahead of the one being multiplied (<= RING - 1)
@@ -130,8 +140,8 @@ __device__ __forceinline__ AGroup read_group(const unsigned char* slot_lane, int
 // pair (rollout t, obstacle o) of this lane in a tile; rows past the end (also: the prefetch of a non-existent next tile)
 // clamp to the last pair and are not stored.  Plain scalars on purpose: a struct carried around the tile loop went through
 // scratch memory
-__device__ __forceinline__ void tile_row(const ScreenArgs& a, long long tile, int wave, int b, unsigned& t, unsigned& o, bool& valid) {
-    long long row = tile * SC_ROWS + wave * 32 + b;
+__device__ __forceinline__ void tile_row(const ScreenArgs& a, long long tile, int wave, int rb, int b, unsigned& t, unsigned& o, bool& valid) {
+    long long row = tile * SC_ROWS + (wave * SC_RB + rb) * 32 + b;
     valid = row < a.total_rows;
     if (!valid) row = a.total_rows - 1;
     t = a.odiv.div((unsigned)row);
@@ -141,7 +151,7 @@ __device__ __forceinline__ void tile_row(const ScreenArgs& a, long long tile, in
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 template <int NHH>
-__global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
+__global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenArgs a) {
     // PERSISTENT: workgroup w multiplies tiles w, w + G, w + 2G, ... (G = gridDim.x = one workgroup per CU).  The weight
     // slices keep streaming through the ring across tile boundaries (the slice sequence is periodic), the bias table is
     // loaded once, and the results wait in LDS until the end -- a store in flight would perturb the counted vmcnt waits of
@@ -193,12 +203,16 @@ __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
         raw[2] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(fq_rs, vq, a.ldFq * 32, 0));
         raw[3] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(fp_rs, vp, a.ldFp * 32, 0));
     };
-    unsigned row_t, row_o;
-    bool row_valid;
-    tile_row(a, blockIdx.x, wave, b, row_t, row_o, row_valid);
-    u4 raw[4];
-    load_inputs(row_t, row_o, raw);
-    float rad = a.radius[row_o];
+    unsigned row_t[SC_RB], row_o[SC_RB];
+    bool row_valid[SC_RB];
+    u4 raw[SC_RB][4];
+    float rad[SC_RB];
+#pragma unroll
+    for (int rb = 0; rb < SC_RB; ++rb) {
+        tile_row(a, blockIdx.x, wave, rb, b, row_t[rb], row_o[rb], row_valid[rb]);
+        load_inputs(row_t[rb], row_o[rb], raw[rb]);
+        rad[rb] = a.radius[row_o[rb]];
+    }
 
     const unsigned char* ring_lane = ring + lane * 16;
     // accumulators start at the bias.  C layout: register r = 4j + i <-> output row 32 fb + 8 j + 4 half + i
@@ -240,126 +254,145 @@ __global__ __launch_bounds__(SC_NT, 2) void k_screen(ScreenArgs a) {
 #endif
         };
         auto slot_ptr = [&](int s) { return ring_lane + ((sigma0 + s) & (SC_RING - 1)) * SC_SLICE; };
-        const bool valid = row_valid;
-        h8 in[2];
-        {
-            const u4 i0 = raw[0] | raw[1], i1 = raw[2] | raw[3];
-            in[0] = __builtin_bit_cast(h8, i0);
-            in[1] = __builtin_bit_cast(h8, i1);
+        h8 in[SC_RB][2];
+#pragma unroll
+        for (int rb = 0; rb < SC_RB; ++rb) {
+            const u4 i0 = raw[rb][0] | raw[rb][1], i1 = raw[rb][2] | raw[rb][3];
+            in[rb][0] = __builtin_bit_cast(h8, i0);
+            in[rb][1] = __builtin_bit_cast(h8, i1);
         }
-        h8 act[16];
+        h8 act[SC_RB][16];
         // ---- step 0: layer 1 on the matrix pipe.  Slice 0 = W1 as 8 row blocks x 2 k-chunks (fragment 2 fb + cc)
         {
             const unsigned char* sl = slot_ptr(0);
             const unsigned char* sl_next = slot_ptr(1);
-            // group g = row blocks 2g, 2g+1 (two MFMAs each); their ReLU + conversion runs one group later, under the next
-            // group's MFMAs; the scheduling barriers keep hipcc from batching all 16 MFMAs first (8 live accumulators spill)
-            f32x16 pa, pb;
+            // group g = row blocks 2g, 2g+1 (two MFMAs each and pair block); their ReLU + conversion runs one group later,
+            // under the next group's MFMAs; the scheduling barriers keep hipcc from batching all MFMAs first
+            f32x16 pa[SC_RB], pb[SC_RB];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (g == 1) sync_and_issue(0);
                 const AGroup pre = (g < 3) ? read_group(sl, g + 1) : read_group(sl_next, 0);
-                f32x16 ca = read_bias(0, 2 * g), cb = read_bias(0, 2 * g + 1);
-                ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[0], in[0], ca, 0, 0, 0);
-                cb = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[2], in[0], cb, 0, 0, 0);
-                ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[1], in[1], ca, 0, 0, 0);
-                cb = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[3], in[1], cb, 0, 0, 0);
+                const f32x16 ba = read_bias(0, 2 * g), bb = read_bias(0, 2 * g + 1);
+                f32x16 ca[SC_RB], cb[SC_RB];
+#pragma unroll
+                for (int rb = 0; rb < SC_RB; ++rb) {
+                    ca[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[0], in[rb][0], ba, 0, 0, 0);
+                    cb[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[2], in[rb][0], bb, 0, 0, 0);
+                }
+#pragma unroll
+                for (int rb = 0; rb < SC_RB; ++rb) {
+                    ca[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[1], in[rb][1], ca[rb], 0, 0, 0);
+                    cb[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[3], in[rb][1], cb[rb], 0, 0, 0);
+                }
                 if (g > 0) {
-                    to_act(pa, act[4 * g - 4], act[4 * g - 3]);
-                    to_act(pb, act[4 * g - 2], act[4 * g - 1]);
+#pragma unroll
+                    for (int rb = 0; rb < SC_RB; ++rb) {
+                        to_act(pa[rb], act[rb][4 * g - 4], act[rb][4 * g - 3]);
+                        to_act(pb[rb], act[rb][4 * g - 2], act[rb][4 * g - 1]);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                pa = ca; pb = cb;
+#pragma unroll
+                for (int rb = 0; rb < SC_RB; ++rb) { pa[rb] = ca[rb]; pb[rb] = cb[rb]; }
                 cur = pre;
             }
-            to_act(pa, act[12], act[13]);
-            to_act(pb, act[14], act[15]);
+#pragma unroll
+            for (int rb = 0; rb < SC_RB; ++rb) {
+                to_act(pa[rb], act[rb][12], act[rb][13]);
+                to_act(pb[rb], act[rb][14], act[rb][15]);
+            }
         }
         SC_TL(1);
         // ---- steps 1 .. S-1: hidden->hidden layers and the last layer
-        h8 nxt[16];
-        float dmin = __builtin_inff();
-        f32x16 acc = read_bias(1, 0);
-        unsigned nrow_o = row_o;
+        h8 nxt[SC_RB][16];
+        float dmin[SC_RB];
+        f32x16 acc[SC_RB];
+        {
+            const f32x16 b0 = read_bias(1, 0);
+#pragma unroll
+            for (int rb = 0; rb < SC_RB; ++rb) { acc[rb] = b0; dmin[rb] = __builtin_inff(); }
+        }
+        unsigned nrow_o[SC_RB];
+#pragma unroll
+        for (int rb = 0; rb < SC_RB; ++rb) nrow_o[rb] = row_o[rb];
 #pragma unroll
         for (int s = 1; s < S; ++s) {
-            const int l = (s - 1) >> 3, fb = (s - 1) & 7;      // hidden->hidden layer l (bias row l + 1), output row block fb
+            const int fb = (s - 1) & 7;                        // output row block of hidden->hidden layer (s - 1) >> 3 (bias row + 1)
             const bool last = s == S - 1;
             const unsigned char* sl = slot_ptr(s);
             const unsigned char* sl_next = slot_ptr(s + 1);
-            f32x16 acc_next = acc;
-#ifdef OMDS_SC_TWOACC
-            f32x16 acc2;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-#endif
+            f32x16 acc_next = acc[0];                          // the next step's start values (the bias: the same for every pair block)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (g == 1) sync_and_issue(s);
                 const AGroup pre = (g < 3) ? read_group(sl, g + 1) : read_group(sl_next, 0);
                 if (g == 2 && !last) acc_next = (s + 1 == S - 1) ? read_bias(NHH + 1, 0) : read_bias(((s) >> 3) + 1, s & 7);
                 if (s == S - 2 && g == 2) {   // the next tile's inputs, fetched under the last two steps of this one
-                    unsigned nt;
-                    tile_row(a, blockIdx.x + (long long)(it + 1) * gridDim.x, wave, b, nt, nrow_o, row_valid);
-                    load_inputs(nt, nrow_o, raw);
-                }
-#ifdef OMDS_SC_TWOACC
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[0], act[4 * g + 0], acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[1], act[4 * g + 1], acc2, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[2], act[4 * g + 2], acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[3], act[4 * g + 3], acc2, 0, 0, 0);
-#else
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[i], act[4 * g + i], acc, 0, 0, 0);
-#endif
-                // issue order inside the group: one fragment read of the NEXT group ahead of each MFMA (4 MFMAs = 128+ cycles
-                // of lead for the LDS latency; group 2 also carries the four bias reads of the next step); everything else
-                // (the previous step's epilogue VALU) fills in behind
+                    for (int rb = 0; rb < SC_RB; ++rb) {
+                        unsigned nt;
+                        tile_row(a, blockIdx.x + (long long)(it + 1) * gridDim.x, wave, rb, b, nt, nrow_o[rb], row_valid[rb]);
+                        load_inputs(nt, nrow_o[rb], raw[rb]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int rb = 0; rb < SC_RB; ++rb)
+                        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[i], act[rb][4 * g + i], acc[rb], 0, 0, 0);
+                // issue order inside the group: one fragment read of the NEXT group ahead of each fragment's MFMAs (the
+                // group's MFMAs = 128+ cycles of lead for the LDS latency; group 2 also carries the four bias reads of the
+                // next step); everything else (the previous step's epilogue VALU) fills in behind
                 if (g == 2 && !last) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, SC_RB, 0);
                     }
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, SC_RB, 0);
                     }
                 }
                 cur = pre;
             }
-#ifdef OMDS_SC_TWOACC
-            acc = acc + acc2;
-#endif
             if (!last) {
-                to_act(acc, nxt[2 * fb], nxt[2 * fb + 1]);
-                if (fb == 7) {
 #pragma unroll
-                    for (int cc = 0; cc < 16; ++cc) act[cc] = nxt[cc];
+                for (int rb = 0; rb < SC_RB; ++rb) {
+                    to_act(acc[rb], nxt[rb][2 * fb], nxt[rb][2 * fb + 1]);
+                    if (fb == 7) {
+#pragma unroll
+                        for (int cc = 0; cc < 16; ++cc) act[rb][cc] = nxt[rb][cc];
+                    }
                 }
-                (void)l;
             } else {
                 // last layer: the links sit on the A rows (rows >= C are zero); min over the valid, un-ignored links
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {   // link = 4 half + (r & 3) + 8 (r >> 2); links >= 16 do not exist (OMDS_CPAD)
-                    const int link = 4 * half + (r & 3) + 8 * (r >> 2);
-                    float v = acc[r] / a.out_div - rad;
-                    v = (link >= a.C) ? __builtin_inff() : (((a.ignored >> link) & 1u) ? 1e6f : v);
-                    dmin = fminf(dmin, v);
-                }
+                for (int rb = 0; rb < SC_RB; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {   // link = 4 half + (r & 3) + 8 (r >> 2); links >= 16 do not exist (OMDS_CPAD)
+                        const int link = 4 * half + (r & 3) + 8 * (r >> 2);
+                        float v = acc[rb][r] / a.out_div - rad[rb];
+                        v = (link >= a.C) ? __builtin_inff() : (((a.ignored >> link) & 1u) ? 1e6f : v);
+                        dmin[rb] = fminf(dmin[rb], v);
+                    }
             }
-            acc = acc_next;
+#pragma unroll
+            for (int rb = 0; rb < SC_RB; ++rb) acc[rb] = acc_next;
             if (s == 8) SC_TL(2);
         }
         SC_TL(3);
         // links 0-3, 8-11 sit in lane-half 0, the others in half 1: both min into the pair's LDS slot (ds_min_f32; a cross-lane
         // exchange would keep a lane-index VGPR alive across the whole tile loop)
-        (void)valid;
-        __hip_atomic_fetch_min(&resL[it * SC_ROWS + wave * 32 + b], dmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        row_o = nrow_o;
-        rad = a.radius[row_o];
+#pragma unroll
+        for (int rb = 0; rb < SC_RB; ++rb) {
+            __hip_atomic_fetch_min(&resL[it * SC_ROWS + (wave * SC_RB + rb) * 32 + b], dmin[rb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            row_o[rb] = nrow_o[rb];
+            rad[rb] = a.radius[row_o[rb]];
+        }
     }
     // ---- drain the ring (pieces issued past the last tile still target this workgroup's LDS), then flush the results
     wait_vm_barrier(0);
@@ -382,10 +415,18 @@ struct SelectArgs {
     float two_eps;
 };
 
-__global__ __launch_bounds__(256) void k_select(SelectArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= a.N) return;
+#ifndef OMDS_SEL_WAVES
+#define OMDS_SEL_WAVES 8
+#endif
+constexpr int SEL_WAVES = OMDS_SEL_WAVES;   // rollouts per workgroup (4: 10.5 us, 8: 10.1, 16: 11.4): ONE atomic on the list counter per workgroup (1024 same-address
+                                // atomics, one per rollout, serialise in L2 and were most of this kernel's 19 us)
+__global__ __launch_bounds__(SEL_WAVES * 64) void k_select(SelectArgs a) {
+    __shared__ int wtot[SEL_WAVES];
+    __shared__ int wbase;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t_raw = blockIdx.x * SEL_WAVES + wave;
+    const bool live = t_raw < a.N;                       // waves past the last rollout take part in the barriers with 0 entries
+    const int t = live ? t_raw : a.N - 1;
     const float* row = a.Dmin + (size_t)t * a.O;
     const int O = a.O;
     constexpr int NV = 8;
@@ -441,14 +482,23 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a) {
         const int u = __shfl_up(incl, off);
         if (lane >= off) incl += u;
     }
-    const int wave_total = __shfl(incl, 63);
-    int base = 0;
+    const int wave_total = live ? __shfl(incl, 63) : 0;
+    if (lane == 0) wtot[wave] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sum = 0;
+#pragma unroll
+        for (int w = 0; w < SEL_WAVES; ++w) sum += wtot[w];
+        wbase = atomicAdd(a.total, sum);
+    }
+    __syncthreads();
+    if (!live) return;
+    int base = wbase;
+    for (int w = 0; w < wave; ++w) base += wtot[w];
     if (lane == 0) {
-        base = atomicAdd(a.total, wave_total);
         a.range[2 * t] = base;
         a.range[2 * t + 1] = wave_total;
     }
-    base = __shfl(base, 0);
     int pos = base + incl - cnt;
     const int rbase = t * O;
     if (in_regs) {
@@ -564,7 +614,7 @@ void omds_launch_select(hipStream_t s, const float* Dmin, int B, int O, int k, f
     if (B <= 0) return;
     SelectArgs a;
     a.Dmin = Dmin; a.rowlist = rowlist; a.range = range; a.total = total; a.N = B; a.O = O; a.k = k; a.two_eps = 2.f * eps;
-    hipLaunchKernelGGL(k_select, dim3((B + 3) / 4), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_select, dim3((B + SEL_WAVES - 1) / SEL_WAVES), dim3(SEL_WAVES * 64), 0, s, a);
 }
 
 void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius, int O,

@@ -118,6 +118,26 @@ def test_native_rccl_single_rank_matches_local_update():
     e.close()
 
 
+def test_native_rccl_when_the_library_is_loaded_before_torch():
+    """Load order: a process that loads libomds_hip.so (bound to the ROCm install's HIP runtime) BEFORE importing torch
+    must still get a working communicator -- the library picks the RCCL beside the HIP runtime it is bound to, not the copy
+    a later ``import torch`` maps (that one opens a second HSA runtime and fails with 'no ROCm-capable device')."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from optimalmodulationds_amd.engine import Engine\n"
+        "assert 'torch' not in sys.modules\n"
+        "e = Engine(7, 64, 2, 1, max_obs=8)\n"
+        "import torch\n"
+        "e.comm_init(Engine.comm_unique_id(), 0, 1)\n"
+        "assert e.comm_info() == (0, 1)\n"
+        "e.comm_destroy(); e.close(); print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_shard_4096x64_config4():
     """BASELINE configs[3] per GPU: 4096 rollouts x 64 horizon on the shelf scene (one of 8 shards; rollout_offset of
     rank 3).  Size-independent checks: finite outputs; H network evaluations; sampled (rollout, step) states re-derived

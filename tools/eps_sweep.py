@@ -1,0 +1,15 @@
+import sys, numpy as np
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+from test_gpu_screen import _engine
+for N in (1024, 4096):
+    for eps in (1.5e-2, 1.0e-2, 7.5e-3, 6e-3, 5e-3, 4e-3):
+        e, m, obs, q0, qf = _engine(N, 32)
+        K = 10
+        rng = np.random.RandomState(5)
+        s = (np.arange(K) + 0.5) / K
+        mu_c = (q0 + s[:, None] * (qf - q0) + 0.15 * rng.standard_normal((K, 7))).astype(np.float32)
+        e.set_screening(1, eps)
+        e.sample_policy(mu_c, np.ones(K, np.float32), rng.standard_normal((K, 7)).astype(np.float32), 0.0, 0.0, 3.0, K, seed=100)
+        e.propagate(q0)
+        print(N, eps, e.screen_stats())
+        e.close()
