@@ -58,6 +58,9 @@ typedef struct {
 /* omds_config.flags: the generic step of omds_propagate -- five launches (k_pass1, k_topk, k_pass2, k_modulate,
  * k_rollout_layer1), the only one for n_dof other than 2 and 7 -- instead of the two-launch k_pass1 + k_tail step. */
 #define OMDS_FLAG_UNFUSED_STEP 1
+/* Keep scenes with few obstacles (O <= 32) on the two-launch k_pass1 + k_tail step instead of the one-launch fused
+ * small-scene step (k_step_small) that omds_propagate picks for them by itself.                                      */
+#define OMDS_FLAG_TWO_KERNEL_STEP 2
 
 /* The constants the reference hard-codes inside propagate() (MPPI.py:117-217,277) and
  * LinDS (LinDS.py:9), as parameters; omds_default_params() fills the reference values.   */

@@ -32,7 +32,8 @@ class OmdsParams(C.Structure):
                 ("variant", C.c_uint32), ("cost_terms", C.c_uint32)]
 
 
-FLAG_UNFUSED_STEP = 1   # omds_config.flags
+FLAG_UNFUSED_STEP = 1
+FLAG_TWO_KERNEL_STEP = 2   # keep few-obstacle scenes on k_pass1 + k_tail (omds.h: OMDS_FLAG_TWO_KERNEL_STEP)   # omds_config.flags
 # omds_params.variant / cost_terms bits (include/omds.h)
 VARIANT_KVAL_TIMES_ACT = 1
 VARIANT_NO_BASE_MASK = 2

@@ -463,6 +463,11 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
     if ((rc = upload(ctx, wl, &m.Wl))) return rc;
     if ((rc = upload(ctx, bl, &m.bl))) return rc;
     if ((rc = upload(ctx, wlraw, &m.Wlraw))) return rc;
+    {
+        std::vector<float> whraw((size_t)std::max(m.nhh, 1) * Wd * Wd, 0.f);
+        for (int l = 0; l < m.nhh; ++l) std::memcpy(&whraw[(size_t)l * Wd * Wd], W[l + 1], (size_t)Wd * Wd * sizeof(float));
+        if ((rc = upload(ctx, whraw, &m.Whraw))) return rc;
+    }
     if ((rc = upload(ctx, w1t, &m.W1t))) return rc;
     if ((rc = upload(ctx, b1, &m.b1))) return rc;
     if ((rc = upload(ctx, w1b, &m.W1b))) return rc;
@@ -658,11 +663,21 @@ static int prof_collect(omds_ctx* ctx) {
     return OMDS_OK;
 }
 
+static bool small_step_wanted(omds_ctx* ctx);
+
 static int enqueue_network(omds_ctx* ctx, const float* qT, int ldq, int B) {
     const MlpDev& m = ctx->mlp;
     const int O = ctx->n_obs, k = ctx->cfg.n_closest;
     omds_launch_rollout_layer1(ctx->stream, m, qT, ldq, B, ctx->d_Apre);
     int rc;
+    if (small_step_wanted(ctx)) {   // the arithmetic the step of this context uses: the batch entry point reproduces it bit for bit
+        if ((rc = prof_begin(ctx))) return rc;
+        omds_launch_net_small(ctx->stream, m, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Apre, O, ctx->prm.ignored_links,
+                              ctx->cfg.n_dof, k, qT, ldq, B, ctx->d_gradx, ctx->d_drow, ctx->d_idx, ctx->d_Dmin);
+        if ((rc = prof_end(ctx, (int64_t)B * O, (double)B * O * ctx->f_fwd + (double)B * k * ctx->f_bwd, "k_step_small"))) return rc;
+        CK(hipGetLastError());
+        return OMDS_OK;
+    }
     if ((rc = prof_begin(ctx))) return rc;
     omds_launch_pass1(ctx->stream, m, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
     if ((rc = prof_end(ctx, (int64_t)B * O))) return rc;
@@ -748,9 +763,35 @@ static int calibrate_screen(omds_ctx* ctx, const float* q_center) {
     return OMDS_OK;
 }
 
+// The one-launch small-scene step (step_small.hip) when the scene qualifies and the batch is small enough that the
+// two-kernel step's tail would sit on a fraction of the CUs (at R rollouts per workgroup; beyond ~3 rounds of workgroups
+// k_pass1 + the 16/32-row MFMA tail win back what the extra launch costs).
+static bool small_step_wanted(omds_ctx* ctx) {
+    if (ctx->cfg.flags & (OMDS_FLAG_UNFUSED_STEP | OMDS_FLAG_TWO_KERNEL_STEP)) return false;
+    const int R = omds_step_small_rollouts(ctx->mlp, ctx->cfg.n_dof, ctx->n_obs, ctx->cfg.n_closest);
+    if (R <= 0) return false;
+    static int env = -2;
+    if (env == -2) { const char* e = getenv("OMDS_SMALL_STEP"); env = e ? atoi(e) : -1; }
+    if (env == 0) return false;
+    if (env > 0) return true;
+    return (ctx->cfg.n_traj + R - 1) / R <= 768;
+}
+
 static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) {
     const int N = a.N, H = a.H, n = a.n;
     int rc;
+    if (tail && !screen && small_step_wanted(ctx)) {
+        omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, ctx->d_Apre, nullptr, N);
+        for (int i = 1; i <= H; ++i) {
+            RoctxRange r1("TAG: evaluate NN_2-5 + Modulation-propagation (fused small-scene step)");
+            a.step = i;
+            if ((rc = prof_begin(ctx))) return rc;
+            omds_launch_step_small(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Apre, ctx->n_obs,
+                                   ctx->prm.ignored_links, a);
+            if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs, (double)N * ctx->n_obs * ctx->f_fwd + (double)N * a.k * ctx->f_bwd, "k_step_small"))) return rc;
+        }
+        return OMDS_OK;
+    }
     ExactOut ex{ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->ex_cap};
     if (tail) {
         // two launches per step: k_pass1 over all (rollout, obstacle) pairs, then the rollout-local tail; with screening

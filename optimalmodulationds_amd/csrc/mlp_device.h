@@ -193,17 +193,21 @@ struct OmdsDivisor {
     }
 };
 
-// LIST = false: the tile covers rows row0 .. row0+MT-1 of the virtual rollout-major pair space (row = t*O + o) and writes
-// Dmin[row].  LIST = true (screening, screen_kernel.hip): the tile covers entries row0 .. of `rowlist`, each naming a pair
-// t*O + o; the result overwrites Dmin[pair] (which holds the screening value) and max |old - new| goes to *maxerr_bits.
-// The arithmetic of a row is the same in both forms and independent of the other rows of the tile: bit-identical results.
-template <int MT, int MR, int NR, int ACT, bool LIST = false>
+// MODE 0: the tile covers rows row0 .. row0+MT-1 of the virtual rollout-major pair space (row = t*O + o) and writes
+// Dmin[row].  MODE 1 (LIST; screening, screen_kernel.hip): the tile covers entries row0 .. of `rowlist`, each naming a pair
+// t*O + o; the exact value, what pass 2's forward would compute for the row (pass-2 distance, arg-min link) and the ReLU
+// masks go to ex->... per list entry, and max |screening value - exact value| to *maxerr_bits.  MODE 2 (fused small-O step,
+// step_small.hip): rows as in mode 0, outputs as in mode 1 but indexed by the row within the tile (ex-> pointers are LDS
+// arrays) and the masks stay in the tile's LDS block (maskS, behind rowIdx).
+// The arithmetic of a row is the same in all forms and independent of the other rows of the tile: bit-identical results.
+template <int MT, int MR, int NR, int ACT, int MODE = 0>
 __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const float* __restrict__ Apre,
                                            const float* __restrict__ Bpre, const float* __restrict__ radius, int O,
                                            long long total_rows, uint32_t ignored, float* __restrict__ Dmin,
                                            const long long row0, const OmdsDivisor odiv,
                                            const int* __restrict__ rowlist = nullptr, unsigned* maxerr_bits = nullptr,
                                            const ExactOut* ex = nullptr) {
+    constexpr bool LIST = MODE == 1, EMIT = MODE != 0;
     using G = Geo<MT, MR, NR>;
     float* Hs = smem;                                           // [MT][LDH]
     float* rowRad = smem + MT * LDH;                            // [MT] obstacle radius of each row
@@ -290,7 +294,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const omds_f4 z = av[it] + bv[it];                  // vector add -> two v_pk_add_f32
-            if constexpr (LIST) {                               // layer-1 masks of this row: four ballots, written by lane 0
+            if constexpr (EMIT) {                               // layer-1 masks of this row: four ballots, written by lane 0
                 const unsigned long long b0 = __ballot(z.x > 0.f), b1 = __ballot(z.y > 0.f), b2 = __ballot(z.z > 0.f), b3 = __ballot(z.w > 0.f);
                 if (lane == 0) {
                     uint32_t* ms = maskS + (size_t)(wv + it * G::NW) * nhid * 8;
@@ -389,7 +393,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     hb[(i * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = actf(acc[i][j][r], ACT);
-                    if constexpr (LIST) {   // lanes 0-31 hold row (r&3) + 8(r>>2) of this 32-column block, lanes 32-63 that row + 4
+                    if constexpr (EMIT) {   // lanes 0-31 hold row (r&3) + 8(r>>2) of this 32-column block, lanes 32-63 that row + 4
                         const unsigned long long bal = __ballot(acc[i][j][r] > 0.f);
                         if (lane == 0) {
                             const int rr = wm * MR * 32 + i * 32 + (r & 3) + 8 * (r >> 2);
@@ -436,7 +440,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
         [[maybe_unused]] int yam[4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            if constexpr (LIST) {   // pass 2's arg-min over ALL raw outputs (robot_sdf.py:155) and the distance of that link
+            if constexpr (EMIT) {   // pass 2's arg-min over ALL raw outputs (robot_sdf.py:155) and the distance of that link
                 float bv = pad ? __builtin_inff() : acc[reg] + bj;
                 int bi = j;
 #pragma unroll
@@ -470,6 +474,11 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                     }
                 }
                 if (me > 0.f) atomicMax(maxerr_bits, __builtin_bit_cast(unsigned, me));   // non-negative floats order like their bits
+            }
+        } else if constexpr (MODE == 2) {
+            if (j == 0) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) { ex->D[r4 + reg] = y[reg]; ex->dr[r4 + reg] = ydr[reg]; ex->amin[r4 + reg] = yam[reg]; }
             }
         } else
         if (j == 0) {

@@ -23,6 +23,7 @@ struct MlpDev {
     const float4* Wl;    // [16 kchunk][64 lane] last layer, 16x16x4 B-fragments (channels padded to 16)
     const float* bl;     // [16]
     const float* Wlraw;  // [C][256] last layer, row-major (backward seed)
+    const float* Whraw;  // [nhh][256][256] hidden->hidden layers, row-major [out][in] (the small-O step's 4-row backward streams them)
     const float* W1t;    // [3d][256] first layer transposed
     const float* b1;     // [256]
     const float4* W1b;   // [32 kchunk][64 lane] first layer, backward pack (cols = 3d features, padded to 32)
@@ -264,6 +265,13 @@ bool omds_tail_sel_supported(int n_dof, int k);
 void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
                           float* Apre, int O, const StepArgs& st, const int* rowlist, const int* range, const ExactOut& ex,
                           uint16_t* FqH, int ldF);
+// fused one-launch step for scenes with few obstacles (step_small.hip): rollouts per workgroup, 0 = scene does not qualify
+int omds_step_small_rollouts(const MlpDev& m, int n_dof, int O, int k);
+void omds_launch_step_small(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr, float* Apre,
+                            int O, uint32_t ignored, const StepArgs& st);
+void omds_launch_net_small(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr, float* Apre,
+                           int O, uint32_t ignored, int n_dof, int k, const float* qT, int ldq, int B, float* gradx, float* drow,
+                           int32_t* idx, float* Dmin);
 struct CostArgs {
     int N, H, n;
     uint32_t terms;   // OMDS_COST_* bits

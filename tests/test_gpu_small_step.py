@@ -1,0 +1,129 @@
+"""GPU tests of the fused one-launch step for scenes with few obstacles (csrc/step_small.hip, k_step_small): against the
+two-kernel step (k_pass1 + k_tail, OMDS_FLAG_TWO_KERNEL_STEP), against the oracle at sampled states, over the shapes its
+workgroup geometry distinguishes (R rollouts per workgroup = min(32 / O, 4 / k)).  The reference-captured planar fixtures
+(planar2_*, planar7_*) run through it in test_gpu_parity.py as well -- it is the default step for them."""
+import numpy as np
+import pytest
+
+from helpers import RTOL, assert_close, weights_path
+from oracle import omds_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("all_traj", "closest_dist_all", "kernel_val_all", "dot_products", "kernel_activations", "qdot", "normal")
+
+
+def _scene(O, seed=7):
+    from optimalmodulationds_amd import scenes
+    base = scenes.planar7_scene(4, seed)
+    if O <= base.shape[0]:
+        return base[:O].copy()
+    rng = np.random.RandomState(seed + 1)
+    extra = np.c_[rng.uniform(-7, 7, (O - base.shape[0], 2)), np.zeros(O - base.shape[0]), np.full(O - base.shape[0], 0.5)]
+    return np.concatenate((base, extra.astype(np.float32)))
+
+
+def _engine(N, H, O, k, flags=0):
+    from optimalmodulationds_amd.engine import Engine
+    m = orc.Mlp.from_npz(weights_path("planar7"))
+    obs = _scene(O)
+    q0 = np.zeros(7, np.float32); q0[0] = np.pi / 2
+    qf = np.zeros(7, np.float32); qf[0] = -np.pi / 2
+    e = Engine(7, N, H, k, max_obs=64, flags=flags)
+    e.set_mlp(m.W, m.b)
+    e.set_obstacles(obs)
+    e.params.dt, e.params.dst_thr, e.params.ignored_links = 0.3, 0.25, 0
+    e.push_params()
+    e.set_ds(qf)
+    return e, m, obs, q0, qf
+
+
+def _policy(rng, q0, qf, K):
+    s = (np.arange(K) + 0.5) / max(K, 1)
+    mu_c = (q0 + s[:, None] * (qf - q0) + 0.3 * rng.standard_normal((K, 7))).astype(np.float32)
+    return mu_c, np.full(K, 0.5, np.float32), rng.standard_normal((K, 7)).astype(np.float32)
+
+
+@pytest.mark.parametrize("N,H,O,k", [(1024, 4, 8, 1), (1022, 3, 8, 2), (257, 3, 5, 1), (64, 3, 32, 1), (96, 3, 1, 1),
+                                     (128, 3, 16, 2), (40, 3, 3, 3), (513, 2, 12, 4)])
+def test_fused_small_step_matches_the_two_kernel_step(N, H, O, k):
+    """Same rollouts from both steps, to fp32 rounding: the fused step's forward is k_pass1's 32-row arithmetic, the
+    two-kernel step runs its pass 2 (and for small batches its pass 1) on 16-row tiles -- another order of the k sums --
+    and the 4-row backward sums in yet another order than the MFMA tiles."""
+    from optimalmodulationds_amd import _lib as L
+    outs, names, dg = [], [], []
+    for flags in (0, L.FLAG_TWO_KERNEL_STEP):
+        e, m, obs, q0, qf = _engine(N, H, O, k, flags)
+        rng = np.random.RandomState(3)
+        K = 6
+        mu_c, sg_c, al_c = _policy(rng, q0, qf, K)
+        e.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 0.75, K, seed=21)
+        q_start = (q0 + 0.4 * rng.standard_normal((N, 7))).astype(np.float32)     # per-rollout starts: a spread of states
+        e.prof_enable(1)
+        e.propagate(q_start)
+        names.append(e.prof_read_ex()[3])
+        outs.append(e.get_rollouts())
+        dg.append(e.dist_grad(q_start[: min(N, 256)], want_mindist=True, want_idx=True))
+        e.close()
+    assert names[0] == "k_step_small" and names[1] == "k_pass1", names
+    a, b = outs
+    assert_close(a["closest_dist_all"][:, 0], b["closest_dist_all"][:, 0], 2e-6, "step 1 distance")
+    for key in KEYS:
+        x, y = (a[key], b[key]) if key == "qdot" else (a[key][:, 0], b[key][:, 0])      # qdot is the velocity of step 1
+        assert_close(x, y, 5e-5, "step 1 " + key)      # two fp32 evaluations, each within 2e-5 of the oracle
+        assert_close(a[key], b[key], 1e-2, "free-running " + key)    # later steps compound the rounding through sigmoids and ReLU masks (the oracle-vs-reference free-running bar)
+    assert_close(a["all_traj"][:, 1], b["all_traj"][:, 1], 2e-5, "first integrated state")
+    # the batch entry point follows the step of its context: same selected obstacles (up to exact near-ties), same numbers to rounding
+    assert (dg[0][3] == dg[1][3]).mean() >= 0.999
+    assert_close(dg[0][2], dg[1][2], 2e-6, "pass-1 matrix")
+    assert_close(dg[0][0], dg[1][0], 2e-6, "blended distance")
+    assert_close(dg[0][1], dg[1][1], 2e-5, "blended gradient", floor=float(np.abs(dg[1][1]).max()))
+
+
+def test_fused_small_step_against_the_oracle():
+    """planar 7-DoF, 8 obstacles, k = 1 (BASELINE configs[1] shape, 1024 x 32): sampled (rollout, step) states of a
+    free-running propagate re-derived by the oracle -- distance, gradient direction, kernel values, integrated velocity."""
+    N, H, O, k, K = 1024, 32, 8, 1, 10
+    e, m, obs, q0, qf = _engine(N, H, O, k)
+    rng = np.random.RandomState(11)
+    mu_c, sg_c, al_c = _policy(rng, q0, qf, K)
+    e.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 0.75, K, seed=5)
+    mu, sg, al = e.get_policy_samples()
+    e.propagate(q0)
+    r = e.get_rollouts()
+    assert all(np.isfinite(v).all() for v in r.values())
+    S = 384
+    tt, hh = rng.randint(0, N, S), rng.randint(0, H, S)
+    q = r["all_traj"][tt, hh]
+    d, g, _, idx = orc.distance_repulsion_nn(m, q, obs, k, [])
+    st = orc.modulation_step(q, qf, d, g, mu[tt], sg[tt], al[tt], orc.Params(dst_thr=0.25))
+    scale = max(1.0, float(np.abs(d).max()))
+    assert np.abs(r["closest_dist_all"][tt, hh] - (d - np.float32(0.25))).max() <= 1e-5 * scale
+    ok = orc.rollout_relu_margin(m, q, obs, idx) >= 5e-6
+    assert ok.mean() > 0.9
+    assert_close(r["normal"][tt, hh][ok], st["ghat"][ok], 2e-5, "normal")
+    assert_close(r["kernel_val_all"][tt, hh], st["phi"], RTOL, "rbf")
+    nxt = (hh + 1 < H) & ok
+    vel = (r["all_traj"][tt[nxt], hh[nxt] + 1] - q[nxt]) / np.float32(0.3)
+    assert np.abs(vel - st["u"][nxt]).max() <= 2e-4 * max(1.0, float(np.abs(st["u"]).max()))
+    e.close()
+
+
+def test_small_step_declines_what_it_cannot_do():
+    """tanh networks, skip networks, more than 32 obstacles and k > 4 stay on the two-kernel step (loudly visible in the
+    profiled kernel name), with the same API."""
+    from optimalmodulationds_amd import scenes
+    from optimalmodulationds_amd.engine import Engine
+    m = orc.Mlp.from_npz(weights_path("planar7"))
+    q0 = np.zeros(7, np.float32); q0[0] = np.pi / 2
+    for O, k, act in ((40, 1, "relu"), (8, 5, "relu"), (8, 1, "tanh")):
+        e = Engine(7, 64, 2, k, max_obs=64)
+        e.set_mlp(m.W, m.b, act=act)
+        e.set_obstacles(_scene(O))
+        e.set_ds(-q0)
+        e.sample_policy(None, None, None, 0, 0, 0, 0, seed=1)
+        e.prof_enable(1)
+        e.propagate(q0)
+        assert e.prof_read_ex()[3] == "k_pass1", (O, k, act)
+        assert np.isfinite(e.get_rollouts()["all_traj"]).all()
+        e.close()
