@@ -182,6 +182,7 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
         if (SC_PW > 1) dma16<1024>(src, lane16, dst);
         if (SC_PW > 2) { dma16<2048>(src, lane16, dst); dma16<3072>(src, lane16, dst); }
     };
+    if (a.tl && threadIdx.x == 0) { a.tl[(size_t)blockIdx.x * 8 + 7] = __builtin_readcyclecounter(); a.tl[(size_t)blockIdx.x * 8 + 5] = wall_clock64(); }
     for (int i = tid; i < (NHH + 2) * OMDS_WIDTH; i += SC_NT) biasL[i] = a.bias[i];
     for (int i = tid; i < my_tiles * SC_ROWS; i += SC_NT) resL[i] = __builtin_inff();   // the two lane-halves of a pair min into it
     __syncthreads();   // bias table visible; nothing of the ring is in flight yet (hipcc's fence would drain it)
@@ -394,6 +395,7 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
             rad[rb] = a.radius[row_o[rb]];
         }
     }
+    if (a.tl && threadIdx.x == 0) a.tl[(size_t)blockIdx.x * 8 + 4] = __builtin_readcyclecounter();
     // ---- drain the ring (pieces issued past the last tile still target this workgroup's LDS), then flush the results
     wait_vm_barrier(0);
     __syncthreads();
@@ -401,6 +403,7 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
         const long long r = ((long long)blockIdx.x + (long long)(i / SC_ROWS) * gridDim.x) * SC_ROWS + (i % SC_ROWS);
         if (r < a.total_rows) a.Dmin[r] = resL[i];
     }
+    if (a.tl && threadIdx.x == 0) a.tl[(size_t)blockIdx.x * 8 + 6] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -598,11 +601,19 @@ void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, con
         std::vector<unsigned long long> h((size_t)grid.x * 8);
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h.data(), tl_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        double seg[3] = {0, 0, 0};
+        double seg[3] = {0, 0, 0}, pro = 0, loop = 0, wall = 0;
+        unsigned long long w0 = ~0ull, w1 = 0;
         for (unsigned w = 0; w < grid.x; ++w) {
             const unsigned long long* r = &h[(size_t)w * 8];
             for (int i = 0; i < 3; ++i) seg[i] += (double)(r[i + 1] - r[i]);
+            pro += (double)(r[0] - r[7]);          // kernel start -> first tile
+            loop += (double)(r[4] - r[0]);         // all tiles of the workgroup
+            wall += (double)(r[6] - r[5]);         // 100 MHz wall clock, whole workgroup
+            w0 = std::min(w0, r[5]); w1 = std::max(w1, r[6]);
         }
+        fprintf(stderr, "[k_screen timeline] per workgroup: prologue %.0f cycles, tile loop %.0f cycles, lifetime %.2f us (first start -> last end "
+                        "%.2f us): %.2f GHz over the loop if the rest of the lifetime ran at the same clock\n", pro / grid.x, loop / grid.x,
+                wall / grid.x / 100.0, (double)(w1 - w0) / 100.0, (pro + loop) / grid.x / (wall / grid.x / 100.0) / 1000.0);
         fprintf(stderr, "[k_screen timeline] %u workgroups x %d tiles; first tile, mean cycles: layer-1 step %.0f, first hidden layer %.0f, "
                         "remaining layers %.0f\n", grid.x, tiles_per_wg, seg[0] / grid.x, seg[1] / grid.x, seg[2] / grid.x);
     }

@@ -1,5 +1,9 @@
+"""Candidates per rollout and step of the screened step as a function of the screening bound eps (GPU; prints the screening
+counters after one propagate per setting).  usage: python tests/eps_sweep.py"""
+import os
 import sys, numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 from test_gpu_screen import _engine
 for N in (1024, 4096):
     for eps in (1.5e-2, 1.0e-2, 7.5e-3, 6e-3, 5e-3, 4e-3):

@@ -68,7 +68,7 @@ def test_dist_grad_stages(name):
 
 MARGIN = 5e-6       # relative ReLU margin below which a mask may come out either way under fp32 rounding
 # The reference's own fp32 forward pass differs from exact arithmetic by up to ~3e-7 of the output scale on these networks,
-# the same size as an MFMA fmaf chain's error (tools/accuracy_study.py, profiles/r02_distance_accuracy.txt), so two correct
+# the same size as an MFMA fmaf chain's error (tests/accuracy_study.py, profiles/r02_distance_accuracy.txt), so two correct
 # fp32 evaluations of the distance differ by that much -- and MPPI.py:149-155 feeds the distance to sigmoids of slope 100.
 DIST_ULP = 5e-7     # x max(1, largest network distance of the step): admissible difference between two fp32 evaluations
 

@@ -3,8 +3,9 @@ import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from optimalmodulationds_amd import scenes
 from optimalmodulationds_amd.engine import Engine
-from oracle import omds_oracle as orc
-m = orc.Mlp.from_npz(os.path.join(sys.path[0], "tests/golden/weights/franka.npz"))
+z = np.load(os.path.join(sys.path[0], "tests/golden/weights/franka.npz"))
+nl = len([k for k in z.files if k.startswith("W")])
+class m: W = [z[f"W{i}"] for i in range(nl)]; b = [z[f"b{i}"] for i in range(nl)]
 N = 1024
 e = Engine(7, N, 2, 5, max_obs=512)
 e.set_mlp(m.W, m.b); e.set_obstacles(scenes.shelf_scene())
