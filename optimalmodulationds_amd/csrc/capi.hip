@@ -355,16 +355,21 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
                 }
         std::memcpy(&bh[(size_t)l * Wd], b[l + 1], Wd * sizeof(float));
     }
+    // 16-row packs (v_mfma_f32_16x16x4): the four k of lane group g in steps 0..3 of chunk c are
+    // 16c + pa[g] + {0, 2, 8, 10}, pa = {0, 4, 1, 5} -- the k SEQUENCE of the 32-row kernels (8c'+{0,4,1,5,2,6,3,7}), so a
+    // 16-row tile is bit-identical to a 32-row tile (both MFMAs are fmaf chains in k order, tools/ubench/mfma_order.hip)
+    auto k16 = [](int c, int g, int mm) { return 16 * c + ((g >> 1) + 4 * (g & 1)) + 8 * (mm >> 1) + 2 * (mm & 1); };
     std::vector<float4> wf16(wf.size()), wb16(wf.size());
     for (int l = 0; l < m.nhh; ++l) {
         const float* Wl = W[l + 1];
         for (int cb = 0; cb < 16; ++cb)
             for (int c = 0; c < 16; ++c)
                 for (int lane = 0; lane < 64; ++lane) {
-                    const int j = 16 * cb + (lane & 15), k0 = 16 * c + 4 * (lane >> 4);
+                    const int j = 16 * cb + (lane & 15), g = lane >> 4;
+                    const int k0 = k16(c, g, 0), k1 = k16(c, g, 1), k2 = k16(c, g, 2), k3 = k16(c, g, 3);
                     const size_t o = (((size_t)l * 16 + cb) * 16 + c) * 64 + lane;
-                    wf16[o] = make_float4(Wl[j * Wd + k0], Wl[j * Wd + k0 + 1], Wl[j * Wd + k0 + 2], Wl[j * Wd + k0 + 3]);
-                    wb16[o] = make_float4(Wl[(k0)*Wd + j], Wl[(k0 + 1) * Wd + j], Wl[(k0 + 2) * Wd + j], Wl[(k0 + 3) * Wd + j]);
+                    wf16[o] = make_float4(Wl[j * Wd + k0], Wl[j * Wd + k1], Wl[j * Wd + k2], Wl[j * Wd + k3]);
+                    wb16[o] = make_float4(Wl[k0 * Wd + j], Wl[k1 * Wd + j], Wl[k2 * Wd + j], Wl[k3 * Wd + j]);
                 }
     }
     // last layer: 16x16x4 B-fragments, channels padded to 16
@@ -400,10 +405,10 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
     for (int c = 0; c < 16; ++c)
         for (int jb = 0; jb < 2; ++jb)
             for (int lane = 0; lane < 64; ++lane) {
-                const int f = 16 * jb + (lane & 15), k0 = 16 * c + 4 * (lane >> 4);
+                const int f = 16 * jb + (lane & 15), g = lane >> 4;
                 float v[4] = {0, 0, 0, 0};
                 if (f < F)
-                    for (int mm = 0; mm < 4; ++mm) v[mm] = W[0][(k0 + mm) * F + f];
+                    for (int mm = 0; mm < 4; ++mm) v[mm] = W[0][k16(c, g, mm) * F + f];
                 w1b16[(c * 2 + jb) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
             }
     // fp16 screening network: slices of 32 output rows x 256 k in A-fragment order of v_mfma_f32_32x32x16_f16, with the k

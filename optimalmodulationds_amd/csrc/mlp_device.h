@@ -101,16 +101,24 @@ __device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >
 // [16 x 256] . [256 x 32] on v_mfma_f32_16x16x4_f32 -- the GEMM of the 16-row pass-2 tiles used for small batches,
 // where a tile's chain of dependent GEMMs is the latency of the whole horizon step: half the rows = half the MFMA
 // time per GEMM (3.4 us instead of 6.8 us on the four SIMDs of a CU).
-//   A from LDS: lane l reads H[row = l&15][16c + 4(l>>4) .. +3];  B packed alike (Wf16 / Wb16);
-//   step m of chunk c contracts k = 16c + 4g + m for lane group g = l>>4.  C/D: lane l, reg r -> row 4(l>>4)+r, col l&15.
+//   Lane group g = l>>4 contracts, in steps 0..3 of chunk c, k = 16c + pa[g] + {0, 2, 8, 10} with pa = {0, 4, 1, 5}: the K
+//   index of an MFMA runs over the lane groups, so the products of an output element are added in the order
+//   16c + {0,4,1,5, 2,6,3,7, 8,12,9,13, 10,14,11,15} -- exactly the order of the 32-row kernels (gemm256: chunk of 8 k, step j
+//   adds k = 8c'+j then 8c'+4+j).  Both MFMAs are plain fmaf chains in k order (tools/ubench/mfma_order.hip), so a row gets
+//   the SAME bits from a 16-row and a 32-row tile.  A from LDS: two ds_read2_b32 per chunk; B packed alike (Wf16 / Wb16).
+//   C/D: lane l, reg r -> row 4(l>>4)+r, col l&15.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pa16(int lane) { const int g = lane >> 4; return (g >> 1) + 4 * (g & 1); }
+__device__ __forceinline__ float4 load_a16(const float* arow, int c) {   // arow = H + row * LDH + pa16(lane)
+    return make_float4(arow[16 * c], arow[16 * c + 2], arow[16 * c + 8], arow[16 * c + 10]);
+}
 __device__ __forceinline__ void load_chunk16(const float* arow, __amdgpu_buffer_rsrc_t wrsrc, int wvoff, int c, float4& a, float4 (&w)[2]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const omds_f4 v = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, (j * 16 + c) * 64 * 16, 0));
         w[j] = make_float4(v.x, v.y, v.z, v.w);
     }
-    a = *reinterpret_cast<const float4*>(arow + 16 * c);
+    a = load_a16(arow, c);
 }
 __device__ __forceinline__ void mfma_chunk16(const float4& a, const float4 (&w)[2], f32x4 (&acc)[2]) {
     acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[0].x, acc[0], 0, 0, 0);
@@ -124,7 +132,7 @@ __device__ __forceinline__ void mfma_chunk16(const float4& a, const float4 (&w)[
 }
 // Wp = pack of one layer ([16 colblk16][16 kchunk][64 lane]); wave w produces columns 32w .. 32w+31 (blocks 2w, 2w+1)
 __device__ __forceinline__ void gemm16(const float* __restrict__ Hs, const float4* __restrict__ Wp, int wave, int lane, f32x4 (&acc)[2]) {
-    const float* arow = Hs + (lane & 15) * LDH + 4 * (lane >> 4);
+    const float* arow = Hs + (lane & 15) * LDH + pa16(lane);
     const float4* wbase = Wp + (size_t)__builtin_amdgcn_readfirstlane(wave) * (2 * 16 * 64);
     const __amdgpu_buffer_rsrc_t wp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wbase), 0, 2 * 16 * 64 * 16, 0x00020000);
     const int wv = lane * 16;
@@ -136,7 +144,7 @@ __device__ __forceinline__ void gemm16(const float* __restrict__ Hs, const float
     __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);        \
     __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);       \
     __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);        \
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      \
     __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);        \
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -360,6 +368,16 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
             gemm16(Hs, m.Wf16 + (size_t)l * (16 * 16 * 64), wave, lane, acc);
             __syncthreads();  // every wave has finished reading the tile
             if (l == 0) OMDS_TL(6);
+            if constexpr (EMIT) {   // ReLU masks of this level: row 4g + reg = ballot bits of lanes 16g .. 16g+15, columns 32 wave + 16 j + (lane & 15)
+                uint32_t mw = 0;
+                const int sh = 16 * ((lane & 15) >> 2);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const unsigned long long b0 = __ballot(acc[0][reg] > 0.f), b1 = __ballot(acc[1][reg] > 0.f);
+                    if ((lane & 3) == reg) mw = (uint32_t)((b0 >> sh) & 0xffffu) | ((uint32_t)((b1 >> sh) & 0xffffu) << 16);
+                }
+                if (lane < 16) maskS[((size_t)lane * nhid + (l + 1)) * 8 + wave] = mw;
+            }
 #pragma unroll
             for (int r = 0; r < 8; ++r)
                 Hs[(4 * (lane >> 4) + (r & 3)) * LDH + wave * 32 + 16 * (r >> 2) + (lane & 15)] = actf(acc[r >> 2][r & 3], ACT);
@@ -848,11 +866,11 @@ __device__ __forceinline__ void pass2_backward(const MlpDev& m, const P2Smem& sm
         for (int r = 0; r < 16; ++r) Pw[crow(r, lane) * 32 + (lane & 31)] = acc[r];
     } else {
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        const float* arow = Hs + (lane & 15) * LDH + 4 * (lane >> 4);
+        const float* arow = Hs + (lane & 15) * LDH + pa16(lane);
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             const int c = wave * 2 + cc;
-            const float4 a = *reinterpret_cast<const float4*>(arow + 16 * c);
+            const float4 a = load_a16(arow, c);
             float4 w[2];
             w[0] = m.W1b16[(c * 2 + 0) * 64 + lane];
             w[1] = m.W1b16[(c * 2 + 1) * 64 + lane];

@@ -517,18 +517,23 @@ __global__ __launch_bounds__(SEL_WAVES * 64) void k_select(SelectArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_exact: fp32 pass-1 tiles over the listed rows (32-row tiles, workgroups stride over the tiles)
+// k_exact: fp32 pass-1 tiles over the listed rows, 16 rows per tile (v_mfma_f32_16x16x4 fed in the k order of the 32-row
+// kernels: the same bits per row, mlp_device.h), up to three workgroups resident per CU (78 registers).  A tile is a chain of
+// dependent GEMMs on one CU, so what counts is (a) the granularity -- 9.2 candidates per rollout at N = 1024 are 590 tiles of
+// 16 rows for 768 slots, where 32-row tiles were 295 for 256 CUs and the 39 left over doubled the launch time -- and (b)
+// co-residency: three tiles on a CU fill each other's barrier / epilogue / last-layer gaps.  Measured at 9.9 candidates per
+// rollout: 52.9 us, against 59.6 (32-row tiles, two resident), 64.1 (an equal share of 32 + 16 rows per CU, one after the
+// other) and 58.0 (16-row tiles, two resident).
 // ------------------------------------------------------------------------------------------------
 template <int ACT>
-__global__ __launch_bounds__(512) void k_exact(MlpDev m, const float* __restrict__ Apre, const float* __restrict__ Bpre,
-                                               const float* __restrict__ radius, int O, uint32_t ignored,
-                                               float* __restrict__ Dmin, OmdsDivisor odiv, const int* __restrict__ rowlist,
-                                               const int* __restrict__ total, unsigned* __restrict__ maxerr_bits, ExactOut ex) {
+__global__ __launch_bounds__(512, 6) void k_exact(MlpDev m, const float* __restrict__ Apre, const float* __restrict__ Bpre,
+                                                  const float* __restrict__ radius, int O, uint32_t ignored,
+                                                  float* __restrict__ Dmin, OmdsDivisor odiv, const int* __restrict__ rowlist,
+                                                  const int* __restrict__ total, unsigned* __restrict__ maxerr_bits, ExactOut ex) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = *total;
-    for (int tile = blockIdx.x; tile * 32 < n; tile += gridDim.x) {
-        pass1_tile<32, 1, 1, ACT, true>(m, smem, Apre, Bpre, radius, O, n, ignored, Dmin, (long long)tile * 32, odiv, rowlist,
-                                        maxerr_bits, &ex);
+    for (int blk = blockIdx.x; blk * 16 < n; blk += gridDim.x) {
+        pass1_tile<16, 1, 1, ACT, 1>(m, smem, Apre, Bpre, radius, O, n, ignored, Dmin, (long long)blk * 16, odiv, rowlist, maxerr_bits, &ex);
         __syncthreads();   // the tile buffer is reused by the next tile
     }
 }
@@ -631,19 +636,21 @@ void omds_launch_select(hipStream_t s, const float* Dmin, int B, int O, int k, f
 void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius, int O,
                        int B, uint32_t ignored, float* Dmin, const int* rowlist, const int* total, unsigned* maxerr_bits,
                        const ExactOut& ex) {
-    if (B <= 0) return;
-    const size_t lds = (size_t)32 * LDH * 4 + 32 * 4 + 32 * 4 + (size_t)32 * (OMDS_MAX_HIDDEN + 1) * 8 * 4;
-    static std::atomic<uint64_t> configured{0};
-    if (omds_first_use_on_device(configured)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_exact<OMDS_ACT_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_exact<OMDS_ACT_TANH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (B <= 0 || m.act != OMDS_ACT_RELU) return;   // omds_screen_supported(): ReLU networks only
+    const size_t lds = (size_t)16 * LDH * 4 + 16 * 4 + 16 * 4 + (size_t)16 * (m.nhh + 1) * 8 * 4;
+    static std::atomic<int> ncu_of[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int ncu = ncu_of[dev & 63].load();
+    if (ncu == 0) {
+        ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (ncu <= 0) ncu = 256;
+        ncu_of[dev & 63].store(ncu);
     }
-    // enough workgroups for the typical list (a few candidates per rollout) without striding; longer lists stride
-    const long long tiles_max = ((long long)B * O + 31) / 32;
-    const unsigned grid = (unsigned)std::min<long long>(tiles_max, std::max<long long>(512, ((long long)B * 16 + 31) / 32));
+    // three resident workgroups per CU; longer lists stride (the list length is only known on the device)
+    const long long blocks_max = ((long long)B * O + 15) / 16;
+    const unsigned grid = (unsigned)std::min<long long>(blocks_max, 3LL * ncu);
     const OmdsDivisor od = OmdsDivisor::make((unsigned)O);
-    if (m.act == OMDS_ACT_RELU)
-        hipLaunchKernelGGL((k_exact<OMDS_ACT_RELU>), dim3(grid), dim3(512), lds, s, m, Apre, Bpre, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits, ex);
-    else
-        hipLaunchKernelGGL((k_exact<OMDS_ACT_TANH>), dim3(grid), dim3(512), lds, s, m, Apre, Bpre, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits, ex);
+    hipLaunchKernelGGL((k_exact<OMDS_ACT_RELU>), dim3(grid), dim3(512), lds, s, m, Apre, Bpre, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits, ex);
 }

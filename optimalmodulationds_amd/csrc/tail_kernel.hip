@@ -135,9 +135,9 @@ static size_t tail_lds_bytes(int nhid);
 // by (D, obstacle index) over each rollout's few candidates, masks of the selected entries gathered into the MFMA C layout,
 // the pass-2 backward, then blend / modulation / Euler step / next-step layer 1 exactly as in k_tail.
 // ------------------------------------------------------------------------------------------------
-template <int ND>
+template <int ND, int ROWS>
 __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
-    constexpr int ACT = OMDS_ACT_RELU, ROWS = 32;
+    constexpr int ACT = OMDS_ACT_RELU;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const MlpDev& m = a.m;
     P2Smem sm;
@@ -201,20 +201,21 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
     __syncthreads();
     // ---- the selected entries' masks -> LDS -> 16 bits per thread and layer in the MFMA C layout (what pass 2's forward
     //      would have left in sm.maskL): thread (wave = 32-column block, lane) owns column wave*32 + (lane&31) of rows crow(r, lane)
-    for (int i = tid; i < 32 * nhid * 8; i += P2_NT) {
+    for (int i = tid; i < ROWS * nhid * 8; i += P2_NT) {
         const int r = i / (nhid * 8);
         maskRow[i] = sel[r] >= 0 ? a.ex.mask[(size_t)sel[r] * nhid * 8 + (i - r * nhid * 8)] : 0u;
     }
     __syncthreads();
     {
-        const int col = wave * 32 + (lane & 31);
-        const int w1 = (col & 3) * 2 + (col >> 7), b1 = (col >> 2) & 31;     // layer 1: ballot of component col&3, lane col>>2
+        using G = P2Geo<ROWS>;
         for (int l = 0; l < nhid; ++l) {
             uint32_t bits = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t* mr = maskRow + ((size_t)crow(r, lane) * nhid + l) * 8;
-                const uint32_t bit = (l == 0) ? ((mr[w1] >> b1) & 1u) : ((mr[wave] >> (lane & 31)) & 1u);
+            for (int r = 0; r < G::NV; ++r) {
+                const int col = G::col(r, wave, lane);
+                const uint32_t* mr = maskRow + ((size_t)G::row(r, lane) * nhid + l) * 8;
+                // layer 1: ballot of component col & 3, lane col >> 2; later layers: one ballot half per 32-column block
+                const uint32_t bit = (l == 0) ? ((mr[(col & 3) * 2 + (col >> 7)] >> ((col >> 2) & 31)) & 1u) : ((mr[col >> 5] >> (col & 31)) & 1u);
                 bits |= bit << r;
             }
             sm.maskL[l * P2_NT + tid] = (uint16_t)bits;
@@ -279,16 +280,27 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
     }
 }
 
-template <int ND>
+template <int ND, int ROWS>
 static void launch_tail_sel_t(hipStream_t s, const TailArgs& a) {
     static std::atomic<uint64_t> configured{0};
     const size_t extra = 32 * 4;   // sel
     if (omds_first_use_on_device(configured)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail_sel<ND>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail_sel<ND, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(tail_lds_bytes(OMDS_MAX_HIDDEN + 1) + extra));
     }
-    const int RW = 32 / a.st.k;
-    hipLaunchKernelGGL((k_tail_sel<ND>), dim3((a.t_end - a.t_begin + RW - 1) / RW), dim3(P2_NT), tail_lds_bytes(a.m.nhh + 1) + extra, s, a);
+    const int RW = ROWS / a.st.k;
+    hipLaunchKernelGGL((k_tail_sel<ND, ROWS>), dim3((a.t_end - a.t_begin + RW - 1) / RW), dim3(P2_NT), tail_lds_bytes(a.m.nhh + 1) + extra, s, a);
+}
+
+// 16-row tiles (bit-identical to 32-row ones, mlp_device.h) while their workgroups still fit the CUs two at a time: twice as
+// many, half as long, and the second resident fills the first one's top-k / gather / modulation phases
+static int tail_sel_rows(int N, int k) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("OMDS_TAIL_SEL_ROWS"); forced = e ? atoi(e) : 0; }
+    if (k > 16) return 32;
+    if (forced == 16 || forced == 32) return forced;
+    const int RW16 = 16 / k;
+    return (N + RW16 - 1) / RW16 <= 512 ? 16 : 32;
 }
 
 bool omds_tail_sel_supported(int n_dof, int k) { return (n_dof == 7 || n_dof == 2) && k >= 1 && k <= 32; }
@@ -303,8 +315,9 @@ void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Bpre, con
     a.slot0 = 0; a.n_slots = 0; a.dbg_stop = 0;
     a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Dmin = nullptr; a.Apre = Apre; a.dscr = nullptr; a.O = O; a.st = st;
     a.rowlist = rowlist; a.range = range; a.ex = ex;
-    if (st.n == 7) launch_tail_sel_t<7>(s, a);
-    else launch_tail_sel_t<2>(s, a);
+    const bool r16 = tail_sel_rows(st.N, st.k) == 16;
+    if (st.n == 7) { if (r16) launch_tail_sel_t<7, 16>(s, a); else launch_tail_sel_t<7, 32>(s, a); }
+    else { if (r16) launch_tail_sel_t<2, 16>(s, a); else launch_tail_sel_t<2, 32>(s, a); }
 }
 
 static size_t tail_lds_bytes(int nhid) {

