@@ -433,6 +433,12 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
     for (int rb = __builtin_amdgcn_readfirstlane(wave); rb < MT / 16; rb += G::NW) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* arow = Hs + (rb * 16 + (lane & 15)) * LDH + 4 * (lane >> 4);
+        const int r4 = rb * 16 + 4 * (lane >> 4);
+        [[maybe_unused]] float scr[4];   // LIST: the screening values of this lane's four rows (guard), in flight across the MFMA loop
+        if constexpr (LIST) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) scr[reg] = (row0 + r4 + reg < total_rows) ? Dmin[rowIdx[r4 + reg]] : 0.f;
+        }
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const float4 a = *reinterpret_cast<const float4*>(arow + 16 * c);
@@ -450,7 +456,6 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
         const int j = lane & 15;
         const float bj = m.bl[j];
         const bool pad = j >= m.C, ign = (ignored >> j) & 1u;
-        const int r4 = rb * 16 + 4 * (lane >> 4);
         const float4 rr = *reinterpret_cast<const float4*>(rowRad + r4);
         const float rad[4] = {rr.x, rr.y, rr.z, rr.w};
         float y[4];
@@ -458,17 +463,19 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
         [[maybe_unused]] int yam[4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            if constexpr (EMIT) {   // pass 2's arg-min over ALL raw outputs (robot_sdf.py:155) and the distance of that link
-                float bv = pad ? __builtin_inff() : acc[reg] + bj;
-                int bi = j;
-#pragma unroll
-                for (int off = 1; off < 16; off <<= 1) {
-                    const float ov = __shfl_xor(bv, off);
-                    const int oi = __shfl_xor(bi, off);
-                    if ((ov < bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-                }
-                ydr[reg] = bv / m.out_div - rad[reg];
-                yam[reg] = bi;
+            if constexpr (EMIT) {   // pass 2's arg-min over ALL raw outputs (robot_sdf.py:155) and the distance of that link:
+                // the minimum over the 16 link lanes by DPP, then the lowest lane holding it from a ballot (ties: lower link,
+                // as a compare-and-swap reduction by (value, index) would give; eight dependent cross-lane shuffles shorter)
+                const float yv = pad ? __builtin_inff() : acc[reg] + bj;
+                float mn = yv;
+                mn = fminf(mn, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mn), 0xB1, 0xF, 0xF, false)));
+                mn = fminf(mn, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mn), 0x4E, 0xF, 0xF, false)));
+                mn = fminf(mn, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mn), 0x141, 0xF, 0xF, false)));
+                mn = fminf(mn, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mn), 0x140, 0xF, 0xF, false)));
+                const unsigned long long eq = __ballot(yv == mn);
+                const unsigned bits = (unsigned)(eq >> (lane & 48)) & 0xffffu;
+                ydr[reg] = mn / m.out_div - rad[reg];
+                yam[reg] = bits ? __builtin_ctz(bits) : 0;
             }
             float v = (acc[reg] + bj) / m.out_div - rad[reg];
             v = pad ? __builtin_inff() : (ign ? 1e6f : v);
@@ -486,7 +493,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                 for (int reg = 0; reg < 4; ++reg) {
                     const long long e_idx = row0 + r4 + reg;
                     if (e_idx < total_rows) {
-                        const float e = fabsf(Dmin[rowIdx[r4 + reg]] - y[reg]);   // Dmin holds the screening value of the pair
+                        const float e = fabsf(scr[reg] - y[reg]);   // Dmin holds the screening value of the pair
                         if (!(e <= me)) me = (e == e) ? e : __builtin_inff();   // a NaN screening value (fp16 overflow) counts as an infinite error
                         if (e_idx < ex->cap) { ex->D[e_idx] = y[reg]; ex->dr[e_idx] = ydr[reg]; ex->amin[e_idx] = yam[reg]; }
                     }

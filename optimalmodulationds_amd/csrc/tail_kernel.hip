@@ -166,6 +166,29 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
         const int t = t_base + rl;
         if (t >= t_end) break;
         const int base = a.range[2 * t], cnt = a.range[2 * t + 1];
+        if (cnt <= 64) {
+            // the usual case, a few candidates: one per lane, and its rank under (D, obstacle) by comparing with every other
+            // candidate's (value, obstacle) broadcast from its lane -- cnt scalar steps instead of k wave-wide reductions
+            const int e = base + lane;
+            const bool have = lane < cnt && e < a.ex.cap;   // list longer than k_exact's outputs: the host redoes the propagate in fp32
+            const float x = have ? a.ex.D[e] : __builtin_inff();
+            const int o = have ? a.rowlist[e] - t * O : 0x7fffffff;
+            int rank = 0;
+            for (int j = 0; j < cnt; ++j) {
+                const float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), j));
+                const int oj = __builtin_amdgcn_readlane(o, j);
+                rank += ((xj < x) || (xj == x && oj < o)) ? 1 : 0;
+            }
+            if (have && rank < k) {
+                const int r = rl * k + rank;
+                sm.rowT[r] = t;
+                sm.rowO[r] = o;
+                sm.rowMin[r] = a.ex.amin[e];
+                dr[r] = a.ex.dr[e];
+                sel[r] = e;
+            }
+            continue;
+        }
         float pv = -__builtin_inff();
         int po = -1;
         for (int j = 0; j < k; ++j) {
