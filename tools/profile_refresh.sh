@@ -20,6 +20,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d "$OUT/pmc_$c" -- python3 $P > "$OUT/pmc_$c.log" 2>&1
   python3 tools/rocprof_summary.py pmc "$(finddb "$OUT/pmc_$c")" > "$OUT/pmc_$c.txt"
   rm -rf "$OUT/pmc_$c"
+  rocprofv3 --pmc $c -d "$OUT/pmc_p7_$c" -- python3 $P --workload planar7_1024x32 > "$OUT/pmc_p7_$c.log" 2>&1
+  python3 tools/rocprof_summary.py pmc "$(finddb "$OUT/pmc_p7_$c")" > "$OUT/pmc_p7_$c.txt"
+  rm -rf "$OUT/pmc_p7_$c"
 done
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA -d "$OUT/pmc_sq" -- python3 $P > "$OUT/pmc_sq.log" 2>&1
 python3 tools/rocprof_summary.py pmc "$(finddb "$OUT/pmc_sq")" > "$OUT/pmc_sq.txt"
@@ -35,15 +38,16 @@ def table(path):
         if m and m.group(2) in ("FETCH_SIZE", "WRITE_SIZE"):
             t[m.group(1).strip()] = float(m.group(4))
     return t
-f, w = table(out + "/pmc_FETCH_SIZE.txt"), table(out + "/pmc_WRITE_SIZE.txt")
 res = {"_doc": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024 from separate rocprofv3 --pmc passes of "
-               "bench.py --workload franka_shelf_1024x32 (FETCH_SIZE doubled: gfx950 correction of MI355X_MICROARCH.md)",
-       "franka_shelf_1024x32": {}}
-for name in f:
-    short = "k_screen" if "k_screen" in name else "k_tail" if "k_tail" in name else "k_exact" if "k_exact" in name else \
-            "k_select" if "k_select" in name else "k_pass1" if "k_pass1" in name else None
-    if short and name in w:
-        res["franka_shelf_1024x32"][short] = {"fetch_kb": f[name], "write_kb": w[name], "traffic_bytes": int((2 * f[name] + w[name]) * 1024)}
+               "bench.py --workload <workload> (FETCH_SIZE doubled: gfx950 correction of MI355X_MICROARCH.md)"}
+for wl, tag in (("franka_shelf_1024x32", ""), ("planar7_1024x32", "_p7")):
+    f, w = table(out + "/pmc%s_FETCH_SIZE.txt" % tag), table(out + "/pmc%s_WRITE_SIZE.txt" % tag)
+    res[wl] = {}
+    for name in f:
+        short = "k_screen" if "k_screen" in name else "k_step_small" if "k_step_small" in name else "k_tail" if "k_tail" in name else \
+                "k_exact" if "k_exact" in name else "k_select" if "k_select" in name else "k_pass1" if "k_pass1" in name else None
+        if short and name in w:
+            res[wl][short] = {"fetch_kb": f[name], "write_kb": w[name], "traffic_bytes": int((2 * f[name] + w[name]) * 1024)}
 json.dump(res, open(out + "/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
