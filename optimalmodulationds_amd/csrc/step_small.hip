@@ -125,16 +125,20 @@ __global__ __launch_bounds__(SS_NT) void k_step_small(SmallArgs a) {
 
     if (a.dbg_stop == 2) return;
     // ---- 3. backward on the selected rows (VALU, weights streamed once) -------------------------------------------------
-    // All 32 weight rows of a thread's k range are in flight at once; packed FMAs, two rows per instruction.  Measured: 4.2 us
-    // per layer whether or not the next layer's rows are requested ahead of the reduction, and the same with scalar FMAs --
-    // 256 workgroups pulling the same 256 KB through their L1s at once is an L2 problem (32 CUs per XCD on the same lines).
+    // 16 weight rows per thread in flight at once (two halves of its k range: 117 registers instead of 151, the same time);
+    // packed FMAs, two rows per instruction.  Measured: 4.2 us per layer whether or not the next layer's rows are requested
+    // ahead of the reduction, and the same with scalar FMAs -- 256 workgroups pulling the same 256 KB through their L1s at
+    // once is an L2 problem (32 CUs per XCD on the same lines).
+    // Measured and rejected: a RESIDENT form of this kernel (one launch per propagate, the workgroup keeps its rollouts, their
+    // layer-1 halves in LDS and their navigation kernels in registers over all H steps): 1.82 ms per iteration against 1.74 ms
+    // for H launches -- consecutive launches already start with no idle gap, and the loop costs registers (245).
     typedef float f2 __attribute__((ext_vector_type(2)));
     const int jq = tid & 63, kp = tid >> 6;
-    float4 w[32];
-    auto load_w = [&](int l) {
+    float4 w[16];
+    auto load_w = [&](int l, int half) {   // rows 32 kp + 16 half .. + 15 of the thread's k range (16 x 16 B per thread in flight)
         const float4* Wq = reinterpret_cast<const float4*>(m.Whraw + (size_t)l * OMDS_WIDTH * OMDS_WIDTH) + jq;   // W[k][4jq..4jq+3] = Wq[k * 64]
 #pragma unroll
-        for (int u = 0; u < 32; ++u) w[u] = Wq[(size_t)(32 * kp + u) * 64];
+        for (int u = 0; u < 16; ++u) w[u] = Wq[(size_t)(32 * kp + 16 * half + u) * 64];
     };
     if (tid < OMDS_WIDTH) {   // seed: dy[argmin] / dH_last = Wlast[argmin], masked by the last hidden layer
         float v[SS_RK];
@@ -148,22 +152,25 @@ __global__ __launch_bounds__(SS_NT) void k_step_small(SmallArgs a) {
     __syncthreads();
 #pragma unroll 1
     for (int l = m.nhh - 1; l >= 0; --l) {
-        load_w(l);
         f2 acc[4][2];
 #pragma unroll
         for (int c = 0; c < 4; ++c) { acc[c][0] = f2{0.f, 0.f}; acc[c][1] = f2{0.f, 0.f}; }
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            load_w(l, half);
 #pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            const float4 g = gS[32 * kp + u];
-            const f2 glo = {g.x, g.y}, ghi = {g.z, g.w};
-            const float wc[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+            for (int u = 0; u < 16; ++u) {
+                const float4 g = gS[32 * kp + 16 * half + u];
+                const f2 glo = {g.x, g.y}, ghi = {g.z, g.w};
+                const float wc[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f2 ww = {wc[c], wc[c]};
-                acc[c][0] = __builtin_elementwise_fma(glo, ww, acc[c][0]);
-                acc[c][1] = __builtin_elementwise_fma(ghi, ww, acc[c][1]);
+                for (int c = 0; c < 4; ++c) {
+                    const f2 ww = {wc[c], wc[c]};
+                    acc[c][0] = __builtin_elementwise_fma(glo, ww, acc[c][0]);
+                    acc[c][1] = __builtin_elementwise_fma(ghi, ww, acc[c][1]);
+                }
+                if ((u & 3) == 3) asm volatile("" ::: "memory");   // keeps hipcc from reading all gradient rows ahead of the FMAs
             }
-            if ((u & 3) == 3) asm volatile("" ::: "memory");   // keeps hipcc from reading all 32 gradient rows (128 registers) ahead of the FMAs
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) P[kp * OMDS_WIDTH + 4 * jq + c] = make_float4(acc[c][0][0], acc[c][0][1], acc[c][1][0], acc[c][1][1]);
