@@ -57,16 +57,16 @@ __device__ __forceinline__ uint32_t ss_mask_bit(const uint32_t* maskS, int nhid,
     return level == 0 ? (mr[(col & 3) * 2 + (col >> 7)] >> ((col >> 2) & 31)) & 1u : (mr[col >> 5] >> (col & 31)) & 1u;
 }
 
-template <int ND>
-__global__ __launch_bounds__(SS_NT) void k_step_small(SmallArgs a) {
+template <int ND, int TR>
+__global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArgs a) {
     constexpr int ACT = OMDS_ACT_RELU;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const MlpDev& m = a.m;
     const int nhid = m.nhh + 1;
-    // pass1_tile's block: Hs [32][LDH], rowRad [32], rowIdx [32], maskS [32][nhid][8]
+    // pass1_tile's block: Hs [TR][LDH], rowRad [TR], rowIdx [TR], maskS [TR][nhid][8]
     float* Hs = smem;
-    uint32_t* maskS = reinterpret_cast<uint32_t*>(smem + 32 * LDH + 64);
-    float* D1 = reinterpret_cast<float*>(maskS + 32 * nhid * 8);     // [32] pass-1 value of each tile row
+    uint32_t* maskS = reinterpret_cast<uint32_t*>(smem + TR * LDH + 2 * TR);
+    float* D1 = reinterpret_cast<float*>(maskS + TR * nhid * 8);     // [32] pass-1 value of each tile row
     float* Dr = D1 + 32;                                             // [32] pass-2 distance
     int* Amin = reinterpret_cast<int*>(Dr + 32);                     // [32] arg-min link
     int* selRow = Amin + 32;                                         // [SS_RK] tile row of each backward row (-1: none)
@@ -77,16 +77,17 @@ __global__ __launch_bounds__(SS_NT) void k_step_small(SmallArgs a) {
     float* gf = gx + SS_RK * 12;                                     // [SS_RK][33] feature gradients
     float* feat = gf + SS_RK * 33;                                   // [SS_RK][3 ND] next state, sin, cos
     float4* gS = reinterpret_cast<float4*>(feat + SS_RK * 3 * OMDS_MAX_DOF + 4);   // [256] gradient of the four rows at each column
-    float4* P = reinterpret_cast<float4*>(Hs);                       // [8 k parts][256] partial sums (the tile buffer is idle by then)
+    // [8 k parts][256] partial sums: in the 32-row tile buffer (idle by then); the 16-row buffer is too small for them
+    float4* P = TR == 32 ? reinterpret_cast<float4*>(Hs) : gS + OMDS_WIDTH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.B, k = a.st.k, O = a.O, R = a.R;
     const int t_base = blockIdx.x * R;
 
     // ---- 1. forward of the R*O pairs -----------------------------------------------------------------------------
     {
-        const ExactOut ex{D1, Dr, Amin, nullptr, 32};
+        const ExactOut ex{D1, Dr, Amin, nullptr, TR};
         const long long total = (long long)N * O;
-        pass1_tile<32, 1, 1, ACT, 2>(m, smem, a.Apre, a.Bpre, a.radius, O, total, a.ignored, nullptr, (long long)t_base * O, a.odiv,
+        pass1_tile<TR, 1, 1, ACT, 2>(m, smem, a.Apre, a.Bpre, a.radius, O, total, a.ignored, nullptr, (long long)t_base * O, a.odiv,
                                      nullptr, nullptr, &ex);
     }
     if (a.dbg_stop == 1) return;
@@ -286,25 +287,47 @@ __global__ __launch_bounds__(SS_NT) void k_step_small(SmallArgs a) {
     }
 }
 
-static size_t small_lds_bytes(int nhid) {
-    return ((size_t)32 * LDH + 64 + (size_t)32 * nhid * 8) * 4 + (32 * 3 + SS_RK * 3) * 4 +
-           (SS_RK + SS_RK * 12 + SS_RK * 33 + SS_RK * 3 * OMDS_MAX_DOF + 4) * 4 + OMDS_WIDTH * 16 + 16;
+static size_t small_lds_bytes(int nhid, int TR) {
+    return ((size_t)TR * LDH + 2 * TR + (size_t)TR * nhid * 8) * 4 + (32 * 3 + SS_RK * 3) * 4 +
+           (SS_RK + SS_RK * 12 + SS_RK * 33 + SS_RK * 3 * OMDS_MAX_DOF + 4) * 4 + OMDS_WIDTH * 16 + 16 + (TR == 16 ? 8 * OMDS_WIDTH * 16 : 0);
 }
 
-// rollouts per workgroup for (O, k), 0 = the scene does not qualify
-int omds_step_small_rollouts(const MlpDev& m, int n_dof, int O, int k) {
+// rollouts per workgroup for (O, k) on a tile of `rows` rows, 0 = the scene does not qualify
+static int small_rollouts(const MlpDev& m, int n_dof, int O, int k, int rows) {
     if (m.act != OMDS_ACT_RELU || m.skip_mask || (n_dof != 7 && n_dof != 2)) return 0;
-    if (O < 1 || O > 32 || k < 1 || k > SS_RK || k > O) return 0;
-    return std::max(1, std::min(32 / O, SS_RK / k));
+    if (O < 1 || O > rows || k < 1 || k > SS_RK || k > O) return 0;
+    return std::max(1, std::min(rows / O, SS_RK / k));
+}
+int omds_step_small_rollouts(const MlpDev& m, int n_dof, int O, int k) { return small_rollouts(m, n_dof, O, k, 32); }
+// Tile height: 16 rows when that costs no rollouts per workgroup (the cap of four backward rows binds, not the tile: half the
+// forward's MFMA chain for the same work); else 32.  Halving the rollouts per workgroup to get two 16-row workgroups resident
+// per CU (one's backward and modulation under the other's forward) was measured on planar 7-DoF 1024 x 32: 17.0 M against
+// 18.9 M rollout-steps/s -- twice the workgroups stream the backward's weights twice.  OMDS_SMALL_ROWS=16|32 forces one.
+static int small_tile_rows(const MlpDev& m, int n_dof, int O, int k, int B) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("OMDS_SMALL_ROWS"); forced = e ? atoi(e) : 0; }
+    const int r16 = small_rollouts(m, n_dof, O, k, 16), r32 = small_rollouts(m, n_dof, O, k, 32);
+    if (r16 <= 0) return 32;
+    if (forced == 16 || forced == 32) return forced;
+    (void)B;
+    return r16 == r32 ? 16 : 32;
 }
 
-template <int ND>
-static void launch_small_t(hipStream_t s, const SmallArgs& a) {
+template <int ND, int TR>
+static void launch_small_r(hipStream_t s, const SmallArgs& a) {
     static std::atomic<uint64_t> configured{0};
     if (omds_first_use_on_device(configured))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_small<ND>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)small_lds_bytes(OMDS_MAX_HIDDEN + 1));
-    hipLaunchKernelGGL((k_step_small<ND>), dim3((a.B + a.R - 1) / a.R), dim3(SS_NT), small_lds_bytes(a.m.nhh + 1), s, a);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_small<ND, TR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)small_lds_bytes(OMDS_MAX_HIDDEN + 1, TR));
+    hipLaunchKernelGGL((k_step_small<ND, TR>), dim3((a.B + a.R - 1) / a.R), dim3(SS_NT), small_lds_bytes(a.m.nhh + 1, TR), s, a);
+}
+template <int ND>
+static void launch_small_t(hipStream_t s, SmallArgs& a, int k) {
+    const int TR = small_tile_rows(a.m, ND, a.O, k, a.B);
+    a.R = small_rollouts(a.m, ND, a.O, k, TR);
+    if (a.R <= 0) return;
+    if (TR == 16) launch_small_r<ND, 16>(s, a);
+    else launch_small_r<ND, 32>(s, a);
 }
 
 void omds_launch_step_small(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr, float* Apre,
@@ -320,9 +343,9 @@ void omds_launch_step_small(hipStream_t s, const MlpDev& m, const float* Bpre, c
     static int stop = -1;
     if (stop < 0) { const char* e = getenv("OMDS_SMALL_STOP"); stop = e ? atoi(e) : 0; }
     a.dbg_stop = stop;
-    if (a.R <= 0) return;
-    if (st.n == 7) launch_small_t<7>(s, a);
-    else launch_small_t<2>(s, a);
+    if (omds_step_small_rollouts(m, st.n, O, st.k) <= 0) return;
+    if (st.n == 7) launch_small_t<7>(s, a, st.k);
+    else launch_small_t<2>(s, a, st.k);
 }
 
 // the network part alone on B states (qT [n][ldq]); Apre holds their layer-1 halves
@@ -336,7 +359,7 @@ void omds_launch_net_small(hipStream_t s, const MlpDev& m, const float* Bpre, co
     a.B = B; a.qT = qT; a.ldq = ldq;
     a.o_gradx = gradx; a.o_drow = drow; a.o_idx = idx; a.o_Dmin = Dmin;
     a.st.k = k; a.st.n = n_dof; a.st.N = B; a.st.d = m.d;
-    if (a.R <= 0 || B <= 0) return;
-    if (n_dof == 7) launch_small_t<7>(s, a);
-    else launch_small_t<2>(s, a);
+    if (omds_step_small_rollouts(m, n_dof, O, k) <= 0 || B <= 0) return;
+    if (n_dof == 7) launch_small_t<7>(s, a, k);
+    else launch_small_t<2>(s, a, k);
 }
