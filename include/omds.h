@@ -239,9 +239,11 @@ OMDS_API int omds_apply_update(int n_kernels, int n_dof, int horizon, const floa
 
 /* Screening of pass 1 (screen_kernel.hip).  The N*O first-pass evaluations of MPPI.distance_repulsion_nn only feed the
  * sort that picks the k closest obstacles (MPPI.py:245-253); omds_propagate may therefore evaluate them in fp16 and
- * re-evaluate in fp32 only the candidates {o : Da(o) <= k-th smallest Da + 2 eps}, which contain the fp32 top-k (ties
- * included) whenever |Da - D| <= eps.  eps is calibrated per network (8 x the largest error over a calibration batch)
- * and re-measured on every candidate of every propagate; if the margin ever falls below 2 x the propagate is redone
+ * re-evaluate in fp32 only the candidates {o : Da(o) <= tau}, tau = k-th smallest Da + 1.25 eps.  They contain the fp32
+ * top-k (ties included) whenever the rows that are NOT re-evaluated have a screening error <= eps and the exact k-th
+ * smallest candidate stays eps below tau (checked per rollout and step from exact numbers).  eps is calibrated per network
+ * (8 x the largest error over a calibration batch) and re-measured on every candidate of every propagate; if it ever loses
+ * its 2 x margin over the largest error seen, or a rollout fails the slack check, the propagate is redone
  * in fp32.  The distances and gradients a step uses always come from the fp32 pass 2.  omds_dist_grad always uses the
  * fp32 pass 1.  mode: -1 auto (on for ReLU networks when n_traj * n_obs >= 65536; env OMDS_SCREEN=0|1 overrides),
  * 0 off, 1 on; eps > 0 fixes the bound, eps = 0 (re)calibrates.

@@ -194,14 +194,14 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
     CKC(hipMalloc(&ctx->d_Apre, rows2 * OMDS_WIDTH * 4));
     CKC(hipMalloc(&ctx->d_Dmin, N * Om * 4));
     CKC(hipMalloc(&ctx->d_rowlist, N * Om * 4));
-    CKC(hipMalloc(&ctx->d_range, N * 2 * 4));
+    CKC(hipMalloc(&ctx->d_range, N * 4 * 4));
     ctx->ex_cap = (int)std::min<size_t>(N * Om, N * 32);   // 32 candidates per rollout on average; longer lists -> fp32 fallback
     CKC(hipMalloc(&ctx->d_exD, (size_t)ctx->ex_cap * 4));
     CKC(hipMalloc(&ctx->d_exDr, (size_t)ctx->ex_cap * 4));
     CKC(hipMalloc(&ctx->d_exMin, (size_t)ctx->ex_cap * 4));
     CKC(hipMalloc(&ctx->d_exMask, (size_t)ctx->ex_cap * (OMDS_MAX_HIDDEN + 1) * 8 * 4));
     CKC(hipMalloc(&ctx->d_sctotal, (H + 1) * 4));
-    CKC(hipMalloc(&ctx->d_scerr, 4));
+    CKC(hipMalloc(&ctx->d_scerr, 8));
     CKC(hipMalloc(&ctx->d_idx, rows2 * 4));
     CKC(hipMalloc(&ctx->d_gradx, rows2 * d * 4));
     CKC(hipMalloc(&ctx->d_drow, rows2 * 4));
@@ -211,7 +211,7 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
     CKC(hipMalloc(&ctx->d_nngrad, N * n * 4));
     CKC(hipMalloc(&ctx->d_cost, N * 4));
     CKC(hipMalloc(&ctx->d_w, N * 4));
-    const size_t redn = (size_t)omds_red_size((int)Km, (int)n) + 8;
+    const size_t redn = std::max<size_t>((size_t)omds_red_size((int)Km, (int)n) + 8, H + 8);   // also the screening counters of a propagate (2 + H)
     CKC(hipMalloc(&ctx->d_red, redn * 4));
     CKC(hipHostMalloc(&ctx->h_red, redn * 4));
     ctx->stage_bytes = std::max({N * H * std::max(Km, n) * 4, N * Om * 4, Km * n * N * 4, rows2 * OMDS_CPAD * 4});
@@ -808,7 +808,7 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
         omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, ctx->d_Apre, screen ? ctx->d_FqH : nullptr, N);
         if (screen) {
             CK(hipMemsetAsync(ctx->d_sctotal, 0, (size_t)(H + 1) * 4, ctx->stream));
-            CK(hipMemsetAsync(ctx->d_scerr, 0, 4, ctx->stream));
+            CK(hipMemsetAsync(ctx->d_scerr, 0, 8, ctx->stream));
         }
         for (int i = 1; i <= H; ++i) {
             {
@@ -818,7 +818,7 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
                     omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_FqH, ctx->cfg.n_traj, ctx->d_FpH, ctx->cfg.max_obs, ctx->d_radius, ctx->n_obs, N,
                                        ctx->prm.ignored_links, ctx->d_Dmin);
                     if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs, -1.0, "k_screen"))) return rc;
-                    omds_launch_select(ctx->stream, ctx->d_Dmin, N, ctx->n_obs, a.k, ctx->screen_eps, ctx->d_rowlist, ctx->d_range,
+                    omds_launch_select(ctx->stream, ctx->d_Dmin, N, ctx->n_obs, a.k, OMDS_SCREEN_WINDOW * ctx->screen_eps, ctx->d_rowlist, ctx->d_range,
                                        ctx->d_sctotal + (i - 1));
                     omds_launch_exact(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
                                       ctx->prm.ignored_links, ctx->d_Dmin, ctx->d_rowlist, ctx->d_sctotal + (i - 1), ctx->d_scerr, ex);
@@ -832,7 +832,7 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
             a.step = i;
             if (screen)
                 omds_launch_tail_sel(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Apre, ctx->n_obs, a,
-                                     ctx->d_rowlist, ctx->d_range, ex, ctx->d_FqH, N);
+                                     ctx->d_rowlist, ctx->d_range, ex, ctx->d_FqH, N, ctx->screen_eps, ctx->d_scerr + 1);
             else
                 omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, ctx->d_Apre,
                                  ctx->d_dscr, ctx->n_obs, a, 0, N);
@@ -883,21 +883,22 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
         CK(hipGetLastError());
         ctx->have_cost_vals = false;
         if (screen) {
-            CK(hipMemcpyAsync(ctx->h_red, ctx->d_scerr, 4, hipMemcpyDeviceToHost, ctx->stream));
-            CK(hipMemcpyAsync(ctx->h_red + 1, ctx->d_sctotal, (size_t)H * 4, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipMemcpyAsync(ctx->h_red, ctx->d_scerr, 8, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipMemcpyAsync(ctx->h_red + 2, ctx->d_sctotal, (size_t)H * 4, hipMemcpyDeviceToHost, ctx->stream));
         }
         CK(hipStreamSynchronize(ctx->stream));
         if (!screen) break;
         const float err = ctx->h_red[0];   // max |screening - fp32| over every candidate pair of this propagate
         if (err > ctx->screen_err_seen || err != err) ctx->screen_err_seen = err;
-        const int32_t* tot = reinterpret_cast<const int32_t*>(ctx->h_red + 1);
+        const int32_t* tot = reinterpret_cast<const int32_t*>(ctx->h_red + 2);
+        const uint32_t slack_viol = reinterpret_cast<const uint32_t*>(ctx->h_red)[1];   // rollouts whose exact k-th smallest came within eps of tau
         bool overflow = false;   // a step listed more candidates than k_exact's per-entry outputs hold: redo in fp32
         for (int i = 0; i < H; ++i) { ctx->screen_rows += tot[i]; overflow = overflow || tot[i] > ctx->ex_cap; }
         ctx->screen_steps += (double)N * H;
         if (overflow) { ctx->screen_fallbacks++; screen = false; continue; }
         static int noguard = -1;   // OMDS_SCREEN_NOGUARD=1: timing experiments with deliberately broken screening kernels only
         if (noguard < 0) { const char* e = getenv("OMDS_SCREEN_NOGUARD"); noguard = e ? atoi(e) : 0; }
-        if (err <= 0.5f * ctx->screen_eps || noguard) {
+        if ((err <= 0.5f * ctx->screen_eps && slack_viol == 0) || noguard) {
             // accepted (the bound kept a 2x margin over everything seen).  Keep it at >= 4x the largest error seen so far, so
             // that states drifting into regions where the fp16 network is less accurate widen the bound gradually instead
             // of tripping the fallback
@@ -907,7 +908,7 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
         // the calibrated bound lost its 2x margin on live data: this propagate is redone in fp32 and the bound is widened
         // (or screening is switched off when the error is not even finite -- an fp16 overflow inside the network)
         ctx->screen_fallbacks++;
-        if (err == err && err < 3.0e38f) ctx->screen_eps = 4.f * err; else ctx->screen_ok = false;
+        if (err == err && err < 3.0e38f) ctx->screen_eps = std::max(ctx->screen_eps, 4.f * err); else ctx->screen_ok = false;
         screen = false;
     }
     if (ctx->prof_on && (rc = prof_collect(ctx))) return rc;

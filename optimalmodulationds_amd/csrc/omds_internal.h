@@ -96,7 +96,7 @@ struct omds_ctx {
     ScreenDev screen{};
     bool screen_ok = false;      // packs present (ReLU network)
     int screen_mode = -1;        // -1 = auto (on for large pair counts), 0 = off, 1 = forced on
-    float screen_eps = 0.f;      // calibrated bound on |screening value - fp32 value|; 0 = not calibrated yet
+    float screen_eps = 0.f;      // bound assumed on |screening value - fp32 value| of the rows that are not re-evaluated; 0 = not calibrated yet
     bool screen_cal = false;
     int* d_rowlist = nullptr;    // [N*max_obs] candidate pairs
     int* d_range = nullptr;      // [N][2] each rollout's range of the list
@@ -106,7 +106,7 @@ struct omds_ctx {
     int* d_exMin = nullptr;
     uint32_t* d_exMask = nullptr;
     int* d_sctotal = nullptr;    // [H] candidates listed per horizon step
-    unsigned* d_scerr = nullptr; // max |screening - exact| over the candidates (float bits)
+    unsigned* d_scerr = nullptr; // [2]: max |screening - exact| over the candidates (float bits); rollouts whose slack guard failed
     double screen_rows = 0.0;    // statistics since the last omds_prof_reset: candidate rows, (rollout, step)s, fallbacks
     double screen_steps = 0.0;
     long long screen_fallbacks = 0;
@@ -228,6 +228,11 @@ bool omds_screen_supported(const MlpDev& m);
 // only runs the backward: the pass-2 distance, the arg-min link, and the ReLU masks of every hidden layer.  mask layout per
 // entry: [hidden layer][8 words]; layer 0 (the separable layer 1, built one row per wave) holds the four 64-lane ballots of
 // the lanes' float4 components (column 4 l + c = bit l of ballot c), layers >= 1 hold bit (col & 31) of word col >> 5.
+// Window of the candidate list in units of the error bound eps: tau = (k-th smallest screening value) + OMDS_SCREEN_WINDOW * eps.
+// eps bounds the screening error of the rows that are NOT re-evaluated; the extra quarter absorbs the shift of the k-th row
+// itself (a re-evaluated row, whose error is measured: the slack guard of k_tail_sel checks tau - D*_k >= eps per rollout).
+constexpr float OMDS_SCREEN_WINDOW = 1.25f;
+
 struct ExactOut {
     float* D;          // [cap] pass-1 value
     float* dr;         // [cap] pass-2 distance y[argmin] / out_div - radius
@@ -236,7 +241,7 @@ struct ExactOut {
     int cap;           // entries the arrays hold (the list may be longer: the host then redoes the propagate in fp32)
 };
 
-void omds_launch_select(hipStream_t s, const float* Dmin, int B, int O, int k, float eps, int* rowlist, int* range, int* total);
+void omds_launch_select(hipStream_t s, const float* Dmin, int B, int O, int k, float delta, int* rowlist, int* range, int* total);
 void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius, int O,
                        int B, uint32_t ignored, float* Dmin, const int* rowlist, const int* total, unsigned* maxerr_bits,
                        const ExactOut& ex);
@@ -264,7 +269,7 @@ void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const f
 bool omds_tail_sel_supported(int n_dof, int k);
 void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
                           float* Apre, int O, const StepArgs& st, const int* rowlist, const int* range, const ExactOut& ex,
-                          uint16_t* FqH, int ldF);
+                          uint16_t* FqH, int ldF, float e_bound, unsigned* viol);
 // fused one-launch step for scenes with few obstacles (step_small.hip): rollouts per workgroup, 0 = scene does not qualify
 int omds_step_small_rollouts(const MlpDev& m, int n_dof, int O, int k);
 void omds_launch_step_small(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr, float* Apre,

@@ -412,10 +412,10 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
 struct SelectArgs {
     const float* Dmin;    // [N][O] screening values
     int* rowlist;         // [N*O] compact list of candidate rows t*O + o
-    int* range;           // [N][2] start and length of each rollout's entries in the list
+    int* range;           // [N][4] start and length of each rollout's entries in the list, tau (float bits), unused
     int* total;           // number of listed rows (zeroed before the launch)
     int N, O, k;
-    float two_eps;
+    float delta;          // tau = (k-th smallest screening value) + delta
 };
 
 #ifndef OMDS_SEL_WAVES
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(SEL_WAVES * 64) void k_select(SelectArgs a) {
         pv = bv;
         pi = bi;
     }
-    const float tau = pv + a.two_eps;   // pv = +inf (fewer than k finite values): everything is a candidate
+    const float tau = pv + a.delta;   // pv = +inf (fewer than k finite values): everything is a candidate
     // count, reserve a range of the list, write
     int cnt = 0;
     if (in_regs) {
@@ -499,8 +499,9 @@ __global__ __launch_bounds__(SEL_WAVES * 64) void k_select(SelectArgs a) {
     int base = wbase;
     for (int w = 0; w < wave; ++w) base += wtot[w];
     if (lane == 0) {
-        a.range[2 * t] = base;
-        a.range[2 * t + 1] = wave_total;
+        a.range[4 * t] = base;
+        a.range[4 * t + 1] = wave_total;
+        a.range[4 * t + 2] = __builtin_bit_cast(int, tau);   // k_tail_sel checks the rollout's slack against it
     }
     int pos = base + incl - cnt;
     const int rbase = t * O;
@@ -626,10 +627,10 @@ void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, con
 
 bool omds_screen_supported(const MlpDev& m) { return m.act == OMDS_ACT_RELU && m.nhh >= 1 && m.nhh <= 4; }
 
-void omds_launch_select(hipStream_t s, const float* Dmin, int B, int O, int k, float eps, int* rowlist, int* range, int* total) {
+void omds_launch_select(hipStream_t s, const float* Dmin, int B, int O, int k, float delta, int* rowlist, int* range, int* total) {
     if (B <= 0) return;
     SelectArgs a;
-    a.Dmin = Dmin; a.rowlist = rowlist; a.range = range; a.total = total; a.N = B; a.O = O; a.k = k; a.two_eps = 2.f * eps;
+    a.Dmin = Dmin; a.rowlist = rowlist; a.range = range; a.total = total; a.N = B; a.O = O; a.k = k; a.delta = delta;
     hipLaunchKernelGGL(k_select, dim3((B + SEL_WAVES - 1) / SEL_WAVES), dim3(SEL_WAVES * 64), 0, s, a);
 }
 

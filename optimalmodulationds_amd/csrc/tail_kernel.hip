@@ -29,7 +29,9 @@ struct TailArgs {
     int dbg_stop;        // timing experiments only (OMDS_TAIL_STOP): return after phase 1 / 2 / 3
     // screened step (k_tail_sel): the candidate list of k_select and what k_exact computed for its entries
     const int* rowlist;  // [entries] pair t*O + o
-    const int* range;    // [N][2] start, length of each rollout's entries
+    const int* range;    // [N][4] start, length of each rollout's entries, tau of k_select (float bits)
+    float e_bound;       // assumed bound on the screening error of the rows that were NOT re-evaluated
+    unsigned* viol;      // count of rollouts whose slack tau - (exact k-th smallest) fell below e_bound
     ExactOut ex;
     StepArgs st;
 };
@@ -165,7 +167,9 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
     for (int rl = wave; rl < RW; rl += 8) {
         const int t = t_base + rl;
         if (t >= t_end) break;
-        const int base = a.range[2 * t], cnt = a.range[2 * t + 1];
+        const int base = a.range[4 * t], cnt = a.range[4 * t + 1];
+        const float tau = __builtin_bit_cast(float, a.range[4 * t + 2]);
+        if (lane == 0 && cnt < k) atomicAdd(a.viol, 1u);
         if (cnt <= 64) {
             // the usual case, a few candidates: one per lane, and its rank under (D, obstacle) by comparing with every other
             // candidate's (value, obstacle) broadcast from its lane -- cnt scalar steps instead of k wave-wide reductions
@@ -179,6 +183,9 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
                 const int oj = __builtin_amdgcn_readlane(o, j);
                 rank += ((xj < x) || (xj == x && oj < o)) ? 1 : 0;
             }
+            // slack guard: every row that was not listed has a screening value above tau; with an error of at most e_bound its
+            // exact value exceeds tau - e_bound, so it stays out of the k smallest as long as tau - D*_k >= e_bound
+            if (have && rank == k - 1 && !(tau - x >= a.e_bound)) atomicAdd(a.viol, 1u);
             if (have && rank < k) {
                 const int r = rl * k + rank;
                 sm.rowT[r] = t;
@@ -220,6 +227,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
                 sel[r] = be;
             }
         }
+        if (lane == 0 && !(tau - pv >= a.e_bound)) atomicAdd(a.viol, 1u);   // pv = the exact k-th smallest
     }
     __syncthreads();
     // ---- the selected entries' masks -> LDS -> 16 bits per thread and layer in the MFMA C layout (what pass 2's forward
@@ -330,8 +338,10 @@ bool omds_tail_sel_supported(int n_dof, int k) { return (n_dof == 7 || n_dof == 
 
 void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
                           float* Apre, int O, const StepArgs& st, const int* rowlist, const int* range, const ExactOut& ex,
-                          uint16_t* FqH, int ldF) {
+                          uint16_t* FqH, int ldF, float e_bound, unsigned* viol) {
     TailArgs a;
+    a.e_bound = e_bound;
+    a.viol = viol;
     a.FqH = reinterpret_cast<_Float16*>(FqH);
     a.ldF = ldF;
     a.t_begin = 0; a.t_end = st.N;
@@ -397,7 +407,7 @@ void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const f
     static int stop = -1;
     if (stop < 0) { const char* e = getenv("OMDS_TAIL_STOP"); stop = e ? atoi(e) : 0; }
     a.dbg_stop = stop;
-    a.rowlist = nullptr; a.range = nullptr; a.ex = ExactOut{};
+    a.rowlist = nullptr; a.range = nullptr; a.ex = ExactOut{}; a.e_bound = 0.f; a.viol = nullptr;
     a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Dmin = Dmin; a.Apre = Apre; a.dscr = dscr; a.O = O; a.st = st;
     if (rows == 16) {
         if (st.n == 7) launch_tail_t<7, 16>(s, a);

@@ -114,3 +114,31 @@ def test_screened_teacher_forced_fixture():
         e.close()
     for key in KEYS:   # N = 64: the unscreened step runs 16-row pass-2 tiles, the screened one 32-row tiles -> equal to fp32 rounding
         assert np.abs(outs[0][key] - outs[1][key]).max() <= 2e-4 * max(1.0, float(np.abs(outs[0][key]).max())), key
+
+
+def test_guards_trip_on_a_bound_that_is_too_small():
+    """A caller-supplied bound far below the real screening error: the run-time guards (largest error on the re-evaluated
+    rows; per-rollout slack tau - D*_k >= eps) must reject the screened propagate, the fp32 re-run must give the all-fp32
+    result bit for bit, and the bound must have been widened afterwards."""
+    e, m, obs, q0, qf = _engine(1024, 8)
+    K = 10
+    rng = np.random.RandomState(9)
+    s = (np.arange(K) + 0.5) / K
+    mu_c = (q0 + s[:, None] * (qf - q0) + 0.15 * rng.standard_normal((K, 7))).astype(np.float32)
+    sg_c, al_c = np.ones(K, np.float32), rng.standard_normal((K, 7)).astype(np.float32)
+    a = _run(e, q0, 0, K, mu_c, sg_c, al_c, seed=7)
+    e.set_screening(1, 2e-4)
+    e.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 3.0, K, seed=7)
+    e.propagate(q0)
+    b = e.get_rollouts()
+    st = e.screen_stats()
+    assert st["fallbacks"] == 1 and st["eps"] >= 4 * st["max_err_seen"] > 8e-4, st
+    for key in KEYS:
+        assert np.array_equal(a[key], b[key]), key
+    e.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 3.0, K, seed=7)     # with the widened bound the same propagate is accepted
+    e.propagate(q0)
+    c = e.get_rollouts()
+    assert e.screen_stats()["fallbacks"] == 1
+    for key in KEYS:
+        assert np.array_equal(a[key], c[key]), key
+    e.close()
