@@ -128,6 +128,17 @@ OMDS_API int omds_set_ds(omds_ctx* ctx, const float* q_goal);
 /* MPPI_toy's nominal DS (MPPI_toy.py:89-91): velocity = (q - q_goal) @ A, A [n,n] row-major, not
  * normalised.  A == NULL switches back to LinDS.                                            */
 OMDS_API int omds_set_ds_matrix(omds_ctx* ctx, const float* q_goal, const float* A);
+/* SEDS nominal DS (ds_mppi/functions/SEDS.py:8-74): a Gaussian mixture regression x -> velocity on x = q - q_goal with
+ * G components.  The caller passes the quantities SEDS.__init__ / GMR derive from the .mat file (so that a caller who
+ * derives them like the reference -- torch.inverse / torch.det in float32 -- gets the reference's numbers):
+ *   mu_in [G][n]      Mu[:n, j]                          b [G][n]          Mu[n:, j]
+ *   sigma_inv [G][n][n]  inverse(Sigma[:n,:n,j])         A [G][n][n]       Sigma[n:,:n,j] @ inverse(Sigma[:n,:n,j])
+ *   prior [G]         Priors[j]                          den [G]           sqrt(2 pi^n |det Sigma[:n,:n,j]| + 1e-100)
+ * velocity (SEDS.get_velocity): beta_j = clamp(nan_to_num(prior_j N_j / sum), 1e-8), y = sum_j beta_j (b_j + A_j (x - mu_j));
+ * farther than lin_thr from the goal: y / |y|, or -x / |x| where |y| < seds_thr.  G = 0 switches back to LinDS.            */
+OMDS_API int omds_set_ds_seds(omds_ctx* ctx, const float* q_goal, int n_gauss, const float* mu_in, const float* b,
+                              const float* sigma_inv, const float* A, const float* prior, const float* den,
+                              float lin_thr, float seds_thr);
 OMDS_API int omds_set_params(omds_ctx* ctx, const omds_params* p);
 /* Cost(q_f, dh_params) + the q_min/q_max attributes (cost.py:5-12): dh_params [n+1,4]
  * rows (d, theta, a, alpha); q_min/q_max [n].                                             */

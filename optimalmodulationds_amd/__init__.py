@@ -7,7 +7,7 @@ The arithmetic runs in hand-written gfx950 HIP kernels behind the C-ABI declared
 Python host side.  Importing the package does not load the library; constructing ``MPPI``
 does, and fails loudly when the library or a GPU is missing (there is no CPU fallback).
 """
-__all__ = ["MPPI", "TensorPolicyMPPI", "RobotSdfCollisionNet", "LinDS", "Cost", "scenes"]
+__all__ = ["MPPI", "TensorPolicyMPPI", "RobotSdfCollisionNet", "LinDS", "SEDS", "Cost", "scenes"]
 
 from . import scenes  # noqa: E402,F401  (pure numpy; safe without the HIP library)
 
@@ -25,6 +25,9 @@ def __getattr__(name):
     if name == "LinDS":
         from .lin_ds import LinDS
         return LinDS
+    if name == "SEDS":
+        from .seds import SEDS
+        return SEDS
     if name == "Cost":
         from .cost import Cost
         return Cost

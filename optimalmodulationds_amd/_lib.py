@@ -57,6 +57,7 @@ SIGNATURES = {
     "omds_set_obstacles": (C.c_int, [C.c_void_p, F32P, C.c_int]),
     "omds_set_ds": (C.c_int, [C.c_void_p, F32P]),
     "omds_set_ds_matrix": (C.c_int, [C.c_void_p, F32P, F32P]),
+    "omds_set_ds_seds": (C.c_int, [C.c_void_p, F32P, C.c_int, F32P, F32P, F32P, F32P, F32P, F32P, C.c_float, C.c_float]),
     "omds_set_params": (C.c_int, [C.c_void_p, C.POINTER(OmdsParams)]),
     "omds_set_cost": (C.c_int, [C.c_void_p, F32P, F32P, F32P]),
     "omds_set_policy_samples": (C.c_int, [C.c_void_p, F32P, F32P, F32P, C.c_int]),

@@ -117,7 +117,7 @@ static void free_all(omds_ctx* ctx) {
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
                     ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
                     ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
-                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP};
+                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP, ctx->d_seds};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : ctx->mlp_allocs)
@@ -524,6 +524,7 @@ int omds_set_ds(omds_ctx* ctx, const float* q_goal) {
     std::memcpy(ctx->qf, q_goal, ctx->cfg.n_dof * sizeof(float));
     ctx->have_ds = true;
     ctx->have_A = false;
+    ctx->seds_G = 0;
     refresh_goal_fk(ctx);
     return OMDS_OK;
 }
@@ -535,6 +536,34 @@ int omds_set_ds_matrix(omds_ctx* ctx, const float* q_goal, const float* A) {
     CK(hipSetDevice(ctx->dev));
     CK(hipMemcpy(ctx->d_A, A, (size_t)n * n * sizeof(float), hipMemcpyHostToDevice));
     ctx->have_A = true;
+    return OMDS_OK;
+}
+
+int omds_set_ds_seds(omds_ctx* ctx, const float* q_goal, int G, const float* mu_in, const float* b, const float* sigma_inv,
+                     const float* A, const float* prior, const float* den, float lin_thr, float seds_thr) {
+    int rc = omds_set_ds(ctx, q_goal);
+    if (rc || G == 0) return rc;
+    REQUIRE(G >= 1 && G <= 64 && mu_in && b && sigma_inv && A && prior && den, OMDS_ERR_INVALID_ARG,
+            "omds_set_ds_seds: need 1 <= n_gauss <= 64 and non-null component arrays");
+    const int n = ctx->cfg.n_dof, st = omds_seds_stride(n);
+    std::vector<float> pk((size_t)G * st);
+    for (int j = 0; j < G; ++j) {
+        float* p = &pk[(size_t)j * st];
+        std::memcpy(p, mu_in + (size_t)j * n, n * sizeof(float));
+        std::memcpy(p + n, b + (size_t)j * n, n * sizeof(float));
+        p[2 * n] = prior[j];
+        p[2 * n + 1] = den[j];
+        std::memcpy(p + 2 * n + 2, sigma_inv + (size_t)j * n * n, (size_t)n * n * sizeof(float));
+        std::memcpy(p + 2 * n + 2 + n * n, A + (size_t)j * n * n, (size_t)n * n * sizeof(float));
+    }
+    CK(hipSetDevice(ctx->dev));
+    CK(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_seds) { (void)hipFree(ctx->d_seds); ctx->d_seds = nullptr; }
+    CK(hipMalloc(&ctx->d_seds, pk.size() * sizeof(float)));
+    CK(hipMemcpy(ctx->d_seds, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->seds_G = G;
+    ctx->seds_lin_thr = lin_thr;
+    ctx->seds_thr = seds_thr;
     return OMDS_OK;
 }
 
@@ -871,6 +900,8 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
     a.muT = ctx->d_muT; a.sigmaT = ctx->d_sigmaT; a.alphaT = ctx->d_alphaT; a.gradx = ctx->d_gradx; a.drow = ctx->d_drow;
     std::memcpy(a.qf, ctx->qf, sizeof(a.qf));
     a.A = ctx->have_A ? ctx->d_A : nullptr;
+    a.seds = ctx->seds_G > 0 ? ctx->d_seds : nullptr;
+    a.seds_G = ctx->seds_G; a.seds_lin_thr = ctx->seds_lin_thr; a.seds_thr = ctx->seds_thr;
     a.prm = ctx->prm;
     static int fused = -1;   // OMDS_FUSED_TAIL=0 selects the five-kernel step (kept for A/B runs and as the generic path)
     if (fused < 0) { const char* e = getenv("OMDS_FUSED_TAIL"); fused = e ? atoi(e) : 1; }

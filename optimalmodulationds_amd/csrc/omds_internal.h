@@ -124,6 +124,9 @@ struct omds_ctx {
     bool have_ds = false, have_cost = false;
     float qf[OMDS_MAX_DOF] = {0};
     float* d_A = nullptr;        // [n][n] MPPI_toy nominal DS matrix (omds_set_ds_matrix), used when have_A
+    float* d_seds = nullptr;     // [G][omds_seds_stride(n)] SEDS components (omds_set_ds_seds), used when seds_G > 0
+    int seds_G = 0;
+    float seds_lin_thr = 1e-2f, seds_thr = 1e-2f;
     bool have_A = false;
     float qmin[OMDS_MAX_DOF] = {0}, qmax[OMDS_MAX_DOF] = {0};
     float dh[(OMDS_MAX_DOF + 1) * 4] = {0};
@@ -247,6 +250,7 @@ void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const 
                        const ExactOut& ex);
 
 // ---- launchers implemented in rollout_kernels.hip ---------------------------------------------
+__host__ __device__ inline int omds_seds_stride(int n) { return 2 * n + 2 + 2 * n * n; }
 struct StepArgs {
     int N, H, n, K, Kmax, k, d, step;   // step = i in 1..H
     float* trajT; float* distT; float* dotT; float* actT; float* normalT; float* kvalT; float* qdotT;
@@ -255,6 +259,9 @@ struct StepArgs {
     const float* gradx; const float* drow;
     float qf[OMDS_MAX_DOF];
     const float* A;   // [n][n] nominal DS matrix of MPPI_toy (velocity = (q - qf) @ A), nullptr = LinDS
+    const float* seds;   // SEDS components [G][omds_seds_stride(n)]: mu_in[n], b[n], prior, den, sigma_inv[n][n], A[n][n]; nullptr = not SEDS
+    int seds_G;
+    float seds_lin_thr, seds_thr;
     omds_params prm;
 };
 void omds_launch_modulate(hipStream_t s, const StepArgs& a);

@@ -34,7 +34,78 @@ __device__ __forceinline__ void modulate_core(const StepArgs& a, const int i, in
     for (int j = 0; j < ND; ++j) q[j] = q_in[j];
 
     // nominal DS (LinDS.py:11-21) and its norm (MPPI.py:106-108)
-    if (a.A == nullptr) {
+    if (a.seds != nullptr) {
+        // SEDS.get_velocity (SEDS.py:34-74): Gaussian mixture regression on x = q - q_goal; the components are strided over
+        // the NSUB lanes, their weighted outputs and the weight sum meet by shuffles
+        const int st = omds_seds_stride(ND);
+        float x[ND], ysum[ND], psum = 0.f, pj[4];   // up to 4 components per lane (G <= 64, NSUB = 16) or all of them (NSUB = 1, looped below)
+        float dst2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) { x[j] = q[j] - a.qf[j]; dst2 += x[j] * x[j]; ysum[j] = 0.f; }
+        // pass 1: unnormalised responsibilities prior_j N_j(x) and their sum
+        for (int gidx = sub, c = 0; gidx < a.seds_G; gidx += NSUB, ++c) {
+            const float* g = a.seds + (size_t)gidx * st;
+            const float* Si = g + 2 * ND + 2;
+            float dd[ND], prob = 0.f;
+#pragma unroll
+            for (int j = 0; j < ND; ++j) dd[j] = x[j] - g[j];
+#pragma unroll
+            for (int cc = 0; cc < ND; ++cc) {      // prob = sum_c (sum_r dd_r Sinv[r][c]) dd_c   (SEDS.py:31)
+                float t = 0.f;
+#pragma unroll
+                for (int r = 0; r < ND; ++r) t += dd[r] * Si[r * ND + cc];
+                prob += t * dd[cc];
+            }
+            const float pxi = g[2 * ND] * (expf(-0.5f * prob) / g[2 * ND + 1]);
+            if (NSUB > 1 && c < 4) pj[c] = pxi;
+            psum += pxi;
+        }
+        if (NSUB > 1) {
+#pragma unroll
+            for (int off = 1; off < NSUB; off <<= 1) psum += __shfl_xor(psum, off);
+        }
+        // pass 2: beta_j = clamp(nan_to_num(pxi / sum), 1e-8) (SEDS.py:49-51), y = sum_j beta_j (b_j + A_j (x - mu_j))
+        for (int gidx = sub, c = 0; gidx < a.seds_G; gidx += NSUB, ++c) {
+            const float* g = a.seds + (size_t)gidx * st;
+            const float* Aj = g + 2 * ND + 2 + ND * ND;
+            float pxi;
+            if (NSUB > 1 && c < 4) pxi = pj[c];
+            else {   // recompute (one lane per rollout, or more than four components per lane)
+                const float* Si = g + 2 * ND + 2;
+                float prob = 0.f;
+#pragma unroll
+                for (int cc = 0; cc < ND; ++cc) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int r = 0; r < ND; ++r) t += (x[r] - g[r]) * Si[r * ND + cc];
+                    prob += t * (x[cc] - g[cc]);
+                }
+                pxi = g[2 * ND] * (expf(-0.5f * prob) / g[2 * ND + 1]);
+            }
+            float beta = nan_to_num_f(pxi / psum);
+            beta = beta < 1e-8f ? 1e-8f : beta;
+#pragma unroll
+            for (int r = 0; r < ND; ++r) {
+                float yj = g[ND + r];
+#pragma unroll
+                for (int cc = 0; cc < ND; ++cc) yj += Aj[r * ND + cc] * (x[cc] - g[cc]);
+                ysum[r] += beta * yj;
+            }
+        }
+        if (NSUB > 1) {
+#pragma unroll
+            for (int j = 0; j < ND; ++j)
+#pragma unroll
+                for (int off = 1; off < NSUB; off <<= 1) ysum[j] += __shfl_xor(ysum[j], off);
+        }
+        float yn2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) yn2 += ysum[j] * ysum[j];
+        const float dst = sqrtf(dst2), yn = sqrtf(yn2);
+        const bool far = dst > a.seds_lin_thr, weak = yn < a.seds_thr;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) v[j] = far ? (weak ? -x[j] / dst : ysum[j] / yn) : ysum[j];
+    } else if (a.A == nullptr) {
         float dst2 = 0.f;
 #pragma unroll
         for (int j = 0; j < ND; ++j) { const float xd = q[j] - a.qf[j]; v[j] = -xd; dst2 += xd * xd; }

@@ -78,6 +78,17 @@ class Engine:
         a = L.f32(A).reshape(self.n, self.n)
         self._ck(self.lib.omds_set_ds_matrix(self.h, L.fptr(q), L.fptr(a)))
 
+    def set_ds_seds(self, q_goal, mu_in, b, sigma_inv, A, prior, den, lin_thr=1e-2, seds_thr=1e-2):
+        """SEDS nominal DS (SEDS.py): G components; mu_in/b [G,n], sigma_inv/A [G,n,n], prior/den [G] as SEDS.__init__ / GMR
+        derive them from the .mat file (optimalmodulationds_amd.seds.SEDS.device_params)."""
+        q = L.f32(q_goal).reshape(self.n)
+        mu_in, b = L.f32(mu_in), L.f32(b)
+        G = mu_in.shape[0]
+        si, a = L.f32(sigma_inv).reshape(G, self.n, self.n), L.f32(A).reshape(G, self.n, self.n)
+        pr, dn = L.f32(prior).reshape(G), L.f32(den).reshape(G)
+        self._ck(self.lib.omds_set_ds_seds(self.h, L.fptr(q), G, L.fptr(mu_in), L.fptr(b), L.fptr(si), L.fptr(a), L.fptr(pr), L.fptr(dn),
+                                           float(lin_thr), float(seds_thr)))
+
     def push_params(self):
         self._ck(self.lib.omds_set_params(self.h, C.byref(self.params)))
 

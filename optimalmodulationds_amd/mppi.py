@@ -156,7 +156,10 @@ class MPPI:
             mask |= 1 << int(l)
         p.ignored_links = mask
         e.push_params()
-        e.set_ds(_np(self.qf))
+        if hasattr(self.DS, "device_params"):       # SEDS nominal DS (seds.py)
+            e.set_ds_seds(_np(self.qf), *self.DS.device_params(), lin_thr=float(self.DS.lin_thr), seds_thr=float(self.DS.seds_thr))
+        else:
+            e.set_ds(_np(self.qf))
         e.set_cost(_np(self.dh_params), _np(self.Cost.q_min), _np(self.Cost.q_max))
 
     # ---- rollouts (MPPI.py:97-224) -------------------------------------------------------------------

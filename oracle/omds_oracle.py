@@ -166,6 +166,32 @@ def lin_ds_velocity(x, q_goal, lin_thr=0.015):
     return y
 
 
+def seds_velocity(x, q_goal, mu_in, b, sigma_inv, A, prior, den, lin_thr=1e-2, seds_thr=1e-2):
+    """SEDS.get_velocity (FN/SEDS.py:34-74), per state: Gaussian mixture regression on x - q_goal with the per-component
+    quantities SEDS.__init__ / GMR derive (mu_in, b = Mu halves; sigma_inv = inverse(Sigma_ii); A = Sigma_oi @ sigma_inv;
+    den = sqrt(2 pi^n |det Sigma_ii| + 1e-100)); beta = clamp(nan_to_num(prior N / sum), 1e-8); farther than lin_thr from
+    the goal the output is normalised, or replaced by the normalised linear DS where the mixture's output is below seds_thr.
+    (The reference's own normalisation lines only broadcast for one state at a time; this is that per-state behaviour.)"""
+    x = np.asarray(x, dtype=F32)
+    xd = (x - np.asarray(q_goal, dtype=F32).reshape(1, -1)).astype(F32)
+    dd = (xd[:, None, :] - mu_in[None]).astype(F32)                               # [N, G, n]
+    prob = np.einsum("ngr,grc,ngc->ng", dd, sigma_inv, dd).astype(F32)
+    with np.errstate(under="ignore", invalid="ignore", divide="ignore"):
+        pxi = (prior[None] * (np.exp(F32(-0.5) * prob).astype(F32) / den[None])).astype(F32)
+        beta = nan_to_num((pxi / pxi.sum(axis=1, keepdims=True, dtype=F32)).astype(F32))
+    beta = np.maximum(beta, F32(1e-8))
+    y = (beta[:, :, None] * (b[None] + np.einsum("grc,ngc->ngr", A, dd))).sum(axis=1).astype(F32)
+    dst = np.linalg.norm(xd, axis=1).astype(F32)
+    yn = np.linalg.norm(y, axis=1).astype(F32)
+    far, weak = dst > F32(lin_thr), yn < F32(seds_thr)
+    out = y.copy()
+    with np.errstate(invalid="ignore", divide="ignore"):
+        out[far] = y[far] / yn[far, None]
+        lin = far & weak
+        out[lin] = -xd[lin] / dst[lin, None]
+    return out.astype(F32)
+
+
 def generalized_sigmoid(x, y_min, y_max, x0, x1, k):
     """FN/MPPI.py:352-353."""
     with np.errstate(over="ignore"):
@@ -220,6 +246,8 @@ class Params:
     # FN/MPPI_toy.py variant: nominal DS (q - qf) @ A (:89) and kernel values stored times activation (:178-179)
     A: object = None
     kval_times_act: bool = False
+    # SEDS nominal DS (FN/SEDS.py): dict(mu_in, b, sigma_inv, A, prior, den, lin_thr, seds_thr) as seds_velocity takes them
+    seds: object = None
 
 
 @dataclass
@@ -243,7 +271,9 @@ def modulation_step(q_prev, qf, distance_raw, g_raw, mu_tmp, sigma_tmp, alpha_tm
     q_prev = np.asarray(q_prev, dtype=F32)
     K = mu_tmp.shape[1]
     with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
-        if prm.A is None:
+        if prm.seds is not None:
+            v = seds_velocity(q_prev, qf, **prm.seds)                             # :106 with DS = SEDS
+        elif prm.A is None:
             v = lin_ds_velocity(q_prev, qf, prm.lin_thr)                          # :106
         else:
             v = ((q_prev - qf).astype(F32) @ np.asarray(prm.A, dtype=F32)).astype(F32)   # MPPI_toy.py:89

@@ -454,3 +454,35 @@ def test_update_kernel_normal_bases_matches_the_reference():
     assert np.abs(B[:, :, 0] - fx["bases"][:, :, 0]).max() <= 5e-5
     err = np.abs(B - fx["bases"]).max(axis=(1, 2))
     assert (err <= _basis_tol(fx["bases"][:, 0, 0])).all(), err
+
+
+def test_integrator_with_a_seds_nominal_ds():
+    """frankaIntegrator.py:70-73 with the SEDS lines un-commented: DS_ARRAY = [SEDS(<.mat>, q_f)], N = 1, H = 2.  The SEDS object
+    is built from the mixture arrays of the reference's seds_left10.mat (data in the fixture), derives its per-component
+    quantities like the reference does, and the step reproduces the reference's captured velocity."""
+    from optimalmodulationds_amd import MPPI, SEDS, RobotSdfCollisionNet
+    fx, mat = load("franka_seds_integrator_N1"), load("seds_left10")
+    nn_model = RobotSdfCollisionNet(10, 9, [], [256] * 4)
+    nn_model.load_weights(weights_path("franka"), {})
+    q0, qf = torch.tensor(fx["q0"]), torch.tensor(fx["qf"])
+    ds = SEDS({k: mat[k] for k in ("Mu", "Sigma", "Priors", "xT")}, qf.unsqueeze(1))
+    for got, want in zip(ds.device_params(), (fx["seds_mu_in"], fx["seds_b"], fx["seds_sigma_inv"], fx["seds_A"], fx["seds_prior"], fx["seds_den"])):
+        # torch.inverse in float32 of covariances with condition numbers of 10^3 .. 10^4: the derived arrays differ between hosts
+        # (4e-5 between the capture container and the test box) -- as they would for the reference itself
+        assert_close(got, want, 3e-4, "derived SEDS quantities", floor=float(np.abs(want).max()))
+    dh = torch.tensor(fx["dh_params"])
+    step = MPPI(q0, qf, dh, torch.tensor(fx["obs"]), 0.01, 2, 1, [ds], dh[:, 2], nn_model, 5)
+    step.dst_thr = 0.03
+    step.Policy.alpha_s *= 0
+    K = int(fx["K"])
+    step.Policy.update_with_data({"n_kernels": K, "mu_c": fx["it0_mu_c"], "alpha_c": fx["it0_alpha_c"],
+                                  "sigma_c": fx["it0_sigma_c"], "norm_basis": np.zeros((K, 7, 7), np.float32)})
+    step.Policy.sample_policy()
+    step.q_cur = torch.tensor(fx["it0_q_cur"])
+    step.propagate()
+    assert_close(step.qdot.numpy(), fx["it0_qdot"], 1e-3, "integrator qdot with SEDS vs reference (host-derived mixture quantities)")
+    # the host convenience method against the reference's known answers (one state per reference call)
+    ds0 = SEDS({k: mat[k] for k in ("Mu", "Sigma", "Priors", "xT")})
+    y = ds0.get_velocity(torch.tensor(mat["x"])).numpy()
+    ok = np.abs(y - mat["y"]).max(axis=1) <= 5e-5 * max(1.0, float(np.abs(mat["y"]).max()))
+    assert ok.mean() > 0.97     # a couple of states far outside the demonstrations are decided by denormal exponentials

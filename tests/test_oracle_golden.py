@@ -6,7 +6,7 @@ the cost and the cost-weighted policy update."""
 import numpy as np
 import pytest
 
-from helpers import MLP_KINDS, RTOL, SCENARIOS, assert_close, load, weights_path
+from helpers import SEDS_FILES, seds_of, MLP_KINDS, RTOL, SCENARIOS, assert_close, load, weights_path
 from oracle import omds_oracle as orc
 
 
@@ -44,7 +44,7 @@ def test_stage_intermediates(name):
 
 
 def _prm(fx, basis=False):
-    return orc.Params(dst_thr=float(fx["dst_thr"]), lin_thr=float(fx["lin_thr"]), p=int(fx["p"]), want_basis=basis)
+    return orc.Params(dst_thr=float(fx["dst_thr"]), lin_thr=float(fx["lin_thr"]), p=int(fx["p"]), want_basis=basis, seds=seds_of(fx))
 
 
 @pytest.mark.parametrize("name", SCENARIOS)
@@ -160,7 +160,7 @@ def test_torch_baseline_matches_the_numpy_oracle():
     fx = load("franka_sub40_K4")
     m = orc.Mlp.from_npz(weights_path("franka"))
     N, H, k, K = int(fx["N"]), int(fx["H"]), int(fx["k"]), int(fx["K"])
-    prm = orc.Params(dst_thr=float(fx["dst_thr"]), lin_thr=float(fx["lin_thr"]), p=int(fx["p"]))
+    prm = orc.Params(dst_thr=float(fx["dst_thr"]), lin_thr=float(fx["lin_thr"]), p=int(fx["p"]), seds=seds_of(fx))
     pl = TorchPlanner(m, fx["obs"], fx["qf"], fx["dh_params"], fx["cost_q_min"], fx["cost_q_max"], dt=float(fx["dt"]), k=k,
                       ignored_links=[int(l) for l in fx["ignored_links"]], prm=prm)
     mu, sg, al = fx["it0_mu_tmp"][:, :K], fx["it0_sigma_tmp"][:, :K], fx["it0_alpha_tmp"][:, :K]
@@ -181,3 +181,15 @@ def test_torch_baseline_matches_the_numpy_oracle():
                                                       fx["it0_sigma_c"][:K], fx["it0_alpha_c"][:K], mu, sg, al, 0.1, float(fx["ker_thr"]))
     assert_close(w.numpy(), ow, 1e-5, "weights", floor=float(ow.max()))
     assert_close(al_n.numpy(), oal, 2e-5, "alpha_c")
+
+
+@pytest.mark.parametrize("name", SEDS_FILES)
+def test_seds_velocity(name):
+    """SEDS.get_velocity (SEDS.py:59-74) on the reference's shipped mixtures, one state per reference call: near the goal
+    (raw mixture output), near the components, far away (normalised; linear fallback where the mixture is weak)."""
+    fx = load(name)
+    y = orc.seds_velocity(fx["x"], fx["xT"].reshape(-1), fx["mu_in"], fx["b"], fx["sigma_inv"], fx["A"], fx["prior"], fx["den"],
+                          float(fx["lin_thr"]), float(fx["seds_thr"]))
+    # relative to the largest output: the 2-D mixture (fitted in pixel units) answers ~136 near its goal, where b + A (x - mu)
+    # cancels three digits -- 3e-5 between two fp32 summation orders
+    assert_close(y, fx["y"], 5e-5, "SEDS velocity vs reference", floor=1.0)

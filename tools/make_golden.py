@@ -155,14 +155,14 @@ def set_policy_state(mppi, K, rng, q0, qf, sigma_nom, alpha_scale=1.0):
 
 def run_scenario(name, kind, nn_model, *, N, H, dt, obs, k, q0, qf, dst_thr, ker_thr, alpha_s,
                  sigma_nom, K, n_iter=2, ignored_links=None, seed=0, q_cur=None, planar2_limits=False,
-                 p=2, advance="best"):
+                 p=2, advance="best", ds_array=None, extra=None):
     torch.manual_seed(seed)
     rng = np.random.RandomState(seed + 1000)
     dh, dh_a = robot_setup(kind)
     q0_t = torch.from_numpy(np.asarray(q0, dtype=np.float32))
     qf_t = torch.from_numpy(np.asarray(qf, dtype=np.float32))
     obs_t = torch.from_numpy(np.asarray(obs, dtype=np.float32))
-    DS_ARRAY = [LinDS(qf_t), LinDS(q0_t)]
+    DS_ARRAY = ds_array if ds_array is not None else [LinDS(qf_t), LinDS(q0_t)]
     with quiet():
         mppi = MPPI(q0_t, qf_t, dh, obs_t, dt, H, N, DS_ARRAY, dh_a, nn_model, k)
     mppi.Policy.sigma_c_nominal = sigma_nom
@@ -190,6 +190,8 @@ def run_scenario(name, kind, nn_model, *, N, H, dt, obs, k, q0, qf, dst_thr, ker
         "cost_q_min": t2n(mppi.Cost.q_min), "cost_q_max": t2n(mppi.Cost.q_max),
         "n_iter": n_iter,
     }
+    if extra:
+        fx.update(extra)
     for it in range(n_iter):
         P = mppi.Policy
         pre = f"it{it}_"
