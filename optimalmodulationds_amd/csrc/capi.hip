@@ -905,7 +905,8 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
     a.prm = ctx->prm;
     static int fused = -1;   // OMDS_FUSED_TAIL=0 selects the five-kernel step (kept for A/B runs and as the generic path)
     if (fused < 0) { const char* e = getenv("OMDS_FUSED_TAIL"); fused = e ? atoi(e) : 1; }
-    const bool tail = fused && !(ctx->cfg.flags & OMDS_FLAG_UNFUSED_STEP) && omds_tail_supported(n, a.k);
+    // a SEDS nominal DS takes the step of stand-alone kernels: only k_modulate carries that branch (step_device.h)
+    const bool tail = fused && !(ctx->cfg.flags & OMDS_FLAG_UNFUSED_STEP) && omds_tail_supported(n, a.k) && ctx->seds_G == 0;
     bool screen = tail && screen_wanted(ctx);
     if (screen && !ctx->screen_cal && (rc = calibrate_screen(ctx, q_cur))) return rc;
     screen = screen && ctx->screen_ok && ctx->screen_eps > 0.f;

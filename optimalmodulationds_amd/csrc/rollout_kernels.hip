@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void k_modulate(StepArgs a) {
     float q[ND], qn[ND];
 #pragma unroll
     for (int j = 0; j < ND; ++j) q[j] = a.trajT[((size_t)(a.step - 1) * ND + j) * a.N + t];
-    modulate_core<ND, 1>(a, a.step, t, 0, a.gradx, a.drow, t * a.k, q, qn);
+    modulate_core<ND, 1, true>(a, a.step, t, 0, a.gradx, a.drow, t * a.k, q, qn);
 }
 
 template <int ND>

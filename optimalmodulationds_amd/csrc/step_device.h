@@ -24,7 +24,10 @@ __device__ __forceinline__ float gsig(float x, const float* s) {
 // hold the k gradient rows of this rollout starting at row grow0 (global memory or LDS).  q_in is the state
 // all_traj[t, i-1]; q_next receives
 // the integrated state (all lanes).
-template <int ND, int NSUB>
+// WITH_SEDS: compile the SEDS nominal-DS branch in.  Only the stand-alone k_modulate does (omds_propagate routes contexts with a
+// SEDS nominal DS through the step of stand-alone kernels): inlined into the fused step kernels the branch costs them 10-16
+// registers and 1-3 % on every workload, out of line (a device function call) 226 registers and 20 %.
+template <int ND, int NSUB, bool WITH_SEDS = false>
 __device__ __forceinline__ void modulate_core(const StepArgs& a, const int i, int t, int sub, const float* gradx, const float* drow,
                                               int grow0, const float (&q_in)[ND], float (&q_next)[ND]) {
     const int N = a.N;
@@ -34,7 +37,7 @@ __device__ __forceinline__ void modulate_core(const StepArgs& a, const int i, in
     for (int j = 0; j < ND; ++j) q[j] = q_in[j];
 
     // nominal DS (LinDS.py:11-21) and its norm (MPPI.py:106-108)
-    if (a.seds != nullptr) {
+    if (WITH_SEDS && a.seds != nullptr) {
         // SEDS.get_velocity (SEDS.py:34-74): Gaussian mixture regression on x = q - q_goal; the components are strided over
         // the NSUB lanes, their weighted outputs and the weight sum meet by shuffles
         const int st = omds_seds_stride(ND);

@@ -397,7 +397,8 @@ def test_seds_nominal_ds_on_device(name, kind, flags):
     """SEDS nominal DS (omds_set_ds_seds) inside the step kernels: one H = 1 propagate from the fixture's states (near the goal,
     near the mixture components, far away with and without the linear fallback), checked against oracle.modulation_step fed
     the device's own (distance, gradient) -- the oracle's seds_velocity is pinned to the reference's outputs on these very
-    states (test_oracle_golden.py::test_seds_velocity).  flags = 1: the stand-alone k_modulate (one lane per rollout)."""
+    states (test_oracle_golden.py::test_seds_velocity).  A context with a SEDS nominal DS runs the step of stand-alone kernels
+    (k_modulate carries the branch), with or without OMDS_FLAG_UNFUSED_STEP (flags)."""
     from optimalmodulationds_amd import scenes
     from optimalmodulationds_amd.engine import Engine
     fx = load(name)
