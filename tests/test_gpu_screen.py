@@ -142,3 +142,35 @@ def test_guards_trip_on_a_bound_that_is_too_small():
     for key in KEYS:
         assert np.array_equal(a[key], c[key]), key
     e.close()
+
+
+@pytest.mark.parametrize("scene", ["cross", "cloud600", "sub40"])
+def test_screened_propagate_is_bit_identical_on_other_scenes(scene):
+    """The same bit-identity on scenes with other obstacle statistics than the shelf: the 28-sphere cross (few, clustered),
+    a random cloud of 600 spheres around the arm (many near-ties), and 40 shelf spheres (every rollout's candidates are a
+    large share of its obstacles) -- screening forced on, the bound calibrated per scene at the first propagate."""
+    from optimalmodulationds_amd import scenes
+    if scene == "cross":
+        obs = scenes.cross_scene(0.45)
+    elif scene == "sub40":
+        obs = scenes.shelf_scene()[::7][:40]
+    else:
+        rng = np.random.RandomState(3)
+        p = rng.uniform([-0.2, -0.7, 0.0], [0.9, 0.7, 1.1], (600, 3))
+        obs = np.c_[p, rng.uniform(0.02, 0.08, 600)].astype(np.float32)
+    N, H, K = 1024, 8, 10
+    e, m, obs, q0, qf = _engine(N, H, obs=obs)
+    rng = np.random.RandomState(5)
+    s = (np.arange(K) + 0.5) / K
+    mu_c = (q0 + s[:, None] * (qf - q0) + 0.15 * rng.standard_normal((K, 7))).astype(np.float32)
+    sg_c, al_c = np.ones(K, np.float32), rng.standard_normal((K, 7)).astype(np.float32)
+    q = q0.copy()
+    for it in range(6):
+        a = _run(e, q, 0, K, mu_c, sg_c, al_c, seed=300 + it)
+        b = _run(e, q, 1, K, mu_c, sg_c, al_c, seed=300 + it)
+        for key in KEYS:
+            assert np.array_equal(a[key], b[key]), (scene, it, key, float(np.abs(a[key] - b[key]).max()))
+        q = (q + 0.05 * (qf - q0) + 0.02 * rng.standard_normal(7)).astype(np.float32)
+    st = e.screen_stats()
+    assert st["active"] and st["fallbacks"] <= 2 and st["max_err_seen"] <= 0.5 * st["eps"], st
+    e.close()
