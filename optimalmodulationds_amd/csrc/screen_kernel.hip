@@ -571,6 +571,9 @@ void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, con
         if (ncu <= 0) ncu = 256;
         ncu_of[dev & 63].store(ncu);
     }
+    static int cu_cap = -1;   // OMDS_SCREEN_CUS: experiment -- persistent workgroups on a subset of the CUs
+    if (cu_cap < 0) { const char* e = getenv("OMDS_SCREEN_CUS"); cu_cap = e ? atoi(e) : 0; }
+    if (cu_cap > 0) ncu = std::min(ncu, cu_cap);
     long long gl = std::min<long long>(ntiles, ncu);
     gl = std::max<long long>(gl, (ntiles + SC_MAX_TILES - 1) / SC_MAX_TILES);
     const dim3 grid((unsigned)gl);
