@@ -7,11 +7,11 @@
 //
 //   k_screen  : the network on all pairs in fp16 (v_mfma_f32_32x32x16_f16, fp32 accumulate) -> approximate min link
 //               distance Da[t][o].
-//   k_select  : per rollout, tau = (k-th smallest Da) + 2 eps; every obstacle with Da <= tau is a CANDIDATE.  If
-//               |Da - D| <= eps for the fp32 value D of every pair, the candidates contain the k smallest D and
-//               everything tied with the k-th (proof in DESIGN.md 4.1b), so the exact top-k over the candidates is the
-//               exact top-k over all obstacles, ties included.  The candidates of a rollout take a contiguous range of a
-//               compact list (range start and length per rollout).
+//   k_select  : per rollout, tau = (k-th smallest Da) + 1.25 eps; every obstacle with Da <= tau is a CANDIDATE.  If the rows
+//               that are NOT candidates have a screening error Da - D <= eps and the exact k-th smallest candidate stays eps
+//               below tau (the slack guard k_tail_sel checks from exact numbers), the exact top-k over the candidates is the
+//               exact top-k over all obstacles, ties included (proof in DESIGN.md 4.1b).  The candidates of a rollout take a
+//               contiguous range of a compact list (range start, length and tau per rollout).
 //   k_exact   : the fp32 pass-1 tile code (pass1_tile, bit-identical arithmetic per row: an MFMA output element is one
 //               k-ordered fmaf chain of its own row) on the listed rows only.  Per entry it leaves the exact D and what
 //               pass 2's forward would compute for the row (same arithmetic): pass-2 distance, arg-min link, ReLU masks --
