@@ -230,6 +230,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
         if (lane == 0 && !(tau - pv >= a.e_bound)) atomicAdd(a.viol, 1u);   // pv = the exact k-th smallest
     }
     __syncthreads();
+    if (a.dbg_stop == 1) return;   // OMDS_TAIL_SEL_STOP: timing experiments
     // ---- the selected entries' masks -> LDS -> 16 bits per thread and layer in the MFMA C layout (what pass 2's forward
     //      would have left in sm.maskL): thread (wave = 32-column block, lane) owns column wave*32 + (lane&31) of rows crow(r, lane)
     for (int i = tid; i < ROWS * nhid * 8; i += P2_NT) {
@@ -254,10 +255,12 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
     }
     __syncthreads();
 
+    if (a.dbg_stop == 2) return;
     // ---- backward on the selected rows; gradients stay in LDS -----------------------------------------
     const float* qT = a.st.trajT + (size_t)(a.st.step - 1) * ND * N;
     pass2_backward<ACT, ROWS>(m, sm, a.xyzr, t_base * k, N * k, qT, N, gx, 0, nullptr, 0, 0);
     __syncthreads();
+    if (a.dbg_stop == 3) return;
 
     // ---- modulation / policy / Euler step: 16 lanes per rollout -------------------------------------
     {
@@ -345,7 +348,10 @@ void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Bpre, con
     a.FqH = reinterpret_cast<_Float16*>(FqH);
     a.ldF = ldF;
     a.t_begin = 0; a.t_end = st.N;
-    a.slot0 = 0; a.n_slots = 0; a.dbg_stop = 0;
+    a.slot0 = 0; a.n_slots = 0;
+    static int stop = -1;
+    if (stop < 0) { const char* e = getenv("OMDS_TAIL_SEL_STOP"); stop = e ? atoi(e) : 0; }
+    a.dbg_stop = stop;
     a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Dmin = nullptr; a.Apre = Apre; a.dscr = nullptr; a.O = O; a.st = st;
     a.rowlist = rowlist; a.range = range; a.ex = ex;
     const bool r16 = tail_sel_rows(st.N, st.k) == 16;
