@@ -35,6 +35,11 @@ WORKLOADS = {
                                  sigma=1.0, ignored=[0, 1, 2]),
     "planar7_1024x32": dict(kind="planar7", N=1024, H=32, dt=0.3, k=1, dst_thr=0.25, ker_thr=1e-3, alpha_s=0.75,
                             sigma=0.5, ignored=[]),
+    # BASELINE configs[2] as BASELINE.json words it: "learned SDF MLP (256-256-256 tanh)", 4096 x 32 on the shelf.  The reference
+    # ships no tanh weights: tests/golden/weights/franka_tanh.npz is its own MLPRegression(act_fn=Tanh) with seeded weights
+    # (tools/make_golden.py) -- throughput does not depend on the values
+    "franka_tanh_4096x32": dict(kind="franka_tanh", N=4096, H=32, dt=0.5, k=5, dst_thr=0.01, ker_thr=0.1, alpha_s=3.0,
+                                sigma=1.0, ignored=[0, 1, 2], act="tanh"),
     # BASELINE configs[4] per GPU: the obstacle set is replaced every iteration (update_obstacles), kernel
     # normals are re-evaluated (update_kernel_normal_bases) and kernel candidates are searched on the device
     "franka_dynamic_1024x32": dict(kind="franka", N=1024, H=32, dt=0.5, k=5, dst_thr=0.01, ker_thr=0.1, alpha_s=3.0,
@@ -52,7 +57,7 @@ def setup(wl, rank):
     nl = len([k for k in z.files if k.startswith("W")])
     W = [z[f"W{i}"] for i in range(nl)]
     b = [z[f"b{i}"] for i in range(nl)]
-    if w["kind"] == "franka":
+    if w["kind"].startswith("franka"):
         obs, q0, qf, dh = scenes.shelf_scene(), scenes.FRANKA_Q0, scenes.FRANKA_QF, scenes.franka_dh_params()
         from optimalmodulationds_amd.cost import FRANKA_Q_MAX, FRANKA_Q_MIN
         qmin, qmax = np.array(FRANKA_Q_MIN, np.float32), np.array(FRANKA_Q_MAX, np.float32)
@@ -128,15 +133,20 @@ def cpu_baseline(w, W, b, obs, q0, qf, dh, qmin, qmax, K, H_full):
     return out
 
 
-def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, dist, torch, time_fetch=False, prof=True):
-    """Times `steps` planner iterations of `workload` on this rank's GPU; returns a dict of raw numbers."""
+def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, dist, torch, time_fetch=False, prof=True, reps=1,
+            screening=-1):
+    """Times `reps` blocks of exactly `steps` planner iterations of `workload` on this rank's GPU (each block bracketed by a
+    barrier + device synchronisation on both sides, elapsed = max over ranks); returns a dict of raw numbers.
+    screening: -1 = the library's default path, 0 = the all-fp32 step (omds_set_screening(0))."""
     from optimalmodulationds_amd.dist import init_native_comm, sharded_update
     from optimalmodulationds_amd.engine import Engine
     w, W, b, obs, q0, qf, dh, qmin, qmax = setup(workload, rank)
     N, H, n, K = w["N"], w["H"], q0.shape[0], args.kernels
     eng = Engine(n, N, H, w["k"], max_obs=max(64, obs.shape[0]), device=local_rank)
-    eng.set_mlp(W, b)
+    eng.set_mlp(W, b, act=w.get("act", "relu"))
     eng.set_obstacles(obs)
+    if screening >= 0:
+        eng.set_screening(screening)
     p = eng.params
     p.dt, p.dst_thr = w["dt"], w["dst_thr"]
     p.ignored_links = sum(1 << l for l in w["ignored"])
@@ -189,17 +199,21 @@ def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, di
     # same iteration time within noise (back-to-back launches run ~0.7 % slower each), so every launch is timed
     eng.prof_enable(1 if prof else 0)
     eng.prof_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for it in range(steps):
-        iteration(warmup + it)
-    eng.lib.omds_sync(eng.h)
-    barrier()
-    el = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([el], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    els = []
+    for rep in range(reps):
+        barrier()
+        t0 = time.perf_counter()
+        for it in range(steps):
+            iteration(warmup + rep * steps + it)
+        eng.lib.omds_sync(eng.h)
+        barrier()
+        el = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        els.append(el)
+    el = float(np.median(els))
     p1_ms, p1_launches, p1_rows = eng.prof_read()
     _, _, p1_flops, p1_kernel = eng.prof_read_ex()
     fetch_ms = None
@@ -212,7 +226,7 @@ def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, di
 
     scr = eng.screen_stats()
     eng.close()
-    return dict(scr=scr, dh=dh, qmin=qmin, qmax=qmax, w=w, W=W, b=b, obs=obs, q0=q0, qf=qf, N=N, H=H, K=K, el=el, p1_ms=p1_ms, p1_launches=p1_launches,
+    return dict(els=els, scr=scr, dh=dh, qmin=qmin, qmax=qmax, w=w, W=W, b=b, obs=obs, q0=q0, qf=qf, N=N, H=H, K=K, el=el, p1_ms=p1_ms, p1_launches=p1_launches,
                 p1_rows=p1_rows, p1_flops=p1_flops, p1_kernel=p1_kernel, fetch_ms=fetch_ms)
 
 
@@ -224,7 +238,8 @@ def main():
     ap.add_argument("--workload", default="franka_shelf_1024x32", choices=sorted(WORKLOADS))
     ap.add_argument("--kernels", type=int, default=10, help="active RBF navigation kernels K")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the short planar7_1024x32 measurement reported under 'also'")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the all-fp32 figure and the other workloads reported under 'also'")
+    ap.add_argument("--reps", type=int, default=10, help="timed blocks of --steps iterations each; value = median block")
     ap.add_argument("--share-gpu", action="store_true",
                     help="test mode for a 1-GPU box: all ranks use GPU 0 and exchange through the host (gloo); never a scaling number")
     ap.add_argument("--time-fetch", action="store_true", help="also report the cost of fetching all rollout tensors to the host")
@@ -249,38 +264,67 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    r = measure(args, args.workload, args.steps, args.warmup, rank, world, local_rank, use_dist, dist, torch, args.time_fetch)
+    r = measure(args, args.workload, args.steps, args.warmup, rank, world, local_rank, use_dist, dist, torch, args.time_fetch,
+                reps=max(1, args.reps))
     w, W, b, obs, q0, qf, N, H, K, el = (r[k] for k in ("w", "W", "b", "obs", "q0", "qf", "N", "H", "K", "el"))
     p1_ms, p1_launches, p1_rows, fetch_ms = r["p1_ms"], r["p1_launches"], r["p1_rows"], r["fetch_ms"]
+
+    def roofline(rr, workload):
+        ach = rr["p1_flops"] / (rr["p1_ms"] * 1e-3) / 1e12 if rr["p1_ms"] > 0 else 0.0
+        pipe, peak = PEAK_OF.get(rr["p1_kernel"], PEAK_OF["k_pass1"])
+        return {"bound": "mfma", "kernel": rr["p1_kernel"], "pipe": pipe, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                "frac": ach / peak, "traffic": pmc_traffic(workload, rr["p1_kernel"]),
+                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, committed; not re-collected by this run)",
+                "launches": int(rr["p1_launches"]), "avg_launch_ms": rr["p1_ms"] / max(rr["p1_launches"], 1),
+                "flops_per_launch": rr["p1_flops"] / max(rr["p1_launches"], 1)}
+
+    def rate(rr, steps):
+        v = [world * rr["N"] * rr["H"] * steps / e for e in rr["els"]]
+        return {"value": float(np.median(v)), "value_min": float(min(v)), "value_max": float(max(v)), "reps": len(v),
+                "ms_per_step": 1e3 * float(np.median(rr["els"])) / steps,
+                "rep_ms_per_step": [round(1e3 * e / steps, 4) for e in rr["els"]]}
+
+    fp32 = None
     also = None
-    if not args.no_secondary and args.workload != "planar7_1024x32":
-        # BASELINE.json configs[1] (planar 7-DoF, 1024 x 32, 8 obstacles): a launch-latency-bound shape, reported beside
-        r2 = measure(args, "planar7_1024x32", 5, 1, rank, world, local_rank, use_dist, dist, torch, prof=False)
-        also = {"workload": "planar7_1024x32", "value": world * r2["N"] * r2["H"] * 5 / r2["el"], "unit": "rollout-steps/s",
-                "ms_per_step": 1e3 * r2["el"] / 5}
+    if not args.no_secondary:
+        # the same iterations with screening off: every pass-1 row in fp32 (k_pass1 + k_tail), the arithmetic of the reference
+        r32 = measure(args, args.workload, args.steps, 1, rank, world, local_rank, use_dist, dist, torch, reps=3, screening=0)
+        fp32 = dict(rate(r32, args.steps), roofline=roofline(r32, args.workload))
+        also = []
+        for wl2, st2, rp2 in (("planar7_1024x32", 10, 5), ("franka_shelf_4096x32", 5, 3), ("franka_dynamic_1024x32", 10, 3),
+                              ("franka_tanh_4096x32", 5, 3)):
+            if wl2 == args.workload:
+                continue
+            r2 = measure(args, wl2, st2, 1, rank, world, local_rank, use_dist, dist, torch, prof=False, reps=rp2)
+            e2 = dict({"workload": wl2, "unit": "rollout-steps/s", "steps": st2}, **rate(r2, st2))
+            e2["screening"] = {k2: r2["scr"][k2] for k2 in ("active", "eps", "candidates_per_rollout_step", "fallbacks", "audit_max_err",
+                                                          "audit_rows_per_rollout_step", "calibrations", "suspended")}
+            also.append(e2)
     if rank == 0:
-        ach = r["p1_flops"] / (p1_ms * 1e-3) / 1e12 if p1_ms > 0 else 0.0
-        pipe, peak = PEAK_OF.get(r["p1_kernel"], PEAK_OF["k_pass1"])
+        act = w.get("act", "relu")
         out = {
-            "metric": "modulated rollout-steps/sec", "value": world * N * H * args.steps / el,
+            "metric": "modulated rollout-steps/sec", **{k2: v2 for k2, v2 in rate(r, args.steps).items() if k2 not in ("ms_per_step", "rep_ms_per_step")},
             "unit": "rollout-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "ms_per_step": rate(r, args.steps)["ms_per_step"], "rep_ms_per_step": rate(r, args.steps)["rep_ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # dtype = what every number the step RETURNS is computed in.  With screening active the N*O first-pass evaluations
+            # that only feed the obstacle selection run in screen_dtype (fp16 inputs, fp32 accumulate); value_fp32_only is the
+            # same run with every row in fp32
+            "dtype": "f32", "screen_dtype": "f16" if r["scr"]["active"] else None, "data": "synthetic",
             "config": {"workload": args.workload, "rollouts_per_gpu": N, "horizon": H, "obstacles": int(obs.shape[0]),
-                       "n_closest": w["k"], "active_kernels": K, "network": "x".join(str(x.shape[1]) for x in W) + f"x{W[-1].shape[0]} relu (shipped reference weights)",
+                       "n_closest": w["k"], "active_kernels": K, "network": "x".join(str(x.shape[1]) for x in W) + f"x{W[-1].shape[0]} {act} "
+                       + ("(shipped reference weights)" if act == "relu" else "(seeded synthetic weights)"),
                        "parallelism": f"rollout-sharded x{world}", "collectives": (("gloo-host (--share-gpu test mode)" if args.share_gpu else "rccl") if use_dist else "none")},
-            "roofline": {"bound": "mfma", "kernel": r["p1_kernel"], "pipe": pipe, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                         "frac": ach / peak, "traffic": pmc_traffic(args.workload, r["p1_kernel"]),
-                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, committed; not re-collected by this run)",
-                         "launches": int(p1_launches), "avg_launch_ms": p1_ms / max(p1_launches, 1),
-                         "flops_per_launch": r["p1_flops"] / max(p1_launches, 1)},
+            "roofline": roofline(r, args.workload),
         }
-        out["screening"] = r["scr"]   # fp16 screening of pass 1 + exact fp32 re-selection; inactive = fp32 pass 1
+        if fp32 is not None:
+            out["value_fp32_only"] = fp32["value"]
+            out["fp32_only"] = fp32
+        out["screening"] = r["scr"]   # fp16 screening of pass 1 + exact fp32 re-selection + audit sample; inactive = fp32 pass 1
         if fetch_ms is not None:
             out["fetch_all_rollouts_ms"] = fetch_ms
         if also is not None:
             out["also"] = also
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and act == "relu":   # oracle/torch_baseline.py restates the shipped (ReLU) path
             out["cpu_baseline"] = cpu_baseline(w, W, b, obs, q0, qf, r["dh"], r["qmin"], r["qmax"], K, H)
         print(json.dumps(out))
     if use_dist:

@@ -121,7 +121,8 @@ OMDS_API int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims
                              const float* const* W, const float* const* b, int act, float out_div,
                              int n_skips, const int32_t* skip_after);
 
-/* MPPI.update_obstacles (MPPI.py:347-350): xyzr is [O,4] spheres (x,y,z,r). */
+/* MPPI.update_obstacles (MPPI.py:347-350): xyzr is [O,4] spheres (x,y,z,r).  n_obs may exceed config.max_obs: the obstacle
+ * buffers then grow (to twice n_obs) inside the context -- handle, network, samples, communicator and screening state stay. */
 OMDS_API int omds_set_obstacles(omds_ctx* ctx, const float* xyzr, int n_obs);
 /* LinDS(q_goal) / MPPI.reset_DS / switch_DS_idx (LinDS.py:7-10, MPPI.py:76-84). */
 OMDS_API int omds_set_ds(omds_ctx* ctx, const float* q_goal);
@@ -250,17 +251,39 @@ OMDS_API int omds_apply_update(int n_kernels, int n_dof, int horizon, const floa
 
 /* Screening of pass 1 (screen_kernel.hip).  The N*O first-pass evaluations of MPPI.distance_repulsion_nn only feed the
  * sort that picks the k closest obstacles (MPPI.py:245-253); omds_propagate may therefore evaluate them in fp16 and
- * re-evaluate in fp32 only the candidates {o : Da(o) <= tau}, tau = k-th smallest Da + 1.25 eps.  They contain the fp32
- * top-k (ties included) whenever the rows that are NOT re-evaluated have a screening error <= eps and the exact k-th
- * smallest candidate stays eps below tau (checked per rollout and step from exact numbers).  eps is calibrated per network
- * (8 x the largest error over a calibration batch) and re-measured on every candidate of every propagate; if it ever loses
- * its 2 x margin over the largest error seen, or a rollout fails the slack check, the propagate is redone
- * in fp32.  The distances and gradients a step uses always come from the fp32 pass 2.  omds_dist_grad always uses the
- * fp32 pass 1.  mode: -1 auto (on for ReLU networks when n_traj * n_obs >= 65536; env OMDS_SCREEN=0|1 overrides),
- * 0 off, 1 on; eps > 0 fixes the bound, eps = 0 (re)calibrates.
- * omds_screen_stats: active, eps in use, largest error seen on candidates, mean candidates per (rollout, step) and
- * fp32 fallbacks since the last omds_prof_reset / creation (NULL = skip).                                           */
+ * re-evaluate in fp32 only the candidates {o : Da(o) <= tau}, tau = k-th smallest Da + 1.25 eps (and every o whose Da is
+ * not finite).  They contain the fp32 top-k (ties included) whenever the pairs that are NOT re-evaluated have a screening
+ * error Da - D <= eps and the exact k-th smallest candidate stays eps below tau.  The distances and gradients a step uses
+ * always come from the fp32 pass 2, and omds_dist_grad always uses the fp32 pass 1.
+ * The identity with the all-fp32 step is therefore CONDITIONAL on eps, and eps is a measured quantity, not an a-priori one.
+ * What is measured, and when:
+ *   - calibration: eps = 6 x the largest |Da - D| over ~3e5 pairs (states uniform in the joint box + states of the last
+ *     propagate's rollouts, against the current obstacles), at the first screened propagate after omds_set_mlp, after
+ *     omds_set_obstacles when the scene differs from the calibrated one (another count or radius, a sphere moved by more
+ *     than 0.1), after a change of params.ignored_links, and on request (eps < 0 below);
+ *   - every step of every propagate: |Da - D| of every candidate; Da - D of the AUDIT rows, a pseudo-random 1-in-`one_in`
+ *     sample (another one every step) of the pairs that are not candidates, re-evaluated in fp32 by one launch at the end
+ *     of the horizon loop (k_audit); the slack of every rollout (tau - exact k-th smallest >= eps).
+ * A propagate is accepted only while both maxima stay <= eps / 2 and no slack check failed; otherwise it is redone with the
+ * fp32 pass 1 (its results are then the fp32 ones by construction) and eps is widened; three fallbacks in a row suspend
+ * screening until the next calibration.  A row outside the audit sample whose error exceeds eps can still go unseen in
+ * one propagate: the identity is measured on a sample, not proven.
+ * mode: -1 auto (on for ReLU / tanh networks, with or without skip concatenations, when n_traj * n_obs >= 65536; env
+ * OMDS_SCREEN=0|1 overrides), 0 off, 1 on.  eps > 0 sets the bound in place of a calibration (never recalibrated; the run-time checks
+ * still widen it when they must); eps == 0 changes the mode only; eps < 0 discards the calibration (measured again at the next screened propagate).
+ * omds_set_screening_audit: one_in = 0 (no audit sample) or a power of two; default 128 (DESIGN.md 4.1b has the measured cost per rate).
+ * omds_screen_stats: active, eps in use, largest candidate error seen since the last calibration, mean candidates per
+ * (rollout, step) since the last omds_prof_reset, fp32 fallbacks since creation (NULL = skip).
+ * omds_screen_audit_stats: one_in, mean audit rows per (rollout, step) since the last omds_prof_reset, largest audit error
+ * seen since the last calibration, suspended flag, calibrations run since creation.                                   */
 OMDS_API int omds_set_screening(omds_ctx* ctx, int mode, float eps);
+OMDS_API int omds_set_screening_audit(omds_ctx* ctx, int one_in);
+OMDS_API int omds_screen_audit_stats(omds_ctx* ctx, int32_t* one_in, double* audit_rows_per_rollout_step, float* audit_max_err,
+                                     int32_t* suspended, int64_t* calibrations);
+/* Test hook: damages what the screening network sees so that the run-time checks have something to catch.  what = 0: zeroes
+ * fragment `index` (1 KiB) of the fp16 weight pack; what = 1: shifts obstacle `index` by `value` along x in the screening
+ * kernel's input table only (until the next omds_set_obstacles).  The fp32 kernels are never touched.                  */
+OMDS_API int omds_screen_debug_corrupt(omds_ctx* ctx, int what, int index, float value);
 /* Diagnostic: the fp16 screening network alone on q [B,n] -> mindist [B,O] (the values the candidate selection sees). */
 OMDS_API int omds_screen_mindist(omds_ctx* ctx, const float* q, int batch, float* mindist);
 OMDS_API int omds_screen_stats(omds_ctx* ctx, int32_t* active, float* eps, float* max_err_seen,

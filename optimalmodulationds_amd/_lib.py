@@ -87,6 +87,9 @@ SIGNATURES = {
     "omds_weighted_update_sharded": (C.c_int, [C.c_void_p, C.c_float, C.c_float, F32P, F32P, F32P, I32P, F32P, F32P,
                                                F32P]),
     "omds_set_screening": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),
+    "omds_set_screening_audit": (C.c_int, [C.c_void_p, C.c_int]),
+    "omds_screen_audit_stats": (C.c_int, [C.c_void_p, I32P, C.POINTER(C.c_double), F32P, I32P, C.POINTER(C.c_int64)]),
+    "omds_screen_debug_corrupt": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float]),
     "omds_screen_mindist": (C.c_int, [C.c_void_p, F32P, C.c_int, F32P]),
     "omds_screen_stats": (C.c_int, [C.c_void_p, I32P, F32P, F32P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "omds_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
@@ -97,6 +100,7 @@ SIGNATURES = {
     "omds_sync": (C.c_int, [C.c_void_p]),
 }
 
+ABI_VERSION = 300      # omds_version() of the library this binding was written against
 _lib = None
 
 
@@ -131,6 +135,14 @@ def load():
         raise OmdsError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         f"or `make -C optimalmodulationds_amd/csrc` (there is no CPU fallback)")
     lib = C.CDLL(LIB_PATH)
+    try:
+        lib.omds_version.restype = C.c_int
+        have = int(lib.omds_version())
+    except AttributeError:
+        have = -1
+    if have != ABI_VERSION:     # a stale build of an older checkout: say so instead of failing on a missing symbol
+        raise OmdsError(f"{LIB_PATH} is ABI version {have}, this package needs {ABI_VERSION}: rebuild it with "
+                        f"`make -C optimalmodulationds_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`)")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError = header/library mismatch
         fn.restype = res

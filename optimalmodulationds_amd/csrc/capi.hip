@@ -84,7 +84,7 @@ static uint16_t f32_to_f16_bits(float f) {
 
 extern "C" {
 
-int omds_version(void) { return 200; }
+int omds_version(void) { return 300; }
 
 void omds_default_params(omds_params* p) {
     if (!p) return;
@@ -117,7 +117,7 @@ static void free_all(omds_ctx* ctx) {
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
                     ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
                     ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
-                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP, ctx->d_seds};
+                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP, ctx->d_seds, ctx->d_audit_rows, ctx->d_audit_da, ctx->d_ApreAll, ctx->d_featQAll};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : ctx->mlp_allocs)
@@ -153,6 +153,10 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
     ctx->cfg = *cfg;
     ctx->dev = cfg->device;
     omds_default_params(&ctx->prm);
+    if (const char* e = getenv("OMDS_SCREEN_AUDIT")) {   // measurement runs: the audit rate of new contexts (omds_set_screening_audit)
+        const int v = atoi(e);
+        if (v >= 0 && v <= (1 << 20) && (v & (v - 1)) == 0) ctx->audit_one_in = v;
+    }
     auto fail = [&](const std::string& m, int code) {
         g_create_err = m;
         free_all(ctx);
@@ -200,8 +204,8 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
     CKC(hipMalloc(&ctx->d_exDr, (size_t)ctx->ex_cap * 4));
     CKC(hipMalloc(&ctx->d_exMin, (size_t)ctx->ex_cap * 4));
     CKC(hipMalloc(&ctx->d_exMask, (size_t)ctx->ex_cap * (OMDS_MAX_HIDDEN + 1) * 8 * 4));
-    CKC(hipMalloc(&ctx->d_sctotal, (H + 1) * 4));
-    CKC(hipMalloc(&ctx->d_scerr, 8));
+    CKC(hipMalloc(&ctx->d_sctotal, (H + 2) * 4));
+    CKC(hipMalloc(&ctx->d_scerr, 16));
     CKC(hipMalloc(&ctx->d_idx, rows2 * 4));
     CKC(hipMalloc(&ctx->d_gradx, rows2 * d * 4));
     CKC(hipMalloc(&ctx->d_drow, rows2 * 4));
@@ -211,7 +215,7 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
     CKC(hipMalloc(&ctx->d_nngrad, N * n * 4));
     CKC(hipMalloc(&ctx->d_cost, N * 4));
     CKC(hipMalloc(&ctx->d_w, N * 4));
-    const size_t redn = std::max<size_t>((size_t)omds_red_size((int)Km, (int)n) + 8, H + 8);   // also the screening counters of a propagate (2 + H)
+    const size_t redn = std::max<size_t>((size_t)omds_red_size((int)Km, (int)n) + 8, 2 * H + 16);   // also the screening counters of a propagate (4 + 2 (H + 1))
     CKC(hipMalloc(&ctx->d_red, redn * 4));
     CKC(hipHostMalloc(&ctx->h_red, redn * 4));
     ctx->stage_bytes = std::max({N * H * std::max(Km, n) * 4, N * Om * 4, Km * n * N * 4, rows2 * OMDS_CPAD * 4});
@@ -419,7 +423,9 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
     CK(hipMemsetAsync(ctx->d_FqH, 0, (size_t)ctx->cfg.n_traj * 32 * 2, ctx->stream));
     ctx->screen_ok = false;
     ctx->screen_cal = false;
-    ctx->screen_eps = 0.f;
+    if (!ctx->screen_eps_fixed) ctx->screen_eps = 0.f;
+    ctx->screen_suspended = false;
+    ctx->screen_consec = 0;
     std::vector<uint16_t> wh;
     std::vector<float> sbias;
     if (act == OMDS_ACT_RELU && m.nhh >= 1 && m.nhh <= 4 && !skip_mask) {   // skip-connection networks run the fp32 step
@@ -498,14 +504,83 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
     return OMDS_OK;
 }
 
+// The obstacle buffers grow on demand (MPPI.update_obstacles takes any obstacle count at any time, MPPI.py:347-350): everything
+// sized by max_obs is re-allocated at twice the new count; the handle, the network, the policy samples, the communicator and
+// the screening state survive.  Nothing of their old contents is needed: the caller is about to replace the scene.
+static int grow_obstacle_capacity(omds_ctx* ctx, int n_obs) {
+    const size_t N = ctx->cfg.n_traj, k = ctx->cfg.n_closest, H = ctx->cfg.horizon, n = ctx->cfg.n_dof, Km = ctx->cfg.n_kernel_max;
+    const size_t Om = (size_t)std::max(2 * n_obs, 64), rows2 = N * k;
+    REQUIRE((long long)N * (long long)Om < (1LL << 31), OMDS_ERR_INVALID_ARG,
+            "omds_set_obstacles: n_traj * (grown obstacle capacity) must stay below 2^31");
+    CK(hipStreamSynchronize(ctx->stream));
+    void** olds[] = {(void**)&ctx->d_obs, (void**)&ctx->d_Bpre, (void**)&ctx->d_radius, (void**)&ctx->d_FpH, (void**)&ctx->d_Dmin,
+                     (void**)&ctx->d_rowlist, (void**)&ctx->d_featP};
+    const bool had_featP = ctx->d_featP != nullptr;
+    for (void** o : olds) { if (*o) (void)hipFree(*o); *o = nullptr; }
+    CK(hipMalloc(&ctx->d_obs, Om * 4 * 4));
+    CK(hipMalloc(&ctx->d_Bpre, std::max(Om, rows2) * OMDS_WIDTH * 4));
+    CK(hipMalloc(&ctx->d_radius, std::max(Om, rows2) * 4));
+    CK(hipMalloc(&ctx->d_FpH, Om * 32 * 2));
+    CK(hipMemsetAsync(ctx->d_FpH, 0, Om * 32 * 2, ctx->stream));
+    CK(hipMalloc(&ctx->d_Dmin, N * Om * 4));
+    CK(hipMalloc(&ctx->d_rowlist, N * Om * 4));
+    if (had_featP) {
+        CK(hipMalloc(&ctx->d_featP, Om * 32 * 4));
+        CK(hipMemsetAsync(ctx->d_featP, 0, Om * 32 * 4, ctx->stream));
+        ctx->mlp.featP = ctx->d_featP;
+    }
+    const size_t stage = std::max({N * H * std::max(Km, n) * 4, N * Om * 4, Km * n * N * 4, rows2 * OMDS_CPAD * 4});
+    if (stage > ctx->stage_bytes) {
+        (void)hipFree(ctx->d_stage);
+        ctx->d_stage = nullptr;
+        CK(hipMalloc(&ctx->d_stage, stage));
+        ctx->stage_bytes = stage;
+    }
+    const int ex_cap = (int)std::min<size_t>(N * Om, N * 32);
+    if (ex_cap > ctx->ex_cap) {
+        for (void** o : {(void**)&ctx->d_exD, (void**)&ctx->d_exDr, (void**)&ctx->d_exMin, (void**)&ctx->d_exMask}) { if (*o) (void)hipFree(*o); *o = nullptr; }
+        ctx->ex_cap = ex_cap;
+        CK(hipMalloc(&ctx->d_exD, (size_t)ex_cap * 4));
+        CK(hipMalloc(&ctx->d_exDr, (size_t)ex_cap * 4));
+        CK(hipMalloc(&ctx->d_exMin, (size_t)ex_cap * 4));
+        CK(hipMalloc(&ctx->d_exMask, (size_t)ex_cap * (OMDS_MAX_HIDDEN + 1) * 8 * 4));
+    }
+    ctx->cfg.max_obs = (int)Om;
+    ctx->n_obs = 0;
+    return OMDS_OK;
+}
+
+// Has the scene changed enough since the screening bound was calibrated that the calibration batch no longer stands for it?
+// Another obstacle count, another radius, or any sphere more than 0.1 (scene units: metres for the Franka scenes) away from
+// where it was: a translating / vibrating scene (obstacleStreamer.py:125-137) keeps its bound, a swapped scene does not.
+// (Every step of every propagate additionally audits a sample of the unevaluated pairs, omds.h.)
+static bool scene_differs_from_calibration(const omds_ctx* ctx, const float* xyzr, int n_obs) {
+    if (ctx->obs_cal.size() != (size_t)n_obs * 4) return true;
+    for (int i = 0; i < n_obs; ++i) {
+        const float* a = &ctx->obs_cal[(size_t)i * 4];
+        const float* b = xyzr + (size_t)i * 4;
+        for (int c = 0; c < 3; ++c)
+            if (!(std::fabs(a[c] - b[c]) <= 0.1f)) return true;
+        if (!(std::fabs(a[3] - b[3]) <= 1e-6f)) return true;
+    }
+    return false;
+}
+
 int omds_set_obstacles(omds_ctx* ctx, const float* xyzr, int n_obs) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    REQUIRE(xyzr && n_obs >= 1 && n_obs <= ctx->cfg.max_obs, OMDS_ERR_INVALID_ARG,
-            "omds_set_obstacles: need 1 <= n_obs <= max_obs and a non-null [O,4] array");
+    REQUIRE(xyzr && n_obs >= 1, OMDS_ERR_INVALID_ARG, "omds_set_obstacles: need n_obs >= 1 and a non-null [O,4] array");
     REQUIRE(n_obs >= ctx->cfg.n_closest, OMDS_ERR_INVALID_ARG, "omds_set_obstacles: fewer obstacles than n_closest");
     CK(hipSetDevice(ctx->dev));
+    int rc;
+    if (n_obs > ctx->cfg.max_obs && (rc = grow_obstacle_capacity(ctx, n_obs))) return rc;
     CK(hipMemcpyAsync(ctx->d_obs, xyzr, (size_t)n_obs * 16, hipMemcpyHostToDevice, ctx->stream));
     ctx->n_obs = n_obs;
+    if (ctx->screen_cal && !ctx->screen_eps_fixed && scene_differs_from_calibration(ctx, xyzr, n_obs)) {
+        ctx->screen_cal = false;        // calibrate again at the next screened propagate, against THIS scene
+        ctx->screen_suspended = false;
+        ctx->screen_consec = 0;
+    }
+    ctx->obs_now.assign(xyzr, xyzr + (size_t)n_obs * 4);
     if (ctx->have_mlp) {
         omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, n_obs, ctx->d_Bpre, ctx->d_radius, ctx->d_FpH, ctx->cfg.max_obs, ctx->mlp.featP);
         CK(hipGetLastError());
@@ -573,6 +648,11 @@ int omds_set_params(omds_ctx* ctx, const omds_params* p) {
     REQUIRE(p->rbf_p > 0.f, OMDS_ERR_INVALID_ARG, "omds_set_params: rbf_p must be positive");
     REQUIRE((p->cost_terms & ~OMDS_COST_ALL) == 0 && (p->variant & ~3u) == 0, OMDS_ERR_INVALID_ARG,
             "omds_set_params: unknown bits in cost_terms / variant");
+    if (p->ignored_links != ctx->prm.ignored_links && !ctx->screen_eps_fixed) {   // another set of links enters the pass-1 minimum
+        ctx->screen_cal = false;
+        ctx->screen_suspended = false;
+        ctx->screen_consec = 0;
+    }
     ctx->prm = *p;
     return OMDS_OK;
 }
@@ -731,7 +811,7 @@ static int check_ready(omds_ctx* ctx, bool need_ds) {
 
 // ---- screening (screen_kernel.hip): mode, calibration of eps, the per-step launch sequences ---------------------------------
 static bool screen_wanted(omds_ctx* ctx) {
-    if (!ctx->screen_ok) return false;
+    if (!ctx->screen_ok || ctx->screen_suspended) return false;
     int mode = ctx->screen_mode;
     if (mode < 0) {
         static int env = -2;
@@ -745,55 +825,49 @@ static bool screen_wanted(omds_ctx* ctx) {
     return (long long)ctx->cfg.n_traj * ctx->n_obs >= 64LL * 1024 && ctx->n_obs >= 4 * ctx->cfg.n_closest;
 }
 
-// eps = 8 x the largest |screening value - fp32 value| over a calibration batch of up to 1024 states x all obstacles
-// (~3e5 pairs: about what one propagate evaluates per step): half of them uniform inside the joint limits (omds_set_cost) or
-// [-pi, pi], half scattered around the current start state (sigma 0.6 rad, where rollouts live), against the current
-// obstacle set.  Once per omds_set_mlp; the candidates of every later propagate re-measure the error (d_scerr) and trip the
-// fp32 fallback when the margin shrinks below 2x (eps is then set to 4 x the error seen).
+// eps = 6 x the largest |screening value - fp32 value| over a calibration batch of up to 1024 states x all obstacles
+// (~3e5 pairs: about what one propagate evaluates per step), against the CURRENT obstacle set: half of the states uniform
+// inside the joint limits (omds_set_cost) or [-pi, pi], half drawn from the rollouts of the last propagate -- where the next
+// rollouts will live -- or, before the first propagate, scattered around the start state (sigma 0.6 rad).  Everything runs on
+// the device (k_calib_states -> layer 1 -> k_pass1 and k_screen -> k_max_abs_diff); four bytes come back.  Run at the first
+// screened propagate after omds_set_mlp, after omds_set_obstacles with a changed scene (scene_differs_from_calibration), after
+// a change of ignored_links and on request (omds_set_screening(mode, eps < 0)).  Between calibrations every propagate
+// re-measures the error on its candidates and on the audit sample of the unevaluated pairs (omds_propagate).
 static int calibrate_screen(omds_ctx* ctx, const float* q_center) {
     ctx->screen_cal = true;
-    if (ctx->screen_eps > 0.f) return OMDS_OK;   // set by the caller (omds_set_screening)
+    ctx->obs_cal = ctx->obs_now;
+    if (ctx->screen_eps_fixed && ctx->screen_eps > 0.f) return OMDS_OK;   // set by the caller (omds_set_screening)
     const int n = ctx->cfg.n_dof, O = ctx->n_obs;
     const int B = std::min(ctx->cfg.n_traj, 1024);
-    std::vector<float> q((size_t)n * B);          // [n][B]
-    uint64_t st = 0x9E3779B97F4A7C15ull;
-    auto uni = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (float)(((st >> 40) + 0.5) * (1.0 / 16777216.0)); };
+    float lo[OMDS_MAX_DOF], hi[OMDS_MAX_DOF];
     for (int j = 0; j < n; ++j) {
-        const float lo = ctx->have_cost ? ctx->qmin[j] : -3.14159265f, hi = ctx->have_cost ? ctx->qmax[j] : 3.14159265f;
-        for (int t = 0; t < B; ++t) {
-            float v;
-            if (t & 1) {
-                const float g = std::sqrt(-2.f * std::log(uni())) * std::cos(6.2831853f * uni());   // Box-Muller
-                v = std::min(hi, std::max(lo, q_center[j] + 0.6f * g));
-            } else {
-                v = lo + (hi - lo) * uni();
-            }
-            q[(size_t)j * B + t] = v;
-        }
+        lo[j] = ctx->have_cost ? ctx->qmin[j] : -3.14159265f;
+        hi[j] = ctx->have_cost ? ctx->qmax[j] : 3.14159265f;
     }
-    CK(hipMemcpyAsync(ctx->d_qstage, q.data(), q.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    omds_launch_calib_states(ctx->stream, ctx->d_qstage, B, n, lo, hi, q_center, ctx->have_rollouts ? ctx->d_trajT : nullptr,
+                             ctx->cfg.n_traj, ctx->cfg.horizon, 0x9E3779B9u * (unsigned)(ctx->screen_recals + 1));
     omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Apre, ctx->d_FqH, ctx->cfg.n_traj);
-    std::vector<float> ref((size_t)B * O), apx((size_t)B * O);
+    float* apx = ctx->d_stage;   // [B][O] screening values (stage_bytes >= n_traj * max_obs * 4)
     omds_launch_pass1(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
-    CK(hipMemcpyAsync(ref.data(), ctx->d_Dmin, ref.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
-    omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_FqH, ctx->cfg.n_traj, ctx->d_FpH, ctx->cfg.max_obs, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
+    omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_FqH, ctx->cfg.n_traj, ctx->d_FpH, ctx->cfg.max_obs, ctx->d_radius, O, B, ctx->prm.ignored_links, apx);
+    CK(hipMemsetAsync(ctx->d_scerr + 3, 0, 4, ctx->stream));
+    omds_launch_max_abs_diff(ctx->stream, ctx->d_Dmin, apx, (long long)B * O, ctx->d_scerr + 3);
     CK(hipGetLastError());
-    CK(hipMemcpyAsync(apx.data(), ctx->d_Dmin, apx.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
     float worst = 0.f;
-    bool finite = true;
-    for (size_t i = 0; i < ref.size(); ++i) {
-        const float e = std::fabs(apx[i] - ref[i]);
-        if (!(e < 3.0e38f)) { finite = false; break; }
-        worst = std::max(worst, e);
-    }
+    CK(hipMemcpyAsync(&worst, ctx->d_scerr + 3, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    ctx->screen_recals++;
+    ctx->screen_err_seen = 0.f;
+    ctx->screen_audit_err_seen = 0.f;
+    const bool finite = worst < 3.0e38f;
     if (!finite && getenv("OMDS_SCREEN_NOGUARD")) { ctx->screen_eps = 1e-3f; return OMDS_OK; }   // timing experiments only
-    if (!finite) { ctx->screen_ok = false; return OMDS_OK; }   // fp16 range exceeded: this network stays on the fp32 path
-    // the largest error over the ~10^6 pairs a propagate evaluates per iteration was seen at up to 2x the calibration batch's
-    // (3.8e-3 vs 1.9e-3 on the shelf scene), and the number of candidates hardly depends on eps in this range (7.3 per
-    // rollout and step at eps = 8.7e-3, 7.6 at 1.5e-2): 8x leaves the run-time guard (fallback above eps / 2) a 2x margin
-    ctx->screen_eps = std::max(8.f * worst, 1e-12f);
+    if (!finite) { ctx->screen_suspended = true; ctx->screen_eps = 0.f; return OMDS_OK; }   // fp16 range exceeded on this scene: the fp32 step until the next calibration
+    // The largest error over the ~10^7 pairs of a propagate was seen at up to 2x the calibration batch's maximum (3.8e-3 vs
+    // 1.8e-3 .. 2.3e-3 on the shelf scene, depending on the batch drawn): 6x leaves the run-time guard (fallback above
+    // eps / 2) room for a 3x larger error, and the accepted propagates then keep eps at >= 4x the largest error they saw --
+    // on the shelf both routes end at 1.5e-2.  (8x of an unlucky batch, 1.9e-2, costs 1.2 candidates per rollout and step,
+    // which at N = 1024 pushes k_exact past two tiles per CU: 4.8 M against 5.2 M rollout-steps/s.)
+    ctx->screen_eps = std::max(6.f * worst, 1e-12f);
     return OMDS_OK;
 }
 
@@ -809,6 +883,35 @@ static bool small_step_wanted(omds_ctx* ctx) {
     if (env == 0) return false;
     if (env > 0) return true;
     return (ctx->cfg.n_traj + R - 1) / R <= 768;
+}
+
+// Buffers of the audit sample (allocated at the first screened propagate, grown when the scene or the rate asks for more):
+// the list itself -- about N*H*O / one_in entries, room for twice that -- and the layer-1 table of all horizon steps.
+static int prepare_audit(omds_ctx* ctx, AuditSink& au) {
+    au = AuditSink{};
+    const long long N = ctx->cfg.n_traj, H = ctx->cfg.horizon, O = ctx->n_obs;
+    if (ctx->audit_one_in <= 0 || N * H * O >= (1LL << 31)) return OMDS_OK;   // no audit (or a row space beyond 32-bit indices)
+    const long long want = N * H * (2 * O / ctx->audit_one_in + 4);
+    if (want > ctx->audit_cap) {
+        CK(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_audit_rows) (void)hipFree(ctx->d_audit_rows);
+        if (ctx->d_audit_da) (void)hipFree(ctx->d_audit_da);
+        ctx->d_audit_rows = nullptr; ctx->d_audit_da = nullptr; ctx->audit_cap = 0;
+        CK(hipMalloc(&ctx->d_audit_rows, (size_t)want * 4));
+        CK(hipMalloc(&ctx->d_audit_da, (size_t)want * 4));
+        ctx->audit_cap = (int)std::min<long long>(want, 0x7fffffff);
+    }
+    if (!ctx->d_ApreAll) CK(hipMalloc(&ctx->d_ApreAll, (size_t)N * H * OMDS_WIDTH * 4));
+    if (ctx->mlp.featQ && !ctx->d_featQAll) {
+        CK(hipMalloc(&ctx->d_featQAll, (size_t)N * H * 32 * 4));
+        CK(hipMemsetAsync(ctx->d_featQAll, 0, (size_t)N * H * 32 * 4, ctx->stream));
+    }
+    au.rows = ctx->d_audit_rows;
+    au.da = ctx->d_audit_da;
+    au.total = ctx->d_sctotal + (H + 1);
+    au.cap = ctx->audit_cap;
+    au.mask = (unsigned)ctx->audit_one_in - 1u;
+    return OMDS_OK;
 }
 
 static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) {
@@ -834,11 +937,19 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
         // planar7_1024x32 ran 9.0 M rollout-steps/s on one stream, 7.1 / 3.3 / 2.4 M on 2 / 4 / 8 -- and a two-half
         // ping-pong for large batches with event-chained pass-1 launches so that one half's tail runs under the
         // other half's pass 1: parity-green, but the half-size launches drain twice per step, 1.00 M vs 1.03 M.)
-        omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, ctx->d_Apre, screen ? ctx->d_FqH : nullptr, N);
+        // With an audit sample the rollout halves of layer 1 of ALL horizon steps are kept ([H][N][256]: step i reads slab
+        // i - 1, its tail writes slab i) so that k_audit can re-evaluate pairs of any step at the end; otherwise one slab
+        // is updated in place
+        float* apre0 = ctx->d_Apre;
+        size_t apre_slab = 0;
+        AuditSink au{};
         if (screen) {
-            CK(hipMemsetAsync(ctx->d_sctotal, 0, (size_t)(H + 1) * 4, ctx->stream));
-            CK(hipMemsetAsync(ctx->d_scerr, 0, 8, ctx->stream));
+            CK(hipMemsetAsync(ctx->d_sctotal, 0, (size_t)(H + 2) * 4, ctx->stream));
+            CK(hipMemsetAsync(ctx->d_scerr, 0, 16, ctx->stream));
+            if ((rc = prepare_audit(ctx, au))) return rc;
+            if (au.rows) { apre0 = ctx->d_ApreAll; apre_slab = (size_t)N * OMDS_WIDTH; }
         }
+        omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, apre0, screen ? ctx->d_FqH : nullptr, N);
         for (int i = 1; i <= H; ++i) {
             {
                 RoctxRange r1("TAG: evaluate NN_2 (forward pass)");
@@ -847,9 +958,11 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
                     omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_FqH, ctx->cfg.n_traj, ctx->d_FpH, ctx->cfg.max_obs, ctx->d_radius, ctx->n_obs, N,
                                        ctx->prm.ignored_links, ctx->d_Dmin);
                     if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs, -1.0, "k_screen"))) return rc;
+                    au.seed = 0x9E3779B9u * ++ctx->audit_counter;
+                    au.step_row0 = (i - 1) * N;
                     omds_launch_select(ctx->stream, ctx->d_Dmin, N, ctx->n_obs, a.k, OMDS_SCREEN_WINDOW * ctx->screen_eps, ctx->d_rowlist, ctx->d_range,
-                                       ctx->d_sctotal + (i - 1));
-                    omds_launch_exact(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
+                                       ctx->d_sctotal + (i - 1), au);
+                    omds_launch_exact(ctx->stream, ctx->mlp, apre0 + (size_t)(i - 1) * apre_slab, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
                                       ctx->prm.ignored_links, ctx->d_Dmin, ctx->d_rowlist, ctx->d_sctotal + (i - 1), ctx->d_scerr, ex);
                 } else {
                     omds_launch_pass1(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
@@ -860,11 +973,24 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
             RoctxRange r2("TAG: evaluate NN_3-5 + Modulation-propagation");
             a.step = i;
             if (screen)
-                omds_launch_tail_sel(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Apre, ctx->n_obs, a,
+                omds_launch_tail_sel(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, apre0 + (size_t)std::min(i, H - 1) * apre_slab, ctx->n_obs, a,
                                      ctx->d_rowlist, ctx->d_range, ex, ctx->d_FqH, N, ctx->screen_eps, ctx->d_scerr + 1);
             else
                 omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, ctx->d_Apre,
                                  ctx->d_dscr, ctx->n_obs, a, 0, N);
+        }
+        if (screen && au.rows) {
+            // The audit sample of this propagate in one throughput-shaped launch: k_audit on the recorded pairs against the
+            // kept layer-1 slabs of all horizon steps -> d_scerr[2] = max (Da - D)
+            RoctxRange r3("screening audit sample (fp32 re-evaluation of unevaluated pairs)");
+            MlpDev ma = ctx->mlp;
+            if (ma.featQ) {   // skip-connection networks: the encoded joint inputs of every step's states, rebuilt from the stored
+                              // rollouts (trajT [H][n][N] as H slabs; the same kernel, so ApreAll is rewritten with the same bits)
+                ma.featQ = ctx->d_featQAll;
+                omds_launch_rollout_layer1(ctx->stream, ma, ctx->d_trajT, N, H * N, ctx->d_ApreAll, nullptr, 0, N);
+            }
+            omds_launch_audit(ctx->stream, ma, ctx->d_ApreAll, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, ctx->prm.ignored_links,
+                              ctx->d_audit_rows, ctx->d_audit_da, ctx->d_sctotal + (H + 1), ctx->audit_cap, ctx->d_scerr);
         }
     } else {
         for (int i = 1; i <= H; ++i) {   // MPPI.py:101: H network evaluations, the last velocity is not integrated
@@ -909,38 +1035,52 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
     const bool tail = fused && !(ctx->cfg.flags & OMDS_FLAG_UNFUSED_STEP) && omds_tail_supported(n, a.k) && ctx->seds_G == 0;
     bool screen = tail && screen_wanted(ctx);
     if (screen && !ctx->screen_cal && (rc = calibrate_screen(ctx, q_cur))) return rc;
-    screen = screen && ctx->screen_ok && ctx->screen_eps > 0.f;
+    screen = screen && ctx->screen_ok && !ctx->screen_suspended && ctx->screen_eps > 0.f;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if ((rc = enqueue_rollouts(ctx, a, tail, screen))) return rc;
         CK(hipGetLastError());
         ctx->have_cost_vals = false;
         if (screen) {
-            CK(hipMemcpyAsync(ctx->h_red, ctx->d_scerr, 8, hipMemcpyDeviceToHost, ctx->stream));
-            CK(hipMemcpyAsync(ctx->h_red + 2, ctx->d_sctotal, (size_t)H * 4, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipMemcpyAsync(ctx->h_red, ctx->d_scerr, 16, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipMemcpyAsync(ctx->h_red + 4, ctx->d_sctotal, (size_t)(H + 2) * 4, hipMemcpyDeviceToHost, ctx->stream));
         }
         CK(hipStreamSynchronize(ctx->stream));
+        ctx->have_rollouts = true;
         if (!screen) break;
-        const float err = ctx->h_red[0];   // max |screening - fp32| over every candidate pair of this propagate
+        // What this propagate MEASURED about the screening values it relied on:
+        //   err   = max |Da - D| over every candidate pair (the rows nearest the decision threshold, all re-evaluated);
+        //   aerr  = max (Da - D) over the audit sample, a uniform pseudo-random 1 in audit_one_in (another one every step) of
+        //           the pairs that were NOT re-evaluated -- the population the selection rule's assumption is about --
+        //           evaluated in fp32 by k_audit at the end of the horizon loop;
+        //   slack = rollouts whose exact k-th smallest candidate came within eps of tau.
+        // Accepted only while both errors keep a 2x margin to eps and no slack check failed; otherwise redone in fp32.
+        const float err = ctx->h_red[0], aerr = ctx->h_red[2];
         if (err > ctx->screen_err_seen || err != err) ctx->screen_err_seen = err;
-        const int32_t* tot = reinterpret_cast<const int32_t*>(ctx->h_red + 2);
-        const uint32_t slack_viol = reinterpret_cast<const uint32_t*>(ctx->h_red)[1];   // rollouts whose exact k-th smallest came within eps of tau
-        bool overflow = false;   // a step listed more candidates than k_exact's per-entry outputs hold: redo in fp32
+        if (aerr > ctx->screen_audit_err_seen || aerr != aerr) ctx->screen_audit_err_seen = aerr;
+        const int32_t* tot = reinterpret_cast<const int32_t*>(ctx->h_red + 4);
+        const uint32_t slack_viol = reinterpret_cast<const uint32_t*>(ctx->h_red)[1];
+        bool overflow = false;   // a step listed more rows than k_exact's per-entry outputs hold: redo in fp32
         for (int i = 0; i < H; ++i) { ctx->screen_rows += tot[i]; overflow = overflow || tot[i] > ctx->ex_cap; }
+        ctx->screen_audit_rows += std::min<double>(tot[H + 1], ctx->audit_cap);   // entries k_audit evaluated
         ctx->screen_steps += (double)N * H;
-        if (overflow) { ctx->screen_fallbacks++; screen = false; continue; }
         static int noguard = -1;   // OMDS_SCREEN_NOGUARD=1: timing experiments with deliberately broken screening kernels only
         if (noguard < 0) { const char* e = getenv("OMDS_SCREEN_NOGUARD"); noguard = e ? atoi(e) : 0; }
-        if ((err <= 0.5f * ctx->screen_eps && slack_viol == 0) || noguard) {
-            // accepted (the bound kept a 2x margin over everything seen).  Keep it at >= 4x the largest error seen so far, so
-            // that states drifting into regions where the fp16 network is less accurate widen the bound gradually instead
-            // of tripping the fallback
-            if (!noguard && 4.f * err > ctx->screen_eps) ctx->screen_eps = 4.f * err;
+        const float worst = (err != err || aerr != aerr) ? __builtin_inff() : std::max(err, aerr);
+        if ((!overflow && worst <= 0.5f * ctx->screen_eps && slack_viol == 0) || noguard) {
+            // accepted.  Keep the bound at >= 4x the largest error seen, so that states drifting into regions where the fp16
+            // network is less accurate widen it gradually instead of tripping the fallback
+            if (!noguard && 4.f * worst > ctx->screen_eps) ctx->screen_eps = 4.f * worst;
+            ctx->screen_consec = 0;
             break;
         }
-        // the calibrated bound lost its 2x margin on live data: this propagate is redone in fp32 and the bound is widened
-        // (or screening is switched off when the error is not even finite -- an fp16 overflow inside the network)
+        // the bound lost its margin on live data (or the list outgrew its buffers): this propagate is redone in fp32 -- its
+        // results are the fp32 ones by construction -- and the bound is widened.  Three in a row: the screening network is
+        // not usable on this scene (out of its fp16 range, a scene far from the calibration batch, corrupted weights); the
+        // context stays on the fp32 step until the next calibration (omds_set_obstacles with a changed scene, omds_set_mlp,
+        // omds_set_screening(mode, eps < 0))
         ctx->screen_fallbacks++;
-        if (err == err && err < 3.0e38f) ctx->screen_eps = std::max(ctx->screen_eps, 4.f * err); else ctx->screen_ok = false;
+        if (!overflow && worst < 3.0e38f) ctx->screen_eps = std::max(ctx->screen_eps, 4.f * worst);
+        if (++ctx->screen_consec >= 3 || !(worst < 3.0e38f)) ctx->screen_suspended = true;
         screen = false;
     }
     if (ctx->prof_on && (rc = prof_collect(ctx))) return rc;
@@ -1244,10 +1384,58 @@ int omds_kernel_candidates(omds_ctx* ctx, float thr_dist, float thr_kernel, floa
 // ---- screening controls ------------------------------------------------------------------------------
 int omds_set_screening(omds_ctx* ctx, int mode, float eps) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    REQUIRE(mode >= -1 && mode <= 1 && !(eps < 0.f), OMDS_ERR_INVALID_ARG, "omds_set_screening: mode in {-1, 0, 1}, eps >= 0");
+    REQUIRE(mode >= -1 && mode <= 1 && eps == eps, OMDS_ERR_INVALID_ARG, "omds_set_screening: mode in {-1, 0, 1}, eps not NaN");
     ctx->screen_mode = mode;
-    if (eps > 0.f) { ctx->screen_eps = eps; ctx->screen_cal = true; }
-    else if (ctx->screen_cal) { ctx->screen_cal = false; ctx->screen_eps = 0.f; }   // eps = 0: calibrate again at the next propagate
+    if (eps > 0.f) {            // the caller's bound instead of a calibration (the run-time checks still widen it when they must)
+        ctx->screen_eps = eps; ctx->screen_eps_fixed = true; ctx->screen_cal = true;
+        ctx->obs_cal = ctx->obs_now;
+        ctx->screen_suspended = false; ctx->screen_consec = 0;
+    } else if (eps < 0.f) {     // forget the calibration: measured again at the next screened propagate
+        ctx->screen_eps = 0.f; ctx->screen_eps_fixed = false; ctx->screen_cal = false;
+        ctx->screen_suspended = false; ctx->screen_consec = 0;
+    }                           // eps == 0: the mode only; bound, calibration and everything measured so far stay
+    return OMDS_OK;
+}
+int omds_set_screening_audit(omds_ctx* ctx, int one_in) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(one_in >= 0 && one_in <= (1 << 20) && (one_in & (one_in - 1)) == 0, OMDS_ERR_INVALID_ARG,
+            "omds_set_screening_audit: one_in must be 0 (no audit rows) or a power of two <= 2^20");
+    ctx->audit_one_in = one_in;
+    return OMDS_OK;
+}
+int omds_screen_audit_stats(omds_ctx* ctx, int32_t* one_in, double* audit_rows_per_rollout_step, float* audit_max_err,
+                            int32_t* suspended, int64_t* calibrations) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    if (one_in) *one_in = ctx->audit_one_in;
+    if (audit_rows_per_rollout_step) *audit_rows_per_rollout_step = ctx->screen_steps > 0 ? ctx->screen_audit_rows / ctx->screen_steps : 0.0;
+    if (audit_max_err) *audit_max_err = ctx->screen_audit_err_seen;
+    if (suspended) *suspended = ctx->screen_suspended ? 1 : 0;
+    if (calibrations) *calibrations = ctx->screen_recals;
+    return OMDS_OK;
+}
+// Test hook (tests/test_gpu_screen_audit.py): damages the screening network's inputs so that the run-time checks have
+// something to catch.  what = 0: zeroes weight fragment `index` (1 KiB of slice index / 16) of the fp16 pack -- every
+// screening value moves; what = 1: shifts obstacle `index` by `value` along x in the SCREENING input table only (undone by
+// the next omds_set_obstacles) -- the fp16 network sees that one sphere elsewhere, so only the audit rows can notice.
+int omds_screen_debug_corrupt(omds_ctx* ctx, int what, int index, float value) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(ctx->screen_ok, OMDS_ERR_UNSUPPORTED, "omds_screen_debug_corrupt: no screening network for this model");
+    CK(hipSetDevice(ctx->dev));
+    CK(hipStreamSynchronize(ctx->stream));
+    if (what == 0) {
+        const int nfrag = (ctx->mlp.nhh * 8 + 2) * 16;
+        REQUIRE(index >= 0 && index < nfrag, OMDS_ERR_INVALID_ARG, "omds_screen_debug_corrupt: fragment index out of range");
+        CK(hipMemset(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(ctx->screen.Wh)) + (size_t)index * 1024, 0, 1024));
+        return OMDS_OK;
+    }
+    REQUIRE(what == 1 && index >= 0 && index < ctx->n_obs, OMDS_ERR_INVALID_ARG, "omds_screen_debug_corrupt: what in {0, 1}, obstacle index in range");
+    const int n = ctx->cfg.n_dof, d = ctx->mlp.d, ld = ctx->cfg.max_obs;
+    const float x = ctx->obs_now[(size_t)index * 4] + value;
+    const float f[3] = {x, std::sin(x), std::cos(x)};
+    for (int part = 0; part < 3; ++part) {
+        const uint16_t h = f32_to_f16_bits(f[part]);
+        CK(hipMemcpy(ctx->d_FpH + omds_screen_fidx(part * d + n, index, ld), &h, 2, hipMemcpyHostToDevice));
+    }
     return OMDS_OK;
 }
 // Diagnostic: the screening network alone on a batch (what k_select sees), for tests and for measuring eps.
@@ -1296,6 +1484,7 @@ int omds_prof_reset(omds_ctx* ctx) {
     ctx->prof.used = 0;
     ctx->screen_rows = 0.0;
     ctx->screen_steps = 0.0;
+    ctx->screen_audit_rows = 0.0;
     return OMDS_OK;
 }
 int omds_prof_read_ex(omds_ctx* ctx, double* ms, int64_t* launches, double* flops, const char** kernel) {

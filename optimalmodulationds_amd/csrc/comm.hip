@@ -9,6 +9,7 @@
 // then ONE D2H copy + stream sync and the O(K n) host arithmetic of omds_apply_update.  RCCL (xGMI on the box) is
 // dlopen'ed the first time a communicator is asked for: single-GPU processes never load it.  The copy beside the loaded
 // HIP runtime is used (in a process that imported PyTorch first that is PyTorch's own, already mapped).
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -34,8 +35,17 @@ struct Rccl {
         // on whether torch or this library was loaded first, and an RCCL from the other set opens a second, uninitialised
         // HSA runtime: "no ROCm-capable device is detected" at ncclCommInitRank).  If that is the copy the process already
         // has mapped, dlopen returns the same handle -- no second RCCL.
+        // OMDS_RCCL_LIB: use exactly this library (deployments with several ROCm installs; the test of the failure path)
+        if (const char* forced = getenv("OMDS_RCCL_LIB")) {
+            handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!handle) {
+                const char* e = dlerror();   // ONE call: dlerror() clears the message it returns
+                err = std::string("RCCL not available (OMDS_RCCL_LIB=") + forced + "): " + (e ? e : "dlopen failed");
+                return;
+            }
+        }
         Dl_info info{};
-        if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+        if (!handle && dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
             std::string dir(info.dli_fname);
             const size_t slash = dir.rfind('/');
             if (slash != std::string::npos) {
@@ -58,7 +68,11 @@ struct Rccl {
                 if (handle) break;
             }
         }
-        if (!handle) { err = std::string("RCCL not available: ") + (dlerror() ? dlerror() : "dlopen failed"); return; }
+        if (!handle) {
+            const char* e = dlerror();       // ONE call: the second would return NULL (std::string + nullptr is undefined)
+            err = std::string("RCCL not available: ") + (e ? e : "dlopen failed");
+            return;
+        }
 #define OMDS_RCCL_SYM(f)                                                                   \
     f = reinterpret_cast<decltype(f)>(dlsym(handle, "nccl" #f));                           \
     if (!f) { err = "RCCL symbol nccl" #f " missing"; handle = nullptr; return; }

@@ -206,7 +206,9 @@ struct OmdsDivisor {
 // t*O + o; the exact value, what pass 2's forward would compute for the row (pass-2 distance, arg-min link) and the ReLU
 // masks go to ex->... per list entry, and max |screening value - exact value| to *maxerr_bits.  MODE 2 (fused small-O step,
 // step_small.hip): rows as in mode 0, outputs as in mode 1 but indexed by the row within the tile (ex-> pointers are LDS
-// arrays) and the masks stay in the tile's LDS block (maskS, behind rowIdx).
+// arrays) and the masks stay in the tile's LDS block (maskS, behind rowIdx).  MODE 4 (audit sample, k_audit): rows as in
+// mode 1, the rollout index of a pair running over all horizon steps' states; no outputs but max (ex->Da[entry] - exact value)
+// into maxerr_bits[2].
 // The arithmetic of a row is the same in all forms and independent of the other rows of the tile: bit-identical results.
 template <int MT, int MR, int NR, int ACT, int MODE = 0>
 __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const float* __restrict__ Apre,
@@ -215,7 +217,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                                            const long long row0, const OmdsDivisor odiv,
                                            const int* __restrict__ rowlist = nullptr, unsigned* maxerr_bits = nullptr,
                                            const ExactOut* ex = nullptr) {
-    constexpr bool LIST = MODE == 1, EMIT = MODE != 0;
+    constexpr bool LIST = MODE == 1 || MODE == 4, EMIT = MODE == 1 || MODE == 2;
     using G = Geo<MT, MR, NR>;
     float* Hs = smem;                                           // [MT][LDH]
     float* rowRad = smem + MT * LDH;                            // [MT] obstacle radius of each row
@@ -437,7 +439,8 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
         [[maybe_unused]] float scr[4];   // LIST: the screening values of this lane's four rows (guard), in flight across the MFMA loop
         if constexpr (LIST) {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) scr[reg] = (row0 + r4 + reg < total_rows) ? Dmin[rowIdx[r4 + reg]] : 0.f;
+            for (int reg = 0; reg < 4; ++reg)   // the pair's screening value: k_screen's matrix, or (audit list) the copy k_select took
+                scr[reg] = (row0 + r4 + reg < total_rows) ? (MODE == 4 ? ex->Da[row0 + r4 + reg] : Dmin[rowIdx[r4 + reg]]) : 0.f;
         }
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
@@ -493,12 +496,17 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                 for (int reg = 0; reg < 4; ++reg) {
                     const long long e_idx = row0 + r4 + reg;
                     if (e_idx < total_rows) {
-                        const float e = fabsf(scr[reg] - y[reg]);   // Dmin holds the screening value of the pair
+                        // candidates (MODE 1): |Da - D| -> maxerr_bits[0].  Audit sample (MODE 4: pairs that were NOT candidates):
+                        // the one-sided Da - D the selection rule bounds by eps -> maxerr_bits[2]; a non-candidate whose
+                        // screening value is too LOW is harmless, one too HIGH by more than eps could hide a top-k row
+                        const float e = MODE == 4 ? scr[reg] - y[reg] : fabsf(scr[reg] - y[reg]);
                         if (!(e <= me)) me = (e == e) ? e : __builtin_inff();   // a NaN screening value (fp16 overflow) counts as an infinite error
-                        if (e_idx < ex->cap) { ex->D[e_idx] = y[reg]; ex->dr[e_idx] = ydr[reg]; ex->amin[e_idx] = yam[reg]; }
+                        if constexpr (MODE == 1) {
+                            if (e_idx < ex->cap) { ex->D[e_idx] = y[reg]; ex->dr[e_idx] = ydr[reg]; ex->amin[e_idx] = yam[reg]; }
+                        }
                     }
                 }
-                if (me > 0.f) atomicMax(maxerr_bits, __builtin_bit_cast(unsigned, me));   // non-negative floats order like their bits
+                if (me > 0.f) atomicMax(maxerr_bits + (MODE == 4 ? 2 : 0), __builtin_bit_cast(unsigned, me));   // non-negative floats order like their bits
             }
         } else if constexpr (MODE == 2) {
             if (j == 0) {
@@ -517,7 +525,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
             }
         }
     }
-    if constexpr (LIST) {   // the tile's rows are consecutive list entries: one contiguous block of masks
+    if constexpr (MODE == 1) {   // the tile's rows are consecutive list entries: one contiguous block of masks
         __syncthreads();
         const long long words = (long long)((total_rows - row0 < MT) ? (total_rows - row0) : MT) * nhid * 8;
         for (int i = tid; i < words; i += G::NT) {

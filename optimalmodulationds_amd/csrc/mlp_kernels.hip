@@ -28,11 +28,12 @@
 // layer-1 halves
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rollout_layer1(MlpDev m, const float* __restrict__ qT, int ldq, int B,
-                                                        float* __restrict__ Apre, _Float16* __restrict__ FqH, int ldF) {
+                                                        float* __restrict__ Apre, _Float16* __restrict__ FqH, int ldF, int slab) {
     __shared__ float f[3 * OMDS_MAX_DOF];
     const int t = blockIdx.x, c = threadIdx.x, n = m.n_dof, d = m.d;
     if (c < n) {
-        const float q = qT[(size_t)c * ldq + t];
+        const int h = slab > 0 ? t / slab : 0;   // slab > 0: row t is rollout t - h*slab of state slab h ([n][ldq] each)
+        const float q = qT[((size_t)h * n + c) * ldq + (t - h * slab)];
         f[c] = q;
         f[n + c] = sinf(q);
         f[2 * n + c] = cosf(q);
@@ -186,9 +187,9 @@ __global__ __launch_bounds__(256) void k_blend(const float* __restrict__ gradx, 
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-void omds_launch_rollout_layer1(hipStream_t s, const MlpDev& m, const float* qT, int ldq, int B, float* Apre, uint16_t* FqH, int ldF) {
+void omds_launch_rollout_layer1(hipStream_t s, const MlpDev& m, const float* qT, int ldq, int B, float* Apre, uint16_t* FqH, int ldF, int slab) {
     if (B <= 0) return;
-    hipLaunchKernelGGL(k_rollout_layer1, dim3(B), dim3(256), 0, s, m, qT, ldq, B, Apre, reinterpret_cast<_Float16*>(FqH), ldF);
+    hipLaunchKernelGGL(k_rollout_layer1, dim3(B), dim3(256), 0, s, m, qT, ldq, B, Apre, reinterpret_cast<_Float16*>(FqH), ldF, slab);
 }
 
 void omds_launch_obstacle_layer1(hipStream_t s, const MlpDev& m, const float* xyzr, int O, float* Bpre, float* radius, uint16_t* FpH, int ldF,

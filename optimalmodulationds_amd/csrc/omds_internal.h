@@ -105,12 +105,29 @@ struct omds_ctx {
     float* d_exDr = nullptr;
     int* d_exMin = nullptr;
     uint32_t* d_exMask = nullptr;
-    int* d_sctotal = nullptr;    // [H] candidates listed per horizon step
-    unsigned* d_scerr = nullptr; // [2]: max |screening - exact| over the candidates (float bits); rollouts whose slack guard failed
-    double screen_rows = 0.0;    // statistics since the last omds_prof_reset: candidate rows, (rollout, step)s, fallbacks
+    int* d_sctotal = nullptr;    // [H+2]: candidate rows listed per horizon step; [H+1]: audit entries recorded in this propagate
+    int* d_audit_rows = nullptr; // [audit_cap] audit sample of a propagate: pair rows into d_ApreAll's row space, their screening values
+    float* d_audit_da = nullptr;
+    int audit_cap = 0;
+    float* d_ApreAll = nullptr;  // [H][N][256] rollout half of layer 1 at the states of every horizon step (kept by a screened propagate with an audit sample)
+    float* d_featQAll = nullptr; // [H*N][32] skip-connection networks: the encoded joint inputs likewise
+    unsigned* d_scerr = nullptr; // [4]: max |screening - exact| over the candidates (float bits); rollouts whose slack guard failed;
+                                 //      max (screening - exact) over the audit sample (float bits); calibration scratch
+    double screen_rows = 0.0;    // statistics since the last omds_prof_reset: candidate rows, (rollout, step)s, audit rows
     double screen_steps = 0.0;
-    long long screen_fallbacks = 0;
-    float screen_err_seen = 0.f;
+    double screen_audit_rows = 0.0;
+    long long screen_fallbacks = 0;      // since creation
+    long long screen_recals = 0;         // calibrations run since creation
+    float screen_err_seen = 0.f;         // largest |Da - D| seen on candidates since the last calibration
+    float screen_audit_err_seen = 0.f;   // largest Da - D seen on audit rows since the last calibration
+    bool screen_eps_fixed = false;       // eps given by the caller (omds_set_screening(mode, eps > 0)): never recalibrated
+    bool screen_suspended = false;       // three propagates in a row fell back to fp32: the fp32 step until the next calibration
+    int screen_consec = 0;               // consecutive fallbacks
+    int audit_one_in = 128;              // a non-candidate pair is audited with probability 1 / audit_one_in (power of two; 0 = no audit)
+    unsigned audit_counter = 0;          // feeds the audit hash: another sample every step of every propagate
+    std::vector<float> obs_cal;          // the obstacle set the bound was calibrated against (omds_set_obstacles compares)
+    std::vector<float> obs_now;          // host copy of the current obstacle set
+    bool have_rollouts = false;          // d_trajT holds the rollouts of a finished propagate (calibration draws states from them)
     // scene
     int n_obs = 0;
     float* d_obs = nullptr;      // [max_obs][4]
@@ -210,7 +227,10 @@ int omds_update_impl(omds_ctx* ctx, bool use_comm, float rate, float ker_thr, fl
 // of the screening kernel's input tables, [4 pieces][ldF rows][8] (omds_screen_fidx).  ldF is the table's CAPACITY
 // (n_traj / max_obs), never the batch: the slots the other operand owns must stay zero, and a batch-dependent stride would
 // alias them with data of an earlier call
-void omds_launch_rollout_layer1(hipStream_t s, const MlpDev& m, const float* qT, int ldq, int B, float* Apre, uint16_t* FqH = nullptr, int ldF = 0);
+// slab > 0: the B rows are `B / slab` consecutive [n][ldq] state slabs of `slab` rollouts each (the stored rollouts trajT
+// [H][n][N] as ONE batch of H*N states: row h*slab + t reads qT[(h*n + c) * ldq + t])
+void omds_launch_rollout_layer1(hipStream_t s, const MlpDev& m, const float* qT, int ldq, int B, float* Apre, uint16_t* FqH = nullptr, int ldF = 0,
+                                int slab = 0);
 void omds_launch_obstacle_layer1(hipStream_t s, const MlpDev& m, const float* xyzr, int O, float* Bpre, float* radius, uint16_t* FpH = nullptr, int ldF = 0,
                                  float* featP = nullptr);
 void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
@@ -242,9 +262,28 @@ struct ExactOut {
     int* amin;         // [cap] arg-min link over all raw outputs
     uint32_t* mask;    // [cap][nhid][8]
     int cap;           // entries the arrays hold (the list may be longer: the host then redoes the propagate in fp32)
+    const float* Da = nullptr;   // audit list only (pass1_tile mode 4): [entries] screening value of each listed pair
 };
 
-void omds_launch_select(hipStream_t s, const float* Dmin, int B, int O, int k, float delta, int* rowlist, int* range, int* total);
+// Audit sample of a propagate: k_select records a non-candidate pair when (hash(pair ^ seed) & mask) == 0 as
+// (row = (step_row0 + t) * O + o, screening value); rows == nullptr: no audit.  omds_launch_audit evaluates the list in fp32
+// against the layer-1 table of all horizon steps' states and leaves max (Da - D) in maxerr_bits[2].
+struct AuditSink {
+    int* rows = nullptr;
+    float* da = nullptr;
+    int* total = nullptr;
+    int cap = 0;
+    unsigned mask = 0xffffffffu, seed = 0;
+    int step_row0 = 0;
+};
+void omds_launch_select(hipStream_t s, const float* Dmin, int B, int O, int k, float delta, int* rowlist, int* range, int* total,
+                        const AuditSink& au);
+void omds_launch_audit(hipStream_t s, const MlpDev& m, const float* ApreAll, const float* Bpre, const float* radius, int O,
+                       uint32_t ignored, const int* rows, const float* da, const int* total, int cap, unsigned* maxerr_bits);
+// calibration of the screening bound on the device: the batch of states, and max |x - y| into *out_bits (float bits, atomicMax)
+void omds_launch_calib_states(hipStream_t s, float* qT, int B, int n, const float* lo, const float* hi, const float* center,
+                              const float* trajT, int N, int H, unsigned seed);
+void omds_launch_max_abs_diff(hipStream_t s, const float* x, const float* y, long long n, unsigned* out_bits);
 void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius, int O,
                        int B, uint32_t ignored, float* Dmin, const int* rowlist, const int* total, unsigned* maxerr_bits,
                        const ExactOut& ex);

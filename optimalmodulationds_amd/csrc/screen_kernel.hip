@@ -416,7 +416,22 @@ struct SelectArgs {
     int* total;           // number of listed rows (zeroed before the launch)
     int N, O, k;
     float delta;          // tau = (k-th smallest screening value) + delta
+    // AUDIT sample: a non-candidate pair is recorded when (hash(pair ^ audit_seed) & audit_mask) == 0 (mask 0xffffffff: never)
+    // as (row = (step_row0 + t) * O + o, screening value) in a list of the whole propagate; k_audit re-evaluates them at its end
+    unsigned audit_mask;
+    unsigned audit_seed;  // changes with every horizon step and propagate, so that over time every pair gets audited
+    int* audit_rows;      // [audit_cap]
+    float* audit_da;      // [audit_cap]
+    int* audit_total;     // entries recorded so far in this propagate (may exceed audit_cap: the excess is dropped)
+    int audit_cap;
+    int step_row0;        // (step - 1) * N: row of rollout 0 in the all-steps layer-1 table k_audit reads
 };
+
+// lowbias32 (an integer hash with good avalanche): which non-candidate pairs k_exact re-evaluates as AUDIT rows
+__device__ __forceinline__ unsigned omds_audit_hash(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
 
 #ifndef OMDS_SEL_WAVES
 #define OMDS_SEL_WAVES 8
@@ -424,8 +439,8 @@ struct SelectArgs {
 constexpr int SEL_WAVES = OMDS_SEL_WAVES;   // rollouts per workgroup (4: 10.5 us, 8: 10.1, 16: 11.4): ONE atomic on the list counter per workgroup (1024 same-address
                                 // atomics, one per rollout, serialise in L2 and were most of this kernel's 19 us)
 __global__ __launch_bounds__(SEL_WAVES * 64) void k_select(SelectArgs a) {
-    __shared__ int wtot[SEL_WAVES];
-    __shared__ int wbase;
+    __shared__ int wtot[SEL_WAVES], watot[SEL_WAVES];
+    __shared__ int wbase, wabase;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t_raw = blockIdx.x * SEL_WAVES + wave;
     const bool live = t_raw < a.N;                       // waves past the last rollout take part in the barriers with 0 entries
@@ -471,49 +486,76 @@ __global__ __launch_bounds__(SEL_WAVES * 64) void k_select(SelectArgs a) {
         pi = bi;
     }
     const float tau = pv + a.delta;   // pv = +inf (fewer than k finite values): everything is a candidate
+    // Candidates: everything not above tau, and every non-finite value (NaN / +inf = an fp16 overflow inside the network:
+    // nothing is known about such a row).  AUDIT sample: a pseudo-random subset of the pairs that are NOT candidates -- the
+    // population the selection rule makes an assumption about (screening error <= eps) -- goes with its screening value into
+    // the propagate's audit list; k_audit evaluates those pairs in fp32 once the horizon loop is done.
+    const int rbase = t * O;
+    auto is_cand = [&](float x) { return !(x > tau) || !(x < __builtin_inff()); };
+    auto is_audit = [&](int o) { return (omds_audit_hash((unsigned)(rbase + o) ^ a.audit_seed) & a.audit_mask) == 0u; };
     // count, reserve a range of the list, write
-    int cnt = 0;
+    int cnt = 0, acnt = 0;
     if (in_regs) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) { const int o = lane + 64 * i; cnt += (o < O && !(v[i] > tau)) ? 1 : 0; }
+        for (int i = 0; i < NV; ++i) {
+            const int o = lane + 64 * i;
+            const bool c = o < O && is_cand(v[i]);
+            cnt += c ? 1 : 0;
+            acnt += (o < O && !c && is_audit(o)) ? 1 : 0;
+        }
     } else {
-        for (int o = lane; o < O; o += 64) cnt += !(row[o] > tau) ? 1 : 0;
+        for (int o = lane; o < O; o += 64) {
+            const bool c = is_cand(row[o]);
+            cnt += c ? 1 : 0;
+            acnt += (!c && is_audit(o)) ? 1 : 0;
+        }
     }
-    int incl = cnt;   // inclusive scan over the lanes
+    int incl = cnt, aincl = acnt;   // inclusive scans over the lanes
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const int u = __shfl_up(incl, off);
-        if (lane >= off) incl += u;
+        const int u = __shfl_up(incl, off), ua = __shfl_up(aincl, off);
+        if (lane >= off) { incl += u; aincl += ua; }
     }
-    const int wave_total = live ? __shfl(incl, 63) : 0;
-    if (lane == 0) wtot[wave] = wave_total;
+    const int wave_total = live ? __shfl(incl, 63) : 0, wave_audit = live ? __shfl(aincl, 63) : 0;
+    if (lane == 0) { wtot[wave] = wave_total; watot[wave] = wave_audit; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int sum = 0;
+        int sum = 0, asum = 0;
 #pragma unroll
-        for (int w = 0; w < SEL_WAVES; ++w) sum += wtot[w];
+        for (int w = 0; w < SEL_WAVES; ++w) { sum += wtot[w]; asum += watot[w]; }
         wbase = atomicAdd(a.total, sum);
+        wabase = asum ? atomicAdd(a.audit_total, asum) : 0;
     }
     __syncthreads();
     if (!live) return;
-    int base = wbase;
-    for (int w = 0; w < wave; ++w) base += wtot[w];
+    int base = wbase, abase = wabase;
+    for (int w = 0; w < wave; ++w) { base += wtot[w]; abase += watot[w]; }
     if (lane == 0) {
         a.range[4 * t] = base;
         a.range[4 * t + 1] = wave_total;
         a.range[4 * t + 2] = __builtin_bit_cast(int, tau);   // k_tail_sel checks the rollout's slack against it
     }
-    int pos = base + incl - cnt;
-    const int rbase = t * O;
+    int pos = base + incl - cnt, apos = abase + aincl - acnt;
+    const int arow0 = (a.step_row0 + t) * O;
+    auto put_audit = [&](int o, float x) {
+        if (apos < a.audit_cap) { a.audit_rows[apos] = arow0 + o; a.audit_da[apos] = x; }
+        ++apos;
+    };
     if (in_regs) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int o = lane + 64 * i;
-            if (o < O && !(v[i] > tau)) a.rowlist[pos++] = rbase + o;
+            if (o < O) {
+                if (is_cand(v[i])) a.rowlist[pos++] = rbase + o;
+                else if (is_audit(o)) put_audit(o, v[i]);
+            }
         }
     } else {
-        for (int o = lane; o < O; o += 64)
-            if (!(row[o] > tau)) a.rowlist[pos++] = rbase + o;
+        for (int o = lane; o < O; o += 64) {
+            const float x = row[o];
+            if (is_cand(x)) a.rowlist[pos++] = rbase + o;
+            else if (is_audit(o)) put_audit(o, x);
+        }
     }
 }
 
@@ -537,6 +579,104 @@ __global__ __launch_bounds__(512, 6) void k_exact(MlpDev m, const float* __restr
         pass1_tile<16, 1, 1, ACT, 1>(m, smem, Apre, Bpre, radius, O, n, ignored, Dmin, (long long)blk * 16, odiv, rowlist, maxerr_bits, &ex);
         __syncthreads();   // the tile buffer is reused by the next tile
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_audit: the audit sample of a whole propagate (k_select recorded (row, screening value) of a pseudo-random subset of the
+// pairs that were NOT candidates) evaluated in fp32 with the pass-1 tile code -- 64-row tiles, the throughput shape of
+// k_pass1, because nothing waits for this launch but the end of the propagate -- against the layer-1 table of ALL horizon
+// steps' states ([H*N][256], rebuilt from the stored rollouts by k_rollout_layer1, the arithmetic of the step itself).
+// Output: max (Da - D) over the sample, the one-sided error the selection rule bounds by eps (maxerr_bits[2]).
+// ------------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(512) void k_audit(MlpDev m, const float* __restrict__ ApreAll, const float* __restrict__ Bpre,
+                                               const float* __restrict__ radius, int O, uint32_t ignored, OmdsDivisor odiv,
+                                               const int* __restrict__ rows, const int* __restrict__ total, int cap,
+                                               unsigned* __restrict__ maxerr_bits, ExactOut ex) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n = min(*total, cap);
+    for (int blk = blockIdx.x; blk * 64 < n; blk += gridDim.x) {
+        pass1_tile<64, 2, 1, ACT, 4>(m, smem, ApreAll, Bpre, radius, O, n, ignored, nullptr, (long long)blk * 64, odiv, rows, maxerr_bits, &ex);
+        __syncthreads();
+    }
+}
+
+void omds_launch_audit(hipStream_t s, const MlpDev& m, const float* ApreAll, const float* Bpre, const float* radius, int O,
+                       uint32_t ignored, const int* rows, const float* da, const int* total, int cap, unsigned* maxerr_bits) {
+    if (cap <= 0) return;
+    const size_t lds = (size_t)64 * LDH * 4 + 64 * 4 + 64 * 4;
+    static std::atomic<uint64_t> configured{0};
+    if (omds_first_use_on_device(configured)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_audit<OMDS_ACT_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_audit<OMDS_ACT_TANH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    ExactOut ex{};
+    ex.Da = da;
+    // the list length is only known on the device: a grid of two resident 64-row workgroups per CU strides over it
+    const unsigned grid = (unsigned)std::min<long long>(((long long)cap + 63) / 64, 512);
+    const OmdsDivisor od = OmdsDivisor::make((unsigned)O);
+    if (m.act == OMDS_ACT_RELU)
+        hipLaunchKernelGGL((k_audit<OMDS_ACT_RELU>), dim3(grid), dim3(512), lds, s, m, ApreAll, Bpre, radius, O, ignored, od, rows, total, cap, maxerr_bits, ex);
+    else
+        hipLaunchKernelGGL((k_audit<OMDS_ACT_TANH>), dim3(grid), dim3(512), lds, s, m, ApreAll, Bpre, radius, O, ignored, od, rows, total, cap, maxerr_bits, ex);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Calibration of the screening bound on the device (capi.hip: calibrate_screen): B states -- the even ones uniform inside the
+// joint box, the odd ones drawn from the rollouts of the last propagate (where the next rollouts will live), or scattered
+// around the start state while there are none yet -- and the largest |screening value - fp32 value| over their B x O pairs.
+// ------------------------------------------------------------------------------------------------
+struct CalibArgs {
+    float* qT;             // [n][B] out
+    int B, n;
+    float lo[OMDS_MAX_DOF], hi[OMDS_MAX_DOF], center[OMDS_MAX_DOF];
+    const float* trajT;    // [H][n][N] rollouts of the last propagate, or nullptr
+    int N, H;
+    unsigned seed;
+};
+__global__ __launch_bounds__(256) void k_calib_states(CalibArgs a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.B) return;
+    auto uni = [&](unsigned salt) { return ((omds_audit_hash((unsigned)t * 0x9E3779B1u + salt + a.seed) >> 8) + 0.5f) * (1.f / 16777216.f); };
+    if ((t & 1) && a.trajT) {
+        const unsigned r = omds_audit_hash((unsigned)t + 0x51ED270Bu * a.seed);
+        const int tt = (int)(r % (unsigned)a.N), hh = (int)((r >> 16) % (unsigned)a.H);
+        for (int j = 0; j < a.n; ++j) a.qT[(size_t)j * a.B + t] = a.trajT[((size_t)hh * a.n + j) * a.N + tt];
+        return;
+    }
+    for (int j = 0; j < a.n; ++j) {
+        float v;
+        if (t & 1) {   // Box-Muller scatter (sigma 0.6 rad) around the start state, clamped to the box
+            const float g = sqrtf(-2.f * logf(uni(2 * j + 1))) * cosf(6.2831853f * uni(2 * j + 2));
+            v = fminf(a.hi[j], fmaxf(a.lo[j], a.center[j] + 0.6f * g));
+        } else {
+            v = a.lo[j] + (a.hi[j] - a.lo[j]) * uni(2 * j + 1);
+        }
+        a.qT[(size_t)j * a.B + t] = v;
+    }
+}
+void omds_launch_calib_states(hipStream_t s, float* qT, int B, int n, const float* lo, const float* hi, const float* center,
+                              const float* trajT, int N, int H, unsigned seed) {
+    CalibArgs a;
+    a.qT = qT; a.B = B; a.n = n; a.trajT = trajT; a.N = N; a.H = H; a.seed = seed;
+    for (int j = 0; j < OMDS_MAX_DOF; ++j) { a.lo[j] = j < n ? lo[j] : 0.f; a.hi[j] = j < n ? hi[j] : 0.f; a.center[j] = j < n ? center[j] : 0.f; }
+    hipLaunchKernelGGL(k_calib_states, dim3((B + 255) / 256), dim3(256), 0, s, a);
+}
+// *out_bits = max(*out_bits, max_i |x[i] - y[i]|) as float bits; a non-finite difference counts as +inf
+__global__ __launch_bounds__(256) void k_max_abs_diff(const float* __restrict__ x, const float* __restrict__ y, long long n, unsigned* out_bits) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float e = fabsf(x[i] - y[i]);
+        if (!(e <= m)) m = (e < __builtin_inff()) ? e : __builtin_inff();
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out_bits, __builtin_bit_cast(unsigned, m));
+}
+void omds_launch_max_abs_diff(hipStream_t s, const float* x, const float* y, long long n, unsigned* out_bits) {
+    if (n <= 0) return;
+    const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_max_abs_diff, dim3(grid), dim3(256), 0, s, x, y, n, out_bits);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -630,10 +770,13 @@ void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, con
 
 bool omds_screen_supported(const MlpDev& m) { return m.act == OMDS_ACT_RELU && m.nhh >= 1 && m.nhh <= 4; }
 
-void omds_launch_select(hipStream_t s, const float* Dmin, int B, int O, int k, float delta, int* rowlist, int* range, int* total) {
+void omds_launch_select(hipStream_t s, const float* Dmin, int B, int O, int k, float delta, int* rowlist, int* range, int* total,
+                        const AuditSink& au) {
     if (B <= 0) return;
     SelectArgs a;
     a.Dmin = Dmin; a.rowlist = rowlist; a.range = range; a.total = total; a.N = B; a.O = O; a.k = k; a.delta = delta;
+    a.audit_mask = au.rows ? au.mask : 0xffffffffu; a.audit_seed = au.seed; a.audit_rows = au.rows; a.audit_da = au.da;
+    a.audit_total = au.total; a.audit_cap = au.cap; a.step_row0 = au.step_row0;
     hipLaunchKernelGGL(k_select, dim3((B + SEL_WAVES - 1) / SEL_WAVES), dim3(SEL_WAVES * 64), 0, s, a);
 }
 

@@ -85,7 +85,9 @@ def sharded_update(cost_sum_fn, local_sums_fn, K, n, H, rate, ker_thr, mu_c, sig
 
 
 def shift_policy_means_sharded(mppi, group=None):
-    """Drop-in for ``MPPI.shift_policy_means`` when ``mppi`` holds one shard of the rollouts."""
+    """``MPPI.shift_policy_means`` over the shards of ``group`` in the HOST-MEDIATED form (torch.distributed all-reduces of
+    the library's partial sums): for launchers without RCCL and the world-size-2 gloo tests.  On GPUs use
+    ``mppi.init_comm(group)`` once and then plain ``mppi.shift_policy_means()`` -- the native RCCL exchange."""
     if mppi.cur_cost is None:
         mppi._push()
         mppi._engine.cost(fetch=False)

@@ -64,9 +64,11 @@ class Engine:
             self._ck(self.lib.omds_set_mlp(self.h, nl, L.iptr(dims), Wp, bp, a, float(out_div)))
 
     def set_obstacles(self, obs):
+        """Any obstacle count: beyond ``max_obs`` the context grows its obstacle buffers (omds.h)."""
         obs = L.f32(obs).reshape(-1, 4)
         self._ck(self.lib.omds_set_obstacles(self.h, L.fptr(obs), obs.shape[0]))
         self.n_obs = obs.shape[0]
+        self.max_obs = max(self.max_obs, self.n_obs)
 
     def set_ds(self, q_goal):
         q = L.f32(q_goal).reshape(self.n)
@@ -269,8 +271,17 @@ class Engine:
 
     # ---- screening of pass 1 (fp16 + exact re-selection) ----------------------------------------
     def set_screening(self, mode=-1, eps=0.0):
-        """mode: -1 auto, 0 off (fp32 pass 1), 1 on; eps > 0 fixes the error bound, 0 = calibrate."""
+        """mode: -1 auto, 0 off (fp32 pass 1), 1 on; eps > 0 fixes the error bound, 0 keeps bound and calibration
+        (mode change only), < 0 discards the calibration (measured again at the next screened propagate)."""
         self._ck(self.lib.omds_set_screening(self.h, int(mode), float(eps)))
+
+    def set_screening_audit(self, one_in=64):
+        """Audit sample of the pairs the screened step does not re-evaluate: 1 in ``one_in`` (power of two), 0 = none."""
+        self._ck(self.lib.omds_set_screening_audit(self.h, int(one_in)))
+
+    def screen_debug_corrupt(self, what, index, value=0.0):
+        """Test hook (omds.h): 0 = zero a weight fragment of the fp16 pack, 1 = shift an obstacle in the screening inputs."""
+        self._ck(self.lib.omds_screen_debug_corrupt(self.h, int(what), int(index), float(value)))
 
     def screen_mindist(self, q):
         q = L.f32(q).reshape(-1, self.n)
@@ -283,8 +294,13 @@ class Engine:
         cand, fb = C.c_double(), C.c_int64()
         self._ck(self.lib.omds_screen_stats(self.h, C.byref(act), C.cast(C.byref(eps), L.F32P), C.cast(C.byref(err), L.F32P),
                                             C.byref(cand), C.byref(fb)))
+        one_in, susp, aerr = C.c_int32(), C.c_int32(), C.c_float()
+        arows, ncal = C.c_double(), C.c_int64()
+        self._ck(self.lib.omds_screen_audit_stats(self.h, C.byref(one_in), C.byref(arows), C.cast(C.byref(aerr), L.F32P),
+                                                  C.byref(susp), C.byref(ncal)))
         return dict(active=bool(act.value), eps=eps.value, max_err_seen=err.value, candidates_per_rollout_step=cand.value,
-                    fallbacks=fb.value)
+                    fallbacks=fb.value, audit_one_in=one_in.value, audit_rows_per_rollout_step=arows.value,
+                    audit_max_err=aerr.value, suspended=bool(susp.value), calibrations=ncal.value)
 
     # ---- measurement --------------------------------------------------------------------------
     def prof_enable(self, on=True):

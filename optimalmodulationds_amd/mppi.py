@@ -119,29 +119,11 @@ class MPPI:
         """MPPI.py:347-350."""
         self.obs = torch.as_tensor(_np(obs)).reshape(-1, 4)
         self.n_obs = self.obs.shape[0]
-        if self.n_obs > self._max_obs:
-            self._grow_obstacle_capacity(self.n_obs)       # the reference takes any obstacle count at any time
+        # the reference takes any obstacle count at any time: the context grows its own obstacle buffers (omds_set_obstacles),
+        # so the handle -- network, samples, RCCL communicator, screening state -- survives
         self._engine.set_obstacles(self.obs.numpy())
+        self._max_obs = self._engine.max_obs
         return 0
-
-    def _grow_obstacle_capacity(self, n_obs):
-        """A larger device context (obstacle buffers are sized at creation) carrying over the network, the parameters
-        and the current policy samples; device rollouts of the old context are dropped (the next propagate refills them)."""
-        old = self._engine
-        samples = old.get_policy_samples() if old.K else None
-        self._max_obs = int(max(2 * n_obs, 64))
-        new = Engine(self.n_dof, self.N_traj, self.dt_H, self.n_closest_obs, self._max_obs, device=self._device)
-        m = self.nn_model.model
-        new.set_mlp(m.W, m.b, m.act, skip_after=getattr(m, 'skip_after', ()))
-        new.params = old.params
-        new.push_params()
-        if samples is not None:
-            new.set_policy_samples(*samples)
-        self._engine = new
-        self.Policy._engine = new
-        self._cache = {}
-        self.cur_cost = None
-        old.close()
 
     # ---- parameters -> device ----------------------------------------------------------------------
     def _push(self):
@@ -232,21 +214,38 @@ class MPPI:
         self.cur_cost = torch.from_numpy(self._engine.cost())
         return self.cur_cost
 
+    def init_comm(self, group=None):
+        """Multi-GPU (one process per GPU, this object holds one shard of the rollouts; pass ``rollout_offset = rank * N_traj``
+        to the constructor): creates the library's RCCL communicator over the ranks of ``group`` (any torch.distributed
+        backend, it only carries the 128-byte id).  From then on ``shift_policy_means`` / ``get_qdot`` reduce over ALL shards
+        on the device (csrc/comm.hip).  Raises OmdsError if RCCL is unusable -- there is no fallback."""
+        from .dist import init_native_comm
+        return init_native_comm(self._engine, group)
+
     def get_qdot(self, mode='best'):
         if self.cur_cost is None:
             self.get_cost()
+        if self._engine.comm_info()[1] > 1:      # sharded: the arg-min / weighted mean over the rollouts of every rank
+            K = self.Policy.n_kernels
+            P = self.Policy
+            _, _, _, _, qw, qb, _ = self._engine.weighted_update_sharded(0.0, self.ker_thr, P.mu_c.numpy()[:K], P.sigma_c.numpy()[:K],
+                                                                         P.alpha_c.numpy()[:K], want_best=(mode == 'best'))
+            return torch.from_numpy(qb if mode == 'best' else qw)
         return torch.from_numpy(self._engine.get_qdot(mode))
 
     def shift_policy_means(self):
+        """MPPI.py:331-345.  With a communicator (``init_comm``) the sums run over the rollouts of every rank: two all-reduces
+        on the context stream inside ``omds_weighted_update_sharded``; without one the same call is the single-shard update."""
         if self.cur_cost is None:
             self.get_cost()
         P = self.Policy
         K = P.n_kernels
-        mu, sg, al, mask, _ = self._engine.weighted_update(self.policy_upd_rate, self.ker_thr, P.mu_c.numpy(),
-                                                           P.sigma_c.numpy(), P.alpha_c.numpy())
+        mu, sg, al, mask, qw, _, _ = self._engine.weighted_update_sharded(self.policy_upd_rate, self.ker_thr, P.mu_c.numpy(),
+                                                                          P.sigma_c.numpy(), P.alpha_c.numpy())
         if K > 0:
             P.mu_c[:K] = torch.from_numpy(mu)
             P.sigma_c[:K] = torch.from_numpy(sg)
             P.alpha_c[:K] = torch.from_numpy(al)
         self.update_mask = torch.from_numpy(mask)
+        self.qdot_weighted = torch.from_numpy(qw)
         return 0, int(mask.sum())

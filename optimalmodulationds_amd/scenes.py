@@ -3,7 +3,8 @@
 Every scene is a float32 array ``[O, 4]`` of spheres ``(x, y, z, r)`` -- the obstacle tensor
 format the reference streams between its processes (reference
 ``python_scripts/ds_mppi/obstacleStreamer.py:84-109`` for the shelf,
-``obstacleStreamerBenchmark.py:30-51`` for the cross, ``scripts/standalonePlanar7d.py:68-73``
+``obstacleStreamerBenchmark.py:30-51`` for the cross, ``obstacleStreamer.py:28-82`` for the I-shape,
+ring, wall and line, ``scripts/standalonePlanar7d.py:68-73``
 and ``scripts/standalonePlanar2d.py:76-77`` for the planar robots).  The geometry is restated
 here from those descriptions; nothing is imported from the reference.
 """
@@ -59,6 +60,56 @@ def cross_scene(z_drop: float = 0.0) -> np.ndarray:
     left = c + np.array([0, -length, 0, 0], dtype=F32)
     right = c + np.array([0, length, 0, 0], dtype=F32)
     return np.vstack((_segment(top, bottom, 2 * n_pts), _segment(left, right, 2 * n_pts))).astype(F32)
+
+
+def tshape_scene() -> np.ndarray:
+    """The 60-sphere I-shape in front of the robot (r = 0.05 m): a top bar and a bottom bar of 20 spheres across y at
+    x = 0.4 m, joined by a vertical bar of 20 (``obstacleStreamer.py:28-51``, the streamer's 'tshape')."""
+    x, half_w, z_lo, height, r, n_bar = 0.4, 0.4, 0.1, 0.75, 0.05, 20
+    top = _segment([x, -half_w, z_lo + height, r], [x, half_w, z_lo + height, r], n_bar)
+    bottom = top - np.array([0, 0, height, 0], dtype=F32)
+    middle = _segment([x, 0.0, z_lo, r], [x, 0.0, z_lo + height, r], n_bar)
+    return np.vstack((top, middle, bottom)).astype(F32)
+
+
+def ring_scene() -> np.ndarray:
+    """21 spheres (r = 0.03 m) on a circle of radius 0.2 m in the y-z plane at x = 0.55, z = 0.6; first and last coincide,
+    as the streamer's closed ``linspace(0, 2 pi, 21)`` makes them (``obstacleStreamer.py:53-64``)."""
+    ang = np.linspace(0.0, 2.0 * math.pi, 21, dtype=F32)
+    ring = np.zeros((21, 4), dtype=F32)
+    ring[:, 0] = 0.55
+    ring[:, 1] = 0.2 * np.cos(ang)
+    ring[:, 2] = 0.6 + 0.2 * np.sin(ang)
+    ring[:, 3] = 0.03
+    return ring
+
+
+def wall_scene() -> np.ndarray:
+    """The streamer's 'wall' (``obstacleStreamer.py:66-82``): two spheres (r = 0.05 m) 0.1 m apart along x at z = 0.6,
+    each followed by a column of two (itself again and the sphere 0.1 m below) -- 6 rows, two of them duplicates."""
+    r, n_pts = 0.05, 2
+    length = max(1, 2 * n_pts - 2) * r
+    line = _segment([0.6, 0.0, 0.5 + length, r], [0.6 + length, 0.0, 0.5 + length, r], n_pts)
+    parts = [line]
+    for sphere in line:
+        parts.append(_segment(sphere, sphere - np.array([0, 0, length, 0], dtype=F32), n_pts))
+    return np.vstack(parts).astype(F32)
+
+
+def line_scene() -> np.ndarray:
+    """What the streamer sends for 'line': by the time of its main loop the name is bound to the shelf's top row -- 6
+    spheres (r = 0.03 m) along x above the shelf (``obstacleStreamer.py:93-94,129-130``)."""
+    return shelf_scene()[:6].copy()
+
+
+def placeholder_scene(n: int = 1) -> np.ndarray:
+    """The far-away placeholder sphere(s) drivers start with before the first real scene arrives
+    (``obstacleStreamer.py:133-134``: one sphere of 1 cm at x = 10.3 m; ``n`` copies for ``n_closest_obs`` > 1)."""
+    return np.tile(np.array([[10.3, 0.0, 0.0, 0.01]], dtype=F32), (n, 1))
+
+
+STREAMED_SCENES = {"shelf": shelf_scene, "tshape": tshape_scene, "ring": ring_scene, "wall": wall_scene, "line": line_scene,
+                   "cross": cross_scene}
 
 
 def planar7_scene(n_extra: int = 4, seed: int = 7) -> np.ndarray:

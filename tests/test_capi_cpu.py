@@ -128,3 +128,50 @@ def test_fk_num_mirror_matches_reference_vectors():
         assert len(dh_fk(q[0], dh)) == q.shape[1] + 1
         for b in range(q.shape[0]):   # last sample point of every link = the end point the FK cost compares
             assert np.abs(orc.link_endpoints(fx[kind + "_q"][b], fx[kind + "_dh"]) - fx[kind + "_links4"][b, :, -1, :]).max() < 2e-6
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """A host without a loadable librccl must end in OMDS_ERR_RCCL with a message (the documented 'no fallback, raises'),
+    never in a crash inside the loader.  Own process: the RCCL loader is a per-process singleton."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from optimalmodulationds_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "buf = (C.c_uint8 * 128)()\n"
+        "rc = lib.omds_comm_unique_id(buf)\n"
+        "msg = (lib.omds_comm_last_error() or b'').decode()\n"
+        "print('RC', rc, '|', msg)\n"
+        "from optimalmodulationds_amd.engine import Engine\n"
+        "try:\n"
+        "    Engine.comm_unique_id()\n"
+        "except _lib.OmdsError as e:\n"
+        "    print('RAISED', e)\n"
+    )
+    env = dict(os.environ, OMDS_RCCL_LIB="/nonexistent/librccl-not-here.so")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "RC 3 |" in r.stdout and "RCCL not available" in r.stdout and "librccl-not-here" in r.stdout, r.stdout
+    assert "RAISED" in r.stdout
+
+
+def test_stale_library_version_is_reported(tmp_path, lib):
+    """A build of another ABI version is refused with a message that says how to rebuild (not a bare AttributeError)."""
+    from optimalmodulationds_amd import _lib
+    assert lib.omds_version() == _lib.ABI_VERSION
+    import subprocess
+    import sys
+    code = (
+        "import sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from optimalmodulationds_amd import _lib\n"
+        "_lib.ABI_VERSION = 299\n"
+        "try:\n"
+        "    _lib.load()\n"
+        "except _lib.OmdsError as e:\n"
+        "    print('RAISED', e)\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "RAISED" in r.stdout and "ABI version 300" in r.stdout and "rebuild" in r.stdout, r.stdout + r.stderr

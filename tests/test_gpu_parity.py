@@ -301,8 +301,8 @@ def test_error_paths():
         eng.set_mlp([np.zeros((384, 30), np.float32), wide, np.zeros((9, 384), np.float32)],
                     [np.zeros(384, np.float32), np.zeros(384, np.float32), np.zeros(9, np.float32)])
     eng.set_mlp(m.W, m.b)
-    with pytest.raises(L.OmdsError, match="max_obs"):
-        eng.set_obstacles(np.zeros((9, 4), np.float32))
+    eng.set_obstacles(np.zeros((9, 4), np.float32))         # beyond max_obs = 8: the context grows its obstacle buffers
+    assert eng.max_obs >= 9
     with pytest.raises(L.OmdsError, match="n_closest"):
         eng.set_obstacles(np.zeros((1, 4), np.float32))     # fewer obstacles than k
     eng.set_obstacles(np.ones((4, 4), np.float32))
@@ -444,7 +444,7 @@ def test_seds_nominal_ds_on_device(name, kind, flags):
     # denormal or 0 -- mixture output or linear fallback -- hangs on the last bit of its Mahalanobis form
     ddm = (q - qf)[:, None, :] - seds["mu_in"][None]
     denorm = (-0.5 * np.einsum("ngr,grc,ngc->ng", ddm, seds["sigma_inv"], ddm)).max(axis=1) < -85.0
-    edge = cancel | denorm | (np.abs(st["unorm"] - prm.norm_clamp) < 1e-4) | (np.abs(st["distance"]) < 1e-6) | (np.abs(st["ga"] - prm.goal_act_cut) < 1e-6) | \
+    edge = cancel | denorm | near_thr | (np.abs(st["unorm"] - prm.norm_clamp) < 1e-4) | (np.abs(st["distance"]) < 1e-6) | (np.abs(st["ga"] - prm.goal_act_cut) < 1e-6) | \
            (np.abs(np.linalg.norm(v, axis=1) - 1e-2) < 1e-4) | ~np.isfinite(st["u"]).all(axis=1)
     keep = ~edge
     # far outside the demonstrations the responsibilities are ratios of exp(-100 .. -10^5): order-sensitive in fp32 for ~40 % of
@@ -456,4 +456,12 @@ def test_seds_nominal_ds_on_device(name, kind, flags):
     # nominal DS (franka_seds_integrator_N1) passes the generic tests at their usual bars
     assert_close(r["dot_products"][keep, 0], st["dot"][keep], 2e-4, "normal . nominal direction")
     assert np.abs(r["qdot"][keep] - st["u"][keep]).max() <= 2e-4 * scale, float(np.abs(r["qdot"][keep] - st["u"][keep]).max())
+    # where fp32 is well conditioned -- some component's exponent above -20, so the responsibilities are ratios of normal
+    # numbers -- the device must agree at the bar of every other stage
+    well = keep & ((-0.5 * np.einsum("ngr,grc,ngc->ng", ddm, seds["sigma_inv"], ddm)).max(axis=1) > -20.0)
+    print(f"SEDS {name}: kept {keep.mean():.2f}, well-conditioned {well.mean():.2f}, "
+          f"max err kept {float(np.abs(r['qdot'][keep] - st['u'][keep]).max()):.2e}"
+          + (f", well {float(np.abs(r['qdot'][well] - st['u'][well]).max()):.2e}" if well.any() else ""))
+    if well.any():
+        assert np.abs(r["qdot"][well] - st["u"][well]).max() <= 5e-5 * scale, float(np.abs(r["qdot"][well] - st["u"][well]).max())
     eng.close()
