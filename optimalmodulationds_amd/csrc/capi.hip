@@ -117,12 +117,13 @@ static void free_all(omds_ctx* ctx) {
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
                     ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
                     ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
-                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP, ctx->d_seds, ctx->d_audit_rows, ctx->d_audit_da, ctx->d_ApreAll, ctx->d_featQAll};
+                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP, ctx->d_seds, ctx->d_audit_rows, ctx->d_audit_da, ctx->d_ApreAll, ctx->d_featQAll, ctx->d_FqS, ctx->d_FpS, ctx->d_listDa, ctx->d_sinks};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : ctx->mlp_allocs)
         if (p) (void)hipFree(p);
     if (ctx->h_red) (void)hipHostFree(ctx->h_red);
+    if (ctx->h_sinks) (void)hipHostFree(ctx->h_sinks);
     for (auto e : ctx->prof.start) (void)hipEventDestroy(e);
     for (auto e : ctx->prof.stop) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -198,6 +199,7 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
     CKC(hipMalloc(&ctx->d_Apre, rows2 * OMDS_WIDTH * 4));
     CKC(hipMalloc(&ctx->d_Dmin, N * Om * 4));
     CKC(hipMalloc(&ctx->d_rowlist, N * Om * 4));
+    CKC(hipMalloc(&ctx->d_listDa, N * Om * 4));
     CKC(hipMalloc(&ctx->d_range, N * 4 * 4));
     ctx->ex_cap = (int)std::min<size_t>(N * Om, N * 32);   // 32 candidates per rollout on average; longer lists -> fp32 fallback
     CKC(hipMalloc(&ctx->d_exD, (size_t)ctx->ex_cap * 4));
@@ -205,6 +207,8 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
     CKC(hipMalloc(&ctx->d_exMin, (size_t)ctx->ex_cap * 4));
     CKC(hipMalloc(&ctx->d_exMask, (size_t)ctx->ex_cap * (OMDS_MAX_HIDDEN + 1) * 8 * 4));
     CKC(hipMalloc(&ctx->d_sctotal, (H + 2) * 4));
+    CKC(hipMalloc(&ctx->d_sinks, H * sizeof(SelectSink)));
+    CKC(hipHostMalloc(&ctx->h_sinks, H * sizeof(SelectSink)));
     CKC(hipMalloc(&ctx->d_scerr, 16));
     CKC(hipMalloc(&ctx->d_idx, rows2 * 4));
     CKC(hipMalloc(&ctx->d_gradx, rows2 * d * 4));
@@ -428,7 +432,18 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
     ctx->screen_consec = 0;
     std::vector<uint16_t> wh;
     std::vector<float> sbias;
-    if (act == OMDS_ACT_RELU && m.nhh >= 1 && m.nhh <= 4 && !skip_mask) {   // skip-connection networks run the fp32 step
+    // Behind a skip concatenation (level L = output of Linear L) the consuming layer's input columns are packed in a VIRTUAL
+    // order: its own c0 = out_dims[L] columns first, the 3d concatenated input columns LAST (virtual 256 - 3d .. 255 = k-chunks
+    // 14 and 15 whatever c0 is -- the K order of a dot product is free), zeros in between: omds_screen_sidx puts the inputs there
+    auto real_col = [&](int consumer, int v) -> int {   // virtual input column v of Linear `consumer` -> column of Wpad, -1 = zero
+        const int L = consumer - 1;
+        if (L < 0 || !((skip_mask >> L) & 1u)) return v;
+        const int c0 = out_dims[L];
+        if (v < c0) return v;
+        if (v >= Wd - F) return c0 + (v - (Wd - F));
+        return -1;
+    };
+    if ((act == OMDS_ACT_RELU || act == OMDS_ACT_TANH) && m.nhh >= 1 && m.nhh <= 4) {
         const int nsl = m.nhh * 8 + 2;
         wh.assign((size_t)nsl * 16 * 64 * 8, 0);
         sbias.assign((size_t)(m.nhh + 2) * Wd, 0.f);
@@ -443,13 +458,14 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
                     }
         for (int sl = 1; sl < nsl; ++sl) {
             const bool lastl = sl == nsl - 1;
-            const float* Wsrc = lastl ? W[n_linear - 1] : W[(sl - 1) / 8 + 1];
+            const int lin = lastl ? n_linear - 1 : (sl - 1) / 8 + 1;   // the Linear layer this slice belongs to
+            const float* Wsrc = W[lin];
             const int fb = lastl ? 0 : (sl - 1) % 8, rows = lastl ? C : Wd;
             for (int cc = 0; cc < 16; ++cc)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
-                        const int r = 32 * fb + (lane & 31), kk = 16 * cc + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
-                        const float v = (r < rows) ? Wsrc[(size_t)r * Wd + kk] : 0.f;
+                        const int r = 32 * fb + (lane & 31), kk = real_col(lin, 16 * cc + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3));
+                        const float v = (r < rows && kk >= 0) ? Wsrc[(size_t)r * Wd + kk] : 0.f;
                         wh[(((size_t)sl * 16 + cc) * 64 + lane) * 8 + j] = f32_to_f16_bits(v);
                     }
         }
@@ -464,6 +480,15 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
         if ((rc = upload(ctx, sbias, &ctx->screen.bias))) return rc;
         ctx->screen.Wh = dwh;
         ctx->screen_ok = true;
+        if (skip_mask) {   // the concatenation operands of the screening kernel (omds_screen_sidx), beside FqH / FpH
+            const size_t bq = (size_t)ctx->cfg.n_traj * 32 * 2, bp = (size_t)ctx->cfg.max_obs * 32 * 2;
+            if (!ctx->d_FqS) CK(hipMalloc(&ctx->d_FqS, bq));
+            if (!ctx->d_FpS) CK(hipMalloc(&ctx->d_FpS, bp));
+            CK(hipMemsetAsync(ctx->d_FqS, 0, bq, ctx->stream));
+            CK(hipMemsetAsync(ctx->d_FpS, 0, bp, ctx->stream));
+            m.scrQ = ctx->d_FqS;
+            m.scrP = ctx->d_FpS;
+        }
     }
     if ((rc = upload(ctx, wf16, &m.Wf16))) return rc;
     if ((rc = upload(ctx, wb16, &m.Wb16))) return rc;
@@ -514,8 +539,8 @@ static int grow_obstacle_capacity(omds_ctx* ctx, int n_obs) {
             "omds_set_obstacles: n_traj * (grown obstacle capacity) must stay below 2^31");
     CK(hipStreamSynchronize(ctx->stream));
     void** olds[] = {(void**)&ctx->d_obs, (void**)&ctx->d_Bpre, (void**)&ctx->d_radius, (void**)&ctx->d_FpH, (void**)&ctx->d_Dmin,
-                     (void**)&ctx->d_rowlist, (void**)&ctx->d_featP};
-    const bool had_featP = ctx->d_featP != nullptr;
+                     (void**)&ctx->d_rowlist, (void**)&ctx->d_listDa, (void**)&ctx->d_featP, (void**)&ctx->d_FpS};
+    const bool had_featP = ctx->d_featP != nullptr, had_FpS = ctx->d_FpS != nullptr;
     for (void** o : olds) { if (*o) (void)hipFree(*o); *o = nullptr; }
     CK(hipMalloc(&ctx->d_obs, Om * 4 * 4));
     CK(hipMalloc(&ctx->d_Bpre, std::max(Om, rows2) * OMDS_WIDTH * 4));
@@ -524,6 +549,12 @@ static int grow_obstacle_capacity(omds_ctx* ctx, int n_obs) {
     CK(hipMemsetAsync(ctx->d_FpH, 0, Om * 32 * 2, ctx->stream));
     CK(hipMalloc(&ctx->d_Dmin, N * Om * 4));
     CK(hipMalloc(&ctx->d_rowlist, N * Om * 4));
+    CK(hipMalloc(&ctx->d_listDa, N * Om * 4));
+    if (had_FpS) {
+        CK(hipMalloc(&ctx->d_FpS, Om * 32 * 2));
+        CK(hipMemsetAsync(ctx->d_FpS, 0, Om * 32 * 2, ctx->stream));
+        ctx->mlp.scrP = ctx->d_FpS;
+    }
     if (had_featP) {
         CK(hipMalloc(&ctx->d_featP, Om * 32 * 4));
         CK(hipMemsetAsync(ctx->d_featP, 0, Om * 32 * 4, ctx->stream));
@@ -887,8 +918,9 @@ static bool small_step_wanted(omds_ctx* ctx) {
 
 // Buffers of the audit sample (allocated at the first screened propagate, grown when the scene or the rate asks for more):
 // the list itself -- about N*H*O / one_in entries, room for twice that -- and the layer-1 table of all horizon steps.
-static int prepare_audit(omds_ctx* ctx, AuditSink& au) {
-    au = AuditSink{};
+static int prepare_audit(omds_ctx* ctx, SelectSink& sk) {
+    sk.audit_rows = nullptr; sk.audit_da = nullptr; sk.audit_total = ctx->d_sctotal + (ctx->cfg.horizon + 1); sk.audit_cap = 0;
+    sk.audit_mask = 0xffffffffu;
     const long long N = ctx->cfg.n_traj, H = ctx->cfg.horizon, O = ctx->n_obs;
     if (ctx->audit_one_in <= 0 || N * H * O >= (1LL << 31)) return OMDS_OK;   // no audit (or a row space beyond 32-bit indices)
     const long long want = N * H * (2 * O / ctx->audit_one_in + 4);
@@ -906,11 +938,10 @@ static int prepare_audit(omds_ctx* ctx, AuditSink& au) {
         CK(hipMalloc(&ctx->d_featQAll, (size_t)N * H * 32 * 4));
         CK(hipMemsetAsync(ctx->d_featQAll, 0, (size_t)N * H * 32 * 4, ctx->stream));
     }
-    au.rows = ctx->d_audit_rows;
-    au.da = ctx->d_audit_da;
-    au.total = ctx->d_sctotal + (H + 1);
-    au.cap = ctx->audit_cap;
-    au.mask = (unsigned)ctx->audit_one_in - 1u;
+    sk.audit_rows = ctx->d_audit_rows;
+    sk.audit_da = ctx->d_audit_da;
+    sk.audit_cap = ctx->audit_cap;
+    sk.audit_mask = (unsigned)ctx->audit_one_in - 1u;
     return OMDS_OK;
 }
 
@@ -942,28 +973,52 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
         // is updated in place
         float* apre0 = ctx->d_Apre;
         size_t apre_slab = 0;
-        AuditSink au{};
+        SelectSink sink{};
+        // ReLU networks: k_exact leaves masks and k_tail_sel runs the backward only; when a rollout's obstacles fit a
+        // workgroup's LDS, k_screen selects in its flush phase (no matrix, no k_select).  tanh networks: k_screen writes the
+        // matrix, k_exact puts the exact values of the candidates into it and k_tail works from the matrix as in the fp32 step
+        const bool relu = ctx->mlp.act == OMDS_ACT_RELU;
+        static int fuse_env = -2;   // OMDS_SCREEN_FUSE_SELECT=0: keep k_select as its own launch (A/B runs)
+        if (fuse_env == -2) { const char* e = getenv("OMDS_SCREEN_FUSE_SELECT"); fuse_env = e ? atoi(e) : 1; }
+        const bool fuse_select = screen && relu && fuse_env != 0 && omds_screen_can_select(ctx->n_obs);
         if (screen) {
             CK(hipMemsetAsync(ctx->d_sctotal, 0, (size_t)(H + 2) * 4, ctx->stream));
             CK(hipMemsetAsync(ctx->d_scerr, 0, 16, ctx->stream));
-            if ((rc = prepare_audit(ctx, au))) return rc;
-            if (au.rows) { apre0 = ctx->d_ApreAll; apre_slab = (size_t)N * OMDS_WIDTH; }
+            sink.rowlist = ctx->d_rowlist;
+            sink.listDa = fuse_select ? ctx->d_listDa : nullptr;
+            sink.range = ctx->d_range;
+            sink.k = a.k;
+            sink.delta = OMDS_SCREEN_WINDOW * ctx->screen_eps;
+            if ((rc = prepare_audit(ctx, sink))) return rc;
+            if (sink.audit_rows) { apre0 = ctx->d_ApreAll; apre_slab = (size_t)N * OMDS_WIDTH; }
+        }
+        ex.Da = sink.listDa;
+        SelectSink* d_sinks = static_cast<SelectSink*>(ctx->d_sinks);
+        if (screen) {   // the sinks of all steps in one copy (the pinned staging is free: the previous propagate has been synchronised)
+            SelectSink* hs = static_cast<SelectSink*>(ctx->h_sinks);
+            for (int i = 1; i <= H; ++i) {
+                hs[i - 1] = sink;
+                hs[i - 1].total = ctx->d_sctotal + (i - 1);
+                hs[i - 1].audit_seed = 0x9E3779B9u * ++ctx->audit_counter;
+                hs[i - 1].step_row0 = (i - 1) * N;
+            }
+            CK(hipMemcpyAsync(d_sinks, hs, (size_t)H * sizeof(SelectSink), hipMemcpyHostToDevice, ctx->stream));
         }
         omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, apre0, screen ? ctx->d_FqH : nullptr, N);
         for (int i = 1; i <= H; ++i) {
+            float* apre_i = apre0 + (size_t)(i - 1) * apre_slab;
+            float* apre_next = apre0 + (size_t)std::min(i, H - 1) * apre_slab;
             {
                 RoctxRange r1("TAG: evaluate NN_2 (forward pass)");
                 if ((rc = prof_begin(ctx))) return rc;
                 if (screen) {
+                    sink = static_cast<const SelectSink*>(ctx->h_sinks)[i - 1];
                     omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_FqH, ctx->cfg.n_traj, ctx->d_FpH, ctx->cfg.max_obs, ctx->d_radius, ctx->n_obs, N,
-                                       ctx->prm.ignored_links, ctx->d_Dmin);
+                                       ctx->prm.ignored_links, ctx->d_Dmin, fuse_select ? d_sinks + (i - 1) : nullptr);
                     if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs, -1.0, "k_screen"))) return rc;
-                    au.seed = 0x9E3779B9u * ++ctx->audit_counter;
-                    au.step_row0 = (i - 1) * N;
-                    omds_launch_select(ctx->stream, ctx->d_Dmin, N, ctx->n_obs, a.k, OMDS_SCREEN_WINDOW * ctx->screen_eps, ctx->d_rowlist, ctx->d_range,
-                                       ctx->d_sctotal + (i - 1), au);
-                    omds_launch_exact(ctx->stream, ctx->mlp, apre0 + (size_t)(i - 1) * apre_slab, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
-                                      ctx->prm.ignored_links, ctx->d_Dmin, ctx->d_rowlist, ctx->d_sctotal + (i - 1), ctx->d_scerr, ex);
+                    if (!fuse_select) omds_launch_select(ctx->stream, ctx->d_Dmin, N, ctx->n_obs, sink);
+                    omds_launch_exact(ctx->stream, ctx->mlp, apre_i, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
+                                      ctx->prm.ignored_links, ctx->d_Dmin, ctx->d_rowlist, sink.total, ctx->d_scerr, ex);
                 } else {
                     omds_launch_pass1(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
                                       ctx->prm.ignored_links, ctx->d_Dmin);
@@ -972,14 +1027,17 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
             }
             RoctxRange r2("TAG: evaluate NN_3-5 + Modulation-propagation");
             a.step = i;
-            if (screen)
-                omds_launch_tail_sel(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, apre0 + (size_t)std::min(i, H - 1) * apre_slab, ctx->n_obs, a,
+            if (screen && relu)
+                omds_launch_tail_sel(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, apre_next, ctx->n_obs, a,
                                      ctx->d_rowlist, ctx->d_range, ex, ctx->d_FqH, N, ctx->screen_eps, ctx->d_scerr + 1);
+            else if (screen)
+                omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, apre_i,
+                                 ctx->d_dscr, ctx->n_obs, a, 0, N, ctx->d_FqH, N, apre_next, ctx->d_range, ctx->screen_eps, ctx->d_scerr + 1);
             else
                 omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, ctx->d_Apre,
                                  ctx->d_dscr, ctx->n_obs, a, 0, N);
         }
-        if (screen && au.rows) {
+        if (screen && sink.audit_rows) {
             // The audit sample of this propagate in one throughput-shaped launch: k_audit on the recorded pairs against the
             // kept layer-1 slabs of all horizon steps -> d_scerr[2] = max (Da - D)
             RoctxRange r3("screening audit sample (fp32 re-evaluation of unevaluated pairs)");
@@ -990,7 +1048,7 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
                 omds_launch_rollout_layer1(ctx->stream, ma, ctx->d_trajT, N, H * N, ctx->d_ApreAll, nullptr, 0, N);
             }
             omds_launch_audit(ctx->stream, ma, ctx->d_ApreAll, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, ctx->prm.ignored_links,
-                              ctx->d_audit_rows, ctx->d_audit_da, ctx->d_sctotal + (H + 1), ctx->audit_cap, ctx->d_scerr);
+                              sink.audit_rows, sink.audit_da, sink.audit_total, sink.audit_cap, ctx->d_scerr);
         }
     } else {
         for (int i = 1; i <= H; ++i) {   // MPPI.py:101: H network evaluations, the last velocity is not integrated

@@ -208,7 +208,8 @@ struct OmdsDivisor {
 // step_small.hip): rows as in mode 0, outputs as in mode 1 but indexed by the row within the tile (ex-> pointers are LDS
 // arrays) and the masks stay in the tile's LDS block (maskS, behind rowIdx).  MODE 4 (audit sample, k_audit): rows as in
 // mode 1, the rollout index of a pair running over all horizon steps' states; no outputs but max (ex->Da[entry] - exact value)
-// into maxerr_bits[2].
+// into maxerr_bits[2].  MODE 3 (screened step of tanh networks): rows as in mode 1; the exact value overwrites the pair's
+// screening value in Dmin, max |screening - exact| goes to *maxerr_bits, nothing else is kept.
 // The arithmetic of a row is the same in all forms and independent of the other rows of the tile: bit-identical results.
 template <int MT, int MR, int NR, int ACT, int MODE = 0>
 __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const float* __restrict__ Apre,
@@ -217,7 +218,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                                            const long long row0, const OmdsDivisor odiv,
                                            const int* __restrict__ rowlist = nullptr, unsigned* maxerr_bits = nullptr,
                                            const ExactOut* ex = nullptr) {
-    constexpr bool LIST = MODE == 1 || MODE == 4, EMIT = MODE == 1 || MODE == 2;
+    constexpr bool LIST = MODE == 1 || MODE == 3 || MODE == 4, EMIT = MODE == 1 || MODE == 2;
     using G = Geo<MT, MR, NR>;
     float* Hs = smem;                                           // [MT][LDH]
     float* rowRad = smem + MT * LDH;                            // [MT] obstacle radius of each row
@@ -438,9 +439,10 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
         const int r4 = rb * 16 + 4 * (lane >> 4);
         [[maybe_unused]] float scr[4];   // LIST: the screening values of this lane's four rows (guard), in flight across the MFMA loop
         if constexpr (LIST) {
+            const bool have_da = MODE == 4 || ex->Da != nullptr;   // the pair's screening value: the copy the selection took, or k_screen's matrix
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg)   // the pair's screening value: k_screen's matrix, or (audit list) the copy k_select took
-                scr[reg] = (row0 + r4 + reg < total_rows) ? (MODE == 4 ? ex->Da[row0 + r4 + reg] : Dmin[rowIdx[r4 + reg]]) : 0.f;
+            for (int reg = 0; reg < 4; ++reg)
+                scr[reg] = (row0 + r4 + reg < total_rows) ? (have_da ? ex->Da[row0 + r4 + reg] : Dmin[rowIdx[r4 + reg]]) : 0.f;
         }
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
@@ -504,6 +506,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                         if constexpr (MODE == 1) {
                             if (e_idx < ex->cap) { ex->D[e_idx] = y[reg]; ex->dr[e_idx] = ydr[reg]; ex->amin[e_idx] = yam[reg]; }
                         }
+                        if constexpr (MODE == 3) Dmin[rowIdx[r4 + reg]] = y[reg];   // the exact value takes the screening value's place
                     }
                 }
                 if (me > 0.f) atomicMax(maxerr_bits + (MODE == 4 ? 2 : 0), __builtin_bit_cast(unsigned, me));   // non-negative floats order like their bits

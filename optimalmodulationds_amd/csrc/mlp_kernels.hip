@@ -41,6 +41,12 @@ __global__ __launch_bounds__(256) void k_rollout_layer1(MlpDev m, const float* _
             FqH[omds_screen_fidx(c, t, ldF)] = (_Float16)q;
             FqH[omds_screen_fidx(d + c, t, ldF)] = (_Float16)f[n + c];
             FqH[omds_screen_fidx(2 * d + c, t, ldF)] = (_Float16)f[2 * n + c];
+            if (m.scrQ) {   // skip-connection networks: the same values at the slots of the concatenated columns
+                _Float16* S = reinterpret_cast<_Float16*>(m.scrQ);
+                S[omds_screen_sidx(c, 3 * d, t, ldF)] = (_Float16)q;
+                S[omds_screen_sidx(d + c, 3 * d, t, ldF)] = (_Float16)f[n + c];
+                S[omds_screen_sidx(2 * d + c, 3 * d, t, ldF)] = (_Float16)f[2 * n + c];
+            }
         }
         if (m.featQ) {   // skip-connection networks: the encoded input itself, concatenated behind a hidden layer
             m.featQ[(size_t)t * 32 + c] = q;
@@ -70,6 +76,12 @@ __global__ __launch_bounds__(256) void k_obstacle_layer1(MlpDev m, const float* 
             FpH[omds_screen_fidx(n + c, o, ldF)] = (_Float16)p;
             FpH[omds_screen_fidx(d + n + c, o, ldF)] = (_Float16)f[3 + c];
             FpH[omds_screen_fidx(2 * d + n + c, o, ldF)] = (_Float16)f[6 + c];
+            if (m.scrP) {
+                _Float16* S = reinterpret_cast<_Float16*>(m.scrP);
+                S[omds_screen_sidx(n + c, 3 * d, o, ldF)] = (_Float16)p;
+                S[omds_screen_sidx(d + n + c, 3 * d, o, ldF)] = (_Float16)f[3 + c];
+                S[omds_screen_sidx(2 * d + n + c, 3 * d, o, ldF)] = (_Float16)f[6 + c];
+            }
         }
         if (featP) {
             featP[(size_t)o * 32 + n + c] = p;

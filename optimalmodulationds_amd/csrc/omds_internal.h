@@ -46,6 +46,10 @@ struct MlpDev {
     uint8_t skip_col[OMDS_MAX_HIDDEN + 1];
     float* featQ;        // [Apre rows][32] joint part of the encoded input of each Apre row (others 0); null without skips
     float* featP;        // [max_obs][32] obstacle part of each Bpre row
+    // the same encoded input as fp16 at the slots of the CONCATENATED columns of the screening kernel (omds_screen_sidx), written
+    // beside FqH / FpH with their row capacities; null without skips or without a screening network
+    uint16_t* scrQ;      // [4 pieces][n_traj][8]
+    uint16_t* scrP;      // [4 pieces][max_obs][8]
 #ifdef OMDS_TIMELINE
     unsigned long long* tl;   // diagnostic build only (make TIMELINE=1): [workgroup][8] phase timestamps of k_pass1
 #endif
@@ -61,6 +65,16 @@ struct ScreenDev {
 // screening kernel: 16-byte piece kappa / 8 (= k-chunk kappa / 16, lane-half (kappa / 8) & 1), slot kappa % 8
 __host__ __device__ inline size_t omds_screen_fidx(int kappa, int t, int stride) {
     return ((size_t)(kappa >> 3) * stride + t) * 8 + (kappa & 7);
+}
+
+// The screening kernel's weight pack puts the 3d concatenated input columns of a layer behind a skip concatenation LAST: virtual
+// columns 256 - 3d .. 255 = k-chunks 14 and 15 (the K order of a dot product is free).  Element index of feature kappa
+// (< 3d <= 32) of row t in the skip tables: virtual column v -> chunk v / 16 - 14, C-layout slot as for every hidden activation
+// (lane-half ((v & 15) >> 2) & 1, slot 4 ((v & 15) >> 3) + (v & 3)); 16-byte piece 2 chunk + half
+__host__ __device__ inline size_t omds_screen_sidx(int kappa, int F, int t, int stride) {
+    const int v = 256 - F + kappa, f = v & 15;
+    const int piece = 2 * ((v >> 4) - 14) + ((f >> 2) & 1), slot = 4 * (f >> 3) + (f & 3);
+    return ((size_t)piece * stride + t) * 8 + slot;
 }
 
 // hipFuncSetAttribute applies to the current device only: true the first time a kernel is launched on each device.
@@ -136,6 +150,11 @@ struct omds_ctx {
     float* d_featQ = nullptr;    // [n_traj*n_closest][32] / [max_obs][32] encoded inputs (skip-connection networks, MlpDev::featQ/featP)
     float* d_featP = nullptr;
     uint16_t* d_FqH = nullptr;   // [4][batch][8] rollout states likewise
+    uint16_t* d_FqS = nullptr;   // skip-connection networks with a screening network: MlpDev::scrQ / scrP
+    uint16_t* d_FpS = nullptr;
+    float* d_listDa = nullptr;   // [N*max_obs] screening values of the candidate list (k_screen's selecting flush)
+    void* d_sinks = nullptr;     // [H] SelectSink of every horizon step of the running propagate (device copy + pinned staging)
+    void* h_sinks = nullptr;
     float* d_radius = nullptr;   // [max_obs]
     // DS / cost
     bool have_ds = false, have_cost = false;
@@ -243,9 +262,14 @@ void omds_launch_blend(hipStream_t s, const float* gradx, const float* drow, int
                        float softmax_k, float* dist, float* nngrad);
 
 // ---- launchers implemented in screen_kernel.hip -----------------------------------------------
+struct SelectSink;
+// sel != nullptr (a DEVICE pointer to the step's sink; needs omds_screen_can_select(O)): every workgroup owns whole rollouts
+// and its flush phase selects their candidates from LDS -- Dmin is not written and no k_select runs; otherwise the N x O
+// matrix goes to Dmin
 void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, const uint16_t* FqH, int ldFq, const uint16_t* FpH,
-                        int ldFp, const float* radius, int O, int B, uint32_t ignored, float* Dmin);
+                        int ldFp, const float* radius, int O, int B, uint32_t ignored, float* Dmin, const SelectSink* sel = nullptr);
 bool omds_screen_supported(const MlpDev& m);
+bool omds_screen_can_select(int O);
 // What k_exact leaves behind for the screened step's tail (k_tail_sel), per entry of the candidate list: the pass-1 value,
 // and everything pass 2's forward would produce for that row -- its arithmetic is the same bit for bit -- so that the tail
 // only runs the backward: the pass-2 distance, the arg-min link, and the ReLU masks of every hidden layer.  mask layout per
@@ -265,19 +289,26 @@ struct ExactOut {
     const float* Da = nullptr;   // audit list only (pass1_tile mode 4): [entries] screening value of each listed pair
 };
 
-// Audit sample of a propagate: k_select records a non-candidate pair when (hash(pair ^ seed) & mask) == 0 as
-// (row = (step_row0 + t) * O + o, screening value); rows == nullptr: no audit.  omds_launch_audit evaluates the list in fp32
-// against the layer-1 table of all horizon steps' states and leaves max (Da - D) in maxerr_bits[2].
-struct AuditSink {
-    int* rows = nullptr;
-    float* da = nullptr;
-    int* total = nullptr;
-    int cap = 0;
-    unsigned mask = 0xffffffffu, seed = 0;
-    int step_row0 = 0;
+// What the selection (k_select, or the flush phase of k_screen) produces per horizon step
+struct SelectSink {
+    int* rowlist = nullptr;   // [N*O] compact list of candidate rows t*O + o
+    float* listDa = nullptr;  // [N*O] their screening values (what k_exact compares its exact values with), or nullptr
+    int* range = nullptr;     // [N][4] start and length of each rollout's entries in the list, tau (float bits), unused
+    int* total = nullptr;     // number of listed rows (zeroed before the launch)
+    int k = 0;
+    float delta = 0.f;        // tau = (k-th smallest screening value) + delta
+    // AUDIT sample: a non-candidate pair is recorded when (hash(pair ^ audit_seed) & audit_mask) == 0 (mask
+    // 0xffffffff: never) as (row = (step_row0 + t) * O + o, screening value) in a list of the whole propagate;
+    // omds_launch_audit evaluates the list in fp32 against the layer-1 slabs of all horizon steps: max (Da - D) -> maxerr_bits[2]
+    unsigned audit_mask = 0xffffffffu;
+    unsigned audit_seed = 0;  // changes with every horizon step and propagate, so that over time every pair gets audited
+    int* audit_rows = nullptr;   // [audit_cap]
+    float* audit_da = nullptr;   // [audit_cap]
+    int* audit_total = nullptr;  // entries recorded so far in this propagate (may exceed audit_cap: the excess is dropped)
+    int audit_cap = 0;
+    int step_row0 = 0;        // (step - 1) * N: row of rollout 0 in the all-steps layer-1 table k_audit reads
 };
-void omds_launch_select(hipStream_t s, const float* Dmin, int B, int O, int k, float delta, int* rowlist, int* range, int* total,
-                        const AuditSink& au);
+void omds_launch_select(hipStream_t s, const float* Dmin, int B, int O, const SelectSink& sel);
 void omds_launch_audit(hipStream_t s, const MlpDev& m, const float* ApreAll, const float* Bpre, const float* radius, int O,
                        uint32_t ignored, const int* rows, const float* da, const int* total, int cap, unsigned* maxerr_bits);
 // calibration of the screening bound on the device: the batch of states, and max |x - y| into *out_bits (float bits, atomicMax)
@@ -308,9 +339,13 @@ void omds_launch_modulate(hipStream_t s, const StepArgs& a);
 bool omds_tail_supported(int n_dof, int k);
 int omds_tail_scratch_rows(int N, int k);
 int omds_tail_rows(int N, int k);            // pass-2 tile height (16 | 32) for a batch of N rollouts with k closest obstacles   // rows of the tanh-derivative scratch the tail may touch (either tile height)
+// ApreOut: where the next step's layer-1 halves go (nullptr: in place).  guard_range / e_bound / viol: screened tanh step --
+// Dmin holds exact values on the candidates and screening values elsewhere; the tail counts the rollouts whose k-th smallest
+// value is not e_bound below k_select's tau (range[4 t + 2]) into *viol
 void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
                       const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st, int t_begin, int t_end,
-                      uint16_t* FqH = nullptr, int ldF = 0);
+                      uint16_t* FqH = nullptr, int ldF = 0, float* ApreOut = nullptr, const int* guard_range = nullptr,
+                      float e_bound = 0.f, unsigned* viol = nullptr);
 // screened step's tail: top-k over the candidates k_exact evaluated + pass-2 backward on its masks + the rest of k_tail
 bool omds_tail_sel_supported(int n_dof, int k);
 void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,

@@ -73,20 +73,35 @@ struct ScreenArgs {
     const float* bias;       // [nhh + 2][256]: layer 1, hidden->hidden, the last layer's (padded with zeros)
     const _Float16* FqH;     // [4 pieces][ldFq rows][8]: fp16 network inputs of the rollouts (q, sin q, cos q at their feature slots)
     const _Float16* FpH;     // [4][ldFp][8]: obstacle points likewise (omds_screen_fidx)
-    int ldFq, ldFp;          // row capacities of the two tables
+    const _Float16* FqS;     // skip-connection networks: the same inputs at the slots of the CONCATENATED columns (omds_screen_sidx)
+    const _Float16* FpS;
+    int ldFq, ldFp;          // row capacities of the tables
     const float* radius;
     float* Dmin;
     long long total_rows;
+    // workgroup w owns units_base + (w < units_rem) consecutive UNITS of `unit` pairs (a unit = a 256-pair tile, or -- when the
+    // flush phase selects -- a whole rollout of O pairs), starting at unit w * units_base + min(w, units_rem)
+    int unit, units_base, units_rem;
     int B, O;
     uint32_t ignored;
+    uint32_t skip_mask;      // bit L: the encoded input is concatenated behind level L (MlpDev::skip_mask)
     OmdsDivisor odiv;
     int nhh, C;
     float out_div;
     int res_tiles;           // tiles per workgroup (capacity of the result buffer in LDS)
+    const SelectSink* sel;   // device memory, or nullptr.  Non-null: the flush phase selects each rollout's candidates instead of writing
+                             // Dmin.  A pointer on purpose: as kernel arguments the sink's 20 dwords were loaded at entry and held in
+                             // SGPRs across the tile loop (SGPR spills 36 -> 114)
     unsigned long long* tl;  // diagnostic (OMDS_SCREEN_TL=1): [workgroup][8] s_memtime stamps, nullptr otherwise
     int dbg;                 // timing experiments only (OMDS_SCREEN_DBG): 1 = no weight streaming after the prologue,
                              // 2 = no layer-1 loads, 4 = no per-slice wait + barrier
 };
+
+// lowbias32 (an integer hash with good avalanche): which non-candidate pairs enter the audit sample
+__device__ __forceinline__ unsigned omds_audit_hash(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
 
 // LDS-DMA: 16 bytes per lane from gsrc (per-lane address) to LDS [lds_dst + 16 * lane] (lds_dst wave-uniform).  Invisible
 // to hipcc's s_waitcnt bookkeeping by design: completion is waited for with counted vmcnt below.
@@ -120,10 +135,20 @@ __device__ __forceinline__ void wait_vm_barrier(int n) {
     }
 }
 
-__device__ __forceinline__ h2 relu_pk(float a, float b) {
-    h2 p = {(_Float16)a, (_Float16)b};                 // v_cvt_pk_f16_f32 (round to nearest even)
-    const h2 z = {(_Float16)0, (_Float16)0};
-    return __builtin_elementwise_max(p, z);            // v_pk_max_f16
+// two fp32 pre-activations -> two fp16 activations (the next layer's B operand).  ReLU: convert, then one packed max.
+// tanh: 1 - 2 / (1 + exp(2x)) in fp32 (v_exp_f32 / v_rcp_f32: +inf and 0 give the saturated values, tanh(0) = 0 exactly), then
+// convert -- about 11 VALU instructions per pair against 2 (DESIGN.md 4.1b has what that costs beside the MFMAs)
+template <int ACT>
+__device__ __forceinline__ h2 act_pk(float a, float b) {
+    if constexpr (ACT == OMDS_ACT_RELU) {
+        h2 p = {(_Float16)a, (_Float16)b};                 // v_cvt_pk_f16_f32 (round to nearest even)
+        const h2 z = {(_Float16)0, (_Float16)0};
+        return __builtin_elementwise_max(p, z);            // v_pk_max_f16
+    } else {
+        const float ea = __builtin_amdgcn_exp2f(a * 2.885390081777927f), eb = __builtin_amdgcn_exp2f(b * 2.885390081777927f);
+        const float ta = __builtin_fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + ea), 1.f), tb = __builtin_fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + eb), 1.f);
+        return h2{(_Float16)ta, (_Float16)tb};
+    }
 }
 
 // A fragments of one group (4 k-chunks) of a slice
@@ -137,27 +162,181 @@ __device__ __forceinline__ AGroup read_group(const unsigned char* slot_lane, int
 
 #define SC_TL(i) do { if (a.tl && threadIdx.x == 0 && it == 0) a.tl[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 
-// pair (rollout t, obstacle o) of this lane in a tile; rows past the end (also: the prefetch of a non-existent next tile)
-// clamp to the last pair and are not stored.  Plain scalars on purpose: a struct carried around the tile loop went through
-// scratch memory
-__device__ __forceinline__ void tile_row(const ScreenArgs& a, long long tile, int wave, int rb, int b, unsigned& t, unsigned& o, bool& valid) {
-    long long row = tile * SC_ROWS + (wave * SC_RB + rb) * 32 + b;
-    valid = row < a.total_rows;
-    if (!valid) row = a.total_rows - 1;
+// pair (rollout t, obstacle o) of this lane in tile `tile` of the workgroup's chunk [p0, p1); rows past the end (also: the
+// prefetch of a non-existent next tile) clamp to the chunk's last pair and are not stored.  Plain scalars on purpose: a
+// struct carried around the tile loop went through scratch memory
+__device__ __forceinline__ void tile_row(const ScreenArgs& a, long long p0, long long p1, int tile, int wave, int rb, int b, unsigned& t, unsigned& o) {
+    long long row = p0 + (long long)tile * SC_ROWS + (wave * SC_RB + rb) * 32 + b;
+    if (row >= p1) row = p1 - 1;
     t = a.odiv.div((unsigned)row);
     o = (unsigned)row - t * (unsigned)a.O;
 }
 
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
-template <int NHH>
+// wave-wide minimum of a float, result uniform over the wave (NaN never wins: v_min_f32 returns the other operand): four DPP
+// steps inside each row of 16 lanes (the patterns of pass1_tile's link minimum), then the four rows meet through SGPRs --
+// ~10 instructions where a __shfl_xor butterfly is 6 dependent ds_bpermute round trips
+__device__ __forceinline__ float wave_min_f32(float v) {
+    v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false)));
+    v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false)));
+    v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false)));
+    v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false)));
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return fminf(fminf(r0, r1), fminf(r2, r3));
+}
+// number of set bits of a wave mask below this lane
+__device__ __forceinline__ int lanes_below(unsigned long long mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// One wave = one rollout: from the rollout's O screening values (row: global memory or LDS) to its candidates in the list
+// and its share of the audit sample.  All SEL_WAVES waves of the workgroup call it together (two barriers inside: ONE atomic on
+// the list counter per workgroup -- 1024 same-address atomics, one per rollout, serialise in L2 and were half of the first
+// k_select); `live` = this wave has a rollout.  Everything cross-lane is a ballot or a DPP step: this runs in the flush phase
+// of k_screen, on the critical path of every horizon step, and a shuffle-based version took 9 us there.
+constexpr int SEL_WAVES = 8;
+struct SelectShared { int wtot[SEL_WAVES], watot[SEL_WAVES], wbase, wabase; };
+template <typename RowPtr>
+__device__ __forceinline__ void select_rollout(const SelectSink& a, SelectShared& sh, RowPtr row, int t, bool live, int O, int lane, int wave) {
+    constexpr int NV = 8;
+    float v[NV];
+    const bool in_regs = O <= 64 * NV;   // rows of up to 512 values sit in registers; longer rows are re-read
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { const int o = lane + 64 * i; v[i] = (o < O) ? row[o] : __builtin_nanf(""); }   // NaN padding never wins a minimum
+    }
+    // k-th smallest value, multiplicities counted: at most k rounds of "smallest value above the previous one, and how many
+    // entries hold it".  NaN entries (an fp16 overflow inside the network) never win a round; they are made candidates below.
+    float kth = __builtin_inff(), prev = 0.f;
+    int remaining = a.k;
+    for (int round = 0; round < a.k; ++round) {
+        float loc = __builtin_inff();
+        if (in_regs) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) loc = (round == 0 || v[i] > prev) ? fminf(loc, v[i]) : loc;
+        } else {
+            for (int o = lane; o < O; o += 64) { const float x = row[o]; loc = (round == 0 || x > prev) ? fminf(loc, x) : loc; }
+        }
+        const float m = wave_min_f32(loc);
+        int c = 0;
+        if (in_regs) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) c += __popcll(__ballot(v[i] == m));
+        } else {
+            for (int o0 = 0; o0 < O; o0 += 64) { const int o = o0 + lane; c += __popcll(__ballot(o < O && row[o] == m)); }
+        }
+        kth = m;
+        if (c >= remaining || !(m < __builtin_inff())) break;   // +inf: fewer than k finite values -- everything becomes a candidate
+        remaining -= c;
+        prev = m;
+    }
+    const float tau = kth + a.delta;
+    // Candidates: everything not above tau, and every non-finite value (NaN / +inf = an fp16 overflow inside the network:
+    // nothing is known about such a row).  AUDIT sample: a pseudo-random subset of the pairs that are NOT candidates -- the
+    // population the selection rule makes an assumption about (screening error <= eps) -- goes with its screening value into
+    // the propagate's audit list; k_audit evaluates those pairs in fp32 once the horizon loop is done.
+    const int rbase = t * O;
+    const bool auditing = a.audit_mask != 0xffffffffu;
+    auto is_cand = [&](float x) { return !(x > tau) || !(x < __builtin_inff()); };
+    auto is_audit = [&](int o) { return auditing && (omds_audit_hash((unsigned)(rbase + o) ^ a.audit_seed) & a.audit_mask) == 0u; };
+    // one ballot pair per group of 64 obstacles: totals are scalar popcounts, a lane's list position is the number of set bits
+    // below it -- no scans, no shuffles.  (The order of a rollout's entries in the list is group-major; nothing depends on it.)
+    unsigned long long cm[NV], am[NV];
+    int wave_total = 0, wave_audit = 0;
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int o = lane + 64 * i;
+            const bool c = o < O && is_cand(v[i]);
+            cm[i] = __ballot(c);
+            am[i] = __ballot(o < O && !c && is_audit(o));
+            wave_total += __popcll(cm[i]);
+            wave_audit += __popcll(am[i]);
+        }
+    } else {
+        for (int o0 = 0; o0 < O; o0 += 64) {
+            const int o = o0 + lane;
+            const bool c = o < O && is_cand(row[o]);
+            wave_total += __popcll(__ballot(c));
+            wave_audit += __popcll(__ballot(o < O && !c && is_audit(o)));
+        }
+    }
+    if (!live) { wave_total = 0; wave_audit = 0; }
+    if (lane == 0) { sh.wtot[wave] = wave_total; sh.watot[wave] = wave_audit; }
+    __syncthreads();
+    // the two list counters are bumped by two different waves at once: their L2 round trips overlap
+    if (threadIdx.x == 0) {
+        int sum = 0;
+#pragma unroll
+        for (int w = 0; w < SEL_WAVES; ++w) sum += sh.wtot[w];
+        sh.wbase = atomicAdd(a.total, sum);
+    } else if (threadIdx.x == 64) {
+        int asum = 0;
+#pragma unroll
+        for (int w = 0; w < SEL_WAVES; ++w) asum += sh.watot[w];
+        sh.wabase = asum ? atomicAdd(a.audit_total, asum) : 0;
+    }
+    __syncthreads();
+    if (live) {
+        int base = sh.wbase, abase = sh.wabase;
+        for (int w = 0; w < wave; ++w) { base += sh.wtot[w]; abase += sh.watot[w]; }
+        if (lane == 0) {
+            a.range[4 * t] = base;
+            a.range[4 * t + 1] = wave_total;
+            a.range[4 * t + 2] = __builtin_bit_cast(int, tau);   // k_tail_sel checks the rollout's slack against it
+        }
+        const int arow0 = (a.step_row0 + t) * O;
+        if (in_regs) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int o = lane + 64 * i;
+                if ((cm[i] >> lane) & 1ull) {
+                    const int pos = base + lanes_below(cm[i]);
+                    a.rowlist[pos] = rbase + o;
+                    if (a.listDa) a.listDa[pos] = v[i];
+                } else if ((am[i] >> lane) & 1ull) {
+                    const int apos = abase + lanes_below(am[i]);
+                    if (apos < a.audit_cap) { a.audit_rows[apos] = arow0 + o; a.audit_da[apos] = v[i]; }
+                }
+                base += __popcll(cm[i]);
+                abase += __popcll(am[i]);
+            }
+        } else {
+            for (int o0 = 0; o0 < O; o0 += 64) {
+                const int o = o0 + lane;
+                const float x = o < O ? row[o] : 0.f;
+                const bool c = o < O && is_cand(x), au = o < O && !c && is_audit(o);
+                const unsigned long long cmk = __ballot(c), amk = __ballot(au);
+                if (c) {
+                    const int pos = base + lanes_below(cmk);
+                    a.rowlist[pos] = rbase + o;
+                    if (a.listDa) a.listDa[pos] = x;
+                } else if (au) {
+                    const int apos = abase + lanes_below(amk);
+                    if (apos < a.audit_cap) { a.audit_rows[apos] = arow0 + o; a.audit_da[apos] = x; }
+                }
+                base += __popcll(cmk);
+                abase += __popcll(amk);
+            }
+        }
+    }
+    __syncthreads();   // the shared counters are reused by the workgroup's next round of rollouts
+}
+
+template <int NHH, int ACT, bool SKIP>
 __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenArgs a) {
-    // PERSISTENT: workgroup w multiplies tiles w, w + G, w + 2G, ... (G = gridDim.x = one workgroup per CU).  The weight
-    // slices keep streaming through the ring across tile boundaries (the slice sequence is periodic), the bias table is
-    // loaded once, and the results wait in LDS until the end -- a store in flight would perturb the counted vmcnt waits of
-    // the LDS-DMA pieces (stores and loads retire out of order with respect to each other).  Measured on the one-tile-per-
-    // workgroup form (OMDS_SCREEN_TL): of 57 kcycles per tile slot 14 were the refill gap between two workgroups of a CU,
-    // 12 the layer-1 operand loads and first-slice latency, and only 29 the slice loop.
+    // PERSISTENT: workgroup w multiplies the tiles of its own contiguous chunk of the pair space (one workgroup per CU).
+    // The weight slices keep streaming through the ring across tile boundaries (the slice sequence is periodic), the bias
+    // table is loaded once, and the results wait in LDS until the end -- a store in flight would perturb the counted vmcnt
+    // waits of the LDS-DMA pieces (stores and loads retire out of order with respect to each other).  Measured on the
+    // one-tile-per-workgroup form (OMDS_SCREEN_TL): of 57 kcycles per tile slot 14 were the refill gap between two
+    // workgroups of a CU, 12 the layer-1 operand loads and first-slice latency, and only 29 the slice loop.
+    // A chunk of WHOLE rollouts (a.sel.rowlist != nullptr) ends with every screening value of those rollouts in this
+    // workgroup's LDS: the flush phase then does k_select's work from there -- k-th smallest, window, list append, audit
+    // sample -- and the N x O matrix is never written or re-read (one launch and 2 x 1.2 MB less per horizon step).
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // the small tables first: their ds_read offsets then fit the 16-bit immediate from ONE base register (behind the 64 KB
     // ring hipcc kept a base VGPR per 256-byte window alive across the tile loop, and spilled them)
@@ -168,8 +347,12 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
     const int b = lane & 31, half = lane >> 5;
     constexpr int S = NHH * 8 + 2;                 // slice steps of a tile: layer 1, 8 per hidden->hidden layer, the last layer
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
-    const long long ntiles = (a.total_rows + SC_ROWS - 1) / SC_ROWS;
-    const int my_tiles = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);   // >= 1: the grid never exceeds ntiles
+    const int wg = blockIdx.x;                                                  // this workgroup's pairs [p0, p1)
+    const long long p0 = ((long long)wg * a.units_base + (wg < a.units_rem ? wg : a.units_rem)) * a.unit;
+    const long long p1e = p0 + (long long)(a.units_base + (wg < a.units_rem ? 1 : 0)) * a.unit;
+    const long long p1 = p1e < a.total_rows ? p1e : a.total_rows;
+    const int my_pairs = (int)(p1 - p0);
+    const int my_tiles = (my_pairs + SC_ROWS - 1) / SC_ROWS;                    // >= 1: the grid never exceeds the chunks
 
     // slice `sl` of the network -> ring slot `slot`; this wave moves fragments PW*w .. PW*w + PW-1
     const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.Wh) + (SC_PW * wave) * 1024;   // wave-uniform
@@ -204,14 +387,31 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
         raw[2] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(fq_rs, vq, a.ldFq * 32, 0));
         raw[3] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(fp_rs, vp, a.ldFp * 32, 0));
     };
-    unsigned row_t[SC_RB], row_o[SC_RB];
-    bool row_valid[SC_RB];
+    // skip-connection networks: the same encoded input at the slots of the concatenated columns.  The host packs the
+    // layer behind a concatenation with those columns LAST (virtual columns 256 - 3d .. 255 = k-chunks 14 and 15, whatever
+    // the width of the layer in front: the K order of a dot product is free), so the concatenation is a bitwise OR into
+    // act[14], act[15] -- zeros there, the padded units of the narrower layer -- and one table serves every level
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t sq_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(SKIP ? a.FqS : a.FqH), 0, 0x7fffffff, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t sp_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(SKIP ? a.FpS : a.FpH), 0, 0x7fffffff, 0x00020000);
+    auto load_skip = [&](unsigned rt, unsigned ro, u4 (&sk)[2]) {
+        unsigned hh = (unsigned)half;
+        asm volatile("" : "+v"(hh));
+        const int vq = (int)((hh * (unsigned)a.ldFq + rt) * 16u), vp = (int)((hh * (unsigned)a.ldFp + ro) * 16u);
+        sk[0] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(sq_rs, vq, 0, 0)) |
+                __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(sp_rs, vp, 0, 0));
+        sk[1] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(sq_rs, vq, a.ldFq * 32, 0)) |
+                __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(sp_rs, vp, a.ldFp * 32, 0));
+    };
+    unsigned row_o[SC_RB];
     u4 raw[SC_RB][4];
+    [[maybe_unused]] u4 skn[SC_RB][2];   // SKIP: the next tile's concatenation operands, fetched with its inputs
     float rad[SC_RB];
 #pragma unroll
     for (int rb = 0; rb < SC_RB; ++rb) {
-        tile_row(a, blockIdx.x, wave, rb, b, row_t[rb], row_o[rb], row_valid[rb]);
-        load_inputs(row_t[rb], row_o[rb], raw[rb]);
+        unsigned rt;
+        tile_row(a, p0, p1, 0, wave, rb, b, rt, row_o[rb]);
+        load_inputs(rt, row_o[rb], raw[rb]);
+        if constexpr (SKIP) load_skip(rt, row_o[rb], skn[rb]);
         rad[rb] = a.radius[row_o[rb]];
     }
 
@@ -228,10 +428,10 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
         return r;
     };
     auto to_act = [&](const f32x16& acc, h8& lo, h8& hi) {   // registers 0-7 are the slots of chunk 2 fb of the next layer, 8-15 of 2 fb + 1
-        const h2 p0 = relu_pk(acc[0], acc[1]), p1 = relu_pk(acc[2], acc[3]), p2 = relu_pk(acc[4], acc[5]), p3 = relu_pk(acc[6], acc[7]);
-        const h2 p4 = relu_pk(acc[8], acc[9]), p5 = relu_pk(acc[10], acc[11]), p6 = relu_pk(acc[12], acc[13]), p7 = relu_pk(acc[14], acc[15]);
-        lo = h8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
-        hi = h8{p4[0], p4[1], p5[0], p5[1], p6[0], p6[1], p7[0], p7[1]};
+        const h2 q0 = act_pk<ACT>(acc[0], acc[1]), q1 = act_pk<ACT>(acc[2], acc[3]), q2 = act_pk<ACT>(acc[4], acc[5]), q3 = act_pk<ACT>(acc[6], acc[7]);
+        const h2 q4 = act_pk<ACT>(acc[8], acc[9]), q5 = act_pk<ACT>(acc[10], acc[11]), q6 = act_pk<ACT>(acc[12], acc[13]), q7 = act_pk<ACT>(acc[14], acc[15]);
+        lo = h8{q0[0], q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1]};
+        hi = h8{q4[0], q4[1], q5[0], q5[1], q6[0], q6[1], q7[0], q7[1]};
     };
 
     // ---- the slice pipeline.  Global step sigma = it * S + s multiplies slice s (ring slot sigma % RING) in 4 groups of 4
@@ -255,19 +455,39 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
 #endif
         };
         auto slot_ptr = [&](int s) { return ring_lane + ((sigma0 + s) & (SC_RING - 1)) * SC_SLICE; };
+        if (it * SC_ROWS + wave * SC_RB * 32 >= my_pairs) {
+            // all pairs of this wave lie past the end of the chunk (the partial last tile of a chunk of whole rollouts): it keeps
+            // the ring moving -- its DMA pieces, the barriers -- and issues no MFMA.  The matrix pipe is power-limited under this
+            // kernel: multiplying clamped duplicates would slow the waves that have real pairs (measured: 99 -> 108 us at N = 1024)
+            for (int s = 0; s < S; ++s) sync_and_issue(s);
+            continue;
+        }
         h8 in[SC_RB][2];
+        [[maybe_unused]] h8 sk[SC_RB][2];
 #pragma unroll
         for (int rb = 0; rb < SC_RB; ++rb) {
             const u4 i0 = raw[rb][0] | raw[rb][1], i1 = raw[rb][2] | raw[rb][3];
             in[rb][0] = __builtin_bit_cast(h8, i0);
             in[rb][1] = __builtin_bit_cast(h8, i1);
+            if constexpr (SKIP) { sk[rb][0] = __builtin_bit_cast(h8, skn[rb][0]); sk[rb][1] = __builtin_bit_cast(h8, skn[rb][1]); }
         }
         h8 act[SC_RB][16];
+        auto concat = [&](int level) {   // wave-uniform test; the OR touches 8 registers
+            if constexpr (SKIP) {
+                if ((a.skip_mask >> level) & 1u) {
+#pragma unroll
+                    for (int rb = 0; rb < SC_RB; ++rb) {
+                        act[rb][14] = __builtin_bit_cast(h8, __builtin_bit_cast(u4, act[rb][14]) | __builtin_bit_cast(u4, sk[rb][0]));
+                        act[rb][15] = __builtin_bit_cast(h8, __builtin_bit_cast(u4, act[rb][15]) | __builtin_bit_cast(u4, sk[rb][1]));
+                    }
+                }
+            }
+        };
         // ---- step 0: layer 1 on the matrix pipe.  Slice 0 = W1 as 8 row blocks x 2 k-chunks (fragment 2 fb + cc)
         {
             const unsigned char* sl = slot_ptr(0);
             const unsigned char* sl_next = slot_ptr(1);
-            // group g = row blocks 2g, 2g+1 (two MFMAs each and pair block); their ReLU + conversion runs one group later,
+            // group g = row blocks 2g, 2g+1 (two MFMAs each and pair block); their activation + conversion runs one group later,
             // under the next group's MFMAs; the scheduling barriers keep hipcc from batching all MFMAs first
             f32x16 pa[SC_RB], pb[SC_RB];
 #pragma unroll
@@ -303,6 +523,7 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
                 to_act(pa[rb], act[rb][12], act[rb][13]);
                 to_act(pb[rb], act[rb][14], act[rb][15]);
             }
+            concat(0);
         }
         SC_TL(1);
         // ---- steps 1 .. S-1: hidden->hidden layers and the last layer
@@ -333,8 +554,9 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
 #pragma unroll
                     for (int rb = 0; rb < SC_RB; ++rb) {
                         unsigned nt;
-                        tile_row(a, blockIdx.x + (long long)(it + 1) * gridDim.x, wave, rb, b, nt, nrow_o[rb], row_valid[rb]);
+                        tile_row(a, p0, p1, it + 1, wave, rb, b, nt, nrow_o[rb]);
                         load_inputs(nt, nrow_o[rb], raw[rb]);
+                        if constexpr (SKIP) load_skip(nt, nrow_o[rb], skn[rb]);
                     }
                 }
 #pragma unroll
@@ -369,6 +591,7 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
                         for (int cc = 0; cc < 16; ++cc) act[rb][cc] = nxt[rb][cc];
                     }
                 }
+                if (fb == 7) concat(((s - 1) >> 3) + 1);
             } else {
                 // last layer: the links sit on the A rows (rows >= C are zero); min over the valid, un-ignored links
 #pragma unroll
@@ -399,164 +622,41 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
     // ---- drain the ring (pieces issued past the last tile still target this workgroup's LDS), then flush the results
     wait_vm_barrier(0);
     __syncthreads();
-    for (int i = tid; i < my_tiles * SC_ROWS; i += SC_NT) {
-        const long long r = ((long long)blockIdx.x + (long long)(i / SC_ROWS) * gridDim.x) * SC_ROWS + (i % SC_ROWS);
-        if (r < a.total_rows) a.Dmin[r] = resL[i];
+    if (a.sel) {
+        // the chunk is whole rollouts: resL[rl * O .. +O) are the screening values of rollout t0 + rl
+        SelectShared& sh = *reinterpret_cast<SelectShared*>(ring);   // the ring is drained and idle
+        const SelectSink sel = *a.sel;
+        const int O = a.O;
+        const int t0 = (int)a.odiv.div((unsigned)p0);
+        const int n_roll = my_pairs / O;
+        for (int r0 = 0; r0 < n_roll; r0 += SEL_WAVES) {
+            const int rl = r0 + wave;
+            const bool live = rl < n_roll;
+            const int rr = live ? rl : n_roll - 1;
+            select_rollout(sel, sh, (const __attribute__((address_space(3))) float*)resL + rr * O, t0 + rr, live, O, lane, wave);
+        }
+    } else {
+        for (int i = tid; i < my_pairs; i += SC_NT) a.Dmin[p0 + i] = resL[i];
     }
     if (a.tl && threadIdx.x == 0) a.tl[(size_t)blockIdx.x * 8 + 6] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_select: one wave per rollout.  Row of up to 512 approximate distances in registers (longer rows: from memory).
+// k_select: one wave per rollout (select_rollout above), for the steps whose k_screen writes the matrix: rows too long for a
+// workgroup's LDS, and the tanh / skip-less-tail path that needs the matrix (k_exact writes the exact values into it).
 // ------------------------------------------------------------------------------------------------
 struct SelectArgs {
     const float* Dmin;    // [N][O] screening values
-    int* rowlist;         // [N*O] compact list of candidate rows t*O + o
-    int* range;           // [N][4] start and length of each rollout's entries in the list, tau (float bits), unused
-    int* total;           // number of listed rows (zeroed before the launch)
-    int N, O, k;
-    float delta;          // tau = (k-th smallest screening value) + delta
-    // AUDIT sample: a non-candidate pair is recorded when (hash(pair ^ audit_seed) & audit_mask) == 0 (mask 0xffffffff: never)
-    // as (row = (step_row0 + t) * O + o, screening value) in a list of the whole propagate; k_audit re-evaluates them at its end
-    unsigned audit_mask;
-    unsigned audit_seed;  // changes with every horizon step and propagate, so that over time every pair gets audited
-    int* audit_rows;      // [audit_cap]
-    float* audit_da;      // [audit_cap]
-    int* audit_total;     // entries recorded so far in this propagate (may exceed audit_cap: the excess is dropped)
-    int audit_cap;
-    int step_row0;        // (step - 1) * N: row of rollout 0 in the all-steps layer-1 table k_audit reads
+    int N, O;
+    SelectSink sel;
 };
-
-// lowbias32 (an integer hash with good avalanche): which non-candidate pairs k_exact re-evaluates as AUDIT rows
-__device__ __forceinline__ unsigned omds_audit_hash(unsigned x) {
-    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-    return x;
-}
-
-#ifndef OMDS_SEL_WAVES
-#define OMDS_SEL_WAVES 8
-#endif
-constexpr int SEL_WAVES = OMDS_SEL_WAVES;   // rollouts per workgroup (4: 10.5 us, 8: 10.1, 16: 11.4): ONE atomic on the list counter per workgroup (1024 same-address
-                                // atomics, one per rollout, serialise in L2 and were most of this kernel's 19 us)
 __global__ __launch_bounds__(SEL_WAVES * 64) void k_select(SelectArgs a) {
-    __shared__ int wtot[SEL_WAVES], watot[SEL_WAVES];
-    __shared__ int wbase, wabase;
+    __shared__ SelectShared sh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t_raw = blockIdx.x * SEL_WAVES + wave;
     const bool live = t_raw < a.N;                       // waves past the last rollout take part in the barriers with 0 entries
     const int t = live ? t_raw : a.N - 1;
-    const float* row = a.Dmin + (size_t)t * a.O;
-    const int O = a.O;
-    constexpr int NV = 8;
-    float v[NV];
-    const bool in_regs = O <= 64 * NV;
-    if (in_regs) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) { const int o = lane + 64 * i; v[i] = (o < O) ? row[o] : __builtin_inff(); }
-    }
-    // k-th smallest value (multiplicities counted): k rounds of "smallest (value, index) after the previous one".
-    // NaN entries (an fp16 overflow inside the network) never win a round; they are made candidates below.
-    float pv = -__builtin_inff();
-    int pi = -1;
-    for (int j = 0; j < a.k; ++j) {
-        float bv = __builtin_inff();
-        int bi = 0x7fffffff;
-        if (in_regs) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int o = lane + 64 * i;
-                const float x = v[i];
-                const bool after = (x > pv) || (x == pv && o > pi);
-                if (o < O && after && ((x < bv) || (x == bv && o < bi))) { bv = x; bi = o; }
-            }
-        } else {
-            for (int o = lane; o < O; o += 64) {
-                const float x = row[o];
-                const bool after = (x > pv) || (x == pv && o > pi);
-                if (after && ((x < bv) || (x == bv && o < bi))) { bv = x; bi = o; }
-            }
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float ov = __shfl_xor(bv, off);
-            const int oi = __shfl_xor(bi, off);
-            if ((ov < bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-        pv = bv;
-        pi = bi;
-    }
-    const float tau = pv + a.delta;   // pv = +inf (fewer than k finite values): everything is a candidate
-    // Candidates: everything not above tau, and every non-finite value (NaN / +inf = an fp16 overflow inside the network:
-    // nothing is known about such a row).  AUDIT sample: a pseudo-random subset of the pairs that are NOT candidates -- the
-    // population the selection rule makes an assumption about (screening error <= eps) -- goes with its screening value into
-    // the propagate's audit list; k_audit evaluates those pairs in fp32 once the horizon loop is done.
-    const int rbase = t * O;
-    auto is_cand = [&](float x) { return !(x > tau) || !(x < __builtin_inff()); };
-    auto is_audit = [&](int o) { return (omds_audit_hash((unsigned)(rbase + o) ^ a.audit_seed) & a.audit_mask) == 0u; };
-    // count, reserve a range of the list, write
-    int cnt = 0, acnt = 0;
-    if (in_regs) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int o = lane + 64 * i;
-            const bool c = o < O && is_cand(v[i]);
-            cnt += c ? 1 : 0;
-            acnt += (o < O && !c && is_audit(o)) ? 1 : 0;
-        }
-    } else {
-        for (int o = lane; o < O; o += 64) {
-            const bool c = is_cand(row[o]);
-            cnt += c ? 1 : 0;
-            acnt += (!c && is_audit(o)) ? 1 : 0;
-        }
-    }
-    int incl = cnt, aincl = acnt;   // inclusive scans over the lanes
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int u = __shfl_up(incl, off), ua = __shfl_up(aincl, off);
-        if (lane >= off) { incl += u; aincl += ua; }
-    }
-    const int wave_total = live ? __shfl(incl, 63) : 0, wave_audit = live ? __shfl(aincl, 63) : 0;
-    if (lane == 0) { wtot[wave] = wave_total; watot[wave] = wave_audit; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int sum = 0, asum = 0;
-#pragma unroll
-        for (int w = 0; w < SEL_WAVES; ++w) { sum += wtot[w]; asum += watot[w]; }
-        wbase = atomicAdd(a.total, sum);
-        wabase = asum ? atomicAdd(a.audit_total, asum) : 0;
-    }
-    __syncthreads();
-    if (!live) return;
-    int base = wbase, abase = wabase;
-    for (int w = 0; w < wave; ++w) { base += wtot[w]; abase += watot[w]; }
-    if (lane == 0) {
-        a.range[4 * t] = base;
-        a.range[4 * t + 1] = wave_total;
-        a.range[4 * t + 2] = __builtin_bit_cast(int, tau);   // k_tail_sel checks the rollout's slack against it
-    }
-    int pos = base + incl - cnt, apos = abase + aincl - acnt;
-    const int arow0 = (a.step_row0 + t) * O;
-    auto put_audit = [&](int o, float x) {
-        if (apos < a.audit_cap) { a.audit_rows[apos] = arow0 + o; a.audit_da[apos] = x; }
-        ++apos;
-    };
-    if (in_regs) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int o = lane + 64 * i;
-            if (o < O) {
-                if (is_cand(v[i])) a.rowlist[pos++] = rbase + o;
-                else if (is_audit(o)) put_audit(o, v[i]);
-            }
-        }
-    } else {
-        for (int o = lane; o < O; o += 64) {
-            const float x = row[o];
-            if (is_cand(x)) a.rowlist[pos++] = rbase + o;
-            else if (is_audit(o)) put_audit(o, x);
-        }
-    }
+    select_rollout(a.sel, sh, a.Dmin + (size_t)t * a.O, t, live, a.O, lane, wave);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -568,7 +668,7 @@ __global__ __launch_bounds__(SEL_WAVES * 64) void k_select(SelectArgs a) {
 // rollout: 52.9 us, against 59.6 (32-row tiles, two resident), 64.1 (an equal share of 32 + 16 rows per CU, one after the
 // other) and 58.0 (16-row tiles, two resident).
 // ------------------------------------------------------------------------------------------------
-template <int ACT>
+template <int ACT, int MODE>
 __global__ __launch_bounds__(512, 6) void k_exact(MlpDev m, const float* __restrict__ Apre, const float* __restrict__ Bpre,
                                                   const float* __restrict__ radius, int O, uint32_t ignored,
                                                   float* __restrict__ Dmin, OmdsDivisor odiv, const int* __restrict__ rowlist,
@@ -576,7 +676,7 @@ __global__ __launch_bounds__(512, 6) void k_exact(MlpDev m, const float* __restr
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = *total;
     for (int blk = blockIdx.x; blk * 16 < n; blk += gridDim.x) {
-        pass1_tile<16, 1, 1, ACT, 1>(m, smem, Apre, Bpre, radius, O, n, ignored, Dmin, (long long)blk * 16, odiv, rowlist, maxerr_bits, &ex);
+        pass1_tile<16, 1, 1, ACT, MODE>(m, smem, Apre, Bpre, radius, O, n, ignored, Dmin, (long long)blk * 16, odiv, rowlist, maxerr_bits, &ex);
         __syncthreads();   // the tile buffer is reused by the next tile
     }
 }
@@ -684,23 +784,7 @@ void omds_launch_max_abs_diff(hipStream_t s, const float* x, const float* y, lon
 // ------------------------------------------------------------------------------------------------
 size_t omds_screen_lds_bytes(int nhh) { return (size_t)SC_RING * SC_SLICE + (size_t)(nhh + 2) * OMDS_WIDTH * 4; }
 
-void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, const uint16_t* FqH, int ldFq, const uint16_t* FpH,
-                        int ldFp, const float* radius, int O, int B, uint32_t ignored, float* Dmin) {
-    const long long total = (long long)B * O;
-    if (total <= 0) return;
-    ScreenArgs a;
-    a.Wh = reinterpret_cast<const _Float16*>(sd.Wh);
-    a.bias = sd.bias;
-    a.FqH = reinterpret_cast<const _Float16*>(FqH); a.FpH = reinterpret_cast<const _Float16*>(FpH);
-    a.ldFq = ldFq; a.ldFp = ldFp;
-    a.radius = radius; a.Dmin = Dmin; a.B = B;
-    a.total_rows = total; a.O = O; a.ignored = ignored; a.odiv = OmdsDivisor::make((unsigned)O);
-    a.nhh = m.nhh; a.C = m.C; a.out_div = m.out_div;
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("OMDS_SCREEN_DBG"); dbg = e ? atoi(e) : 0; }
-    a.dbg = dbg;
-    // persistent: one workgroup per CU (256 on MI355X; more only when a workgroup's result buffer would overflow its LDS)
-    const long long ntiles = (total + SC_ROWS - 1) / SC_ROWS;
+static int omds_cu_count() {
     static std::atomic<int> ncu_of[64];   // CUs per device, asked once
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -711,13 +795,72 @@ void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, con
         if (ncu <= 0) ncu = 256;
         ncu_of[dev & 63].store(ncu);
     }
+    return ncu;
+}
+
+// the flush phase can select when a rollout's O screening values fit a workgroup's result buffer
+bool omds_screen_can_select(int O) { return O <= SC_MAX_TILES * SC_ROWS; }
+
+template <int NHH, int ACT, bool SKIP>
+static void launch_screen_t(hipStream_t s, dim3 grid, size_t lds, size_t lds_max, const ScreenArgs& a) {
+    static std::atomic<uint64_t> configured{0};
+    if (omds_first_use_on_device(configured))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_screen<NHH, ACT, SKIP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    hipLaunchKernelGGL((k_screen<NHH, ACT, SKIP>), grid, dim3(SC_NT), lds, s, a);
+}
+template <int NHH>
+static void launch_screen_n(hipStream_t s, dim3 grid, size_t lds, size_t lds_max, const ScreenArgs& a, int act, bool skip) {
+    if (act == OMDS_ACT_RELU) { if (skip) launch_screen_t<NHH, OMDS_ACT_RELU, true>(s, grid, lds, lds_max, a); else launch_screen_t<NHH, OMDS_ACT_RELU, false>(s, grid, lds, lds_max, a); }
+    else { if (skip) launch_screen_t<NHH, OMDS_ACT_TANH, true>(s, grid, lds, lds_max, a); else launch_screen_t<NHH, OMDS_ACT_TANH, false>(s, grid, lds, lds_max, a); }
+}
+
+void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, const uint16_t* FqH, int ldFq, const uint16_t* FpH,
+                        int ldFp, const float* radius, int O, int B, uint32_t ignored, float* Dmin, const SelectSink* sel) {
+    // sel: DEVICE pointer to this step's sink (capi.hip uploads the sinks of all horizon steps before the loop)
+    const long long total = (long long)B * O;
+    if (total <= 0) return;
+    ScreenArgs a;
+    a.Wh = reinterpret_cast<const _Float16*>(sd.Wh);
+    a.bias = sd.bias;
+    a.FqH = reinterpret_cast<const _Float16*>(FqH); a.FpH = reinterpret_cast<const _Float16*>(FpH);
+    a.FqS = reinterpret_cast<const _Float16*>(m.scrQ); a.FpS = reinterpret_cast<const _Float16*>(m.scrP);
+    a.ldFq = ldFq; a.ldFp = ldFp;
+    a.radius = radius; a.Dmin = Dmin; a.B = B;
+    a.total_rows = total; a.O = O; a.ignored = ignored; a.odiv = OmdsDivisor::make((unsigned)O);
+    a.nhh = m.nhh; a.C = m.C; a.out_div = m.out_div;
+    a.skip_mask = m.skip_mask;
+    a.sel = nullptr;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("OMDS_SCREEN_DBG"); dbg = e ? atoi(e) : 0; }
+    a.dbg = dbg;
+    // persistent: one workgroup per CU (256 on MI355X; more only when a workgroup's result buffer would overflow its LDS),
+    // each with a contiguous chunk of the pair space
+    int ncu = omds_cu_count();
     static int cu_cap = -1;   // OMDS_SCREEN_CUS: experiment -- persistent workgroups on a subset of the CUs
     if (cu_cap < 0) { const char* e = getenv("OMDS_SCREEN_CUS"); cu_cap = e ? atoi(e) : 0; }
     if (cu_cap > 0) ncu = std::min(ncu, cu_cap);
-    long long gl = std::min<long long>(ntiles, ncu);
-    gl = std::max<long long>(gl, (ntiles + SC_MAX_TILES - 1) / SC_MAX_TILES);
+    long long gl;
+    int tiles_per_wg;
+    if (sel && omds_screen_can_select(O)) {
+        // whole rollouts per workgroup: the flush phase selects (no matrix, no k_select)
+        const long long Rmax = std::max<long long>(1, (long long)SC_MAX_TILES * SC_ROWS / O);   // rollouts whose values fit the result buffer
+        gl = std::max<long long>(std::min<long long>(B, ncu), ((long long)B + Rmax - 1) / Rmax);
+        a.unit = O;
+        a.units_base = (int)(B / gl);
+        a.units_rem = (int)(B % gl);
+        tiles_per_wg = (int)(((long long)(a.units_base + (a.units_rem ? 1 : 0)) * O + SC_ROWS - 1) / SC_ROWS);
+        a.sel = sel;
+        a.Dmin = nullptr;
+    } else {
+        const long long ntiles = (total + SC_ROWS - 1) / SC_ROWS;
+        gl = std::min<long long>(ntiles, ncu);
+        gl = std::max<long long>(gl, (ntiles + SC_MAX_TILES - 1) / SC_MAX_TILES);
+        tiles_per_wg = (int)((ntiles + gl - 1) / gl);
+        a.unit = SC_ROWS;
+        a.units_base = (int)(ntiles / gl);
+        a.units_rem = (int)(ntiles % gl);
+    }
     const dim3 grid((unsigned)gl);
-    const int tiles_per_wg = (int)((ntiles + gl - 1) / gl);
     const size_t lds = omds_screen_lds_bytes(m.nhh) + (size_t)tiles_per_wg * SC_ROWS * 4;
     a.res_tiles = tiles_per_wg;
     const size_t lds_max = omds_screen_lds_bytes(4) + (size_t)SC_MAX_TILES * SC_ROWS * 4;
@@ -731,21 +874,14 @@ void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, con
         (void)hipMemsetAsync(tl_buf, 0, (size_t)grid.x * 8 * sizeof(unsigned long long), s);
         a.tl = tl_buf;
     }
-#define OMDS_SCREEN_LAUNCH(NHH)                                                                                          \
-    case NHH: {                                                                                                         \
-        static std::atomic<uint64_t> configured{0};                                                                     \
-        if (omds_first_use_on_device(configured))                                                                       \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_screen<NHH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); \
-        hipLaunchKernelGGL((k_screen<NHH>), grid, dim3(SC_NT), lds, s, a);                                             \
-    } break;
+    const bool skip = m.skip_mask != 0;
     switch (m.nhh) {
-        OMDS_SCREEN_LAUNCH(1)
-        OMDS_SCREEN_LAUNCH(2)
-        OMDS_SCREEN_LAUNCH(3)
-        OMDS_SCREEN_LAUNCH(4)
+        case 1: launch_screen_n<1>(s, grid, lds, lds_max, a, m.act, skip); break;
+        case 2: launch_screen_n<2>(s, grid, lds, lds_max, a, m.act, skip); break;
+        case 3: launch_screen_n<3>(s, grid, lds, lds_max, a, m.act, skip); break;
+        case 4: launch_screen_n<4>(s, grid, lds, lds_max, a, m.act, skip); break;
         default: break;   // omds_screen_supported() keeps other depths on the fp32 path
     }
-#undef OMDS_SCREEN_LAUNCH
     if (a.tl) {
         std::vector<unsigned long long> h((size_t)grid.x * 8);
         (void)hipStreamSynchronize(s);
@@ -768,36 +904,31 @@ void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, con
     }
 }
 
-bool omds_screen_supported(const MlpDev& m) { return m.act == OMDS_ACT_RELU && m.nhh >= 1 && m.nhh <= 4; }
+bool omds_screen_supported(const MlpDev& m) { return (m.act == OMDS_ACT_RELU || m.act == OMDS_ACT_TANH) && m.nhh >= 1 && m.nhh <= 4; }
 
-void omds_launch_select(hipStream_t s, const float* Dmin, int B, int O, int k, float delta, int* rowlist, int* range, int* total,
-                        const AuditSink& au) {
+void omds_launch_select(hipStream_t s, const float* Dmin, int B, int O, const SelectSink& sel) {
     if (B <= 0) return;
     SelectArgs a;
-    a.Dmin = Dmin; a.rowlist = rowlist; a.range = range; a.total = total; a.N = B; a.O = O; a.k = k; a.delta = delta;
-    a.audit_mask = au.rows ? au.mask : 0xffffffffu; a.audit_seed = au.seed; a.audit_rows = au.rows; a.audit_da = au.da;
-    a.audit_total = au.total; a.audit_cap = au.cap; a.step_row0 = au.step_row0;
+    a.Dmin = Dmin; a.N = B; a.O = O; a.sel = sel;
     hipLaunchKernelGGL(k_select, dim3((B + SEL_WAVES - 1) / SEL_WAVES), dim3(SEL_WAVES * 64), 0, s, a);
 }
 
+// ReLU networks: mode 1 -- per entry the exact value, pass 2's distance / arg-min link and the ReLU masks, for k_tail_sel.
+// tanh networks: mode 3 -- the exact value replaces the screening value in the matrix Dmin itself (candidates only); k_tail then
+// takes its top-k from the matrix (every non-candidate still holds a screening value > tau, above every row that matters) and
+// runs its own forward: a tanh backward needs 1 - h^2 of every unit, 3 KB per row instead of the 140 B of masks.
 void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius, int O,
                        int B, uint32_t ignored, float* Dmin, const int* rowlist, const int* total, unsigned* maxerr_bits,
                        const ExactOut& ex) {
-    if (B <= 0 || m.act != OMDS_ACT_RELU) return;   // omds_screen_supported(): ReLU networks only
+    if (B <= 0) return;
     const size_t lds = (size_t)16 * LDH * 4 + 16 * 4 + 16 * 4 + (size_t)16 * (m.nhh + 1) * 8 * 4;
-    static std::atomic<int> ncu_of[64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    int ncu = ncu_of[dev & 63].load();
-    if (ncu == 0) {
-        ncu = 256;
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (ncu <= 0) ncu = 256;
-        ncu_of[dev & 63].store(ncu);
-    }
+    const int ncu = omds_cu_count();
     // three resident workgroups per CU; longer lists stride (the list length is only known on the device)
     const long long blocks_max = ((long long)B * O + 15) / 16;
     const unsigned grid = (unsigned)std::min<long long>(blocks_max, 3LL * ncu);
     const OmdsDivisor od = OmdsDivisor::make((unsigned)O);
-    hipLaunchKernelGGL((k_exact<OMDS_ACT_RELU>), dim3(grid), dim3(512), lds, s, m, Apre, Bpre, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits, ex);
+    if (m.act == OMDS_ACT_RELU)
+        hipLaunchKernelGGL((k_exact<OMDS_ACT_RELU, 1>), dim3(grid), dim3(512), lds, s, m, Apre, Bpre, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits, ex);
+    else
+        hipLaunchKernelGGL((k_exact<OMDS_ACT_TANH, 3>), dim3(grid), dim3(512), lds, s, m, Apre, Bpre, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits, ex);
 }

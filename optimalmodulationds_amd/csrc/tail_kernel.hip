@@ -19,6 +19,7 @@ struct TailArgs {
     const float* xyzr;
     const float* Dmin;   // [N][O]
     float* Apre;         // [N][256] in: this step, out: next step (rows of the workgroup's own rollouts)
+    float* ApreOut;      // where the next step's rows go: Apre itself, or the next slab when all steps' halves are kept
     _Float16* FqH;       // next step's states as fp16 network inputs for the screening kernel (nullptr: not screening)
     int ldF;             // row capacity of FqH
     float* dscr;         // tanh derivative scratch
@@ -63,7 +64,14 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
     for (int rl = wave; rl < RW; rl += 8) {
         const int t = t_base + rl;
         if (t >= t_end) break;
-        topk_row(a.Dmin + (size_t)t * O, O, k, lane, [&](int j, int bi) { sm.rowT[rl * k + j] = t; sm.rowO[rl * k + j] = bi; });
+        topk_row(a.Dmin + (size_t)t * O, O, k, lane, [&](int j, int bi) {
+            sm.rowT[rl * k + j] = t;
+            sm.rowO[rl * k + j] = bi;
+            // screened step of a tanh network: the matrix holds exact values on the candidates and screening values (all above
+            // tau) elsewhere; the k smallest are exact ones, and no unevaluated row can belong among them, as long as the k-th
+            // stays e_bound below tau (the slack guard)
+            if (a.range && j == k - 1 && !(__builtin_bit_cast(float, a.range[4 * t + 2]) - a.Dmin[(size_t)t * O + bi] >= a.e_bound)) atomicAdd(a.viol, 1u);
+        });
     }
     __syncthreads();
     if (a.dbg_stop == 1) return;
@@ -96,6 +104,12 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
                     a.FqH[omds_screen_fidx(sub, t, a.ldF)] = (_Float16)v;
                     a.FqH[omds_screen_fidx(d + sub, t, a.ldF)] = (_Float16)feat[rl * 3 * ND + ND + sub];
                     a.FqH[omds_screen_fidx(2 * d + sub, t, a.ldF)] = (_Float16)feat[rl * 3 * ND + 2 * ND + sub];
+                    if (m.scrQ) {   // skip-connection networks: the concatenation operand of the screening kernel
+                        _Float16* S = reinterpret_cast<_Float16*>(m.scrQ);
+                        S[omds_screen_sidx(sub, 3 * d, t, a.ldF)] = (_Float16)v;
+                        S[omds_screen_sidx(d + sub, 3 * d, t, a.ldF)] = (_Float16)feat[rl * 3 * ND + ND + sub];
+                        S[omds_screen_sidx(2 * d + sub, 3 * d, t, a.ldF)] = (_Float16)feat[rl * 3 * ND + 2 * ND + sub];
+                    }
                 }
             }
         }
@@ -117,7 +131,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
             for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)(d + j) * OMDS_WIDTH + c], f[ND + j], acc);
 #pragma unroll
             for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)(2 * d + j) * OMDS_WIDTH + c], f[2 * ND + j], acc);
-            a.Apre[(size_t)t * OMDS_WIDTH + c] = acc;
+            a.ApreOut[(size_t)t * OMDS_WIDTH + c] = acc;
         }
         if (m.featQ)   // skip-connection networks: the encoded joint inputs of the next step (as k_rollout_layer1 writes them)
             for (int e = tid; e < RW * 3 * ND; e += P2_NT) {
@@ -283,6 +297,12 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
                     a.FqH[omds_screen_fidx(sub, t, a.ldF)] = (_Float16)v;
                     a.FqH[omds_screen_fidx(d + sub, t, a.ldF)] = (_Float16)feat[rl * 3 * ND + ND + sub];
                     a.FqH[omds_screen_fidx(2 * d + sub, t, a.ldF)] = (_Float16)feat[rl * 3 * ND + 2 * ND + sub];
+                    if (m.scrQ) {   // skip-connection networks: the concatenation operand of the screening kernel
+                        _Float16* S = reinterpret_cast<_Float16*>(m.scrQ);
+                        S[omds_screen_sidx(sub, 3 * d, t, a.ldF)] = (_Float16)v;
+                        S[omds_screen_sidx(d + sub, 3 * d, t, a.ldF)] = (_Float16)feat[rl * 3 * ND + ND + sub];
+                        S[omds_screen_sidx(2 * d + sub, 3 * d, t, a.ldF)] = (_Float16)feat[rl * 3 * ND + 2 * ND + sub];
+                    }
                 }
             }
         }
@@ -304,7 +324,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
             for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)(d + j) * OMDS_WIDTH + c], f[ND + j], acc);
 #pragma unroll
             for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)(2 * d + j) * OMDS_WIDTH + c], f[2 * ND + j], acc);
-            a.Apre[(size_t)t * OMDS_WIDTH + c] = acc;
+            a.ApreOut[(size_t)t * OMDS_WIDTH + c] = acc;
         }
         if (m.featQ)   // skip-connection networks: the encoded joint inputs of the next step (as k_rollout_layer1 writes them)
             for (int e = tid; e < RW * 3 * ND; e += P2_NT) {
@@ -352,7 +372,7 @@ void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Bpre, con
     static int stop = -1;
     if (stop < 0) { const char* e = getenv("OMDS_TAIL_SEL_STOP"); stop = e ? atoi(e) : 0; }
     a.dbg_stop = stop;
-    a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Dmin = nullptr; a.Apre = Apre; a.dscr = nullptr; a.O = O; a.st = st;
+    a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Dmin = nullptr; a.Apre = Apre; a.ApreOut = Apre; a.dscr = nullptr; a.O = O; a.st = st;
     a.rowlist = rowlist; a.range = range; a.ex = ex;
     const bool r16 = tail_sel_rows(st.N, st.k) == 16;
     if (st.n == 7) { if (r16) launch_tail_sel_t<7, 16>(s, a); else launch_tail_sel_t<7, 32>(s, a); }
@@ -401,7 +421,8 @@ int omds_tail_scratch_rows(int N, int k) {
 }
 
 void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
-                      const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st, int t_begin, int t_end, uint16_t* FqH, int ldF) {
+                      const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st, int t_begin, int t_end, uint16_t* FqH, int ldF,
+                      float* ApreOut, const int* guard_range, float e_bound, unsigned* viol) {
     TailArgs a;
     a.FqH = reinterpret_cast<_Float16*>(FqH);
     a.ldF = ldF;
@@ -413,8 +434,8 @@ void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const f
     static int stop = -1;
     if (stop < 0) { const char* e = getenv("OMDS_TAIL_STOP"); stop = e ? atoi(e) : 0; }
     a.dbg_stop = stop;
-    a.rowlist = nullptr; a.range = nullptr; a.ex = ExactOut{}; a.e_bound = 0.f; a.viol = nullptr;
-    a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Dmin = Dmin; a.Apre = Apre; a.dscr = dscr; a.O = O; a.st = st;
+    a.rowlist = nullptr; a.range = guard_range; a.ex = ExactOut{}; a.e_bound = e_bound; a.viol = viol;
+    a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Dmin = Dmin; a.Apre = Apre; a.ApreOut = ApreOut ? ApreOut : Apre; a.dscr = dscr; a.O = O; a.st = st;
     if (rows == 16) {
         if (st.n == 7) launch_tail_t<7, 16>(s, a);
         else launch_tail_t<2, 16>(s, a);

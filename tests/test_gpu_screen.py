@@ -174,3 +174,87 @@ def test_screened_propagate_is_bit_identical_on_other_scenes(scene):
     st = e.screen_stats()
     assert st["active"] and st["fallbacks"] <= 2 and st["max_err_seen"] <= 0.5 * st["eps"], st
     e.close()
+
+
+def _net_engine(kind, N, H, obs):
+    """Franka context with one of the weight sets under tests/golden/weights (activation and skip layout from the file)."""
+    from optimalmodulationds_amd import scenes
+    from optimalmodulationds_amd.engine import Engine
+    m = orc.Mlp.from_npz(weights_path(kind))
+    e = Engine(7, N, H, 5, max_obs=max(64, obs.shape[0]))
+    e.set_mlp(m.W, m.b, act=m.act, skip_after=m.skip_after)
+    e.set_obstacles(obs)
+    e.params.dt, e.params.dst_thr, e.params.ignored_links = 0.5, 0.01, 0b111
+    e.push_params()
+    e.set_ds(scenes.FRANKA_QF)
+    return e
+
+
+@pytest.mark.parametrize("kind,N,H,iters", [("franka_tanh", 1024, 8, 6), ("franka_skip", 1024, 8, 6), ("franka_tanh", 4096, 32, 2),
+                                            ("franka_skip", 4096, 16, 2)])
+def test_screened_tanh_and_skip_networks_are_bit_identical(kind, N, H, iters):
+    """BASELINE configs[2] as worded (256-256-256 tanh) and the reference's skip-connection layout
+    (MLPRegression(skips=[2]), network_macros_mod.py:117-146) through the screened step: k_screen with the tanh epilogue /
+    the concatenation stage; ReLU + skip keeps k_exact's masks and k_tail_sel, tanh takes the matrix route (k_exact writes
+    the exact values into Dmin, k_tail runs its own forward).  Two contexts (fp32 pass 1 / screened), every returned array
+    equal, free-running from drifting start states."""
+    from optimalmodulationds_amd import scenes
+    obs = scenes.shelf_scene()
+    e0, e1 = _net_engine(kind, N, H, obs), _net_engine(kind, N, H, obs)
+    e0.set_screening(0)
+    e1.set_screening(1)
+    q0, qf = scenes.FRANKA_Q0, scenes.FRANKA_QF
+    K = 10
+    rng = np.random.RandomState(5)
+    s = (np.arange(K) + 0.5) / K
+    mu_c = (q0 + s[:, None] * (qf - q0) + 0.15 * rng.standard_normal((K, 7))).astype(np.float32)
+    sg_c, al_c = np.ones(K, np.float32), rng.standard_normal((K, 7)).astype(np.float32)
+    q = q0.copy()
+    for it in range(iters):
+        outs = []
+        for e in (e0, e1):
+            e.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 3.0, K, seed=70 + it)
+            e.propagate(q)
+            outs.append(e.get_rollouts())
+        for key in KEYS:
+            assert np.array_equal(outs[0][key], outs[1][key]), (kind, it, key, float(np.nanmax(np.abs(outs[0][key] - outs[1][key]))))
+        q = (q + 0.05 * (qf - q0) + 0.02 * rng.standard_normal(7)).astype(np.float32)
+    st = e1.screen_stats()
+    print(kind, N, H, st)
+    assert st["active"] and not st["suspended"] and st["fallbacks"] <= 2, st
+    assert st["max_err_seen"] <= 0.5 * st["eps"] and st["audit_max_err"] <= 0.5 * st["eps"], st
+    assert st["audit_rows_per_rollout_step"] > 1.0, st
+    e0.close()
+    e1.close()
+
+
+@pytest.mark.parametrize("name,kind", [("franka_tanh_shelf_K4", "franka_tanh"), ("franka_skip_shelf_K4", "franka_skip")])
+def test_screened_tanh_and_skip_fixtures(name, kind):
+    """The reference-generated tanh / skip rollout fixtures (its own MLPRegression with act_fn=Tanh / skips=[2]) through
+    the screened step, teacher-forced from the fixture's start states: the same numbers as the fp32 step."""
+    fx = load(name)
+    from optimalmodulationds_amd.engine import Engine
+    m = orc.Mlp.from_npz(weights_path(kind))
+    N, H, K = int(fx["N"]), int(fx["H"]), int(fx["K"])
+    outs = []
+    for mode in (0, 1):
+        e = Engine(7, N, H, int(fx["k"]), max_obs=512)
+        e.set_mlp(m.W, m.b, act=m.act, skip_after=m.skip_after)
+        e.set_obstacles(fx["obs"])
+        e.params.dt, e.params.dst_thr = float(fx["dt"]), float(fx["dst_thr"])
+        e.params.ignored_links = sum(1 << int(l) for l in fx["ignored_links"])
+        e.push_params()
+        e.set_ds(fx["qf"])
+        e.set_screening(mode)
+        e.set_policy_samples(fx["it0_mu_tmp"][:, :K], fx["it0_sigma_tmp"][:, :K], fx["it0_alpha_tmp"][:, :K])
+        e.propagate(fx["it0_q_cur"])
+        outs.append(e.get_rollouts())
+        if mode:
+            st = e.screen_stats()
+            assert st["active"] and st["fallbacks"] == 0, st
+        e.close()
+    for key in KEYS:   # small N: the unscreened relu step may pick 16-row pass-2 tiles where k_tail_sel picks its own height -> the same bits either way (gemm16)
+        assert np.array_equal(outs[0][key], outs[1][key]), (key, float(np.nanmax(np.abs(outs[0][key] - outs[1][key]))))
+    # and against the reference's own rollouts of the fixture (first step from the fixture's start states)
+    ref = fx["it0_all_traj"]
+    assert np.abs(outs[1]["all_traj"][:, 1] - ref[:, 1]).max() <= 2e-4, float(np.abs(outs[1]["all_traj"][:, 1] - ref[:, 1]).max())

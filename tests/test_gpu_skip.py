@@ -59,31 +59,30 @@ def test_facade_class_with_skips_matches_the_reference_vectors():
 
 
 def test_skip_network_rollouts_all_step_variants_agree():
-    """The fused step, the step as stand-alone kernels and a forced-on screening request (which a skip network declines: it
-    runs the fp32 step) give the same rollouts; pass 1 (feature tables) and pass 2 (features recomputed) see the same
-    network: the pass-1 value of the closest obstacle equals the pass-2 distance when no link is ignored."""
+    """The fused fp32 step, the step as stand-alone kernels, and the SCREENED step -- forced on, and chosen by the library itself
+    at this size (k_screen's concatenation stage + k_exact's masks + k_tail_sel) -- give the same rollouts, the screened ones bit
+    for bit; pass 1 (feature tables) and pass 2 (features recomputed) see the same network: the pass-1 value of the closest
+    obstacle equals the pass-2 distance when no link is ignored."""
     from optimalmodulationds_amd import scenes
     from optimalmodulationds_amd import _lib as L
     from optimalmodulationds_amd.engine import Engine
     m = orc.Mlp.from_npz(weights_path("franka_skip"))
     obs, q0, qf = scenes.shelf_scene(), scenes.FRANKA_Q0, scenes.FRANKA_QF
     outs = []
-    for flags, mode in ((0, -1), (L.FLAG_UNFUSED_STEP, -1), (0, 1)):
+    for flags, mode in ((0, 0), (L.FLAG_UNFUSED_STEP, 0), (0, 1), (0, -1)):
         e = Engine(7, 1024, 4, 5, max_obs=512, flags=flags)
         e.set_mlp(m.W, m.b, act=m.act, skip_after=m.skip_after)
         e.set_obstacles(obs)
         e.params.dt, e.params.dst_thr, e.params.ignored_links = 0.5, 0.01, 0
         e.push_params()
         e.set_ds(qf)
-        try:
-            e.set_screening(mode)
-        except L.OmdsError:
-            assert mode == 1          # declining loudly is fine too
+        e.set_screening(mode)
         e.sample_policy(None, None, None, 0, 0, 0, 0, seed=3)
         e.propagate(q0)
-        assert not e.screen_stats()["active"]
+        st = e.screen_stats()
+        assert st["active"] == (mode != 0) and st["fallbacks"] == 0, st
         outs.append(e.get_rollouts())
-        if flags == 0 and mode == -1:
+        if flags == 0 and mode == 0:
             q = outs[0]["all_traj"][:64, 2]
             d, g, mind, idx = e.dist_grad(q, want_mindist=True, want_idx=True)
             do, go, mindo, idxo = orc.distance_repulsion_nn(m, q, obs, 5, [])
@@ -93,6 +92,7 @@ def test_skip_network_rollouts_all_step_variants_agree():
     for key in ("all_traj", "closest_dist_all", "dot_products", "qdot"):
         assert_close(outs[1][key], outs[0][key], 2e-4, "unfused vs fused " + key)
         assert np.array_equal(outs[2][key], outs[0][key]), key
+        assert np.array_equal(outs[3][key], outs[0][key]), key
 
 
 def test_set_mlp_ex_rejects_inconsistent_layouts():
