@@ -227,6 +227,8 @@ OMDS_API const char* omds_comm_last_error(void);
 OMDS_API int omds_comm_init_rank(omds_ctx* ctx, const uint8_t* id128, int rank, int world);
 OMDS_API int omds_comm_destroy(omds_ctx* ctx);
 OMDS_API int omds_comm_info(const omds_ctx* ctx, int32_t* rank, int32_t* world);
+/* 1 while the context owns a communicator (a single-rank one included), else 0. */
+OMDS_API int omds_comm_active(const omds_ctx* ctx);
 OMDS_API int omds_weighted_update_sharded(omds_ctx* ctx, float rate, float ker_thr, float* mu_c, float* sigma_c,
                                           float* alpha_c, int32_t* mask_out, float* qdot_weighted, float* qdot_best,
                                           float* n_total_out);

@@ -84,6 +84,7 @@ SIGNATURES = {
     "omds_comm_init_rank": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
     "omds_comm_destroy": (C.c_int, [C.c_void_p]),
     "omds_comm_info": (C.c_int, [C.c_void_p, I32P, I32P]),
+    "omds_comm_active": (C.c_int, [C.c_void_p]),
     "omds_weighted_update_sharded": (C.c_int, [C.c_void_p, C.c_float, C.c_float, F32P, F32P, F32P, I32P, F32P, F32P,
                                                F32P]),
     "omds_set_screening": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),

@@ -154,6 +154,8 @@ int omds_comm_destroy(omds_ctx* ctx) {
     return OMDS_OK;
 }
 
+int omds_comm_active(const omds_ctx* ctx) { return (ctx && ctx->comm) ? 1 : 0; }
+
 int omds_comm_info(const omds_ctx* ctx, int32_t* rank, int32_t* world) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
     if (rank) *rank = ctx->comm_rank;

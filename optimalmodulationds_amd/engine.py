@@ -239,6 +239,10 @@ class Engine:
         self._ck(self.lib.omds_comm_info(self.h, C.byref(r), C.byref(w)))
         return r.value, w.value
 
+    def comm_active(self):
+        """True while the context owns an RCCL communicator (a single-rank one included)."""
+        return bool(self.lib.omds_comm_active(self.h))
+
     def weighted_update_sharded(self, rate, ker_thr, mu_c, sigma_c, alpha_c, want_best=False):
         """MPPI.shift_policy_means + get_qdot over all shards of the communicator (all-reduces on the context
         stream, device buffers).  Returns (mu, sigma, alpha, mask, qdot_weighted, qdot_best | None, n_total)."""

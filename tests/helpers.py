@@ -23,8 +23,14 @@ def weights_path(kind):
     return os.path.join(GOLDEN, "weights", kind + ".npz")
 
 
+OWN = 0.0   # floor of distance / velocity comparisons: the tensor's own largest magnitude is the scale
+
+
 def rel_err(a, b, floor=1.0):
-    """max |a-b| / max(floor, max|b|): relative to the tensor's scale, NaN-pattern must agree."""
+    """max |a-b| / max(floor, max|b|), NaN-pattern must agree.  The default floor 1.0 is the natural scale of joint angles
+    (radians), unit normals, dot products, activations and RBF values; DISTANCE and VELOCITY tensors pass ``floor=OWN``: Franka
+    distances are <= 0.5 m and modulated velocities often <= 0.1, so that "1e-5" means 1e-5 of the values compared, not 1e-5
+    absolute."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     assert a.shape == b.shape, (a.shape, b.shape)
@@ -33,7 +39,7 @@ def rel_err(a, b, floor=1.0):
     if a.size == 0:
         return 0.0
     d = np.abs(np.where(na, 0, a) - np.where(nb, 0, b))
-    scale = max(floor, float(np.abs(np.where(nb, 0, b)).max()))
+    scale = max(floor, float(np.abs(np.where(nb, 0, b)).max()), 1e-30)
     return float(d.max()) / scale
 
 
@@ -41,6 +47,37 @@ def assert_close(a, b, tol, what, floor=1.0):
     e = rel_err(a, b, floor)
     assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
     return e
+
+
+DIST_ULP = 5e-7     # x max(1, largest network distance of the step): admissible difference between two fp32 evaluations of
+                    # the distance network (tools/studies/accuracy_study.py, profiles/r02_distance_accuracy.txt: the reference's
+                    # own distance is this far from the float64 value of the same network)
+
+
+def velocity_envelope(q, qf, d_raw, grads, mu, sg, al, prm, delta):
+    """Per component [lo, hi] of the modulated velocity when the network distance moves within +-delta, for each of the given
+    blended gradients / normals (only their direction enters the step)."""
+    from oracle import omds_oracle as orc
+    us = [orc.modulation_step(q, qf, (d_raw + np.float32(s * delta)).astype(np.float32), g, mu, sg, al, prm)["u"]
+          for s in (-1.0, -0.5, 0.0, 0.5, 1.0) for g in grads]
+    us = np.stack(us)
+    return us.min(axis=0), us.max(axis=0)
+
+
+def assert_velocity_in_envelope(u_dev, q, qf, d_raw, grads, mu, sg, al, prm, d_scale, what, pad=0.0):
+    """The device's modulated velocity must lie, per component, in the interval the oracle's modulation spans when the network
+    distance moves by +-DIST_ULP * max(1, d_scale) -- MPPI.py:149-155 multiplies a distance difference by sigmoid slopes of up
+    to 100, so two valid fp32 evaluations of the network differ by more than 1e-5 in the velocity near an obstacle -- for each
+    of the given normals (the oracle's and the device's own, equal to 2e-5), widened by RTOL x the velocity scale (+ pad, for
+    velocities recovered as (q_next - q) / dt).  Returns the largest excess over the un-widened envelope."""
+    delta = DIST_ULP * max(1.0, float(d_scale))
+    lo, hi = velocity_envelope(q, qf, d_raw, grads, mu, sg, al, prm, delta)
+    uscale = max(1.0, float(np.abs(hi).max()))
+    tol = RTOL * uscale + pad
+    u_dev = np.asarray(u_dev)
+    excess = float(np.maximum(np.maximum(lo - u_dev, u_dev - hi), 0).max()) if u_dev.size else 0.0
+    assert excess <= tol, f"{what}: modulated velocity {excess:.3e} outside the +-{delta:.1e} distance envelope (allowed {tol:.1e})"
+    return excess
 
 
 def seds_of(fx):

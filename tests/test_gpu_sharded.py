@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import weights_path
+from helpers import assert_velocity_in_envelope, weights_path
 from oracle import omds_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -160,13 +160,14 @@ def test_shard_4096x64_config4():
     q = r["all_traj"][tt, hh]
     d, g, _, idx = orc.distance_repulsion_nn(m, q, obs, k, [0, 1, 2])
     st = orc.modulation_step(q, qf, d, g, mu[tt], sg[tt], al[tt], orc.Params(dst_thr=0.01))
-    assert np.abs(r["closest_dist_all"][tt, hh] - (d - np.float32(0.01))).max() <= 1e-5
+    assert np.abs(r["closest_dist_all"][tt, hh] - (d - np.float32(0.01))).max() <= 1e-6
     ok = orc.rollout_relu_margin(m, q, obs, idx) >= 5e-6
     assert ok.mean() > 0.5
     assert np.abs(r["kernel_val_all"][tt, hh] - st["phi"]).max() <= 1e-5
     nxt = (hh + 1 < H) & ok
     vel = (r["all_traj"][tt[nxt], hh[nxt] + 1] - q[nxt]) / np.float32(0.5)
-    assert np.abs(vel - st["u"][nxt]).max() <= 2e-4
+    assert_velocity_in_envelope(vel, q[nxt], qf, d[nxt], (g[nxt], r["normal"][tt[nxt], hh[nxt]]), mu[tt][nxt], sg[tt][nxt], al[tt][nxt],
+                                orc.Params(dst_thr=0.01), float(np.abs(d).max()), "sampled velocities", pad=4e-6 * max(1.0, float(np.abs(q).max())) / 0.5)
     cost = e.cost()
     ocost, _ = orc.evaluate_costs(r["all_traj"], r["closest_dist_all"], qf, dh, qmin, qmax)
     assert np.abs(cost - ocost).max() <= 1e-5 * max(1.0, np.abs(ocost).max())
@@ -176,3 +177,92 @@ def test_shard_4096x64_config4():
     assert nt == N and np.array_equal(mask, omask)
     assert np.abs(nal - oal).max() <= 2e-5 * max(1.0, np.abs(oal).max())
     e.close()
+
+
+def test_communicator_and_screening_state_survive_obstacle_growth():
+    """A rank whose scene outgrows its obstacle buffers (MPPI.update_obstacles takes any count, MPPI.py:347-350) must stay in
+    the collective: omds_set_obstacles grows the buffers inside the context -- the handle, the RCCL communicator, the
+    screening mode and the policy samples survive -- and the sharded update afterwards is the update of the new scene."""
+    from optimalmodulationds_amd import scenes
+    from optimalmodulationds_amd.cost import FRANKA_Q_MAX, FRANKA_Q_MIN
+    from optimalmodulationds_amd.engine import Engine
+    N, H, K = 512, 6, 8
+    m, obs, q0, qf, dh, qmin, qmax, make, mu_c, sg_c, al_c = _setup(N, H, K=K)
+    e = Engine(7, N, H, 5, max_obs=64)
+    e.set_mlp(m.W, m.b)
+    e.set_obstacles(obs[::8][:36])
+    e.params.dt, e.params.dst_thr, e.params.ignored_links = 0.5, 0.01, 0b111
+    e.push_params()
+    e.set_ds(qf)
+    e.set_cost(dh, np.array(FRANKA_Q_MIN, np.float32), np.array(FRANKA_Q_MAX, np.float32))
+    e.set_screening(1)
+    e.comm_init(Engine.comm_unique_id(), 0, 1)
+    e.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 3.0, K, seed=5)
+    e.propagate(q0)
+    assert e.comm_active() and e.screen_stats()["active"] and e.max_obs == 64
+    e.set_obstacles(obs)                                   # 294 > 64: grows
+    assert e.max_obs >= 294 and e.comm_active()
+    st = e.screen_stats()
+    assert st["active"], st                                # the screening request survived (the bound is recalibrated: new scene)
+    e.propagate(q0)
+    e.cost(fetch=False)
+    got = e.weighted_update_sharded(0.1, 0.1, mu_c, sg_c, al_c, want_best=True)
+    assert e.screen_stats()["calibrations"] == 2
+    ref_e = make(N)                                        # a fresh context on the big scene, fp32 step, no communicator
+    ref_e.set_screening(0)
+    ref_e.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 3.0, K, seed=5)
+    ref_e.propagate(q0)
+    ref_e.cost(fetch=False)
+    ref = ref_e.weighted_update_sharded(0.1, 0.1, mu_c, sg_c, al_c, want_best=True)
+    for a, b in zip(got[:6], ref[:6]):
+        assert np.array_equal(a, b)
+    e.comm_destroy()
+    e.close()
+    ref_e.close()
+
+
+def test_facade_shift_policy_means_uses_the_native_sharded_update():
+    """MPPI.init_comm + MPPI.shift_policy_means / get_qdot (the reference's API, MPPI.py:319-345): with a (single-rank)
+    communicator the facade goes through omds_weighted_update_sharded and gives the numbers of the local update."""
+    import torch
+    from optimalmodulationds_amd import MPPI, LinDS, RobotSdfCollisionNet, scenes
+    nn = RobotSdfCollisionNet(10, 9, [], [256] * 4)
+    nn.load_weights(weights_path("franka"), {'device': 'cpu', 'dtype': torch.float32})
+    outs = []
+    for with_comm in (False, True):
+        ds = LinDS(torch.tensor(scenes.FRANKA_QF))
+        mppi = MPPI(torch.tensor(scenes.FRANKA_Q0), torch.tensor(scenes.FRANKA_QF), torch.tensor(scenes.franka_dh_params()),
+                    torch.tensor(scenes.shelf_scene()[::6]), 0.5, 6, 256, [ds], None, nn, 5, seed=7)
+        mppi.dst_thr, mppi.ker_thr = 0.01, 0.1
+        mppi.Policy.alpha_s = 3.0
+        rng = np.random.RandomState(0)
+        for i in range(4):
+            mppi.Policy.add_kernel(torch.tensor((scenes.FRANKA_Q0 + 0.2 * rng.standard_normal(7)).astype(np.float32)), 1.0, torch.eye(7))
+        if with_comm:
+            assert mppi.init_comm() == (0, 1) and mppi._engine.comm_active()
+        mppi.Policy.sample_policy()
+        mppi.propagate()
+        mppi.get_cost()
+        mppi.shift_policy_means()
+        outs.append((mppi.Policy.mu_c.clone(), mppi.Policy.alpha_c.clone(), mppi.update_mask.clone(), mppi.get_qdot('best').clone(),
+                     mppi.get_qdot('weighted').clone(), mppi.qdot_weighted.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_bench_under_torchrun_single_rank_uses_rccl():
+    """The exact command line the driver uses for the scaling bench, at one rank: a child process started from here (the
+    launcher and the worker initialise the GPU themselves), rc 0, one JSON line, collectives = rccl."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--reps", "2",
+           "--no-cpu-baseline", "--no-secondary"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["config"]["collectives"] == "rccl" and d["value"] > 1e5, d
+    assert d["scaling"] == "weak" and d["steps"] == 3 and d["reps"] == 2

@@ -51,5 +51,5 @@ for wl, tag in (("franka_shelf_1024x32", ""), ("planar7_1024x32", "_p7")):
 json.dump(res, open(out + "/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
-python3 tests/parity_report.py 4096 1024 > "$OUT/parity_fullsize.txt" 2>&1
+python3 -m pytest tests/test_gpu_fullsize_parity.py -q -s > "$OUT/parity_fullsize.txt" 2>&1
 ls -la "$OUT"

@@ -2,7 +2,7 @@
 counters after one propagate per setting).  usage: python tests/eps_sweep.py"""
 import os
 import sys, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 from test_gpu_screen import _engine
 for N in (1024, 4096):

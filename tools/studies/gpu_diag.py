@@ -2,7 +2,7 @@
 with the worst rollout's context printed."""
 import sys, os
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 from helpers import SCENARIOS, load, weights_path
 from oracle import omds_oracle as orc

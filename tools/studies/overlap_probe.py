@@ -3,7 +3,7 @@ threads, against one context of N rollouts -- does overlapping one group's power
 latency-bound k_exact / k_tail_sel pay?  usage: OMDS_SCREEN_CUS=160 python tests/overlap_probe.py [G]"""
 import os, sys, threading, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 from test_gpu_screen import _engine
 
