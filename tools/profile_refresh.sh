@@ -2,15 +2,15 @@
 # Regenerates the rocprofv3 summaries committed under profiles/ (run on the GPU box through gpurun from the repo root).
 # Every rocprofv3 call has python3 directly after "--"; counters are collected in their own passes.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 OUT=$PWD/gpurun_out/prof_$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-B="bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary"
-P="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary"
-python3 bench.py --steps 10 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.err"
+B="bench.py --steps 5 --warmup 1 --reps 1 --no-cpu-baseline --no-secondary"
+P="bench.py --steps 2 --warmup 1 --reps 1 --no-cpu-baseline --no-secondary"
+python3 bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
 finddb() { find "$1" -name '*_results.db' | head -1; }
-for wl in franka_shelf_1024x32 franka_shelf_4096x32 planar7_1024x32; do
+for wl in franka_shelf_1024x32 franka_shelf_4096x32 planar7_1024x32 franka_tanh_4096x32 franka_dynamic_1024x32; do
   rocprofv3 --kernel-trace --stats -d "$OUT/kt_$wl" -- python3 $B --workload $wl > "$OUT/kt_$wl.log" 2>&1
   python3 tools/rocprof_summary.py stats "$(finddb "$OUT/kt_$wl")" > "$OUT/stats_$wl.txt"
   tail -1 "$OUT/kt_$wl.log" | grep '^{' > "$OUT/bench_profiled_$wl.json"
@@ -45,7 +45,7 @@ for wl, tag in (("franka_shelf_1024x32", ""), ("planar7_1024x32", "_p7")):
     res[wl] = {}
     for name in f:
         short = "k_screen" if "k_screen" in name else "k_step_small" if "k_step_small" in name else "k_tail" if "k_tail" in name else \
-                "k_exact" if "k_exact" in name else "k_select" if "k_select" in name else "k_pass1" if "k_pass1" in name else None
+                "k_exact" if "k_exact" in name else "k_select" if "k_select" in name else "k_audit" if "k_audit" in name else "k_pass1" if "k_pass1" in name else None
         if short and name in w:
             res[wl][short] = {"fetch_kb": f[name], "write_kb": w[name], "traffic_bytes": int((2 * f[name] + w[name]) * 1024)}
 json.dump(res, open(out + "/pmc_traffic.json", "w"), indent=1)
