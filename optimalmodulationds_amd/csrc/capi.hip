@@ -117,13 +117,16 @@ static void free_all(omds_ctx* ctx) {
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
                     ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
                     ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
-                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP, ctx->d_seds, ctx->d_audit_rows, ctx->d_audit_da, ctx->d_ApreAll, ctx->d_featQAll, ctx->d_FqS, ctx->d_FpS, ctx->d_listDa, ctx->d_sinks};
+                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP, ctx->d_seds, ctx->d_audit_rows, ctx->d_audit_da, ctx->d_ApreAll, ctx->d_featQAll, ctx->d_FqS, ctx->d_FpS, ctx->d_listDa, ctx->d_sinks, ctx->d_qcur};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : ctx->mlp_allocs)
         if (p) (void)hipFree(p);
     if (ctx->h_red) (void)hipHostFree(ctx->h_red);
     if (ctx->h_sinks) (void)hipHostFree(ctx->h_sinks);
+    if (ctx->h_in) (void)hipHostFree(ctx->h_in);
+    if (ctx->ev_in_q) (void)hipEventDestroy(ctx->ev_in_q);
+    if (ctx->ev_in_means) (void)hipEventDestroy(ctx->ev_in_means);
     for (auto e : ctx->prof.start) (void)hipEventDestroy(e);
     for (auto e : ctx->prof.stop) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -196,6 +199,7 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
     CKC(hipMalloc(&ctx->d_sigmaT, Km * N * 4));
     CKC(hipMalloc(&ctx->d_alphaT, Km * n * N * 4));
     CKC(hipMalloc(&ctx->d_means, Km * (2 * n + 1) * 4));
+    CKC(hipMalloc(&ctx->d_qcur, OMDS_MAX_DOF * 4));
     CKC(hipMalloc(&ctx->d_Apre, rows2 * OMDS_WIDTH * 4));
     CKC(hipMalloc(&ctx->d_Dmin, N * Om * 4));
     CKC(hipMalloc(&ctx->d_rowlist, N * Om * 4));
@@ -222,6 +226,9 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
     const size_t redn = std::max<size_t>((size_t)omds_red_size((int)Km, (int)n) + 8, 2 * H + 16);   // also the screening counters of a propagate (4 + 2 (H + 1))
     CKC(hipMalloc(&ctx->d_red, redn * 4));
     CKC(hipHostMalloc(&ctx->h_red, redn * 4));
+    CKC(hipHostMalloc(&ctx->h_in, (Km * (2 * n + 1) + OMDS_MAX_DOF) * 4));   // pinned staging of the small per-iteration inputs
+    CKC(hipEventCreateWithFlags(&ctx->ev_in_q, hipEventDisableTiming));
+    CKC(hipEventCreateWithFlags(&ctx->ev_in_means, hipEventDisableTiming));
     ctx->stage_bytes = std::max({N * H * std::max(Km, n) * 4, N * Om * 4, Km * n * N * 4, rows2 * OMDS_CPAD * 4});
     CKC(hipMalloc(&ctx->d_stage, ctx->stage_bytes));
     CKC(hipMalloc(&ctx->d_cflags, N * H));
@@ -731,12 +738,15 @@ int omds_sample_policy(omds_ctx* ctx, const float* mu_c, const float* sigma_c, c
     if (K == 0) return OMDS_OK;
     REQUIRE(mu_c && sigma_c && alpha_c, OMDS_ERR_INVALID_ARG, "omds_sample_policy: null mean array");
     const int N = ctx->cfg.n_traj, n = ctx->cfg.n_dof;
-    std::vector<float> means((size_t)K * (2 * n + 1));
-    std::memcpy(means.data(), mu_c, (size_t)K * n * 4);
-    std::memcpy(means.data() + (size_t)K * n, sigma_c, (size_t)K * 4);
-    std::memcpy(means.data() + (size_t)K * n + K, alpha_c, (size_t)K * n * 4);
-    CK(hipMemcpyAsync(ctx->d_means, means.data(), means.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));  // 'means' is pageable stack memory
+    // through pinned staging: no stream synchronisation here.  The staging is normally rewritten one planner iteration later,
+    // behind the synchronisations of omds_propagate and the update; the event covers back-to-back calls
+    CK(hipEventSynchronize(ctx->ev_in_means));
+    float* means = ctx->h_in + OMDS_MAX_DOF;
+    std::memcpy(means, mu_c, (size_t)K * n * 4);
+    std::memcpy(means + (size_t)K * n, sigma_c, (size_t)K * 4);
+    std::memcpy(means + (size_t)K * n + K, alpha_c, (size_t)K * n * 4);
+    CK(hipMemcpyAsync(ctx->d_means, means, (size_t)K * (2 * n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipEventRecord(ctx->ev_in_means, ctx->stream));
     omds_launch_sample(ctx->stream, N, n, K, ctx->d_means, mu_s, sigma_s, alpha_s, seed, rollout_offset, ctx->d_muT,
                        ctx->d_sigmaT, ctx->d_alphaT);
     CK(hipGetLastError());
@@ -1072,11 +1082,16 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
     if (per_rollout) {
         CK(hipMemcpyAsync(ctx->d_stage, q_cur, (size_t)N * n * 4, hipMemcpyHostToDevice, ctx->stream));
         omds_launch_transpose(ctx->stream, ctx->d_stage, ctx->d_trajT, N, n);
+        CK(hipStreamSynchronize(ctx->stream));  // q_cur is caller memory
     } else {
-        CK(hipMemcpyAsync(ctx->d_means, q_cur, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-        omds_launch_broadcast_q(ctx->stream, ctx->d_means, n, N, ctx->d_trajT);
+        // pinned staging + a device slot of its own (d_qcur): no synchronisation, and the policy means that k_sample may not
+        // have consumed yet (d_means) stay untouched
+        CK(hipEventSynchronize(ctx->ev_in_q));
+        std::memcpy(ctx->h_in, q_cur, (size_t)n * 4);
+        CK(hipMemcpyAsync(ctx->d_qcur, ctx->h_in, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        CK(hipEventRecord(ctx->ev_in_q, ctx->stream));
+        omds_launch_broadcast_q(ctx->stream, ctx->d_qcur, n, N, ctx->d_trajT);
     }
-    CK(hipStreamSynchronize(ctx->stream));  // q_cur is caller memory; d_means is reused below by nobody until sample
     StepArgs a{};
     a.N = N; a.H = H; a.n = n; a.K = ctx->n_kernels; a.Kmax = ctx->cfg.n_kernel_max; a.k = ctx->cfg.n_closest; a.d = ctx->mlp.d;
     a.trajT = ctx->d_trajT; a.distT = ctx->d_distT; a.dotT = ctx->d_dotT; a.actT = ctx->d_actT; a.normalT = ctx->d_normalT;

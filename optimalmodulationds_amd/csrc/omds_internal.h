@@ -204,6 +204,9 @@ struct omds_ctx {
     float* d_w = nullptr;        // [N] unnormalised weights
     float* d_red = nullptr;      // packed reduction buffer
     float* h_red = nullptr;      // pinned mirror
+    float* h_in = nullptr;       // pinned staging of the small per-iteration inputs: [0, 7) q_cur, then the policy means
+    float* d_qcur = nullptr;     // [n] start state of a broadcast propagate
+    hipEvent_t ev_in_q = nullptr, ev_in_means = nullptr;   // the H2D copies out of h_in have executed (back-to-back calls)
     bool have_cost_vals = false;
     // kernel-candidate scratch
     unsigned char* d_cflags = nullptr;  // [N][H]
