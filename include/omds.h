@@ -291,6 +291,26 @@ OMDS_API int omds_screen_mindist(omds_ctx* ctx, const float* q, int batch, float
 OMDS_API int omds_screen_stats(omds_ctx* ctx, int32_t* active, float* eps, float* max_err_seen,
                                double* cand_per_rollout_step, int64_t* fallbacks);
 
+/* SDF training (mlp_learn/train_sdf.py:96-151): full-batch regression of the distance network on a data set
+ * (x [B, d] raw inputs = joint angles then the obstacle point, y [B, C] link distances) -- per epoch one forward through
+ * [x, sin x, cos x] -> Linear + act ... -> Linear (network_macros_mod.py:137-146), F.mse_loss(reduction = 'mean'), the backward
+ * through every layer and one torch.optim.Adam step (single-tensor arithmetic: lerp of exp_avg, bias-corrected step size,
+ * denom = sqrt(exp_avg_sq) / sqrt(bc2) + eps), all on the device in exact-fp32 MFMA GEMMs (csrc/train.hip).  The scheduler
+ * (ReduceLROnPlateau), validation metrics and the checkpoint dictionary of the reference stay on the host
+ * (tools/train_sdf_hip.py).  A trainer is its own object (no omds_ctx needed); dims[n_linear + 1] = {3 d, hidden ..., C}; W[i] is
+ * [dims[i+1], dims[i]] row-major like torch.  omds_trainer_set_weights also resets the optimizer state and step count.
+ * omds_trainer_step returns the loss BEFORE the update (what train_sdf.py prints as train loss); omds_trainer_eval runs the
+ * forward + loss on the current data set without an update (pred_out [B, C] or NULL).                                   */
+typedef struct omds_trainer omds_trainer;
+OMDS_API int omds_trainer_create(int device, int n_linear, const int32_t* dims, int act, omds_trainer** out);
+OMDS_API void omds_trainer_destroy(omds_trainer* tr);
+OMDS_API const char* omds_trainer_last_error(const omds_trainer* tr);
+OMDS_API int omds_trainer_set_weights(omds_trainer* tr, const float* const* W, const float* const* b);
+OMDS_API int omds_trainer_get_weights(omds_trainer* tr, float* const* W, float* const* b);
+OMDS_API int omds_trainer_set_data(omds_trainer* tr, const float* x, const float* y, int batch);
+OMDS_API int omds_trainer_step(omds_trainer* tr, float lr, float beta1, float beta2, float eps, float* loss_out);
+OMDS_API int omds_trainer_eval(omds_trainer* tr, float* mse_out, float* pred_out);
+
 /* Measurement: when enabled, launches of the dominant kernel (k_pass1) are bracketed by HIP events on the
  * context stream -- every launch for on == 1, every on-th launch for on > 1 (an event record between two
  * kernels idles the GPU for ~6 us, so throughput runs sample) -- and omds_prof_read returns the summed elapsed

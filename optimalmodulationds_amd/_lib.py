@@ -93,6 +93,14 @@ SIGNATURES = {
     "omds_screen_debug_corrupt": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float]),
     "omds_screen_mindist": (C.c_int, [C.c_void_p, F32P, C.c_int, F32P]),
     "omds_screen_stats": (C.c_int, [C.c_void_p, I32P, F32P, F32P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "omds_trainer_create": (C.c_int, [C.c_int, C.c_int, I32P, C.c_int, C.POINTER(C.c_void_p)]),
+    "omds_trainer_destroy": (None, [C.c_void_p]),
+    "omds_trainer_last_error": (C.c_char_p, [C.c_void_p]),
+    "omds_trainer_set_weights": (C.c_int, [C.c_void_p, C.POINTER(F32P), C.POINTER(F32P)]),
+    "omds_trainer_get_weights": (C.c_int, [C.c_void_p, C.POINTER(F32P), C.POINTER(F32P)]),
+    "omds_trainer_set_data": (C.c_int, [C.c_void_p, F32P, F32P, C.c_int]),
+    "omds_trainer_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, F32P]),
+    "omds_trainer_eval": (C.c_int, [C.c_void_p, F32P, F32P]),
     "omds_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "omds_prof_reset": (C.c_int, [C.c_void_p]),
     "omds_prof_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
@@ -101,7 +109,7 @@ SIGNATURES = {
     "omds_sync": (C.c_int, [C.c_void_p]),
 }
 
-ABI_VERSION = 300      # omds_version() of the library this binding was written against
+ABI_VERSION = 310      # omds_version() of the library this binding was written against
 _lib = None
 
 

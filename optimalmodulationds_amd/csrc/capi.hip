@@ -84,7 +84,7 @@ static uint16_t f32_to_f16_bits(float f) {
 
 extern "C" {
 
-int omds_version(void) { return 300; }
+int omds_version(void) { return 310; }
 
 void omds_default_params(omds_params* p) {
     if (!p) return;

@@ -1,0 +1,410 @@
+// SDF training on the device (gfx950): what mlp_learn/train_sdf.py:96-151 does per epoch -- a FULL-BATCH forward of the
+// distance network (network_macros_mod.py:137-146: [x, sin x, cos x] -> Linear + act ... -> Linear), F.mse_loss(reduction =
+// 'mean'), backward through every layer and one torch.optim.Adam step -- as exact-fp32 MFMA GEMMs.  The scheduler
+// (ReduceLROnPlateau), the validation metrics and the checkpoint dictionary stay on the host (tools/train_sdf_hip.py): they are
+// O(1) per epoch.
+//
+// One GEMM kernel serves the three shapes of a layer (B = batch rows, the large dimension):
+//   forward            Z  [B x out] = H [B x in]   . W^T            (W is [out x in], row-major like torch)
+//   input gradient     Gi [B x in]  = G [B x out]  . W
+//   weight gradient    dW [out x in] = G^T         . H              (contraction over B: split over workgroups, the partial
+//                                                                    products summed in a fixed order -- deterministic)
+// 64 x 64 output tiles, 4 waves, v_mfma_f32_32x32x2_f32 (an fmaf chain in k order, tools/ubench/mfma_order.hip), operands staged
+// through LDS 16 k at a time with either operand read transposed.  Everything else of a step is elementwise or a column sum.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "omds_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int TM = 128, TN = 128, TK = 16;
+
+// C[z] (M x N, ldc) = opA(A) (M x K) . opB(B) (K x N) over k in [z * kchunk, min(K, (z + 1) * kchunk)).
+// TA: A is stored [K][M] (lda = row stride of the stored matrix); else [M][K].  TB: B is stored [N][K]; else [K][N].
+// 128 x 128 output tile per workgroup, 4 waves in 2 x 2, each wave 64 x 64 as 2 x 2 MFMA tiles: four MFMAs per four LDS
+// operand reads (a 64 x 64 workgroup tile with one MFMA per two reads ran 28 TFLOP/s on the training shapes).
+// EPI 0: C = product.  EPI 1 (forward): C = act(product + bias[n]) (act < 0: none).  EPI 2 (input gradient): C = product * act'(z)
+// read from the layer's stored activation aux[m][n] = act(z) -- the elementwise passes over [B x width] fused into the stores.
+template <bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                              float* __restrict__ C, int ldc, int M, int N, int K, int kchunk, size_t cstride,
+                                              const float* __restrict__ aux, int act) {
+    __shared__ float As[TK][TM + 32];   // [k][m]; row stride 160 floats: the two k rows a wave reads at once fall into disjoint banks
+    __shared__ float Bs[TK][TN + 32];   // [k][n]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int k_begin = blockIdx.z * kchunk, k_end = min(K, k_begin + kchunk);
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int k0 = k_begin; k0 < k_end; k0 += TK) {
+        // stage the two operand tiles (zeros outside the matrices): 128 x 16 elements each, 8 per thread
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = tid + 256 * e;
+            {   // A tile
+                int m, kk;
+                if (TA) { m = idx & 127; kk = idx >> 7; } else { kk = idx & 15; m = idx >> 4; }   // fastest index = the stored matrix's contiguous one
+                const int gm = m0 + m, gk = k0 + kk;
+                float v = 0.f;
+                if (gm < M && gk < k_end) v = TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
+                As[kk][m] = v;
+            }
+            {   // B tile
+                int n, kk;
+                if (TB) { kk = idx & 15; n = idx >> 4; } else { n = idx & 127; kk = idx >> 7; }
+                const int gn = n0 + n, gk = k0 + kk;
+                float v = 0.f;
+                if (gn < N && gk < k_end) v = TB ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn];
+                Bs[kk][n] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < TK; kk += 2) {
+            const float a0 = As[kk + (lane >> 5)][wm + (lane & 31)], a1 = As[kk + (lane >> 5)][wm + 32 + (lane & 31)];
+            const float b0 = Bs[kk + (lane >> 5)][wn + (lane & 31)], b1 = Bs[kk + (lane >> 5)][wn + 32 + (lane & 31)];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* Cz = C + (size_t)blockIdx.z * cstride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {   // C/D layout: lane l, register r -> row (r & 3) + 8 (r >> 2) + 4 (l >> 5), col l & 31
+                const int gm = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), gn = n0 + wn + 32 * j + (lane & 31);
+                if (gm < M && gn < N) {
+                    float v = acc[i][j][r];
+                    if constexpr (EPI == 1) {
+                        v += aux[gn];
+                        v = act == 0 ? fmaxf(v, 0.f) : (act == 1 ? tanhf(v) : v);
+                    } else if constexpr (EPI == 2) {
+                        const float h = aux[(size_t)gm * ldc + gn];
+                        v = act == 0 ? (h > 0.f ? v : 0.f) : v * (1.f - h * h);
+                    }
+                    Cz[(size_t)gm * ldc + gn] = v;
+                }
+            }
+}
+
+__global__ void k_sum_partials(const float* __restrict__ P, int S, size_t n, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += P[(size_t)z * n + i];   // fixed order
+    out[i] = s;
+}
+
+// [x, sin x, cos x] (network_macros_mod.py:139-140)
+__global__ void k_encode(const float* __restrict__ x, int B, int d, float* __restrict__ H0) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * d) return;
+    const size_t r = i / d;
+    const int j = (int)(i - r * d);
+    const float v = x[i];
+    H0[r * 3 * d + j] = v;
+    H0[r * 3 * d + d + j] = sinf(v);
+    H0[r * 3 * d + 2 * d + j] = cosf(v);
+}
+
+// G = 2 (pred - y) / count  (the gradient of F.mse_loss(..., reduction='mean')); per-block partial sums of (pred - y)^2 in double
+__global__ __launch_bounds__(256) void k_mse(const float* __restrict__ pred, const float* __restrict__ y, size_t n, float scale,
+                                             float* __restrict__ G, double* __restrict__ partial) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float dlt = pred[i] - y[i];
+        if (G) G[i] = scale * dlt;
+        s += (double)dlt * (double)dlt;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// column sums of G [rows x N] (the bias gradient): rows split over blockIdx.y, partials summed in a fixed order afterwards
+__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ G, size_t rows, int N, size_t rows_per, float* __restrict__ P) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    const size_t r0 = (size_t)blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+    float s = 0.f;
+    for (size_t r = r0; r < r1; ++r) s += G[r * N + c];
+    P[(size_t)blockIdx.y * N + c] = s;
+}
+
+// torch.optim.Adam (default flags: no amsgrad, no weight decay, not capturable), the single-tensor arithmetic:
+//   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g g;  denom = sqrt(v) / sqrt(bc2) + eps;  p -= (lr / bc1) * m / denom
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                       float b1, float b2, float eps, float step_size, float bc2_sqrt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);        // torch: exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;       // torch: exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+}
+
+}  // namespace
+
+struct omds_trainer {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int L = 0, act = 0, d = 0;
+    std::vector<int> dims;                 // [L + 1]: 3 d, hidden ..., C
+    std::vector<float*> W, b, gW, gb, mW, mb, vW, vb;
+    int B = 0, cap = 0;                    // rows of the current data set, rows the activation buffers hold
+    float* x = nullptr; float* y = nullptr;
+    std::vector<float*> H;                 // [L + 1] activations: H[0] = encoded input ... H[L] = prediction
+    float* G[2] = {nullptr, nullptr};      // gradient ping-pong [cap x max width]
+    float* partial = nullptr;              // split-K partials of the weight gradient / column-sum partials
+    size_t partial_floats = 0;
+    double* lossp = nullptr; double* h_lossp = nullptr;
+    long long step = 0;
+};
+
+static thread_local std::string g_train_err;
+#define TCK(expr)                                                                          \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) { tr->err = std::string(#expr) + ": " + hipGetErrorString(_e); return OMDS_ERR_HIP; } \
+    } while (0)
+
+static void trainer_free_data(omds_trainer* tr) {
+    for (float* p : {tr->x, tr->y, tr->G[0], tr->G[1]}) if (p) (void)hipFree(p);
+    tr->x = tr->y = tr->G[0] = tr->G[1] = nullptr;
+    for (float*& p : tr->H) { if (p) (void)hipFree(p); p = nullptr; }
+    tr->cap = 0;
+}
+
+template <bool TA, bool TB, int EPI>
+static void launch_gemm(hipStream_t s, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
+                        int splits, int kchunk, size_t cstride, const float* aux = nullptr, int act = -1) {
+    const dim3 grid((N + TN - 1) / TN, (M + TM - 1) / TM, splits);
+    hipLaunchKernelGGL((k_gemm<TA, TB, EPI>), grid, dim3(256), 0, s, A, lda, Bm, ldb, C, ldc, M, N, K, kchunk, cstride, aux, act);
+}
+
+static int forward(omds_trainer* tr, int B) {
+    hipStream_t s = tr->stream;
+    const int d = tr->d;
+    hipLaunchKernelGGL(k_encode, dim3((unsigned)(((size_t)B * d + 255) / 256)), dim3(256), 0, s, tr->x, B, d, tr->H[0]);
+    for (int i = 0; i < tr->L; ++i) {
+        const int in = tr->dims[i], out = tr->dims[i + 1];
+        launch_gemm<false, true, 1>(s, tr->H[i], in, tr->W[i], in, tr->H[i + 1], out, B, out, in, 1, in, 0, tr->b[i], i + 1 < tr->L ? tr->act : -1);
+    }
+    return OMDS_OK;
+}
+
+static int mse(omds_trainer* tr, int B, float* G, double* loss) {
+    const size_t n = (size_t)B * tr->dims[tr->L];
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_mse, dim3(blocks), dim3(256), 0, tr->stream, tr->H[tr->L], tr->y, n, 2.f / (float)n, G, tr->lossp);
+    TCK(hipMemcpyAsync(tr->h_lossp, tr->lossp, (size_t)blocks * 8, hipMemcpyDeviceToHost, tr->stream));
+    TCK(hipStreamSynchronize(tr->stream));
+    double sum = 0.0;
+    for (int i = 0; i < blocks; ++i) sum += tr->h_lossp[i];
+    *loss = sum / (double)n;
+    return OMDS_OK;
+}
+
+extern "C" {
+
+const char* omds_trainer_last_error(const omds_trainer* tr) { return tr ? tr->err.c_str() : g_train_err.c_str(); }
+
+int omds_trainer_create(int device, int n_linear, const int32_t* dims, int act, omds_trainer** out) {
+    if (!out || !dims || n_linear < 2 || n_linear > OMDS_MAX_HIDDEN + 1 || (act != OMDS_ACT_RELU && act != OMDS_ACT_TANH) || dims[0] % 3 != 0) {
+        g_train_err = "omds_trainer_create: need 2 <= n_linear <= 9 Linear layers, dims[0] = 3 * (raw inputs), act RELU or TANH";
+        return OMDS_ERR_INVALID_ARG;
+    }
+    for (int i = 0; i <= n_linear; ++i)
+        if (dims[i] < 1 || dims[i] > 4096) { g_train_err = "omds_trainer_create: layer widths must be in 1 .. 4096"; return OMDS_ERR_INVALID_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_train_err = std::string("omds_trainer_create: no HIP device available (") + hipGetErrorString(e) + "); this library has no CPU fallback";
+        return OMDS_ERR_HIP;
+    }
+    if (device < 0 || device >= ndev) { g_train_err = "omds_trainer_create: device ordinal out of range"; return OMDS_ERR_INVALID_ARG; }
+    omds_trainer* tr = new (std::nothrow) omds_trainer();
+    if (!tr) { g_train_err = "omds_trainer_create: out of host memory"; return OMDS_ERR_INVALID_ARG; }
+    tr->dev = device; tr->L = n_linear; tr->act = act; tr->d = dims[0] / 3;
+    tr->dims.assign(dims, dims + n_linear + 1);
+    auto fail = [&](const char* what, hipError_t err) { g_train_err = std::string(what) + ": " + hipGetErrorString(err); omds_trainer_destroy(tr); return OMDS_ERR_HIP; };
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&tr->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    size_t wmax = 0;
+    for (int i = 0; i < n_linear; ++i) {
+        const size_t nw = (size_t)dims[i] * dims[i + 1], nb = dims[i + 1];
+        wmax = std::max(wmax, nw);
+        for (auto* vec : {&tr->W, &tr->gW, &tr->mW, &tr->vW}) {
+            float* p = nullptr;
+            if ((e = hipMalloc(&p, nw * 4)) != hipSuccess) return fail("hipMalloc", e);
+            (void)hipMemsetAsync(p, 0, nw * 4, tr->stream);
+            vec->push_back(p);
+        }
+        for (auto* vec : {&tr->b, &tr->gb, &tr->mb, &tr->vb}) {
+            float* p = nullptr;
+            if ((e = hipMalloc(&p, nb * 4)) != hipSuccess) return fail("hipMalloc", e);
+            (void)hipMemsetAsync(p, 0, nb * 4, tr->stream);
+            vec->push_back(p);
+        }
+    }
+    tr->H.assign(n_linear + 1, nullptr);
+    tr->partial_floats = 256 * wmax;     // up to 256 split-K partials of the largest weight gradient
+    if ((e = hipMalloc(&tr->partial, tr->partial_floats * 4)) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMalloc(&tr->lossp, 1024 * 8)) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipHostMalloc(&tr->h_lossp, 1024 * 8)) != hipSuccess) return fail("hipHostMalloc", e);
+    (void)hipStreamSynchronize(tr->stream);
+    *out = tr;
+    return OMDS_OK;
+}
+
+void omds_trainer_destroy(omds_trainer* tr) {
+    if (!tr) return;
+    (void)hipSetDevice(tr->dev);
+    if (tr->stream) (void)hipStreamSynchronize(tr->stream);
+    trainer_free_data(tr);
+    for (auto* vec : {&tr->W, &tr->b, &tr->gW, &tr->gb, &tr->mW, &tr->mb, &tr->vW, &tr->vb})
+        for (float* p : *vec) if (p) (void)hipFree(p);
+    if (tr->partial) (void)hipFree(tr->partial);
+    if (tr->lossp) (void)hipFree(tr->lossp);
+    if (tr->h_lossp) (void)hipHostFree(tr->h_lossp);
+    if (tr->stream) (void)hipStreamDestroy(tr->stream);
+    delete tr;
+}
+
+int omds_trainer_set_weights(omds_trainer* tr, const float* const* W, const float* const* b) {
+    if (!tr) return OMDS_ERR_INVALID_ARG;
+    if (!W || !b) { tr->err = "omds_trainer_set_weights: null argument"; return OMDS_ERR_INVALID_ARG; }
+    TCK(hipSetDevice(tr->dev));
+    for (int i = 0; i < tr->L; ++i) {
+        const size_t nw = (size_t)tr->dims[i] * tr->dims[i + 1], nb = tr->dims[i + 1];
+        TCK(hipMemcpy(tr->W[i], W[i], nw * 4, hipMemcpyHostToDevice));
+        TCK(hipMemcpy(tr->b[i], b[i], nb * 4, hipMemcpyHostToDevice));
+        for (float* p : {tr->mW[i], tr->vW[i]}) TCK(hipMemset(p, 0, nw * 4));   // a fresh optimizer state, like a new torch.optim.Adam
+        for (float* p : {tr->mb[i], tr->vb[i]}) TCK(hipMemset(p, 0, nb * 4));
+    }
+    tr->step = 0;
+    return OMDS_OK;
+}
+
+int omds_trainer_get_weights(omds_trainer* tr, float* const* W, float* const* b) {
+    if (!tr) return OMDS_ERR_INVALID_ARG;
+    if (!W || !b) { tr->err = "omds_trainer_get_weights: null argument"; return OMDS_ERR_INVALID_ARG; }
+    TCK(hipSetDevice(tr->dev));
+    TCK(hipStreamSynchronize(tr->stream));
+    for (int i = 0; i < tr->L; ++i) {
+        TCK(hipMemcpy(W[i], tr->W[i], (size_t)tr->dims[i] * tr->dims[i + 1] * 4, hipMemcpyDeviceToHost));
+        TCK(hipMemcpy(b[i], tr->b[i], (size_t)tr->dims[i + 1] * 4, hipMemcpyDeviceToHost));
+    }
+    return OMDS_OK;
+}
+
+int omds_trainer_set_data(omds_trainer* tr, const float* x, const float* y, int batch) {
+    if (!tr) return OMDS_ERR_INVALID_ARG;
+    if (!x || !y || batch < 1) { tr->err = "omds_trainer_set_data: need batch >= 1 and non-null x [B, d], y [B, C]"; return OMDS_ERR_INVALID_ARG; }
+    TCK(hipSetDevice(tr->dev));
+    TCK(hipStreamSynchronize(tr->stream));
+    if (batch > tr->cap) {
+        trainer_free_data(tr);
+        int wmax = 0;
+        for (int v : tr->dims) wmax = std::max(wmax, v);
+        TCK(hipMalloc(&tr->x, (size_t)batch * tr->d * 4));
+        TCK(hipMalloc(&tr->y, (size_t)batch * tr->dims[tr->L] * 4));
+        for (int i = 0; i <= tr->L; ++i) TCK(hipMalloc(&tr->H[i], (size_t)batch * tr->dims[i] * 4));
+        for (int i = 0; i < 2; ++i) TCK(hipMalloc(&tr->G[i], (size_t)batch * wmax * 4));
+        tr->cap = batch;
+    }
+    TCK(hipMemcpy(tr->x, x, (size_t)batch * tr->d * 4, hipMemcpyHostToDevice));
+    TCK(hipMemcpy(tr->y, y, (size_t)batch * tr->dims[tr->L] * 4, hipMemcpyHostToDevice));
+    tr->B = batch;
+    return OMDS_OK;
+}
+
+// forward + F.mse_loss on the current data set, no update (train_sdf.py:117-121 on the validation split)
+int omds_trainer_eval(omds_trainer* tr, float* mse_out, float* pred_out) {
+    if (!tr) return OMDS_ERR_INVALID_ARG;
+    if (tr->B < 1) { tr->err = "omds_trainer_eval: no data set (omds_trainer_set_data)"; return OMDS_ERR_NOT_INITIALISED; }
+    TCK(hipSetDevice(tr->dev));
+    int rc;
+    if ((rc = forward(tr, tr->B))) return rc;
+    double loss = 0.0;
+    if ((rc = mse(tr, tr->B, nullptr, &loss))) return rc;
+    if (mse_out) *mse_out = (float)loss;
+    if (pred_out) TCK(hipMemcpy(pred_out, tr->H[tr->L], (size_t)tr->B * tr->dims[tr->L] * 4, hipMemcpyDeviceToHost));
+    return OMDS_OK;
+}
+
+// one epoch of train_sdf.py:105-113 on the whole data set: forward, mse_loss, backward, Adam step.  loss_out = the loss BEFORE the step
+int omds_trainer_step(omds_trainer* tr, float lr, float beta1, float beta2, float eps, float* loss_out) {
+    if (!tr) return OMDS_ERR_INVALID_ARG;
+    if (tr->B < 1) { tr->err = "omds_trainer_step: no data set (omds_trainer_set_data)"; return OMDS_ERR_NOT_INITIALISED; }
+    TCK(hipSetDevice(tr->dev));
+    hipStream_t s = tr->stream;
+    const int B = tr->B, L = tr->L;
+    int rc;
+    if ((rc = forward(tr, B))) return rc;
+    double loss = 0.0;
+    float* G = tr->G[0];
+    float* Gn = tr->G[1];
+    if ((rc = mse(tr, B, G, &loss))) return rc;
+    if (loss_out) *loss_out = (float)loss;
+    for (int i = L - 1; i >= 0; --i) {
+        const int in = tr->dims[i], out = tr->dims[i + 1];
+        // dW = G^T . H_i: the contraction runs over the batch; split it so that ~1024 workgroups exist, sum the partials in order
+        const int tiles = ((out + TM - 1) / TM) * ((in + TN - 1) / TN);
+        int splits = std::max(1, std::min({256, 1024 / std::max(tiles, 1), (B + 4 * TK - 1) / (4 * TK)}));
+        while ((size_t)splits * out * in > tr->partial_floats) --splits;
+        int kchunk = ((B + splits - 1) / splits + TK - 1) / TK * TK;
+        splits = (B + kchunk - 1) / kchunk;
+        launch_gemm<true, false, 0>(s, G, out, tr->H[i], in, tr->partial, in, out, in, B, splits, kchunk, (size_t)out * in);
+        hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)(((size_t)out * in + 255) / 256)), dim3(256), 0, s, tr->partial, splits, (size_t)out * in, tr->gW[i]);
+        // db = column sums of G
+        const int rsplit = std::max(1, std::min({2048, B / 256, (int)(tr->partial_floats / (size_t)out)}));
+        const size_t rows_per = ((size_t)B + rsplit - 1) / rsplit;
+        hipLaunchKernelGGL(k_colsum_partial, dim3((out + 255) / 256, rsplit), dim3(256), 0, s, G, (size_t)B, out, rows_per, tr->partial);
+        hipLaunchKernelGGL(k_sum_partials, dim3((out + 255) / 256), dim3(256), 0, s, tr->partial, rsplit, (size_t)out, tr->gb[i]);
+        if (i > 0) {   // gradient at this layer's input, through the activation of the layer in front
+            launch_gemm<false, false, 2>(s, G, out, tr->W[i], in, Gn, in, B, in, out, 1, out, 0, tr->H[i], tr->act);
+            std::swap(G, Gn);
+        }
+    }
+    tr->step++;
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)tr->step), bc2 = 1.0 - std::pow((double)beta2, (double)tr->step);
+    const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)std::sqrt(bc2);
+    for (int i = 0; i < L; ++i) {
+        const size_t nw = (size_t)tr->dims[i] * tr->dims[i + 1], nb = tr->dims[i + 1];
+        hipLaunchKernelGGL(k_adam, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, tr->W[i], tr->gW[i], tr->mW[i], tr->vW[i], nw, beta1, beta2, eps, step_size, bc2_sqrt);
+        hipLaunchKernelGGL(k_adam, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, tr->b[i], tr->gb[i], tr->mb[i], tr->vb[i], nb, beta1, beta2, eps, step_size, bc2_sqrt);
+    }
+    TCK(hipGetLastError());
+    TCK(hipStreamSynchronize(s));
+    return OMDS_OK;
+}
+
+}  // extern "C"

@@ -167,11 +167,11 @@ def test_stale_library_version_is_reported(tmp_path, lib):
         "import sys\n"
         f"sys.path.insert(0, {ROOT!r})\n"
         "from optimalmodulationds_amd import _lib\n"
-        "_lib.ABI_VERSION = 299\n"
+        "_lib.ABI_VERSION = _lib.ABI_VERSION - 1\n"
         "try:\n"
         "    _lib.load()\n"
         "except _lib.OmdsError as e:\n"
         "    print('RAISED', e)\n"
     )
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
-    assert "RAISED" in r.stdout and "ABI version 300" in r.stdout and "rebuild" in r.stdout, r.stdout + r.stderr
+    assert "RAISED" in r.stdout and f"ABI version {_lib.ABI_VERSION}" in r.stdout and "rebuild" in r.stdout, r.stdout + r.stderr

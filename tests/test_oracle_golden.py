@@ -193,3 +193,25 @@ def test_seds_velocity(name):
     # relative to the largest output: the 2-D mixture (fitted in pixel units) answers ~136 near its goal, where b + A (x - mu)
     # cancels three digits -- 3e-5 between two fp32 summation orders
     assert_close(y, fx["y"], 5e-5, "SEDS velocity vs reference", floor=1.0)
+
+
+def test_train_oracle_matches_the_reference_run():
+    """oracle/train_oracle.py (one epoch of train_sdf.py:105-113 + torch's Adam arithmetic in numpy) against the run of the
+    reference's own model class and torch.optim.Adam captured in train_sdf_planar2.npz: the loss of each of the 100 epochs and
+    the weights after 10 and 100 epochs.  Weight DELTAS are compared (what training moved), relative to the largest delta."""
+    from oracle import train_oracle as tro
+    fx = load("train_sdf_planar2")
+    nl = len([k for k in fx if k.startswith("W0_")])
+    st = tro.TrainState([fx[f"W0_{i}"] for i in range(nl)], [fx[f"b0_{i}"] for i in range(nl)])
+    losses = []
+    for e in range(int(fx["epochs"])):
+        losses.append(tro.train_step(st, fx["x"], fx["y"], lr=float(fx["lr"])))
+        if e + 1 in (10, 100):
+            tag = f"W{e + 1}_"
+            dmax = max(float(np.abs(fx[f"{tag}{i}"] - fx[f"W0_{i}"]).max()) for i in range(nl))
+            for i in range(nl):
+                err = float(np.abs((st.W[i] - fx[f"W0_{i}"]) - (fx[f"{tag}{i}"] - fx[f"W0_{i}"])).max())
+                assert err <= 2e-3 * dmax, (e + 1, i, err, dmax)
+    rel = np.abs(np.asarray(losses) - fx["losses"]) / fx["losses"]
+    assert rel.max() <= 1e-5, float(rel.max())
+    assert abs(tro.mse(tro.forward(st, fx["x"])[-1], fx["y"]) - float(fx["final_eval"])) <= 1e-5 * float(fx["final_eval"])
