@@ -116,7 +116,8 @@ OMDS_API int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, cons
  * wider than the previous one's output: W[i] is [out_dims[i], in_dims[i]] with in_dims[0] = 3(n+3) and
  * in_dims[i] = out_dims[i-1] (+ 3(n+3) behind a concatenation, its columns last, as torch.cat((y, x_nerf))
  * orders them).  out_dims[i] + 3(n+3) <= 256 for those layers (the reference narrows them by 3(n+3) itself).
- * n_skips = 0 is omds_set_mlp.  Skip-connection networks run the all-fp32 step (no fp16 screening).      */
+ * n_skips = 0 is omds_set_mlp.  Skip-connection networks are screened like plain ones (the screening kernel ORs the
+ * encoded input into the last two k-chunks of the layer behind a concatenation).                                        */
 OMDS_API int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const int32_t* out_dims,
                              const float* const* W, const float* const* b, int act, float out_div,
                              int n_skips, const int32_t* skip_after);

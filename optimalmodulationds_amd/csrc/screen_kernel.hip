@@ -925,7 +925,9 @@ void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const 
     const int ncu = omds_cu_count();
     // three resident workgroups per CU; longer lists stride (the list length is only known on the device)
     const long long blocks_max = ((long long)B * O + 15) / 16;
-    const unsigned grid = (unsigned)std::min<long long>(blocks_max, 3LL * ncu);
+    static int res = -1;   // OMDS_EXACT_RESIDENT: workgroups per CU the grid is sized for (experiments)
+    if (res < 0) { const char* e = getenv("OMDS_EXACT_RESIDENT"); res = e ? atoi(e) : 3; if (res < 1) res = 3; }
+    const unsigned grid = (unsigned)std::min<long long>(blocks_max, (long long)res * ncu);
     const OmdsDivisor od = OmdsDivisor::make((unsigned)O);
     if (m.act == OMDS_ACT_RELU)
         hipLaunchKernelGGL((k_exact<OMDS_ACT_RELU, 1>), dim3(grid), dim3(512), lds, s, m, Apre, Bpre, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits, ex);

@@ -258,3 +258,65 @@ def test_screened_tanh_and_skip_fixtures(name, kind):
     # and against the reference's own rollouts of the fixture (first step from the fixture's start states)
     ref = fx["it0_all_traj"]
     assert np.abs(outs[1]["all_traj"][:, 1] - ref[:, 1]).max() <= 2e-4, float(np.abs(outs[1]["all_traj"][:, 1] - ref[:, 1]).max())
+
+
+def test_rows_longer_than_a_workgroups_result_buffer_take_the_matrix_route():
+    """O = 6000 obstacles: a rollout's screening values no longer fit one workgroup's LDS (5120), so k_screen writes the
+    matrix and k_select -- its long-row form, values re-read instead of held in registers -- does the selection: same bits."""
+    rng = np.random.RandomState(8)
+    p = rng.uniform([-0.3, -0.8, 0.0], [1.0, 0.8, 1.2], (6000, 3))
+    obs = np.c_[p, rng.uniform(0.01, 0.04, 6000)].astype(np.float32)
+    N, H, K = 96, 3, 4
+    e, m, obs, q0, qf = _engine(N, H, obs=obs)
+    rng = np.random.RandomState(5)
+    mu_c = (q0 + 0.2 * rng.standard_normal((K, 7))).astype(np.float32)
+    sg_c, al_c = np.ones(K, np.float32), rng.standard_normal((K, 7)).astype(np.float32)
+    a = _run(e, q0, 0, K, mu_c, sg_c, al_c, seed=3)
+    b = _run(e, q0, 1, K, mu_c, sg_c, al_c, seed=3)
+    for key in KEYS:
+        assert np.array_equal(a[key], b[key]), (key, float(np.abs(a[key] - b[key]).max()))
+    st = e.screen_stats()
+    assert st["active"] and st["fallbacks"] <= 1 and st["audit_rows_per_rollout_step"] > 10, st
+    e.close()
+
+
+@pytest.mark.parametrize("kind,n,k", [("planar7", 7, 1), ("planar7", 7, 3), ("planar2", 2, 2), ("planar7_128", 7, 2)])
+def test_screened_planar_networks_are_bit_identical(kind, n, k):
+    """The planar robots' networks (15 / 30 inputs, 2 / 7 output channels, distances not divided by 100, no ignored links, the
+    128-wide net zero-padded to 256) on a cloud of 700 discs: the screened step of the 2- and 7-DoF tails, other k."""
+    from optimalmodulationds_amd import scenes
+    from optimalmodulationds_amd.engine import Engine
+    m = orc.Mlp.from_npz(weights_path(kind))
+    rng = np.random.RandomState(12)
+    reach = 6.5 if n == 2 else 7.5
+    obs = np.c_[rng.uniform(-reach, reach, (700, 2)), np.zeros(700), rng.uniform(0.2, 0.6, 700)].astype(np.float32)
+    q0 = np.zeros(n, np.float32); q0[0] = np.pi / 2
+    qf = np.zeros(n, np.float32); qf[0] = -np.pi / 2
+    N, H, K = 512, 6, 4
+    outs, stats = [], None
+    mu_c = (q0 + 0.3 * rng.standard_normal((K, n))).astype(np.float32)
+    sg_c, al_c = np.full(K, 0.5, np.float32), rng.standard_normal((K, n)).astype(np.float32)
+    for mode in (0, 1):
+        e = Engine(n, N, H, k, max_obs=1024)
+        e.set_mlp(m.W, m.b)
+        e.set_obstacles(obs)
+        e.params.dt, e.params.dst_thr, e.params.ignored_links = 0.3, 0.25, 0
+        e.push_params()
+        e.set_ds(qf)
+        e.set_screening(mode)
+        q = q0.copy()
+        runs = []
+        for it in range(3):
+            e.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 0.75, K, seed=20 + it)
+            e.propagate(q)
+            runs.append(e.get_rollouts())
+            q = (q + 0.1 * (qf - q0)).astype(np.float32)
+        outs.append(runs)
+        if mode:
+            stats = e.screen_stats()
+        e.close()
+    for it in range(3):
+        for key in KEYS:
+            assert np.array_equal(outs[0][it][key], outs[1][it][key]), (kind, it, key, float(np.nanmax(np.abs(outs[0][it][key] - outs[1][it][key]))))
+    print(kind, k, stats)
+    assert stats["active"] and not stats["suspended"] and stats["fallbacks"] <= 1, stats
