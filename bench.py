@@ -302,7 +302,7 @@ def main():
             r2 = measure(args, wl2, st2, 1, rank, world, local_rank, use_dist, dist, torch, prof=False, reps=rp2)
             e2 = dict({"workload": wl2, "unit": "rollout-steps/s", "steps": st2}, **rate(r2, st2))
             e2["screening"] = {k2: r2["scr"][k2] for k2 in ("active", "eps", "candidates_per_rollout_step", "fallbacks", "audit_max_err",
-                                                          "audit_rows_per_rollout_step", "calibrations", "suspended")}
+                                                          "audit_rows_per_rollout_step", "calibrations", "suspended", "sweeps", "sweep_max_err")}
             also.append(e2)
     if rank == 0:
         act = w.get("act", "relu")

@@ -267,7 +267,9 @@ OMDS_API int omds_apply_update(int n_kernels, int n_dof, int horizon, const floa
  *   - every step of every propagate: |Da - D| of every candidate; Da - D of the AUDIT rows, a pseudo-random 1-in-`one_in`
  *     sample (another one every step) of the pairs that are not candidates, re-evaluated in fp32 by one launch at the end
  *     of the horizon loop (k_audit); the slack of every rollout (tau - exact k-th smallest >= eps).
- * A propagate is accepted only while both maxima stay <= eps / 2 and no slack check failed; otherwise it is redone with the
+ *   - every 32nd screened propagate (omds_set_screening_sweep): a SWEEP -- all N x O pairs of the propagate's last horizon
+ *     step in fp32 beside all their screening values, max |Da - D| over every one of them.
+ * A propagate is accepted only while all these maxima stay <= eps / 2 and no slack check failed; otherwise it is redone with the
  * fp32 pass 1 (its results are then the fp32 ones by construction) and eps is widened; three fallbacks in a row suspend
  * screening until the next calibration.  A row outside the audit sample whose error exceeds eps can still go unseen in
  * one propagate: the identity is measured on a sample, not proven.
@@ -281,6 +283,10 @@ OMDS_API int omds_apply_update(int n_kernels, int n_dof, int horizon, const floa
  * seen since the last calibration, suspended flag, calibrations run since creation.                                   */
 OMDS_API int omds_set_screening(omds_ctx* ctx, int mode, float eps);
 OMDS_API int omds_set_screening_audit(omds_ctx* ctx, int one_in);
+/* every = 0: no sweeps; default 32.  Stats: the setting, sweeps run since creation, largest |Da - D| a sweep saw since the last
+ * calibration (NULL = skip). */
+OMDS_API int omds_set_screening_sweep(omds_ctx* ctx, int every);
+OMDS_API int omds_screen_sweep_stats(omds_ctx* ctx, int32_t* every, int64_t* sweeps, float* sweep_max_err);
 OMDS_API int omds_screen_audit_stats(omds_ctx* ctx, int32_t* one_in, double* audit_rows_per_rollout_step, float* audit_max_err,
                                      int32_t* suspended, int64_t* calibrations);
 /* Test hook: damages what the screening network sees so that the run-time checks have something to catch.  what = 0: zeroes

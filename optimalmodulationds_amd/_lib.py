@@ -92,6 +92,8 @@ SIGNATURES = {
     "omds_set_screening": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),
     "omds_set_screening_audit": (C.c_int, [C.c_void_p, C.c_int]),
     "omds_screen_audit_stats": (C.c_int, [C.c_void_p, I32P, C.POINTER(C.c_double), F32P, I32P, C.POINTER(C.c_int64)]),
+    "omds_set_screening_sweep": (C.c_int, [C.c_void_p, C.c_int]),
+    "omds_screen_sweep_stats": (C.c_int, [C.c_void_p, I32P, C.POINTER(C.c_int64), F32P]),
     "omds_screen_debug_corrupt": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float]),
     "omds_screen_mindist": (C.c_int, [C.c_void_p, F32P, C.c_int, F32P]),
     "omds_screen_stats": (C.c_int, [C.c_void_p, I32P, F32P, F32P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -111,7 +113,7 @@ SIGNATURES = {
     "omds_sync": (C.c_int, [C.c_void_p]),
 }
 
-ABI_VERSION = 310      # omds_version() of the library this binding was written against
+ABI_VERSION = 320      # omds_version() of the library this binding was written against
 _lib = None
 
 

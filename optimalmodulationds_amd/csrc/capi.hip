@@ -84,7 +84,7 @@ static uint16_t f32_to_f16_bits(float f) {
 
 extern "C" {
 
-int omds_version(void) { return 310; }
+int omds_version(void) { return 320; }
 
 void omds_default_params(omds_params* p) {
     if (!p) return;
@@ -161,6 +161,7 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
         const int v = atoi(e);
         if (v >= 0 && v <= (1 << 20) && (v & (v - 1)) == 0) ctx->audit_one_in = v;
     }
+    if (const char* e = getenv("OMDS_SCREEN_SWEEP")) { const int v = atoi(e); if (v >= 0) ctx->sweep_every = v; }
     auto fail = [&](const std::string& m, int code) {
         g_create_err = m;
         free_all(ctx);
@@ -900,6 +901,7 @@ static int calibrate_screen(omds_ctx* ctx, const float* q_center) {
     ctx->screen_recals++;
     ctx->screen_err_seen = 0.f;
     ctx->screen_audit_err_seen = 0.f;
+    ctx->screen_sweep_err_seen = 0.f;
     const bool finite = worst < 3.0e38f;
     if (!finite && getenv("OMDS_SCREEN_NOGUARD")) { ctx->screen_eps = 1e-3f; return OMDS_OK; }   // timing experiments only
     if (!finite) { ctx->screen_suspended = true; ctx->screen_eps = 0.f; return OMDS_OK; }   // fp16 range exceeded on this scene: the fp32 step until the next calibration
@@ -1060,6 +1062,19 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
             omds_launch_audit(ctx->stream, ma, ctx->d_ApreAll, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, ctx->prm.ignored_links,
                               sink.audit_rows, sink.audit_da, sink.audit_total, sink.audit_cap, ctx->d_scerr);
         }
+        ctx->sweep_now = false;
+        if (screen && ctx->sweep_every > 0 && (ctx->screen_propagates++ % ctx->sweep_every) == 0) {
+            // Every sweep_every-th screened propagate: a COMPLETE check of one horizon step -- the last one, whose inputs are
+            // still in place (layer-1 halves, fp16 tables) -- all N x O pairs in fp32 (k_pass1) beside all N x O screening
+            // values: max |Da - D| -> d_scerr[3].  The audit sample sees every step thinly, the sweep sees one step whole.
+            RoctxRange r4("screening sweep (all pairs of the last step in fp32)");
+            float* apre_last = apre0 + (size_t)(H - 1) * apre_slab;
+            omds_launch_pass1(ctx->stream, ctx->mlp, apre_last, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N, ctx->prm.ignored_links, ctx->d_Dmin);
+            omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_FqH, ctx->cfg.n_traj, ctx->d_FpH, ctx->cfg.max_obs, ctx->d_radius, ctx->n_obs, N,
+                               ctx->prm.ignored_links, ctx->d_stage);
+            omds_launch_max_abs_diff(ctx->stream, ctx->d_Dmin, ctx->d_stage, (long long)N * ctx->n_obs, ctx->d_scerr + 3);
+            ctx->sweep_now = true;
+        }
     } else {
         for (int i = 1; i <= H; ++i) {   // MPPI.py:101: H network evaluations, the last velocity is not integrated
             if ((rc = enqueue_network(ctx, ctx->d_trajT + (size_t)(i - 1) * n * N, N, N))) return rc;
@@ -1127,7 +1142,9 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
         //           evaluated in fp32 by k_audit at the end of the horizon loop;
         //   slack = rollouts whose exact k-th smallest candidate came within eps of tau.
         // Accepted only while both errors keep a 2x margin to eps and no slack check failed; otherwise redone in fp32.
-        const float err = ctx->h_red[0], aerr = ctx->h_red[2];
+        //   serr  = (every sweep_every-th propagate) max |Da - D| over ALL pairs of the last horizon step.
+        const float err = ctx->h_red[0], aerr = ctx->h_red[2], serr = ctx->sweep_now ? ctx->h_red[3] : 0.f;
+        if (ctx->sweep_now) { ctx->screen_sweeps++; if (serr > ctx->screen_sweep_err_seen || serr != serr) ctx->screen_sweep_err_seen = serr; }
         if (err > ctx->screen_err_seen || err != err) ctx->screen_err_seen = err;
         if (aerr > ctx->screen_audit_err_seen || aerr != aerr) ctx->screen_audit_err_seen = aerr;
         const int32_t* tot = reinterpret_cast<const int32_t*>(ctx->h_red + 4);
@@ -1138,7 +1155,7 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
         ctx->screen_steps += (double)N * H;
         static int noguard = -1;   // OMDS_SCREEN_NOGUARD=1: timing experiments with deliberately broken screening kernels only
         if (noguard < 0) { const char* e = getenv("OMDS_SCREEN_NOGUARD"); noguard = e ? atoi(e) : 0; }
-        const float worst = (err != err || aerr != aerr) ? __builtin_inff() : std::max(err, aerr);
+        const float worst = (err != err || aerr != aerr || serr != serr) ? __builtin_inff() : std::max({err, aerr, serr});
         if ((!overflow && worst <= 0.5f * ctx->screen_eps && slack_viol == 0) || noguard) {
             // accepted.  Keep the bound at >= 4x the largest error seen, so that states drifting into regions where the fp16
             // network is less accurate widen it gradually instead of tripping the fallback
@@ -1474,6 +1491,19 @@ int omds_set_screening_audit(omds_ctx* ctx, int one_in) {
     REQUIRE(one_in >= 0 && one_in <= (1 << 20) && (one_in & (one_in - 1)) == 0, OMDS_ERR_INVALID_ARG,
             "omds_set_screening_audit: one_in must be 0 (no audit rows) or a power of two <= 2^20");
     ctx->audit_one_in = one_in;
+    return OMDS_OK;
+}
+int omds_set_screening_sweep(omds_ctx* ctx, int every) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(every >= 0, OMDS_ERR_INVALID_ARG, "omds_set_screening_sweep: every >= 0 (0 = no sweeps)");
+    ctx->sweep_every = every;
+    return OMDS_OK;
+}
+int omds_screen_sweep_stats(omds_ctx* ctx, int32_t* every, int64_t* sweeps, float* sweep_max_err) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    if (every) *every = ctx->sweep_every;
+    if (sweeps) *sweeps = ctx->screen_sweeps;
+    if (sweep_max_err) *sweep_max_err = ctx->screen_sweep_err_seen;
     return OMDS_OK;
 }
 int omds_screen_audit_stats(omds_ctx* ctx, int32_t* one_in, double* audit_rows_per_rollout_step, float* audit_max_err,

@@ -139,6 +139,11 @@ struct omds_ctx {
     int screen_consec = 0;               // consecutive fallbacks
     int audit_one_in = 128;              // a non-candidate pair is audited with probability 1 / audit_one_in (power of two; 0 = no audit)
     unsigned audit_counter = 0;          // feeds the audit hash: another sample every step of every propagate
+    int sweep_every = 32;                // every sweep_every-th screened propagate checks ALL pairs of its last step in fp32 (0 = never)
+    long long screen_propagates = 0;     // screened propagates since creation
+    long long screen_sweeps = 0;         // sweeps run since creation
+    float screen_sweep_err_seen = 0.f;   // largest |Da - D| a sweep saw since the last calibration
+    bool sweep_now = false;              // the propagate being finished carried a sweep (d_scerr[3] is valid)
     std::vector<float> obs_cal;          // the obstacle set the bound was calibrated against (omds_set_obstacles compares)
     std::vector<float> obs_now;          // host copy of the current obstacle set
     bool have_rollouts = false;          // d_trajT holds the rollouts of a finished propagate (calibration draws states from them)

@@ -283,6 +283,10 @@ class Engine:
         """Audit sample of the pairs the screened step does not re-evaluate: 1 in ``one_in`` (power of two), 0 = none."""
         self._ck(self.lib.omds_set_screening_audit(self.h, int(one_in)))
 
+    def set_screening_sweep(self, every=32):
+        """Every ``every``-th screened propagate checks ALL pairs of its last horizon step in fp32 (0 = never)."""
+        self._ck(self.lib.omds_set_screening_sweep(self.h, int(every)))
+
     def screen_debug_corrupt(self, what, index, value=0.0):
         """Test hook (omds.h): 0 = zero a weight fragment of the fp16 pack, 1 = shift an obstacle in the screening inputs."""
         self._ck(self.lib.omds_screen_debug_corrupt(self.h, int(what), int(index), float(value)))
@@ -302,9 +306,12 @@ class Engine:
         arows, ncal = C.c_double(), C.c_int64()
         self._ck(self.lib.omds_screen_audit_stats(self.h, C.byref(one_in), C.byref(arows), C.cast(C.byref(aerr), L.F32P),
                                                   C.byref(susp), C.byref(ncal)))
+        sw_every, sw_n, sw_err = C.c_int32(), C.c_int64(), C.c_float()
+        self._ck(self.lib.omds_screen_sweep_stats(self.h, C.byref(sw_every), C.byref(sw_n), C.byref(sw_err)))
         return dict(active=bool(act.value), eps=eps.value, max_err_seen=err.value, candidates_per_rollout_step=cand.value,
                     fallbacks=fb.value, audit_one_in=one_in.value, audit_rows_per_rollout_step=arows.value,
-                    audit_max_err=aerr.value, suspended=bool(susp.value), calibrations=ncal.value)
+                    audit_max_err=aerr.value, suspended=bool(susp.value), calibrations=ncal.value,
+                    sweep_every=sw_every.value, sweeps=sw_n.value, sweep_max_err=sw_err.value)
 
     # ---- measurement --------------------------------------------------------------------------
     def prof_enable(self, on=True):

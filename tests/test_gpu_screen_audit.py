@@ -229,3 +229,35 @@ def test_mode_changes_keep_the_bound_and_negative_eps_recalibrates():
     assert st3["calibrations"] == 2 and st3["eps"] == pytest.approx(0.02)
     e0.close()
     e1.close()
+
+
+def test_sweep_checks_every_pair_of_a_step_and_catches_what_a_disabled_audit_misses():
+    """The sweep (every 32nd screened propagate by default: ALL N x O pairs of the last horizon step in fp32 beside their
+    screening values) on a clean run stays below the bound; and with the audit sample switched off and a sweep on every
+    propagate, the misplaced far-looking obstacle is caught by the sweep alone."""
+    from optimalmodulationds_amd import scenes
+    N, H = 1024, 8
+    obs = scenes.shelf_scene()
+    q = scenes.FRANKA_Q0.copy()
+    pol = _policy()
+    engines = _pair(N, H, obs)
+    for it in range(34):
+        r = _step_both(engines, q, pol, 700 + it, f"clean #{it}")
+        q = (q + 0.02 * r["qdot"][0]).astype(np.float32)
+    st = engines[1].screen_stats()
+    assert st["sweep_every"] == 32 and st["sweeps"] == 2, st            # propagates 0 and 32
+    assert 0.0 < st["sweep_max_err"] <= 0.5 * st["eps"] and st["fallbacks"] == 0, st
+    for e in engines:
+        e.close()
+    engines = _pair(N, H, obs, audit=0)
+    engines[1].set_screening_sweep(1)
+    q = scenes.FRANKA_Q0.copy()
+    _, _, _, idx = engines[0].dist_grad(q[None], want_idx=True)
+    _step_both(engines, q, pol, 1, "before")
+    eps0 = engines[1].screen_stats()["eps"]
+    engines[1].screen_debug_corrupt(1, int(idx[0, 0]), 1.5)
+    _step_both(engines, q, pol, 2, "swept")                             # identical because the sweep forced the fp32 redo
+    st = engines[1].screen_stats()
+    assert st["fallbacks"] == 1 and st["sweep_max_err"] > 0.5 * eps0 and st["audit_rows_per_rollout_step"] == 0.0, st
+    for e in engines:
+        e.close()
