@@ -261,3 +261,27 @@ def test_sweep_checks_every_pair_of_a_step_and_catches_what_a_disabled_audit_mis
     assert st["fallbacks"] == 1 and st["sweep_max_err"] > 0.5 * eps0 and st["audit_rows_per_rollout_step"] == 0.0, st
     for e in engines:
         e.close()
+
+
+def test_large_radii_and_in_collision_rollouts():
+    """Spheres of radius 0.1 .. 0.3 m scattered through the arm's workspace: most rollouts spend steps in collision (negative
+    thresholded distance, the in-collision branch of the modulation) and the pass-1 values are dominated by the radii."""
+    from optimalmodulationds_amd import scenes
+    rng = np.random.RandomState(21)
+    p = rng.uniform([-0.4, -0.8, 0.0], [0.9, 0.8, 1.2], (250, 3))
+    obs = np.c_[p, rng.uniform(0.1, 0.3, 250)].astype(np.float32)
+    N, H = 1024, 8
+    engines = _pair(N, H, obs)
+    pol = _policy()
+    q = scenes.FRANKA_Q0.copy()
+    ncoll = 0
+    for it in range(5):
+        r = _step_both(engines, q, pol, 60 + it, f"large radii #{it}")
+        ncoll += int((r["closest_dist_all"] < 0).sum())
+        q = (q + 0.05 * (scenes.FRANKA_QF - scenes.FRANKA_Q0)).astype(np.float32)
+    st = engines[1].screen_stats()
+    assert ncoll > 0.2 * 5 * N * H, ncoll                                 # the scene does put the rollouts into collision
+    assert st["active"] and not st["suspended"] and st["fallbacks"] <= 1, st
+    assert st["audit_max_err"] <= 0.5 * st["eps"] and st["sweep_max_err"] <= 0.5 * st["eps"], st
+    for e in engines:
+        e.close()
