@@ -388,6 +388,19 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
                     wb16[o] = make_float4(Wl[k0 * Wd + j], Wl[k1 * Wd + j], Wl[k2 * Wd + j], Wl[k3 * Wd + j]);
                 }
     }
+    // backward pack for the 4-row-group GEMM (v_mfma_f32_4x4x1, mlp_device.h gemm4): the gradient at a layer's inputs is
+    // sum_k G[row][k] W[k][j] (W [out = k][in = j]); lane l of column block cb holds W[4 kq .. 4 kq + 3][64 cb + l]
+    std::vector<float4> wb4((size_t)std::max(m.nhh, 1) * 4 * 64 * 64);
+    for (int l = 0; l < m.nhh; ++l) {
+        const float* Wl = W[l + 1];
+        for (int cb = 0; cb < 4; ++cb)
+            for (int kq = 0; kq < 64; ++kq)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int j = 64 * cb + lane, k0 = 4 * kq;
+                    wb4[(((size_t)l * 4 + cb) * 64 + kq) * 64 + lane] =
+                        make_float4(Wl[(size_t)k0 * Wd + j], Wl[(size_t)(k0 + 1) * Wd + j], Wl[(size_t)(k0 + 2) * Wd + j], Wl[(size_t)(k0 + 3) * Wd + j]);
+                }
+    }
     // last layer: 16x16x4 B-fragments, channels padded to 16
     const float* WL = W[n_linear - 1];
     std::vector<float4> wl(16 * 64);
@@ -500,6 +513,7 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
     }
     if ((rc = upload(ctx, wf16, &m.Wf16))) return rc;
     if ((rc = upload(ctx, wb16, &m.Wb16))) return rc;
+    if ((rc = upload(ctx, wb4, &m.Wb4))) return rc;
     if ((rc = upload(ctx, w1b16, &m.W1b16))) return rc;
     if ((rc = upload(ctx, wf, &m.Wf))) return rc;
     if ((rc = upload(ctx, wb, &m.Wb))) return rc;

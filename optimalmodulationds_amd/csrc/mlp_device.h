@@ -8,6 +8,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define LDH OMDS_LDH
 
+// Diagnostic build (-DOMDS_TAIL_TL, tools/tail_timeline.sh): thread 0 of every k_tail_sel workgroup stamps the shader clock
+// at the phase boundaries; a one-thread kernel prints the table after the launch chosen by OMDS_TAIL_TL_STEP.
+#ifdef OMDS_TAIL_TL
+static __device__ unsigned long long g_tail_tl[1024][20];
+#define OMDS_TL_STAMP(i)                                                                                   \
+    do {                                                                                                   \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) g_tail_tl[blockIdx.x][i] = (i) == 0 || (i) == 19 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define OMDS_TL_STAMP(i)
+#endif
+
 // hidden activation: ReLU (all shipped reference networks) or tanh (MATLAB-prototype style nets)
 __device__ __forceinline__ float actf(float z, int act) { return act == OMDS_ACT_RELU ? fmaxf(z, 0.f) : tanhf(z); }
 
@@ -159,6 +171,93 @@ __device__ __forceinline__ void gemm16(const float* __restrict__ Hs, const float
 #undef OMDS_INTERLEAVE16
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// [4 NG x 256] . [256 x 64] on v_mfma_f32_4x4x1_16B_f32 with the A operand of ONE block broadcast to all 16 blocks
+// (cbsz = 4, abid = g): D[i][lane] = fmaf(A[4g + i], B[lane], C[i][lane]) -- 4 rows x 64 columns x k = 1 per instruction at
+// the full fp32 MFMA rate (tools/ubench/mfma_4x4.hip: 138-142 TFLOP/s by the wall clock from ONE wave per SIMD with 3-5
+// independent chains, against 144-156 for 16x16x4), one fused multiply-add per element (76800 of 76800 random elements).  A
+// GEMM on 4-row groups therefore has a row granularity of 4 where the 16x16x4 / 32x32x2 shapes have 16 / 32, and with K = 1 per
+// instruction the k order of the 32-row kernels (8c + {0,4,1,5,2,6,3,7}) is just the issue order: bit-identical rows again.
+//   A: lane l reads H[row l][k] (one register serves up to 16 row groups; abid picks the group);
+//   B: lane l holds W[k][64 cw + l], packed so that one b128 is four consecutive k (MlpDev::Wb4: [layer][4 cb][64 kq][64 lane]).
+//   acc[g][i] = element (row 4 g + i, column 64 cw + lane).
+// One wave per SIMD does the work (a second one would fetch the same weight fragments a second time), so nothing but its own
+// lookahead hides the L2 round trip: the weights stream through a ring of PD chunks (8 k each) that runs ACROSS the layers of
+// the chain -- the slot of chunk c is asked for chunk c + PD of the same layer or chunk c + PD - 32 of the next one the moment
+// it has been consumed.  sched_barrier pins every request where it is written: left to itself the scheduler sinks the loads
+// to their uses (measured: 7.8 us per layer instead of 4.5).  "No next layer" is a VGPR offset of 0xffffffff: out of range
+// for the buffer, the load returns zeros and moves no data.
+// ------------------------------------------------------------------------------------------------
+constexpr int W4_LAYER_BYTES = 4 * 64 * 64 * 16;
+template <int PD>
+struct W4Ring {
+    float4 w[PD][2];
+    __amdgpu_buffer_rsrc_t rs;
+    int sbase;   // this wave's column block inside a layer pack, bytes
+    int vlane;   // lane * 16
+    __device__ __forceinline__ void bind(const float4* pack, int nl, int cw, int lane) {
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(pack), 0, nl * W4_LAYER_BYTES, 0x00020000);
+        sbase = __builtin_amdgcn_readfirstlane(cw) * (64 * 64 * 16);
+        vlane = lane * 16;
+    }
+    // chunk C (0..31) of layer l into slot S
+    template <int S, int C>
+    __device__ __forceinline__ void issue(int l) {
+        const int voff = l >= 0 ? vlane + l * W4_LAYER_BYTES : -1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const omds_f4 v = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sbase + (2 * C + h) * 64 * 16, 0));
+            w[S][h] = make_float4(v.x, v.y, v.z, v.w);
+        }
+    }
+    template <int C = 0>
+    __device__ __forceinline__ void fill(int l) {
+        if constexpr (C < PD) {
+            issue<C, C>(l);
+            __builtin_amdgcn_sched_barrier(0);
+            fill<C + 1>(l);
+        }
+    }
+};
+
+template <int NG, int G>
+__device__ __forceinline__ void g4_step(float av, float bv, f32x4 (&acc)[NG]) {
+    if constexpr (G < NG) {
+        acc[G] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, acc[G], 4, G, 0);
+        g4_step<NG, G + 1>(av, bv, acc);
+    }
+}
+template <int NG, int PD, int C>
+__device__ __forceinline__ void gemm4_chunks(const float* arow, W4Ring<PD>& R, int l, int l_next, float4 a_lo, float4 a_hi, f32x4 (&acc)[NG]) {
+    if constexpr (C < 32) {   // chunk C = k 8C .. 8C+7, contracted in the order 8C + {0,4,1,5,2,6,3,7}
+        float4 n_lo = a_lo, n_hi = a_hi;
+        if constexpr (C + 1 < 32) {
+            n_lo = *reinterpret_cast<const float4*>(arow + 8 * (C + 1));
+            n_hi = *reinterpret_cast<const float4*>(arow + 8 * (C + 1) + 4);
+        }
+        const float4 w_lo = R.w[C % PD][0], w_hi = R.w[C % PD][1];
+        g4_step<NG, 0>(a_lo.x, w_lo.x, acc);
+        g4_step<NG, 0>(a_hi.x, w_hi.x, acc);
+        g4_step<NG, 0>(a_lo.y, w_lo.y, acc);
+        g4_step<NG, 0>(a_hi.y, w_hi.y, acc);
+        g4_step<NG, 0>(a_lo.z, w_lo.z, acc);
+        g4_step<NG, 0>(a_hi.z, w_hi.z, acc);
+        g4_step<NG, 0>(a_lo.w, w_lo.w, acc);
+        g4_step<NG, 0>(a_hi.w, w_hi.w, acc);
+        if constexpr (C + PD < 32) R.template issue<C % PD, C + PD>(l);
+        else R.template issue<C % PD, C + PD - 32>(l_next);
+        __builtin_amdgcn_sched_barrier(0);
+        gemm4_chunks<NG, PD, C + 1>(arow, R, l, l_next, n_lo, n_hi, acc);
+    }
+}
+// R holds chunks 0 .. PD-1 of layer l (filled, or left by the previous call); on return those of layer l_next
+template <int NG, int PD>
+__device__ __forceinline__ void gemm4(const float* __restrict__ Hs, W4Ring<PD>& R, int l, int l_next, int lane, f32x4 (&acc)[NG]) {
+    static_assert(NG >= 1 && NG <= 8 && 32 % PD == 0, "row groups 0..7 (abid), ring slots that divide the 32 chunks");
+    const float* arow = Hs + (lane & 31) * LDH;   // lanes >= 32 re-read rows 0..31: never selected (abid < 8)
+    gemm4_chunks<NG, PD, 0>(arow, R, l, l_next, *reinterpret_cast<const float4*>(arow), *reinterpret_cast<const float4*>(arow + 4), acc);
+}
 
 template <int MT, int MR, int NR>
 struct Geo {
@@ -596,6 +695,7 @@ struct P2Smem {
     float* P;         // [P2_PSETS][32][33] split-K partials of the first-layer backward (waves 0-3; waves 4-7 use Hs)
     float* gf;        // [32][33] feature gradients
     uint16_t* maskL;  // [nhh+1][512] ReLU masks, 16 bits per thread and layer
+    uint32_t* maskG4; // the same storage seen by the 4-row-group backward: [nhh+1][256 columns], bit e = row e
     int* rowT;        // [32] rollout of each row (-1: padding row)
     int* rowO;        // [32] obstacle of each row
     int* rowMin;      // [32] arg-min link of each row
@@ -639,6 +739,9 @@ template <int ACT, int ROWS>
 __device__ __forceinline__ void pass2_backward(const MlpDev& m, const P2Smem& sm, const float* __restrict__ xyzr, int R0,
                                                int total_rows, const float* __restrict__ qT, int ldq, float* gradx, int dbase,
                                                float* __restrict__ dscr, size_t dlayer, int S0, int dbg = 0);
+template <int ROWS>
+__device__ __forceinline__ void p2_backward_first(const MlpDev& m, const P2Smem& sm, const float* __restrict__ xyzr, int R0,
+                                                  int total_rows, const float* __restrict__ qT, int ldq, float* gradx, int dbase, int dbg = 0);
 
 // Body of pass 2 for the ROWS rows described by sm.rowT / sm.rowO (already in LDS, barrier done by the
 // caller).  R0 = global index of row 0 (tanh scratch, yraw, minidx); outputs go to
@@ -807,11 +910,8 @@ __device__ __forceinline__ void pass2_backward(const MlpDev& m, const P2Smem& sm
     using G = P2Geo<ROWS>;
     constexpr int NV = G::NV;
     float* Hs = sm.Hs;
-    float* P = sm.P;
     float* gf = sm.gf;
     uint16_t* maskL = sm.maskL;
-    int* rowT = sm.rowT;
-    int* rowO = sm.rowO;
     int* rowMin = sm.rowMin;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr bool relu = ACT == OMDS_ACT_RELU;
@@ -839,6 +939,7 @@ __device__ __forceinline__ void pass2_backward(const MlpDev& m, const P2Smem& sm
         }
     }
     __syncthreads();
+    OMDS_TL_STAMP(4);
     if (dbg == 13) return;
 
     // ---- backward through the hidden -> hidden layers ------------------------------------------
@@ -846,7 +947,9 @@ __device__ __forceinline__ void pass2_backward(const MlpDev& m, const P2Smem& sm
         float acc[NV];
         const float zinit[G::NB] = {};
         p2_gemm<ROWS>(Hs, m, l, true, wave, lane, acc, zinit);
+        if (l == m.nhh - 1) OMDS_TL_STAMP(5);
         __syncthreads();
+        if (l == m.nhh - 1) OMDS_TL_STAMP(6);
         const uint32_t bits = maskL[l * P2_NT + tid];
         const bool cap = (m.skip_mask >> l) & 1u;
         const int c0 = m.skip_col[l];
@@ -859,9 +962,24 @@ __device__ __forceinline__ void pass2_backward(const MlpDev& m, const P2Smem& sm
             Hs[row * LDH + col] = acc[r] * dv;
         }
         __syncthreads();
+        if (l == m.nhh - 1) OMDS_TL_STAMP(7);
     }
+    OMDS_TL_STAMP(8);
 
     if (dbg == 14) return;
+    p2_backward_first<ROWS>(m, sm, xyzr, R0, total_rows, qT, ldq, gradx, dbase, dbg);
+}
+
+// The tail of the pass-2 backward: from the gradient at the first layer's pre-activations (sm.Hs) to the input gradients.
+template <int ROWS>
+__device__ __forceinline__ void p2_backward_first(const MlpDev& m, const P2Smem& sm, const float* __restrict__ xyzr, int R0,
+                                                  int total_rows, const float* __restrict__ qT, int ldq, float* gradx, int dbase, int dbg) {
+    float* Hs = sm.Hs;
+    float* P = sm.P;
+    float* gf = sm.gf;
+    int* rowT = sm.rowT;
+    int* rowO = sm.rowO;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ---- first layer backward: g_f[row][f] = sum_c Gz1[row][c] W1[c][f], split-K over the 8 waves -------
     if constexpr (ROWS == 32) {
         f32x16 acc;
@@ -919,4 +1037,60 @@ __device__ __forceinline__ void pass2_backward(const MlpDev& m, const P2Smem& sm
             gradx[(size_t)(dbase + row) * d + jj] = gf[row * 33 + jj] + gf[row * 33 + d + jj] * cosf(x) - gf[row * 33 + 2 * d + jj] * sinf(x);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The hidden part of the pass-2 backward on 4-ROW GROUPS (gemm4): for workgroups whose rows do not fill a 16-row tile.  At
+// N = 1024, k = 5 a CU's share is 4 rollouts = 20 rows: five groups of 4 where the 16-row shape needs two blocks (32 rows of
+// matrix-pipe time) -- 10240 instead of 16384 MFMA cycles per SIMD and layer.  ReLU networks without skip concatenations;
+// the same fmaf chains in the same k order as pass2_backward<ACT, 16 | 32>, so the same bits.
+//   waves 0-3: columns 64 w .. +63 of ALL row groups (one wave per SIMD; weight lookahead of 4 chunks); thread: column 64 w + lane.
+// sm.maskG4[l * 256 + column]: bit e = ReLU mask of element (row e, column) at hidden level l (written by the caller BEFORE
+// this call, which overwrites the tile buffer).  Leaves the gradient at the first layer's pre-activations in sm.Hs
+// (32 rows, the rest 0).
+// ------------------------------------------------------------------------------------------------
+template <int NG>
+__device__ __forceinline__ void pass2_backward_hidden_g4(const MlpDev& m, const P2Smem& sm) {
+    float* Hs = sm.Hs;
+    const int* rowMin = sm.rowMin;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave & 3, col = 64 * cw + lane;
+    const bool mine = wave < 4;   // waves 4-7 take no part in the GEMMs: a second wave per SIMD would fetch the same weight fragments
+                                  // from L2 a second time (0.5 B per FLOP on this shape), and that, not the matrix pipe, then bounds the layer
+    constexpr int PD = 8;
+    W4Ring<PD> ring;
+    if (mine) {   // the first chunks of the first GEMM are on their way during the seed
+        ring.bind(m.Wb4, m.nhh, cw, lane);
+        ring.fill(m.nhh - 1);
+    }
+    // rows past the last group are zero for the first-layer backward, which runs on the whole 32-row tile
+    for (int e = tid; e < (32 - 4 * NG) * OMDS_WIDTH; e += P2_NT) Hs[(4 * NG + e / OMDS_WIDTH) * LDH + (e % OMDS_WIDTH)] = 0.f;
+    // ---- seed: dy[minIdx]/dH_last = Wlast[minIdx], masked by the last hidden layer
+    if (mine) {
+        const uint32_t bseed = sm.maskG4[m.nhh * 256 + (tid & 255)];
+#pragma unroll
+        for (int e = 0; e < 4 * NG; ++e) {
+            const float gz = m.Wlraw[(size_t)rowMin[e] * OMDS_WIDTH + col];
+            Hs[e * LDH + col] = ((bseed >> e) & 1u) ? gz : 0.f;
+        }
+    }
+    __syncthreads();
+    OMDS_TL_STAMP(4);
+    for (int l = m.nhh - 1; l >= 0; --l) {
+        f32x4 acc[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (mine) gemm4<NG, PD>(Hs, ring, l, l - 1, lane, acc);
+        if (l == m.nhh - 1) OMDS_TL_STAMP(5);   // the first GEMM, this wave's share
+        __syncthreads();   // every wave has finished reading the tile
+        if (l == m.nhh - 1) OMDS_TL_STAMP(6);
+        if (mine) {
+            const uint32_t bl = sm.maskG4[l * 256 + (tid & 255)];
+#pragma unroll
+            for (int e = 0; e < 4 * NG; ++e) Hs[e * LDH + col] = ((bl >> e) & 1u) ? acc[e >> 2][e & 3] : 0.f;
+        }
+        __syncthreads();
+        if (l == m.nhh - 1) OMDS_TL_STAMP(7);
+    }
+    OMDS_TL_STAMP(8);
 }

@@ -32,6 +32,7 @@ struct MlpDev {
     const float4* Wf16;  // [nhh][16 colblk16][16 kchunk][64 lane]
     const float4* Wb16;  // same shape, transposed
     const float4* W1b16; // [16 kchunk][2 colblk16][64 lane]
+    const float4* Wb4;   // [nhh][4 colblk64][64 kq][64 lane] backward pack for the 4-row-group GEMM (gemm4): lane l = W[4kq .. +3][64cb + l]
     int nhh;             // number of hidden->hidden layers (= hidden layers - 1)
     int C;               // output channels (links)
     int d;               // raw inputs: n_dof + 3 (obstacle x, y, z), or n_dof + 2 for the toy networks (x, y)

@@ -39,12 +39,14 @@ __device__ __forceinline__ void modulate_core(const StepArgs& a, const int i, in
     // nominal DS (LinDS.py:11-21) and its norm (MPPI.py:106-108)
     if (WITH_SEDS && a.seds != nullptr) {
         // SEDS.get_velocity (SEDS.py:34-74): Gaussian mixture regression on x = q - q_goal; the components are strided over
-        // the NSUB lanes, their weighted outputs and the weight sum meet by shuffles
+        // the NSUB lanes, their weighted outputs and the weight sum meet by shuffles.  The Mahalanobis forms are sums of terms
+        // ~10^4 x their result, so the last bit of every product shows in the output: products and sums are rounded separately
+        // (__fmul_rn / __fadd_rn, never fused), the arithmetic of the reference's elementwise multiply-then-sum and of the oracle
         const int st = omds_seds_stride(ND);
         float x[ND], ysum[ND], psum = 0.f, pj[4];   // up to 4 components per lane (G <= 64, NSUB = 16) or all of them (NSUB = 1, looped below)
         float dst2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < ND; ++j) { x[j] = q[j] - a.qf[j]; dst2 += x[j] * x[j]; ysum[j] = 0.f; }
+        for (int j = 0; j < ND; ++j) { x[j] = q[j] - a.qf[j]; dst2 = __fadd_rn(dst2, __fmul_rn(x[j], x[j])); ysum[j] = 0.f; }
         // pass 1: unnormalised responsibilities prior_j N_j(x) and their sum
         for (int gidx = sub, c = 0; gidx < a.seds_G; gidx += NSUB, ++c) {
             const float* g = a.seds + (size_t)gidx * st;
@@ -56,8 +58,8 @@ __device__ __forceinline__ void modulate_core(const StepArgs& a, const int i, in
             for (int cc = 0; cc < ND; ++cc) {      // prob = sum_c (sum_r dd_r Sinv[r][c]) dd_c   (SEDS.py:31)
                 float t = 0.f;
 #pragma unroll
-                for (int r = 0; r < ND; ++r) t += dd[r] * Si[r * ND + cc];
-                prob += t * dd[cc];
+                for (int r = 0; r < ND; ++r) t = __fadd_rn(t, __fmul_rn(dd[r], Si[r * ND + cc]));
+                prob = __fadd_rn(prob, __fmul_rn(t, dd[cc]));
             }
             const float pxi = g[2 * ND] * (expf(-0.5f * prob) / g[2 * ND + 1]);
             if (NSUB > 1 && c < 4) pj[c] = pxi;
@@ -80,8 +82,8 @@ __device__ __forceinline__ void modulate_core(const StepArgs& a, const int i, in
                 for (int cc = 0; cc < ND; ++cc) {
                     float t = 0.f;
 #pragma unroll
-                    for (int r = 0; r < ND; ++r) t += (x[r] - g[r]) * Si[r * ND + cc];
-                    prob += t * (x[cc] - g[cc]);
+                    for (int r = 0; r < ND; ++r) t = __fadd_rn(t, __fmul_rn(x[r] - g[r], Si[r * ND + cc]));
+                    prob = __fadd_rn(prob, __fmul_rn(t, x[cc] - g[cc]));
                 }
                 pxi = g[2 * ND] * (expf(-0.5f * prob) / g[2 * ND + 1]);
             }
@@ -91,8 +93,8 @@ __device__ __forceinline__ void modulate_core(const StepArgs& a, const int i, in
             for (int r = 0; r < ND; ++r) {
                 float yj = g[ND + r];
 #pragma unroll
-                for (int cc = 0; cc < ND; ++cc) yj += Aj[r * ND + cc] * (x[cc] - g[cc]);
-                ysum[r] += beta * yj;
+                for (int cc = 0; cc < ND; ++cc) yj = __fadd_rn(yj, __fmul_rn(Aj[r * ND + cc], x[cc] - g[cc]));
+                ysum[r] = __fadd_rn(ysum[r], __fmul_rn(beta, yj));
             }
         }
         if (NSUB > 1) {
@@ -103,7 +105,7 @@ __device__ __forceinline__ void modulate_core(const StepArgs& a, const int i, in
         }
         float yn2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < ND; ++j) yn2 += ysum[j] * ysum[j];
+        for (int j = 0; j < ND; ++j) yn2 = __fadd_rn(yn2, __fmul_rn(ysum[j], ysum[j]));
         const float dst = sqrtf(dst2), yn = sqrtf(yn2);
         const bool far = dst > a.seds_lin_thr, weak = yn < a.seds_thr;
 #pragma unroll

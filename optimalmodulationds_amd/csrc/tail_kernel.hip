@@ -171,10 +171,14 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
     uint32_t* maskRow = reinterpret_cast<uint32_t*>(sm.Hs);     // [32][nhid][8] gathered masks; the tile buffer is idle until the seed
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.st.N, k = a.st.k, O = a.O, nhid = m.nhh + 1;
-    const int RW = ROWS / k;                  // rollouts per workgroup
+    // ROWS = 4: the backward runs on 4-row groups (pass2_backward_hidden_g4): G4_ROWS network rows per workgroup
+    constexpr int G4_NG = 5, TROWS = ROWS == 4 ? 4 * G4_NG : ROWS;
+    const int RW = TROWS / k;                 // rollouts per workgroup
     const int t_base = a.t_begin + blockIdx.x * RW;
     const int t_end = a.t_end;
 
+    OMDS_TL_STAMP(0);
+    OMDS_TL_STAMP(1);
     // ---- top-k of each rollout's candidates by (D, obstacle index): k rounds of "smallest after the previous one" ----
     if (tid < P2_MT) { sm.rowT[tid] = -1; sm.rowO[tid] = 0; sm.rowMin[tid] = 0; sel[tid] = -1; dr[tid] = 0.f; }
     __syncthreads();
@@ -244,15 +248,30 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
         if (lane == 0 && !(tau - pv >= a.e_bound)) atomicAdd(a.viol, 1u);   // pv = the exact k-th smallest
     }
     __syncthreads();
+    OMDS_TL_STAMP(2);
     if (a.dbg_stop == 1) return;   // OMDS_TAIL_SEL_STOP: timing experiments
     // ---- the selected entries' masks -> LDS -> 16 bits per thread and layer in the MFMA C layout (what pass 2's forward
     //      would have left in sm.maskL): thread (wave = 32-column block, lane) owns column wave*32 + (lane&31) of rows crow(r, lane)
-    for (int i = tid; i < ROWS * nhid * 8; i += P2_NT) {
+    for (int i = tid; i < TROWS * nhid * 8; i += P2_NT) {
         const int r = i / (nhid * 8);
         maskRow[i] = sel[r] >= 0 ? a.ex.mask[(size_t)sel[r] * nhid * 8 + (i - r * nhid * 8)] : 0u;
     }
     __syncthreads();
-    {
+    if constexpr (ROWS == 4) {
+        // the 4-row-group backward wants, per hidden level and COLUMN, the mask bits of all rows in one word
+        sm.maskG4 = reinterpret_cast<uint32_t*>(sm.maskL);   // (nhh + 1) * 256 words <= the (nhh + 1) * 512 halfwords of maskL
+        for (int i = tid; i < nhid * 256; i += P2_NT) {
+            const int l = i >> 8, col = i & 255;
+            uint32_t bits = 0;
+#pragma unroll
+            for (int e = 0; e < 4 * G4_NG; ++e) {
+                const uint32_t* mr = maskRow + ((size_t)e * nhid + l) * 8;
+                const uint32_t bit = (l == 0) ? ((mr[(col & 3) * 2 + (col >> 7)] >> ((col >> 2) & 31)) & 1u) : ((mr[col >> 5] >> (col & 31)) & 1u);
+                bits |= bit << e;
+            }
+            sm.maskG4[i] = bits;
+        }
+    } else {
         using G = P2Geo<ROWS>;
         for (int l = 0; l < nhid; ++l) {
             uint32_t bits = 0;
@@ -269,11 +288,18 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
     }
     __syncthreads();
 
+    OMDS_TL_STAMP(3);
     if (a.dbg_stop == 2) return;
     // ---- backward on the selected rows; gradients stay in LDS -----------------------------------------
     const float* qT = a.st.trajT + (size_t)(a.st.step - 1) * ND * N;
-    pass2_backward<ACT, ROWS>(m, sm, a.xyzr, t_base * k, N * k, qT, N, gx, 0, nullptr, 0, 0);
+    if constexpr (ROWS == 4) {
+        pass2_backward_hidden_g4<G4_NG>(m, sm);
+        p2_backward_first<32>(m, sm, a.xyzr, t_base * k, N * k, qT, N, gx, 0);
+    } else {
+        pass2_backward<ACT, ROWS>(m, sm, a.xyzr, t_base * k, N * k, qT, N, gx, 0, nullptr, 0, 0);
+    }
     __syncthreads();
+    OMDS_TL_STAMP(9);
     if (a.dbg_stop == 3) return;
 
     // ---- modulation / policy / Euler step: 16 lanes per rollout -------------------------------------
@@ -307,6 +333,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
             }
         }
     }
+    OMDS_TL_STAMP(10);
     if (a.st.step >= a.st.H) return;   // last step: nothing is integrated, no next network evaluation
     __syncthreads();
 
@@ -332,7 +359,20 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
                 if (t < t_end) m.featQ[(size_t)t * 32 + part * d + (cc - part * ND)] = feat[e];
             }
     }
+    OMDS_TL_STAMP(11);
+    OMDS_TL_STAMP(19);
 }
+
+#ifdef OMDS_TAIL_TL
+// one line per workgroup: XCC / CU of thread 0 are not recorded; columns = stamps 0..11 and 19 (0 and 19: s_memrealtime, 100 MHz)
+__global__ void k_tail_tl_dump(int nb) {
+    for (int b = 0; b < nb && b < 1024; ++b) {
+        printf("TL %d", b);
+        for (int i = 0; i < 12; ++i) printf(" %llu", g_tail_tl[b][i]);
+        printf(" %llu\n", g_tail_tl[b][19]);
+    }
+}
+#endif
 
 template <int ND, int ROWS>
 static void launch_tail_sel_t(hipStream_t s, const TailArgs& a) {
@@ -342,17 +382,27 @@ static void launch_tail_sel_t(hipStream_t s, const TailArgs& a) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail_sel<ND, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(tail_lds_bytes(OMDS_MAX_HIDDEN + 1) + extra));
     }
-    const int RW = ROWS / a.st.k;
+    const int RW = (ROWS == 4 ? 20 : ROWS) / a.st.k;
     hipLaunchKernelGGL((k_tail_sel<ND, ROWS>), dim3((a.t_end - a.t_begin + RW - 1) / RW), dim3(P2_NT), tail_lds_bytes(a.m.nhh + 1) + extra, s, a);
+#ifdef OMDS_TAIL_TL
+    {
+        static int want = -2, seen = 0;
+        if (want == -2) { const char* e = getenv("OMDS_TAIL_TL_STEP"); want = e ? atoi(e) : -1; }
+        if (a.st.step == want && ++seen == 3) hipLaunchKernelGGL(k_tail_tl_dump, dim3(1), dim3(1), 0, s, (a.t_end - a.t_begin + RW - 1) / RW);
+    }
+#endif
 }
 
 // 16-row tiles (bit-identical to 32-row ones, mlp_device.h) while their workgroups still fit the CUs two at a time: twice as
 // many, half as long, and the second resident fills the first one's top-k / gather / modulation phases
-static int tail_sel_rows(int N, int k) {
+static int tail_sel_rows(int N, int k, bool g4_ok) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("OMDS_TAIL_SEL_ROWS"); forced = e ? atoi(e) : 0; }
     if (k > 16) return 32;
+    if (forced == 4 && g4_ok && k <= 20) return 4;
     if (forced == 16 || forced == 32) return forced;
+    // 4-row groups (20 rows per workgroup) while their workgroups fit the CUs one at a time: 4 rollouts per CU at N = 1024, k = 5
+    if (forced == 0 && g4_ok && k <= 10 && (N + 20 / k - 1) / (20 / k) <= 256) return 4;
     const int RW16 = 16 / k;
     return (N + RW16 - 1) / RW16 <= 512 ? 16 : 32;
 }
@@ -374,9 +424,9 @@ void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Bpre, con
     a.dbg_stop = stop;
     a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Dmin = nullptr; a.Apre = Apre; a.ApreOut = Apre; a.dscr = nullptr; a.O = O; a.st = st;
     a.rowlist = rowlist; a.range = range; a.ex = ex;
-    const bool r16 = tail_sel_rows(st.N, st.k) == 16;
-    if (st.n == 7) { if (r16) launch_tail_sel_t<7, 16>(s, a); else launch_tail_sel_t<7, 32>(s, a); }
-    else { if (r16) launch_tail_sel_t<2, 16>(s, a); else launch_tail_sel_t<2, 32>(s, a); }
+    const int rows = tail_sel_rows(st.N, st.k, m.skip_mask == 0 && m.nhh >= 1);
+    if (st.n == 7) { if (rows == 4) launch_tail_sel_t<7, 4>(s, a); else if (rows == 16) launch_tail_sel_t<7, 16>(s, a); else launch_tail_sel_t<7, 32>(s, a); }
+    else { if (rows == 4) launch_tail_sel_t<2, 4>(s, a); else if (rows == 16) launch_tail_sel_t<2, 16>(s, a); else launch_tail_sel_t<2, 32>(s, a); }
 }
 
 static size_t tail_lds_bytes(int nhid) {

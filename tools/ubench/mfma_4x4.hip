@@ -16,7 +16,87 @@ __global__ void k4(const float* a, const float* b, const float* c, float* out) {
     for (int i = 0; i < 4; ++i) out[i * 64 + l] = acc[i];
 }
 
+// Issue rate: NACC independent accumulator chains per wave, WPS waves per SIMD, n instructions per chain link.
+template <int NACC>
+__global__ void k_rate(float* out, unsigned long long* cyc, int iters) {
+    const int l = threadIdx.x & 63;
+    f32x4 acc[NACC];
+    for (int g = 0; g < NACC; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float a = (float)l, b = 1.f / (1 + l);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int g = 0; g < NACC; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc[g], 4, 3, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int g = 0; g < NACC; ++g) s += acc[g][0] + acc[g][1] + acc[g][2] + acc[g][3];
+    if (s == 12345.f) out[0] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+template <int NACC>
+void rate(float* out, unsigned long long* cyc, int waves_per_simd) {
+    const int iters = 64;
+    hipLaunchKernelGGL(k_rate<NACC>, dim3(1), dim3(256 * waves_per_simd), 0, 0, out, cyc, iters);
+    hipLaunchKernelGGL(k_rate<NACC>, dim3(1), dim3(256 * waves_per_simd), 0, 0, out, cyc, iters);
+    unsigned long long c;
+    hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+    printf("4x4x1 16B: %d chains, %d wave(s) per SIMD: %.2f cycles per MFMA of the SIMD\n", NACC, waves_per_simd, (double)c / (iters * 16.0 * NACC * waves_per_simd));
+}
+
+// Whole-chip rate by the wall clock: 256 workgroups x 8 waves, every wave n MFMAs on NACC chains
+template <int SHAPE, int NACC>
+__global__ __launch_bounds__(512) void k_chip(float* out, int iters) {
+    const int l = threadIdx.x & 63;
+    f32x4 acc[NACC];
+    for (int g = 0; g < NACC; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float a = (float)l, b = 1.f / (1 + l);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int g = 0; g < NACC; ++g) {
+                if (SHAPE == 4) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc[g], 4, 3, 0);
+                else acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[g], 0, 0, 0);
+            }
+    }
+    float s = 0.f;
+    for (int g = 0; g < NACC; ++g) s += acc[g][0] + acc[g][1] + acc[g][2] + acc[g][3];
+    if (s == 12345.f) out[0] = s;
+}
+template <int SHAPE, int NACC>
+void chip(float* out, int threads) {
+    const int iters = 2000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL((k_chip<SHAPE, NACC>), dim3(256), dim3(threads), 0, 0, out, iters);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k_chip<SHAPE, NACC>), dim3(256), dim3(threads), 0, 0, out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flop = (SHAPE == 4 ? 512.0 : 2048.0) * iters * 16.0 * NACC * (threads / 64) * 256.0;
+    printf("%s, %d chains, %d waves per CU on 256 CUs: %.1f TFLOP/s by the wall clock (%.3f ms)\n", SHAPE == 4 ? "4x4x1 16B " : "16x16x4   ", NACC, threads / 64, flop / ms * 1e-9, ms);
+}
+
 int main() {
+    {
+        float* o;
+        hipMalloc(&o, 4);
+        chip<16, 2>(o, 256); chip<16, 2>(o, 512); chip<16, 4>(o, 512);
+        chip<4, 5>(o, 256); chip<4, 5>(o, 512); chip<4, 3>(o, 512); chip<4, 5>(o, 1024);
+    }
+    {
+        float* o;
+        unsigned long long* c;
+        hipMalloc(&o, 4);
+        hipMalloc(&c, 8);
+        rate<1>(o, c, 1); rate<2>(o, c, 1); rate<3>(o, c, 1); rate<5>(o, c, 1); rate<2>(o, c, 2); rate<3>(o, c, 2); rate<5>(o, c, 2);
+    }
     float *da, *db, *dc, *dout;
     hipMalloc(&da, 128 * 4); hipMalloc(&db, 128 * 4); hipMalloc(&dc, 256 * 4); hipMalloc(&dout, 256 * 4);
     unsigned st = 777;
