@@ -784,7 +784,7 @@ void omds_launch_max_abs_diff(hipStream_t s, const float* x, const float* y, lon
 // ------------------------------------------------------------------------------------------------
 size_t omds_screen_lds_bytes(int nhh) { return (size_t)SC_RING * SC_SLICE + (size_t)(nhh + 2) * OMDS_WIDTH * 4; }
 
-static int omds_cu_count() {
+int omds_cu_count() {
     static std::atomic<int> ncu_of[64];   // CUs per device, asked once
     int dev = 0;
     (void)hipGetDevice(&dev);

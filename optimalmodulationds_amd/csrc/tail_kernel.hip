@@ -401,9 +401,11 @@ static int tail_sel_rows(int N, int k, bool g4_ok) {
     if (k > 16) return 32;
     if (forced == 4 && g4_ok && k <= 20) return 4;
     if (forced == 16 || forced == 32) return forced;
-    // 4-row groups (20 rows per workgroup) while their workgroups fit the CUs one at a time: 4 rollouts per CU at N = 1024, k = 5
-    if (forced == 0 && g4_ok && k <= 10 && (N + 20 / k - 1) / (20 / k) <= 256) return 4;
+    // 4-row groups (20 rows per workgroup) as soon as 16-row tiles would put two workgroups on a CU: 4 rollouts per CU at
+    // N = 1024, k = 5 (one workgroup per CU, 40.5 -> 35 us), four workgroups per CU at N = 4096 (20.5 -> 20.1 ms per iteration
+    // against 32-row tiles).  Below that a lone 16-row tile is the shorter chain (two waves per SIMD on the GEMM).
     const int RW16 = 16 / k;
+    if (forced == 0 && g4_ok && k <= 10 && (N + RW16 - 1) / RW16 > omds_cu_count()) return 4;
     return (N + RW16 - 1) / RW16 <= 512 ? 16 : 32;
 }
 

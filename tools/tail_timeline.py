@@ -18,18 +18,23 @@ for line in (open(sys.argv[1]) if len(sys.argv) > 1 else sys.stdin):
             v = [int(x) for x in line.split()[1:]]
         except ValueError:   # the line the bench's JSON was appended to
             continue
-        if len(v) == 14 and v[1] and v[12]:
+        if len(v) >= 14 and v[1] and v[12]:
             rows.append(v)
 if not rows:
     sys.exit("no TL lines")
 # shader clock from the two real-time stamps (100 MHz) around the cycle stamps 1 and 11
-ghz = statistics.median((r[12] - r[2]) / ((r[13] - r[1]) * 10.0) for r in rows if r[13] > r[1])
+ghz = statistics.median((r[12] - r[2]) / ((r[-1] - r[1]) * 10.0) for r in rows if r[-1] > r[1])
 t0 = min(r[1] for r in rows)
 print("%d workgroups, shader clock %.2f GHz, entries spread over %.2f us, last exit %.2f us after the first entry"
-      % (len(rows), ghz, (max(r[1] for r in rows) - t0) / 100.0, (max(r[13] for r in rows) - t0) / 100.0))
+      % (len(rows), ghz, (max(r[1] for r in rows) - t0) / 100.0, (max(r[-1] for r in rows) - t0) / 100.0))
 print("%-28s %10s %10s   (us after the workgroup's own entry)" % ("phase boundary", "median", "max"))
 for i in range(3, 13):
     d = [(r[i] - r[2]) / (ghz * 1e3) for r in rows]
     print("%-28s %10.2f %10.2f" % (NAMES[i - 1], statistics.median(d), max(d)))
+if len(rows[0]) >= 19:
+    for i, nm in ((13, "mod: q + nominal DS"), (14, "mod: gradient blend"), (15, "mod: normal, sigmoids, act"), (16, "mod: policy"), (17, "mod: velocity")):
+        d = [(r[i] - r[2]) / (ghz * 1e3) for r in rows if r[i]]
+        if d:
+            print("%-28s %10.2f %10.2f" % (nm, statistics.median(d), max(d)))
 late = sorted(rows, key=lambda r: r[1])
 print("entry of the 257th workgroup: %.2f us after the first" % ((late[256][1] - t0) / 100.0) if len(late) > 256 else "at most 256 workgroups")
