@@ -95,6 +95,7 @@ SIGNATURES = {
     "omds_set_screening_sweep": (C.c_int, [C.c_void_p, C.c_int]),
     "omds_screen_sweep_stats": (C.c_int, [C.c_void_p, I32P, C.POINTER(C.c_int64), F32P]),
     "omds_screen_debug_corrupt": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float]),
+    "omds_debug_force_tile_rows": (C.c_int, [C.c_int, C.c_int]),
     "omds_screen_mindist": (C.c_int, [C.c_void_p, F32P, C.c_int, F32P]),
     "omds_screen_stats": (C.c_int, [C.c_void_p, I32P, F32P, F32P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "omds_trainer_create": (C.c_int, [C.c_int, C.c_int, I32P, C.c_int, C.POINTER(C.c_void_p)]),
@@ -113,7 +114,7 @@ SIGNATURES = {
     "omds_sync": (C.c_int, [C.c_void_p]),
 }
 
-ABI_VERSION = 320      # omds_version() of the library this binding was written against
+ABI_VERSION = 321      # omds_version() of the library this binding was written against
 _lib = None
 
 

@@ -84,7 +84,7 @@ static uint16_t f32_to_f16_bits(float f) {
 
 extern "C" {
 
-int omds_version(void) { return 320; }
+int omds_version(void) { return 321; }
 
 void omds_default_params(omds_params* p) {
     if (!p) return;
@@ -1534,6 +1534,13 @@ int omds_screen_audit_stats(omds_ctx* ctx, int32_t* one_in, double* audit_rows_p
 // something to catch.  what = 0: zeroes weight fragment `index` (1 KiB of slice index / 16) of the fp16 pack -- every
 // screening value moves; what = 1: shifts obstacle `index` by `value` along x in the SCREENING input table only (undone by
 // the next omds_set_obstacles) -- the fp16 network sees that one sphere elsewhere, so only the audit rows can notice.
+int omds_debug_force_tile_rows(int tail_sel_rows, int tail_rows) {
+    if (!((tail_sel_rows == 0 || tail_sel_rows == 4 || tail_sel_rows == 16 || tail_sel_rows == 32) && (tail_rows == 0 || tail_rows == 16 || tail_rows == 32)))
+        return OMDS_ERR_INVALID_ARG;
+    omds_force_tile_rows(tail_sel_rows, tail_rows);
+    return OMDS_OK;
+}
+
 int omds_screen_debug_corrupt(omds_ctx* ctx, int what, int index, float value) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
     REQUIRE(ctx->screen_ok, OMDS_ERR_UNSUPPORTED, "omds_screen_debug_corrupt: no screening network for this model");

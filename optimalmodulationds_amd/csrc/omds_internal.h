@@ -358,6 +358,7 @@ void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const f
 // screened step's tail: top-k over the candidates k_exact evaluated + pass-2 backward on its masks + the rest of k_tail
 bool omds_tail_sel_supported(int n_dof, int k);
 int omds_cu_count();   // CUs of the current device (asked once per device)
+void omds_force_tile_rows(int tail_sel_rows, int tail_rows);   // test hook: 0 = the launcher's own choice
 void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
                           float* Apre, int O, const StepArgs& st, const int* rowlist, const int* range, const ExactOut& ex,
                           uint16_t* FqH, int ldF, float e_bound, unsigned* viol);

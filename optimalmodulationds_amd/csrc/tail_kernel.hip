@@ -9,6 +9,8 @@
 // points (omds_dist_grad, omds_mlp_forward_vjp) and for n_dof / k combinations not instantiated here.
 #include <algorithm>
 
+#include <atomic>
+
 #include "mlp_device.h"
 #include "step_device.h"
 
@@ -395,9 +397,20 @@ static void launch_tail_sel_t(hipStream_t s, const TailArgs& a) {
 
 // 16-row tiles (bit-identical to 32-row ones, mlp_device.h) while their workgroups still fit the CUs two at a time: twice as
 // many, half as long, and the second resident fills the first one's top-k / gather / modulation phases
+// Tile shapes forced by the environment (OMDS_TAIL_SEL_ROWS = 4 | 16 | 32, OMDS_TAIL_ROWS = 16 | 32) or by the test hook
+// omds_debug_force_tile_rows: every shape computes the same bits, and the tests say so by running them against each other.
+static std::atomic<int> g_force_sel_rows{-1}, g_force_tail_rows{-1};
+void omds_force_tile_rows(int tail_sel_rows, int tail_rows) {
+    g_force_sel_rows.store(tail_sel_rows);
+    g_force_tail_rows.store(tail_rows);
+}
+static int forced_rows(std::atomic<int>& slot, const char* env) {
+    int f = slot.load();
+    if (f < 0) { const char* e = getenv(env); f = e ? atoi(e) : 0; slot.store(f); }
+    return f;
+}
 static int tail_sel_rows(int N, int k, bool g4_ok) {
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("OMDS_TAIL_SEL_ROWS"); forced = e ? atoi(e) : 0; }
+    const int forced = forced_rows(g_force_sel_rows, "OMDS_TAIL_SEL_ROWS");
     if (k > 16) return 32;
     if (forced == 4 && g4_ok && k <= 20) return 4;
     if (forced == 16 || forced == 32) return forced;
@@ -457,8 +470,7 @@ bool omds_tail_supported(int n_dof, int k) { return (n_dof == 7 || n_dof == 2) &
 
 // 16-row tiles when 32-row tiles would leave most CUs without a workgroup (OMDS_TAIL_ROWS=16|32 forces one)
 int omds_tail_rows(int N, int k) {
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("OMDS_TAIL_ROWS"); forced = e ? atoi(e) : 0; }
+    const int forced = forced_rows(g_force_tail_rows, "OMDS_TAIL_ROWS");
     if (k > 16) return 32;
     if (forced == 16 || forced == 32) return forced;
     const int RW32 = 32 / k;

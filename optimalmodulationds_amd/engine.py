@@ -291,6 +291,10 @@ class Engine:
         """Test hook (omds.h): 0 = zero a weight fragment of the fp16 pack, 1 = shift an obstacle in the screening inputs."""
         self._ck(self.lib.omds_screen_debug_corrupt(self.h, int(what), int(index), float(value)))
 
+    def debug_force_tile_rows(self, tail_sel_rows=0, tail_rows=0):
+        """Test hook (omds.h, process-wide): tile shape of the tail kernels; 0 = the launcher's own choice."""
+        self._ck(self.lib.omds_debug_force_tile_rows(int(tail_sel_rows), int(tail_rows)))
+
     def screen_mindist(self, q):
         q = L.f32(q).reshape(-1, self.n)
         out = np.zeros((q.shape[0], self.n_obs), np.float32)

@@ -320,3 +320,63 @@ def test_screened_planar_networks_are_bit_identical(kind, n, k):
             assert np.array_equal(outs[0][it][key], outs[1][it][key]), (kind, it, key, float(np.nanmax(np.abs(outs[0][it][key] - outs[1][it][key]))))
     print(kind, k, stats)
     assert stats["active"] and not stats["suspended"] and stats["fallbacks"] <= 1, stats
+
+
+@pytest.mark.parametrize("kind,n,k,N", [("planar2", 2, 1, 512), ("planar2", 2, 2, 512), ("planar2", 2, 5, 300), ("planar7", 7, 3, 512),
+                                         ("franka", 7, 5, 1024), ("franka", 7, 4, 250)])
+def test_every_tile_shape_computes_the_same_bits(kind, n, k, N):
+    """The tail kernels choose a tile shape from the batch (32-row, 16-row, and for the screened step the backward on 4-row
+    groups); the choice must not show in the results.  Forces each shape in turn (omds_debug_force_tile_rows) for the screened
+    and the unscreened step and compares every rollout tensor bit for bit -- the 2-DoF tail with the 4-row groups is the
+    case in which a cross-statement multiply-add contraction once differed between two instantiations of the same source."""
+    from optimalmodulationds_amd import scenes
+    from optimalmodulationds_amd.engine import Engine
+    m = orc.Mlp.from_npz(weights_path(kind))
+    rng = np.random.RandomState(5)
+    if kind == "franka":
+        obs, q0, qf = scenes.shelf_scene(), scenes.FRANKA_Q0, scenes.FRANKA_QF
+        dt, thr, ign = 0.5, 0.01, 0b111
+    else:
+        reach = 6.5 if n == 2 else 7.5
+        obs = np.c_[rng.uniform(-reach, reach, (700, 2)), np.zeros(700), rng.uniform(0.2, 0.6, 700)].astype(np.float32)
+        q0 = np.zeros(n, np.float32); q0[0] = np.pi / 2
+        qf = np.zeros(n, np.float32); qf[0] = -np.pi / 2
+        dt, thr, ign = 0.3, 0.25, 0
+    H, K = 6, 4
+    mu_c = (q0 + 0.3 * rng.standard_normal((K, n))).astype(np.float32)
+    sg_c, al_c = np.full(K, 0.5, np.float32), rng.standard_normal((K, n)).astype(np.float32)
+
+    def run(mode, sel_rows, tail_rows):
+        e = Engine(n, N, H, k, max_obs=1024)
+        try:
+            e.debug_force_tile_rows(sel_rows, tail_rows)
+            e.set_mlp(m.W, m.b)
+            e.set_obstacles(obs)
+            e.params.dt, e.params.dst_thr, e.params.ignored_links = dt, thr, ign
+            e.push_params()
+            e.set_ds(qf)
+            e.set_screening(mode)
+            out = []
+            q = q0.copy()
+            for it in range(2):
+                e.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 0.75, K, seed=40 + it)
+                e.propagate(q)
+                out.append(e.get_rollouts())
+                q = (q + 0.1 * (qf - q0)).astype(np.float32)
+            st = e.screen_stats()
+            return out, st
+        finally:
+            e.debug_force_tile_rows(0, 0)
+            e.close()
+
+    ref, _ = run(0, 0, 32)
+    variants = [("unscreened 16-row", 0, 0, 16), ("screened 32-row", 1, 32, 0), ("screened 16-row", 1, 16, 0), ("screened 4-row groups", 1, 4, 0)]
+    for name, mode, sel_rows, tail_rows in variants:
+        if sel_rows == 16 and k > 16:
+            continue
+        got, st = run(mode, sel_rows, tail_rows)
+        if mode:
+            assert st["active"] and st["fallbacks"] == 0, (name, st)   # a fallback would compare the fp32 step with itself
+        for it in range(2):
+            for key in KEYS:
+                assert np.array_equal(ref[it][key], got[it][key], equal_nan=True), (kind, k, name, it, key, float(np.nanmax(np.abs(ref[it][key] - got[it][key]))))
