@@ -77,8 +77,6 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
     float* gf = gx + SS_RK * 12;                                     // [SS_RK][33] feature gradients
     float* feat = gf + SS_RK * 33;                                   // [SS_RK][3 ND] next state, sin, cos
     float4* gS = reinterpret_cast<float4*>(feat + SS_RK * 3 * OMDS_MAX_DOF + 4);   // [256] gradient of the four rows at each column
-    // [8 k parts][256] partial sums: in the 32-row tile buffer (idle by then); the 16-row buffer is too small for them
-    float4* P = TR == 32 ? reinterpret_cast<float4*>(Hs) : gS + OMDS_WIDTH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.B, k = a.st.k, O = a.O, R = a.R;
     const int t_base = blockIdx.x * R;
@@ -92,6 +90,14 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
     }
     if (a.dbg_stop == 1) return;
     if (tid < SS_RK) { selRow[tid] = -1; selT[tid] = 0; selO[tid] = 0; dr[tid] = 0.f; }
+    // the backward's first weights (phase 3) are on their way while the closest obstacles are picked
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const bool mine = wv < 4;    // the GEMM waves, one per SIMD
+    W4Ring<8> ring;
+    if (mine) {
+        ring.bind(m.Wb4, m.nhh, wv, lane);
+        ring.fill(m.nhh - 1);
+    }
     __syncthreads();
 
     // ---- 2. the k closest obstacles of each rollout by (D, obstacle index) ------------------------------------------
@@ -125,74 +131,60 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
     __syncthreads();
 
     if (a.dbg_stop == 2) return;
-    // ---- 3. backward on the selected rows (VALU, weights streamed once) -------------------------------------------------
-    // 16 weight rows per thread in flight at once (two halves of its k range: 117 registers instead of 151, the same time);
-    // packed FMAs, two rows per instruction.  Measured: 4.2 us per layer whether or not the next layer's rows are requested
-    // ahead of the reduction, and the same with scalar FMAs -- 256 workgroups pulling the same 256 KB through their L1s at
-    // once is an L2 problem (32 CUs per XCD on the same lines).
+    // ---- 3. backward on the selected rows: ONE 4-row group on v_mfma_f32_4x4x1 (gemm4, mlp_device.h) -----------------------
+    // Four rows are no 16-row MFMA problem (a 16-row tile would run at the 16-row rate to move four useful rows) but they are
+    // exactly one row group of the 4x4x1 shape: waves 0-3 multiply 64 columns each, 256 dependent MFMAs per layer (one
+    // accumulator chain in the k order of every other kernel: the gradient rows are the two-launch step's bit for bit), the
+    // 256 KB of a layer streaming through a ring of 8 chunks that runs across the layers (1.9 us per layer through the CU's
+    // L1 -- the bound).  The first version ran on the VALU with the k range split over the eight waves: 16 rows per thread
+    // loaded, waited for, 128 packed FMAs, then eight partial sums meeting in LDS -- 7.2 k cycles per layer of which 3.4 k were
+    // the partial-sum write, two barriers and the reduction.
+    // Measured and rejected: the modulation's gradient-independent half (nominal DS, goal activation, RBF policy) on wave 0 under
+    // the first GEMM, the GEMM on waves 4-7 -- the GEMM of the SIMD that wave 0 shares grew by the whole 2.7 us (19.9 -> 19.1 M):
+    // even a single dependent 4x4x1 chain does not share its SIMD's issue with another wave's VALU / transcendental stream.
     // Measured and rejected: a RESIDENT form of this kernel (one launch per propagate, the workgroup keeps its rollouts, their
     // layer-1 halves in LDS and their navigation kernels in registers over all H steps): 1.82 ms per iteration against 1.74 ms
     // for H launches -- consecutive launches already start with no idle gap, and the loop costs registers (245).
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const int jq = tid & 63, kp = tid >> 6;
-    float4 w[16];
-    auto load_w = [&](int l, int half) {   // rows 32 kp + 16 half .. + 15 of the thread's k range (16 x 16 B per thread in flight)
-        const float4* Wq = reinterpret_cast<const float4*>(m.Whraw + (size_t)l * OMDS_WIDTH * OMDS_WIDTH) + jq;   // W[k][4jq..4jq+3] = Wq[k * 64]
-#pragma unroll
-        for (int u = 0; u < 16; ++u) w[u] = Wq[(size_t)(32 * kp + 16 * half + u) * 64];
-    };
-    if (tid < OMDS_WIDTH) {   // seed: dy[argmin] / dH_last = Wlast[argmin], masked by the last hidden layer
-        float v[SS_RK];
-#pragma unroll
-        for (int r = 0; r < SS_RK; ++r) {
-            const int row = selRow[r];
-            v[r] = (row >= 0 && ss_mask_bit(maskS, nhid, row, m.nhh, tid)) ? m.Wlraw[(size_t)Amin[row] * OMDS_WIDTH + tid] : 0.f;
-        }
-        gS[tid] = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int l = m.nhh - 1; l >= 0; --l) {
-        f2 acc[4][2];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { acc[c][0] = f2{0.f, 0.f}; acc[c][1] = f2{0.f, 0.f}; }
-#pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            load_w(l, half);
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const float4 g = gS[32 * kp + 16 * half + u];
-                const f2 glo = {g.x, g.y}, ghi = {g.z, g.w};
-                const float wc[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const f2 ww = {wc[c], wc[c]};
-                    acc[c][0] = __builtin_elementwise_fma(glo, ww, acc[c][0]);
-                    acc[c][1] = __builtin_elementwise_fma(ghi, ww, acc[c][1]);
-                }
-                if ((u & 3) == 3) asm volatile("" ::: "memory");   // keeps hipcc from reading all gradient rows ahead of the FMAs
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) P[kp * OMDS_WIDTH + 4 * jq + c] = make_float4(acc[c][0][0], acc[c][0][1], acc[c][1][0], acc[c][1][1]);
-        __syncthreads();
-        if (tid < OMDS_WIDTH) {
-            float4 s = P[tid];
-#pragma unroll
-            for (int q = 1; q < 8; ++q) {
-                const float4 p = P[q * OMDS_WIDTH + tid];
-                s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
-            }
-            const float sv[4] = {s.x, s.y, s.z, s.w};
-            float v[SS_RK];
+    {
+        const int col = 64 * (wv & 3) + lane;
+        // this thread's ReLU masks, all levels: bit 4 l + r = row r at level l (the GEMM waves: their column)
+        uint32_t mb = 0;
+        int amin[SS_RK];
+        if (mine) {
 #pragma unroll
             for (int r = 0; r < SS_RK; ++r) {
                 const int row = selRow[r];
-                v[r] = (row >= 0 && ss_mask_bit(maskS, nhid, row, l, tid)) ? sv[r] : 0.f;
+                amin[r] = row >= 0 ? Amin[row] : 0;
+                for (int l = 0; l < nhid; ++l)
+                    if (row >= 0 && ss_mask_bit(maskS, nhid, row, l, col)) mb |= 1u << (4 * l + r);
             }
-            gS[tid] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if (mine) {        // seed: dy[argmin] / dH_last = Wlast[argmin], masked by the last hidden layer (the tile buffer is idle since the forward)
+#pragma unroll
+            for (int r = 0; r < SS_RK; ++r)
+                Hs[r * LDH + col] = ((mb >> (4 * m.nhh + r)) & 1u) ? m.Wlraw[(size_t)amin[r] * OMDS_WIDTH + col] : 0.f;
         }
         __syncthreads();
+#pragma unroll 1
+        for (int l = m.nhh - 1; l >= 0; --l) {
+            f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+            if (mine) {
+                gemm4<1, 8>(Hs, ring, l, l - 1, lane, acc);
+            }
+            __syncthreads();   // every wave has read the rows
+            if (mine) {
+                float v[SS_RK];
+#pragma unroll
+                for (int r = 0; r < SS_RK; ++r) {
+                    v[r] = ((mb >> (4 * l + r)) & 1u) ? acc[0][r] : 0.f;
+                    Hs[r * LDH + col] = v[r];
+                }
+                if (l == 0) gS[col] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            __syncthreads();
+        }
+        if (m.nhh == 0 && mine) gS[col] = make_float4(Hs[col], Hs[LDH + col], Hs[2 * LDH + col], Hs[3 * LDH + col]);
+        if (m.nhh == 0) __syncthreads();
     }
     if (a.dbg_stop == 3) return;
     // first layer: g_f[r][f] = sum_c Gz1[r][c] W1[c][f]; 16 lanes per feature, c strided over them
@@ -288,8 +280,10 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
 }
 
 static size_t small_lds_bytes(int nhid, int TR) {
+    // the last term: gemm4's A-operand reads span 32 tile rows (lanes 16-31 are never selected, but they read): a 16-row tile
+    // buffer is followed by at least another 16 rows' worth of allocation
     return ((size_t)TR * LDH + 2 * TR + (size_t)TR * nhid * 8) * 4 + (32 * 3 + SS_RK * 3) * 4 +
-           (SS_RK + SS_RK * 12 + SS_RK * 33 + SS_RK * 3 * OMDS_MAX_DOF + 4) * 4 + OMDS_WIDTH * 16 + 16 + (TR == 16 ? 8 * OMDS_WIDTH * 16 : 0);
+           (SS_RK + SS_RK * 12 + SS_RK * 33 + SS_RK * 3 * OMDS_MAX_DOF + 4) * 4 + OMDS_WIDTH * 16 + 16 + (TR == 16 ? (size_t)16 * LDH * 4 : 0);
 }
 
 // rollouts per workgroup for (O, k) on a tile of `rows` rows, 0 = the scene does not qualify
