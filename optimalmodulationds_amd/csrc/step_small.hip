@@ -131,6 +131,14 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
     __syncthreads();
 
     if (a.dbg_stop == 2) return;
+    // the first-layer backward's weights of this thread (feature tid >> 4, columns (tid & 15) + 16 i): asked for now, used after
+    // the hidden layers
+    float w1b[16];
+    {
+        const int f = tid >> 4, sub = tid & 15;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w1b[i] = f < 3 * m.d ? m.W1t[(size_t)f * OMDS_WIDTH + sub + 16 * i] : 0.f;
+    }
     // ---- 3. backward on the selected rows: ONE 4-row group on v_mfma_f32_4x4x1 (gemm4, mlp_device.h) -----------------------
     // Four rows are no 16-row MFMA problem (a 16-row tile would run at the 16-row rate to move four useful rows) but they are
     // exactly one row group of the 4x4x1 shape: waves 0-3 multiply 64 columns each, 256 dependent MFMAs per layer (one
@@ -192,10 +200,10 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
         const int f = tid >> 4, sub = tid & 15, F = 3 * m.d;
         float s[SS_RK] = {};
         if (f < F) {
-#pragma unroll 4
+#pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int c = sub + 16 * i;
-                const float w = m.W1t[(size_t)f * OMDS_WIDTH + c];
+                const float w = w1b[i];
                 const float4 g = gS[c];
                 s[0] = fmaf(g.x, w, s[0]); s[1] = fmaf(g.y, w, s[1]); s[2] = fmaf(g.z, w, s[2]); s[3] = fmaf(g.w, w, s[3]);
             }
@@ -240,6 +248,18 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
         return;
     }
 
+    // the next step's layer-1 weights of this thread's column: asked for now, used after the modulation (they depend on nothing)
+    float w1n[3 * ND], b1n = 0.f;
+    if (a.st.step < a.st.H) {
+        const int c = tid & 255, d = m.d;
+        b1n = m.b1[c];
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            w1n[j] = m.W1t[(size_t)j * OMDS_WIDTH + c];
+            w1n[ND + j] = m.W1t[(size_t)(d + j) * OMDS_WIDTH + c];
+            w1n[2 * ND + j] = m.W1t[(size_t)(2 * d + j) * OMDS_WIDTH + c];
+        }
+    }
     // ---- 4. modulation / policy / Euler step: 16 lanes per rollout (as k_tail) -----------------------------------------
     {
         const int rl = tid >> 4, sub = tid & 15;
@@ -262,18 +282,18 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
     if (a.st.step >= a.st.H || a.dbg_stop == 5) return;   // last step: nothing is integrated, no next network evaluation
     __syncthreads();
     {   // rollout half of layer 1 for the next step (same arithmetic order as k_rollout_layer1)
-        const int c = tid & 255, d = m.d;
+        const int c = tid & 255;
         for (int rl = tid >> 8; rl < R; rl += 2) {
             const int t = t_base + rl;
             if (t >= N) break;
             const float* f = feat + rl * 3 * ND;
-            float acc = m.b1[c];
+            float acc = b1n;
 #pragma unroll
-            for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)j * OMDS_WIDTH + c], f[j], acc);
+            for (int j = 0; j < ND; ++j) acc = fmaf(w1n[j], f[j], acc);
 #pragma unroll
-            for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)(d + j) * OMDS_WIDTH + c], f[ND + j], acc);
+            for (int j = 0; j < ND; ++j) acc = fmaf(w1n[ND + j], f[ND + j], acc);
 #pragma unroll
-            for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)(2 * d + j) * OMDS_WIDTH + c], f[2 * ND + j], acc);
+            for (int j = 0; j < ND; ++j) acc = fmaf(w1n[2 * ND + j], f[2 * ND + j], acc);
             a.Apre[(size_t)t * OMDS_WIDTH + c] = acc;
         }
     }
