@@ -695,9 +695,20 @@ __global__ __launch_bounds__(512) void k_audit(MlpDev m, const float* __restrict
                                                unsigned* __restrict__ maxerr_bits, ExactOut ex) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = min(*total, cap);
-    for (int blk = blockIdx.x; blk * 64 < n; blk += gridDim.x) {
-        pass1_tile<64, 2, 1, ACT, 4>(m, smem, ApreAll, Bpre, radius, O, n, ignored, nullptr, (long long)blk * 64, odiv, rows, maxerr_bits, &ex);
+    // whole rounds of 64-row tiles over the grid; a last round that would fill at most half the grid's row slots runs on 32-row
+    // tiles, half as long (72 k rows on 512 workgroups are 2.2 rounds of 64 rows: 2 + a half instead of 3)
+    const int G = (int)gridDim.x;
+    const int full = n / (64 * G);                  // rounds in which every workgroup has a full tile
+    const int rest0 = full * 64 * G, rest = n - rest0;
+    for (int r = 0; r < full; ++r) {
+        pass1_tile<64, 2, 1, ACT, 4>(m, smem, ApreAll, Bpre, radius, O, n, ignored, nullptr, ((long long)r * G + blockIdx.x) * 64, odiv, rows, maxerr_bits, &ex);
         __syncthreads();
+    }
+    if (rest > 32 * G) {
+        if ((long long)blockIdx.x * 64 < rest)
+            pass1_tile<64, 2, 1, ACT, 4>(m, smem, ApreAll, Bpre, radius, O, n, ignored, nullptr, rest0 + (long long)blockIdx.x * 64, odiv, rows, maxerr_bits, &ex);
+    } else if ((long long)blockIdx.x * 32 < rest) {
+        pass1_tile<32, 1, 1, ACT, 4>(m, smem, ApreAll, Bpre, radius, O, n, ignored, nullptr, rest0 + (long long)blockIdx.x * 32, odiv, rows, maxerr_bits, &ex);
     }
 }
 
