@@ -1057,7 +1057,7 @@ __device__ __forceinline__ void p2_backward_first(const MlpDev& m, const P2Smem&
 // N = 1024, k = 5 a CU's share is 4 rollouts = 20 rows: five groups of 4 where the 16-row shape needs two blocks (32 rows of
 // matrix-pipe time) -- 10240 instead of 16384 MFMA cycles per SIMD and layer.  ReLU networks without skip concatenations;
 // the same fmaf chains in the same k order as pass2_backward<ACT, 16 | 32>, so the same bits.
-//   waves 0-3: columns 64 w .. +63 of ALL row groups (one wave per SIMD; weight lookahead of 4 chunks); thread: column 64 w + lane.
+//   waves 0-3: columns 64 w .. +63 of ALL row groups (one wave per SIMD: a second one would fetch the same weight fragments from L2 a second time; weights through the 8-chunk ring across the layers); thread: column 64 w + lane.
 // sm.maskG4[l * 256 + column]: bit e = ReLU mask of element (row e, column) at hidden level l (written by the caller BEFORE
 // this call, which overwrites the tile buffer).  Leaves the gradient at the first layer's pre-activations in sm.Hs
 // (32 rows, the rest 0).
