@@ -211,6 +211,13 @@ struct W4Ring {
             w[S][h] = make_float4(v.x, v.y, v.z, v.w);
         }
     }
+    // one half (four k) of chunk C of layer l into slot S
+    template <int S, int C, int HALF>
+    __device__ __forceinline__ void issue_half(int l) {
+        const int voff = l >= 0 ? vlane + l * W4_LAYER_BYTES : -1;
+        const omds_f4 v = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sbase + (2 * C + HALF) * 64 * 16, 0));
+        w[S][HALF] = make_float4(v.x, v.y, v.z, v.w);
+    }
     template <int C = 0>
     __device__ __forceinline__ void fill(int l) {
         if constexpr (C < PD) {
@@ -228,26 +235,49 @@ __device__ __forceinline__ void g4_step(float av, float bv, f32x4 (&acc)[NG]) {
         g4_step<NG, G + 1>(av, bv, acc);
     }
 }
+// Chunk C.  The requests that keep the pipeline full -- the two halves of the ring slot the PREVIOUS chunk has freed, the two
+// LDS reads of the next chunk's A operand -- are each issued behind one group of MFMAs instead of in a cluster at the chunk
+// boundary: an instruction issued in the shadow of a 2-pass MFMA costs nothing, a cluster of them between two MFMAs leaves
+// the matrix pipe idle (9.7 cycles per MFMA with the cluster, against the 8.4 one wave can issue).
 template <int NG, int PD, int C>
 __device__ __forceinline__ void gemm4_chunks(const float* arow, W4Ring<PD>& R, int l, int l_next, float4 a_lo, float4 a_hi, f32x4 (&acc)[NG]) {
     if constexpr (C < 32) {   // chunk C = k 8C .. 8C+7, contracted in the order 8C + {0,4,1,5,2,6,3,7}
+        constexpr int CP = C - 1 + PD;   // the chunk that slot (C - 1) % PD takes next
         float4 n_lo = a_lo, n_hi = a_hi;
-        if constexpr (C + 1 < 32) {
-            n_lo = *reinterpret_cast<const float4*>(arow + 8 * (C + 1));
-            n_hi = *reinterpret_cast<const float4*>(arow + 8 * (C + 1) + 4);
-        }
         const float4 w_lo = R.w[C % PD][0], w_hi = R.w[C % PD][1];
         g4_step<NG, 0>(a_lo.x, w_lo.x, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (C >= 1) {
+            if constexpr (CP < 32) R.template issue_half<(C - 1) % PD, CP, 0>(l);
+            else R.template issue_half<(C - 1) % PD, CP - 32, 0>(l_next);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         g4_step<NG, 0>(a_hi.x, w_hi.x, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (C >= 1) {
+            if constexpr (CP < 32) R.template issue_half<(C - 1) % PD, CP, 1>(l);
+            else R.template issue_half<(C - 1) % PD, CP - 32, 1>(l_next);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         g4_step<NG, 0>(a_lo.y, w_lo.y, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (C + 1 < 32) n_lo = *reinterpret_cast<const float4*>(arow + 8 * (C + 1));
+        __builtin_amdgcn_sched_barrier(0);
         g4_step<NG, 0>(a_hi.y, w_hi.y, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (C + 1 < 32) n_hi = *reinterpret_cast<const float4*>(arow + 8 * (C + 1) + 4);
+        __builtin_amdgcn_sched_barrier(0);
         g4_step<NG, 0>(a_lo.z, w_lo.z, acc);
         g4_step<NG, 0>(a_hi.z, w_hi.z, acc);
         g4_step<NG, 0>(a_lo.w, w_lo.w, acc);
         g4_step<NG, 0>(a_hi.w, w_hi.w, acc);
-        if constexpr (C + PD < 32) R.template issue<C % PD, C + PD>(l);
-        else R.template issue<C % PD, C + PD - 32>(l_next);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (C == 31) {   // the last chunk's own slot: the ring is whole again for the next layer
+            constexpr int CL = 31 + PD - 32;
+            R.template issue_half<31 % PD, CL, 0>(l_next);
+            R.template issue_half<31 % PD, CL, 1>(l_next);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         gemm4_chunks<NG, PD, C + 1>(arow, R, l, l_next, n_lo, n_hi, acc);
     }
 }
