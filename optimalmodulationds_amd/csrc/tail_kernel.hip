@@ -414,11 +414,18 @@ static int tail_sel_rows(int N, int k, bool g4_ok) {
     if (k > 16) return 32;
     if (forced == 4 && g4_ok && k <= 20) return 4;
     if (forced == 16 || forced == 32) return forced;
-    // 4-row groups (20 rows per workgroup) as soon as 16-row tiles would put two workgroups on a CU: 4 rollouts per CU at
-    // N = 1024, k = 5 (one workgroup per CU, 40.5 -> 35 us), four workgroups per CU at N = 4096 (20.5 -> 20.1 ms per iteration
-    // against 32-row tiles).  Below that a lone 16-row tile is the shorter chain (two waves per SIMD on the GEMM).
+    // 4-row groups (20 rows per workgroup) where the busiest CU multiplies less that way: matrix-pipe cycles per layer of the CU
+    // with the most workgroups, 5 groups x 2048 (x 1.1: one wave per SIMD issues a 4x4x1 every 9 cycles, not 8) against 8192 per
+    // 16-row tile.  N = 1024, k = 5: 256 workgroups, one per CU, against 342 tiles of 16 rows (40.5 -> 35 us); N = 4096: four
+    // per CU against six tiles (20.5 -> 20.1 ms per iteration); N = 1500: 375 workgroups would put two on 119 CUs where 500
+    // tiles of 16 rows are two per CU and cheaper.  A lone 16-row tile (no CU with two) is the shorter chain anyway.
     const int RW16 = 16 / k;
-    if (forced == 0 && g4_ok && k <= 10 && (N + RW16 - 1) / RW16 > omds_cu_count()) return 4;
+    if (forced == 0 && g4_ok && k <= 10) {
+        const int ncu = omds_cu_count(), RW4 = 20 / k;
+        const long long wg16 = (N + RW16 - 1) / RW16, wg4 = (N + RW4 - 1) / RW4;
+        const long long cost16 = ((wg16 + ncu - 1) / ncu) * 8192, cost4 = ((wg4 + ncu - 1) / ncu) * (5 * 2048 * 11 / 10);
+        if (wg16 > ncu && cost4 < cost16) return 4;
+    }
     return (N + RW16 - 1) / RW16 <= 512 ? 16 : 32;
 }
 
