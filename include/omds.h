@@ -289,15 +289,8 @@ OMDS_API int omds_set_screening_sweep(omds_ctx* ctx, int every);
 OMDS_API int omds_screen_sweep_stats(omds_ctx* ctx, int32_t* every, int64_t* sweeps, float* sweep_max_err);
 OMDS_API int omds_screen_audit_stats(omds_ctx* ctx, int32_t* one_in, double* audit_rows_per_rollout_step, float* audit_max_err,
                                      int32_t* suspended, int64_t* calibrations);
-/* Test hook: damages what the screening network sees so that the run-time checks have something to catch.  what = 0: zeroes
- * fragment `index` (1 KiB) of the fp16 weight pack; what = 1: shifts obstacle `index` by `value` along x in the screening
- * kernel's input table only (until the next omds_set_obstacles).  The fp32 kernels are never touched.                  */
-OMDS_API int omds_screen_debug_corrupt(omds_ctx* ctx, int what, int index, float value);
-/* Test hook (process-wide): the tile shape of the step's tail kernels instead of the launcher's own choice -- tail_sel_rows in
- * {0, 4, 16, 32} for the screened step (4 = the backward on 4-row groups; ReLU networks without skip concatenations), tail_rows
- * in {0, 16, 32} for the unscreened one; 0 = the launcher chooses.  Every shape computes the same bits per row: the tests run
- * them against each other.                                                                                                   */
-OMDS_API int omds_debug_force_tile_rows(int tail_sel_rows, int tail_rows);
+/* (The two test hooks that damage the screening inputs / force a tile shape are NOT part of this library: they are declared in
+ * include/omds_test.h and exported by libomds_hip_test.so only.)                                                           */
 /* Diagnostic: the fp16 screening network alone on q [B,n] -> mindist [B,O] (the values the candidate selection sees). */
 OMDS_API int omds_screen_mindist(omds_ctx* ctx, const float* q, int batch, float* mindist);
 OMDS_API int omds_screen_stats(omds_ctx* ctx, int32_t* active, float* eps, float* max_err_seen,

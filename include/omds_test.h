@@ -1,0 +1,30 @@
+/*
+ * omds_test.h -- test hooks of the MI355X-native MPPI rollout path.  NOT part of the product ABI: libomds_hip.so does not export
+ * them.  They exist in libomds_hip_test.so (`make test-lib`: the same objects except capi and tail_kernel, which are compiled
+ * with -DOMDS_TEST_HOOKS), which tests/ load explicitly (optimalmodulationds_amd._lib.load_test_hooks()).  Neither library
+ * reads experiment environment variables; those exist only in `make experiment` builds (csrc/omds_internal.h).
+ */
+#ifndef OMDS_TEST_H
+#define OMDS_TEST_H
+
+#include "omds.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Damages what the screening network sees so that the run-time checks of the screened step (omds.h, "Screening of pass 1") have
+ * something to catch.  what = 0: zeroes fragment `index` (1 KiB) of the fp16 weight pack; what = 1: shifts obstacle `index` by
+ * `value` along x in the screening kernel's input table only (until the next omds_set_obstacles).  The fp32 kernels are never
+ * touched.                                                                                                               */
+OMDS_API int omds_screen_debug_corrupt(omds_ctx* ctx, int what, int index, float value);
+/* Process-wide: the tile shape of the step's tail kernels instead of the launcher's own choice -- tail_sel_rows in {0, 4, 16, 32}
+ * for the screened step (4 = the backward on 4-row groups; ReLU networks without skip concatenations), tail_rows in {0, 16, 32}
+ * for the unscreened one; 0 = the launcher chooses again.  Every shape computes the same bits per row: the tests run them against
+ * each other.                                                                                                             */
+OMDS_API int omds_debug_force_tile_rows(int tail_sel_rows, int tail_rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMDS_TEST_H */

@@ -94,8 +94,6 @@ SIGNATURES = {
     "omds_screen_audit_stats": (C.c_int, [C.c_void_p, I32P, C.POINTER(C.c_double), F32P, I32P, C.POINTER(C.c_int64)]),
     "omds_set_screening_sweep": (C.c_int, [C.c_void_p, C.c_int]),
     "omds_screen_sweep_stats": (C.c_int, [C.c_void_p, I32P, C.POINTER(C.c_int64), F32P]),
-    "omds_screen_debug_corrupt": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float]),
-    "omds_debug_force_tile_rows": (C.c_int, [C.c_int, C.c_int]),
     "omds_screen_mindist": (C.c_int, [C.c_void_p, F32P, C.c_int, F32P]),
     "omds_screen_stats": (C.c_int, [C.c_void_p, I32P, F32P, F32P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "omds_trainer_create": (C.c_int, [C.c_int, C.c_int, I32P, C.c_int, C.POINTER(C.c_void_p)]),
@@ -114,11 +112,18 @@ SIGNATURES = {
     "omds_sync": (C.c_int, [C.c_void_p]),
 }
 
-ABI_VERSION = 321      # omds_version() of the library this binding was written against
-_lib = None
+# include/omds_test.h: exported by libomds_hip_test.so only (the product library does not have them)
+TEST_HOOK_SIGNATURES = {
+    "omds_screen_debug_corrupt": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float]),
+    "omds_debug_force_tile_rows": (C.c_int, [C.c_int, C.c_int]),
+}
+TEST_LIB_PATH = os.path.join(_HERE, "csrc", "libomds_hip_test.so")
+
+ABI_VERSION = 400      # omds_version() of the library this binding was written against
+_libs = {}             # path -> bound CDLL
 
 
-def _autobuild():
+def _autobuild(path=LIB_PATH):
     """`make` in csrc/, serialised across processes (torchrun starts one rank per GPU at once) by an exclusive
     lock; the Makefile links to a temporary name and renames, so no rank can dlopen a half-written library."""
     import fcntl
@@ -127,42 +132,49 @@ def _autobuild():
     with open(os.path.join(csrc, ".build.lock"), "w") as lk:
         fcntl.flock(lk, fcntl.LOCK_EX)
         try:
-            if os.path.exists(LIB_PATH):     # another rank built it while this one waited
+            if os.path.exists(path):     # another rank built it while this one waited
                 return
             r = subprocess.run(["make", "-C", csrc, "-j4"], capture_output=True, text=True)
             if r.returncode != 0:
-                raise OmdsError(f"building {LIB_PATH} failed (make exit {r.returncode}):\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}")
+                raise OmdsError(f"building {path} failed (make exit {r.returncode}):\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}")
         finally:
             fcntl.flock(lk, fcntl.LOCK_UN)
 
 
-def load():
-    """dlopen the in-tree library and bind every entry point.  Fails loudly when it is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH) and os.environ.get("OMDS_NO_AUTOBUILD") != "1":
+def load(path=None, extra_signatures=None):
+    """dlopen the in-tree library (or another build of it at ``path``) and bind every entry point.  Fails loudly when it
+    is missing.  A handle created by one loaded library must only be passed to that library (``Engine`` keeps its own)."""
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path) and os.environ.get("OMDS_NO_AUTOBUILD") != "1":
         # the library is built in-tree by __graft_entry__.build(); if a checkout arrives without it, build it
         # here (hipcc, gfx950) -- still no fallback of any kind: without the library nothing runs
-        _autobuild()
-    if not os.path.exists(LIB_PATH):
-        raise OmdsError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        _autobuild(path)
+    if not os.path.exists(path):
+        raise OmdsError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         f"or `make -C optimalmodulationds_amd/csrc` (there is no CPU fallback)")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     try:
         lib.omds_version.restype = C.c_int
         have = int(lib.omds_version())
     except AttributeError:
         have = -1
     if have != ABI_VERSION:     # a stale build of an older checkout: say so instead of failing on a missing symbol
-        raise OmdsError(f"{LIB_PATH} is ABI version {have}, this package needs {ABI_VERSION}: rebuild it with "
+        raise OmdsError(f"{path} is ABI version {have}, this package needs {ABI_VERSION}: rebuild it with "
                         f"`make -C optimalmodulationds_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`)")
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in dict(SIGNATURES, **(extra_signatures or {})).items():
         fn = getattr(lib, name)      # AttributeError = header/library mismatch
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[path] = lib
     return lib
+
+
+def load_test_hooks():
+    """libomds_hip_test.so: the product's objects plus the two hooks of include/omds_test.h (damage the screening inputs, force
+    a tile shape).  For tests only: ``Engine(..., lib=load_test_hooks())``."""
+    return load(TEST_LIB_PATH, TEST_HOOK_SIGNATURES)
 
 
 def f32(a, shape=None):
@@ -173,16 +185,26 @@ def f32(a, shape=None):
 
 
 def fptr(a):
-    return None if a is None else a.ctypes.data
+    """Address of a C-contiguous float32 array (None -> NULL).  The argtypes are plain addresses, so ctypes neither checks the
+    element type nor keeps ``a`` alive: pass a NAMED array that outlives the call -- never an inline temporary such as
+    ``fptr(f32(x))`` or ``fptr(arr[::2].copy())`` -- and convert with ``f32`` first."""
+    if a is None:
+        return None
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"], "fptr: float32, C-contiguous arrays only"
+    return a.ctypes.data
 
 
 def iptr(a):
-    return None if a is None else a.ctypes.data
+    """Address of a C-contiguous int32 array (None -> NULL); the same named-array rule as ``fptr``."""
+    if a is None:
+        return None
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"], "iptr: int32, C-contiguous arrays only"
+    return a.ctypes.data
 
 
-def check(ctx, rc):
+def check(ctx, rc, lib=None):
     if rc != 0:
-        msg = load().omds_last_error(ctx)
+        msg = (lib or load()).omds_last_error(ctx)
         raise OmdsError(f"omds error {rc}: {msg.decode() if msg else '?'}")
 
 

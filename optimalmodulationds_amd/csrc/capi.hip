@@ -12,6 +12,9 @@
 #include <dlfcn.h>
 
 #include "omds_internal.h"
+#ifdef OMDS_TEST_HOOKS
+#include "omds_test.h"
+#endif
 
 static thread_local std::string g_create_err;
 
@@ -84,7 +87,7 @@ static uint16_t f32_to_f16_bits(float f) {
 
 extern "C" {
 
-int omds_version(void) { return 321; }
+int omds_version(void) { return 400; }
 
 void omds_default_params(omds_params* p) {
     if (!p) return;
@@ -157,11 +160,12 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
     ctx->cfg = *cfg;
     ctx->dev = cfg->device;
     omds_default_params(&ctx->prm);
-    if (const char* e = getenv("OMDS_SCREEN_AUDIT")) {   // measurement runs: the audit rate of new contexts (omds_set_screening_audit)
-        const int v = atoi(e);
+    {   // experiment builds: the audit rate / sweep period of new contexts (the release library has omds_set_screening_audit / _sweep)
+        const int v = OMDS_EXP_ENV("OMDS_SCREEN_AUDIT", -1);
         if (v >= 0 && v <= (1 << 20) && (v & (v - 1)) == 0) ctx->audit_one_in = v;
+        const int sw = OMDS_EXP_ENV("OMDS_SCREEN_SWEEP", -1);
+        if (sw >= 0) ctx->sweep_every = sw;
     }
-    if (const char* e = getenv("OMDS_SCREEN_SWEEP")) { const int v = atoi(e); if (v >= 0) ctx->sweep_every = v; }
     auto fail = [&](const std::string& m, int code) {
         g_create_err = m;
         free_all(ctx);
@@ -917,7 +921,7 @@ static int calibrate_screen(omds_ctx* ctx, const float* q_center) {
     ctx->screen_audit_err_seen = 0.f;
     ctx->screen_sweep_err_seen = 0.f;
     const bool finite = worst < 3.0e38f;
-    if (!finite && getenv("OMDS_SCREEN_NOGUARD")) { ctx->screen_eps = 1e-3f; return OMDS_OK; }   // timing experiments only
+    if (!finite && OMDS_EXP_ENV("OMDS_SCREEN_NOGUARD", 0)) { ctx->screen_eps = 1e-3f; return OMDS_OK; }   // experiment builds: timing of deliberately broken screening kernels
     if (!finite) { ctx->screen_suspended = true; ctx->screen_eps = 0.f; return OMDS_OK; }   // fp16 range exceeded on this scene: the fp32 step until the next calibration
     // The largest error over the ~10^7 pairs of a propagate was seen at up to 2x the calibration batch's maximum (3.8e-3 vs
     // 1.8e-3 .. 2.3e-3 on the shelf scene, depending on the batch drawn): 6x leaves the run-time guard (fallback above
@@ -935,8 +939,7 @@ static bool small_step_wanted(omds_ctx* ctx) {
     if (ctx->cfg.flags & (OMDS_FLAG_UNFUSED_STEP | OMDS_FLAG_TWO_KERNEL_STEP)) return false;
     const int R = omds_step_small_rollouts(ctx->mlp, ctx->cfg.n_dof, ctx->n_obs, ctx->cfg.n_closest);
     if (R <= 0) return false;
-    static int env = -2;
-    if (env == -2) { const char* e = getenv("OMDS_SMALL_STEP"); env = e ? atoi(e) : -1; }
+    static const int env = OMDS_EXP_ENV("OMDS_SMALL_STEP", -1);   // experiment builds: 0 / 1 overrides the rule below
     if (env == 0) return false;
     if (env > 0) return true;
     return (ctx->cfg.n_traj + R - 1) / R <= 768;
@@ -1004,8 +1007,7 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
         // workgroup's LDS, k_screen selects in its flush phase (no matrix, no k_select).  tanh networks: k_screen writes the
         // matrix, k_exact puts the exact values of the candidates into it and k_tail works from the matrix as in the fp32 step
         const bool relu = ctx->mlp.act == OMDS_ACT_RELU;
-        static int fuse_env = -2;   // OMDS_SCREEN_FUSE_SELECT=0: keep k_select as its own launch (A/B runs)
-        if (fuse_env == -2) { const char* e = getenv("OMDS_SCREEN_FUSE_SELECT"); fuse_env = e ? atoi(e) : 1; }
+        static const int fuse_env = OMDS_EXP_ENV("OMDS_SCREEN_FUSE_SELECT", 1);   // experiment builds: 0 keeps k_select as its own launch (A/B runs)
         const bool fuse_select = screen && relu && fuse_env != 0 && omds_screen_can_select(ctx->n_obs);
         if (screen) {
             CK(hipMemsetAsync(ctx->d_sctotal, 0, (size_t)(H + 2) * 4, ctx->stream));
@@ -1131,8 +1133,7 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
     a.seds = ctx->seds_G > 0 ? ctx->d_seds : nullptr;
     a.seds_G = ctx->seds_G; a.seds_lin_thr = ctx->seds_lin_thr; a.seds_thr = ctx->seds_thr;
     a.prm = ctx->prm;
-    static int fused = -1;   // OMDS_FUSED_TAIL=0 selects the five-kernel step (kept for A/B runs and as the generic path)
-    if (fused < 0) { const char* e = getenv("OMDS_FUSED_TAIL"); fused = e ? atoi(e) : 1; }
+    static const int fused = OMDS_EXP_ENV("OMDS_FUSED_TAIL", 1);   // experiment builds: 0 selects the five-kernel step (the release library: OMDS_FLAG_UNFUSED_STEP)
     // a SEDS nominal DS takes the step of stand-alone kernels: only k_modulate carries that branch (step_device.h)
     const bool tail = fused && !(ctx->cfg.flags & OMDS_FLAG_UNFUSED_STEP) && omds_tail_supported(n, a.k) && ctx->seds_G == 0;
     bool screen = tail && screen_wanted(ctx);
@@ -1167,8 +1168,7 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
         for (int i = 0; i < H; ++i) { ctx->screen_rows += tot[i]; overflow = overflow || tot[i] > ctx->ex_cap; }
         ctx->screen_audit_rows += std::min<double>(tot[H + 1], ctx->audit_cap);   // entries k_audit evaluated
         ctx->screen_steps += (double)N * H;
-        static int noguard = -1;   // OMDS_SCREEN_NOGUARD=1: timing experiments with deliberately broken screening kernels only
-        if (noguard < 0) { const char* e = getenv("OMDS_SCREEN_NOGUARD"); noguard = e ? atoi(e) : 0; }
+        static const int noguard = OMDS_EXP_ENV("OMDS_SCREEN_NOGUARD", 0);   // experiment builds only: the release library cannot switch the guard off
         const float worst = (err != err || aerr != aerr || serr != serr) ? __builtin_inff() : std::max({err, aerr, serr});
         if ((!overflow && worst <= 0.5f * ctx->screen_eps && slack_viol == 0) || noguard) {
             // accepted.  Keep the bound at >= 4x the largest error seen, so that states drifting into regions where the fp16
@@ -1530,8 +1530,10 @@ int omds_screen_audit_stats(omds_ctx* ctx, int32_t* one_in, double* audit_rows_p
     if (calibrations) *calibrations = ctx->screen_recals;
     return OMDS_OK;
 }
-// Test hook (tests/test_gpu_screen_audit.py): damages the screening network's inputs so that the run-time checks have
-// something to catch.  what = 0: zeroes weight fragment `index` (1 KiB of slice index / 16) of the fp16 pack -- every
+#ifdef OMDS_TEST_HOOKS
+// Test hooks (include/omds_test.h; libomds_hip_test.so only -- the release library does not export them).
+// omds_screen_debug_corrupt (tests/test_gpu_screen_audit.py): damages the screening network's inputs so that the run-time
+// checks have something to catch.  what = 0: zeroes weight fragment `index` (1 KiB of slice index / 16) of the fp16 pack -- every
 // screening value moves; what = 1: shifts obstacle `index` by `value` along x in the SCREENING input table only (undone by
 // the next omds_set_obstacles) -- the fp16 network sees that one sphere elsewhere, so only the audit rows can notice.
 int omds_debug_force_tile_rows(int tail_sel_rows, int tail_rows) {
@@ -1562,6 +1564,7 @@ int omds_screen_debug_corrupt(omds_ctx* ctx, int what, int index, float value) {
     }
     return OMDS_OK;
 }
+#endif   // OMDS_TEST_HOOKS
 // Diagnostic: the screening network alone on a batch (what k_select sees), for tests and for measuring eps.
 int omds_screen_mindist(omds_ctx* ctx, const float* q, int B, float* mindist) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;

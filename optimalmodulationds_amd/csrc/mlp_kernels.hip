@@ -252,16 +252,12 @@ static void launch_pass1_mixed(hipStream_t s, const MlpDev& m, const float* Apre
                        total, O, ignored, (int)n_big, OmdsDivisor::make((unsigned)O), m);
 }
 
-static int g_pass1_variant = -1;  // -1 = auto; set through OMDS_PASS1_VARIANT for experiments
 void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
                        int O, int B, uint32_t ignored, float* Dmin) {
     const long long total = (long long)B * O;
     if (total <= 0) return;
-    if (g_pass1_variant == -1) {
-        const char* e = getenv("OMDS_PASS1_VARIANT");
-        g_pass1_variant = e ? atoi(e) : 0;
-    }
-    int v = g_pass1_variant;
+    static const int forced = OMDS_EXP_ENV("OMDS_PASS1_VARIANT", 0);   // experiment builds: a tile variant instead of the rule below
+    int v = forced;
     // measured on MI355X (profiles/): 64-row tiles (2 workgroups per CU) beat 128-row tiles at N*O = 301k rows
     // (129 vs 123 TFLOP/s: shorter tail) and tie at 1.2M rows (134 TFLOP/s)
     // and ending the launch on one "round" of 32-row tiles (variant 11) shortens the drain: 135 vs 133 TFLOP/s

@@ -9,6 +9,19 @@
 
 #include "omds.h"
 
+// Experiment knobs.  Environment variables that change a kernel choice or a tile shape, switch a run-time guard off or make a
+// kernel return early (timing experiments: wrong results by design) exist only in builds with -DOMDS_EXPERIMENT (`make experiment`,
+// `make variant`, `make timeline`: libraries the package loads only when OMDS_LIB names them).  The release library reads
+// OMDS_SCREEN (0 | 1: the screening mode of contexts left on "auto"), OMDS_ROCTX and OMDS_RCCL_LIB, nothing else.
+#ifdef OMDS_EXPERIMENT
+#include <cstdlib>
+#define OMDS_EXP_ENV(name, dflt) ([&]() -> int { const char* _e = getenv(name); return _e ? atoi(_e) : (dflt); }())
+#define OMDS_DBG(x) (x)
+#else
+#define OMDS_EXP_ENV(name, dflt) (dflt)
+#define OMDS_DBG(x) 0
+#endif
+
 constexpr int OMDS_WIDTH = 256;        // hidden width the MFMA kernels are specialised for
 constexpr int OMDS_LDH = 260;          // LDS row stride of the activation tile (floats): 256 + 4 pad
 constexpr int OMDS_CPAD = 16;          // output channels padded to one 16-wide MFMA tile
@@ -358,7 +371,9 @@ void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const f
 // screened step's tail: top-k over the candidates k_exact evaluated + pass-2 backward on its masks + the rest of k_tail
 bool omds_tail_sel_supported(int n_dof, int k);
 int omds_cu_count();   // CUs of the current device (asked once per device)
-void omds_force_tile_rows(int tail_sel_rows, int tail_rows);   // test hook: 0 = the launcher's own choice
+#ifdef OMDS_TEST_HOOKS
+void omds_force_tile_rows(int tail_sel_rows, int tail_rows);   // test hook (libomds_hip_test.so): 0 = the launcher's own choice
+#endif
 void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
                           float* Apre, int O, const StepArgs& st, const int* rowlist, const int* range, const ExactOut& ex,
                           uint16_t* FqH, int ldF, float e_bound, unsigned* viol);

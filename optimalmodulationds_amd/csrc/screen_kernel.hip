@@ -447,8 +447,8 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
         SC_TL(0);
         auto sync_and_issue = [&](int s) {
 #ifdef OMDS_SC_EXPERIMENT   // timing experiments only (variant builds): OMDS_SCREEN_DBG 4 = no wait + barrier, 1 = no weight streaming
-            if (!(a.dbg & 4)) wait_vm_barrier(SC_PW * (SC_DIST - 2));
-            if (!(a.dbg & 1)) issue((s + SC_DIST) % S, (sigma0 + s + SC_DIST) & (SC_RING - 1));
+            if (!(OMDS_DBG(a.dbg) & 4)) wait_vm_barrier(SC_PW * (SC_DIST - 2));
+            if (!(OMDS_DBG(a.dbg) & 1)) issue((s + SC_DIST) % S, (sigma0 + s + SC_DIST) & (SC_RING - 1));
 #else
             wait_vm_barrier(SC_PW * (SC_DIST - 2));
             issue((s + SC_DIST) % S, (sigma0 + s + SC_DIST) & (SC_RING - 1));
@@ -841,14 +841,12 @@ void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, con
     a.nhh = m.nhh; a.C = m.C; a.out_div = m.out_div;
     a.skip_mask = m.skip_mask;
     a.sel = nullptr;
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("OMDS_SCREEN_DBG"); dbg = e ? atoi(e) : 0; }
+    static const int dbg = OMDS_EXP_ENV("OMDS_SCREEN_DBG", 0);
     a.dbg = dbg;
     // persistent: one workgroup per CU (256 on MI355X; more only when a workgroup's result buffer would overflow its LDS),
     // each with a contiguous chunk of the pair space
     int ncu = omds_cu_count();
-    static int cu_cap = -1;   // OMDS_SCREEN_CUS: experiment -- persistent workgroups on a subset of the CUs
-    if (cu_cap < 0) { const char* e = getenv("OMDS_SCREEN_CUS"); cu_cap = e ? atoi(e) : 0; }
+    static const int cu_cap = OMDS_EXP_ENV("OMDS_SCREEN_CUS", 0);   // experiment builds: persistent workgroups on a subset of the CUs
     if (cu_cap > 0) ncu = std::min(ncu, cu_cap);
     long long gl;
     int tiles_per_wg;
@@ -876,9 +874,8 @@ void omds_launch_screen(hipStream_t s, const ScreenDev& sd, const MlpDev& m, con
     a.res_tiles = tiles_per_wg;
     const size_t lds_max = omds_screen_lds_bytes(4) + (size_t)SC_MAX_TILES * SC_ROWS * 4;
     // diagnostic timeline (OMDS_SCREEN_TL=1): phase stamps of every workgroup's FIRST tile, summarised on stderr
-    static int tl_on = -1;
+    static const int tl_on = OMDS_EXP_ENV("OMDS_SCREEN_TL", 0);
     static unsigned long long* tl_buf = nullptr;
-    if (tl_on < 0) { const char* e = getenv("OMDS_SCREEN_TL"); tl_on = e ? atoi(e) : 0; }
     a.tl = nullptr;
     if (tl_on && grid.x <= 65536) {
         if (!tl_buf) (void)hipMalloc(&tl_buf, (size_t)65536 * 8 * sizeof(unsigned long long));
@@ -936,8 +933,7 @@ void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const 
     const int ncu = omds_cu_count();
     // three resident workgroups per CU; longer lists stride (the list length is only known on the device)
     const long long blocks_max = ((long long)B * O + 15) / 16;
-    static int res = -1;   // OMDS_EXACT_RESIDENT: workgroups per CU the grid is sized for (experiments)
-    if (res < 0) { const char* e = getenv("OMDS_EXACT_RESIDENT"); res = e ? atoi(e) : 3; if (res < 1) res = 3; }
+    static const int res = std::max(1, OMDS_EXP_ENV("OMDS_EXACT_RESIDENT", 3));   // workgroups per CU the grid is sized for (experiment builds: another count)
     const unsigned grid = (unsigned)std::min<long long>(blocks_max, (long long)res * ncu);
     const OmdsDivisor od = OmdsDivisor::make((unsigned)O);
     if (m.act == OMDS_ACT_RELU)

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
         pass1_tile<TR, 1, 1, ACT, 2>(m, smem, a.Apre, a.Bpre, a.radius, O, total, a.ignored, nullptr, (long long)t_base * O, a.odiv,
                                      nullptr, nullptr, &ex);
     }
-    if (a.dbg_stop == 1) return;
+    if (OMDS_DBG(a.dbg_stop) == 1) return;
     if (tid < SS_RK) { selRow[tid] = -1; selT[tid] = 0; selO[tid] = 0; dr[tid] = 0.f; }
     // the backward's first weights (phase 3) are on their way while the closest obstacles are picked
     const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
     }
     __syncthreads();
 
-    if (a.dbg_stop == 2) return;
+    if (OMDS_DBG(a.dbg_stop) == 2) return;
     // the first-layer backward's weights of this thread (feature tid >> 4, columns (tid & 15) + 16 i): asked for now, used after
     // the hidden layers
     float w1b[16];
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
         if (m.nhh == 0 && mine) gS[col] = make_float4(Hs[col], Hs[LDH + col], Hs[2 * LDH + col], Hs[3 * LDH + col]);
         if (m.nhh == 0) __syncthreads();
     }
-    if (a.dbg_stop == 3) return;
+    if (OMDS_DBG(a.dbg_stop) == 3) return;
     // first layer: g_f[r][f] = sum_c Gz1[r][c] W1[c][f]; 16 lanes per feature, c strided over them
     {
         const int f = tid >> 4, sub = tid & 15, F = 3 * m.d;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
         }
     }
     __syncthreads();
-    if (a.dbg_stop == 4) return;
+    if (OMDS_DBG(a.dbg_stop) == 4) return;
     if (a.o_gradx != nullptr) {   // network-only form
         const int d = m.d;
         for (int e = tid; e < R * k * d; e += SS_NT) {
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
             }
         }
     }
-    if (a.st.step >= a.st.H || a.dbg_stop == 5) return;   // last step: nothing is integrated, no next network evaluation
+    if (a.st.step >= a.st.H || OMDS_DBG(a.dbg_stop) == 5) return;   // last step: nothing is integrated, no next network evaluation
     __syncthreads();
     {   // rollout half of layer 1 for the next step (same arithmetic order as k_rollout_layer1)
         const int c = tid & 255;
@@ -318,8 +318,7 @@ int omds_step_small_rollouts(const MlpDev& m, int n_dof, int O, int k) { return 
 // per CU (one's backward and modulation under the other's forward) was measured on planar 7-DoF 1024 x 32: 17.0 M against
 // 18.9 M rollout-steps/s -- twice the workgroups stream the backward's weights twice.  OMDS_SMALL_ROWS=16|32 forces one.
 static int small_tile_rows(const MlpDev& m, int n_dof, int O, int k, int B) {
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("OMDS_SMALL_ROWS"); forced = e ? atoi(e) : 0; }
+    static const int forced = OMDS_EXP_ENV("OMDS_SMALL_ROWS", 0);   // experiment builds
     const int r16 = small_rollouts(m, n_dof, O, k, 16), r32 = small_rollouts(m, n_dof, O, k, 32);
     if (r16 <= 0) return 32;
     if (forced == 16 || forced == 32) return forced;
@@ -354,8 +353,7 @@ void omds_launch_step_small(hipStream_t s, const MlpDev& m, const float* Bpre, c
     a.qT = st.trajT + (size_t)(st.step - 1) * st.n * st.N;
     a.ldq = st.N;
     a.st = st;
-    static int stop = -1;
-    if (stop < 0) { const char* e = getenv("OMDS_SMALL_STOP"); stop = e ? atoi(e) : 0; }
+    static const int stop = OMDS_EXP_ENV("OMDS_SMALL_STOP", 0);
     a.dbg_stop = stop;
     if (omds_step_small_rollouts(m, st.n, O, st.k) <= 0) return;
     if (st.n == 7) launch_small_t<7>(s, a, st.k);

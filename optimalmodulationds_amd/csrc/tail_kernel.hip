@@ -76,14 +76,14 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
         });
     }
     __syncthreads();
-    if (a.dbg_stop == 1) return;
+    if (OMDS_DBG(a.dbg_stop) == 1) return;
 
     // ---- forward + backward on the selected rows; gradients and distances stay in LDS ------------
     const float* qT = a.st.trajT + (size_t)(a.st.step - 1) * ND * N;
     pass2_body<ACT, ROWS>(m, sm, a.Apre, a.Bpre, a.radius, a.xyzr, t_base * k, N * k, qT, N, gx, dr, 0, nullptr, nullptr,
-                                 a.dscr, (size_t)a.n_slots * ROWS * OMDS_WIDTH, (a.slot0 + (int)blockIdx.x) * ROWS, a.dbg_stop);
+                                 a.dscr, (size_t)a.n_slots * ROWS * OMDS_WIDTH, (a.slot0 + (int)blockIdx.x) * ROWS, OMDS_DBG(a.dbg_stop));
     __syncthreads();
-    if (a.dbg_stop == 2) return;
+    if (OMDS_DBG(a.dbg_stop) == 2) return;
 
     // ---- modulation / policy / Euler step: 16 lanes per rollout -------------------------------------
     {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
             }
         }
     }
-    if (a.st.step >= a.st.H || a.dbg_stop == 3) return;   // last step: nothing is integrated, no next network evaluation
+    if (a.st.step >= a.st.H || OMDS_DBG(a.dbg_stop) == 3) return;   // last step: nothing is integrated, no next network evaluation
     __syncthreads();
 
     // ---- rollout half of layer 1 for the next step (same arithmetic order as k_rollout_layer1) --------
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
     }
     __syncthreads();
     OMDS_TL_STAMP(2);
-    if (a.dbg_stop == 1) return;   // OMDS_TAIL_SEL_STOP: timing experiments
+    if (OMDS_DBG(a.dbg_stop) == 1) return;   // OMDS_TAIL_SEL_STOP: timing experiments
     // ---- the selected entries' masks -> LDS -> 16 bits per thread and layer in the MFMA C layout (what pass 2's forward
     //      would have left in sm.maskL): thread (wave = 32-column block, lane) owns column wave*32 + (lane&31) of rows crow(r, lane)
     for (int i = tid; i < TROWS * nhid * 8; i += P2_NT) {
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
     __syncthreads();
 
     OMDS_TL_STAMP(3);
-    if (a.dbg_stop == 2) return;
+    if (OMDS_DBG(a.dbg_stop) == 2) return;
     // ---- backward on the selected rows; gradients stay in LDS -----------------------------------------
     const float* qT = a.st.trajT + (size_t)(a.st.step - 1) * ND * N;
     if constexpr (ROWS == 4) {
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
     }
     __syncthreads();
     OMDS_TL_STAMP(9);
-    if (a.dbg_stop == 3) return;
+    if (OMDS_DBG(a.dbg_stop) == 3) return;
 
     // ---- modulation / policy / Euler step: 16 lanes per rollout -------------------------------------
     {
@@ -388,8 +388,8 @@ static void launch_tail_sel_t(hipStream_t s, const TailArgs& a) {
     hipLaunchKernelGGL((k_tail_sel<ND, ROWS>), dim3((a.t_end - a.t_begin + RW - 1) / RW), dim3(P2_NT), tail_lds_bytes(a.m.nhh + 1) + extra, s, a);
 #ifdef OMDS_TAIL_TL
     {
-        static int want = -2, seen = 0;
-        if (want == -2) { const char* e = getenv("OMDS_TAIL_TL_STEP"); want = e ? atoi(e) : -1; }
+        static int seen = 0;
+        static const int want = OMDS_EXP_ENV("OMDS_TAIL_TL_STEP", -1);
         if (a.st.step == want && ++seen == 3) hipLaunchKernelGGL(k_tail_tl_dump, dim3(1), dim3(1), 0, s, (a.t_end - a.t_begin + RW - 1) / RW);
     }
 #endif
@@ -397,20 +397,21 @@ static void launch_tail_sel_t(hipStream_t s, const TailArgs& a) {
 
 // 16-row tiles (bit-identical to 32-row ones, mlp_device.h) while their workgroups still fit the CUs two at a time: twice as
 // many, half as long, and the second resident fills the first one's top-k / gather / modulation phases
-// Tile shapes forced by the environment (OMDS_TAIL_SEL_ROWS = 4 | 16 | 32, OMDS_TAIL_ROWS = 16 | 32) or by the test hook
-// omds_debug_force_tile_rows: every shape computes the same bits, and the tests say so by running them against each other.
-static std::atomic<int> g_force_sel_rows{-1}, g_force_tail_rows{-1};
+// Tile shapes forced by the test hook omds_debug_force_tile_rows (libomds_hip_test.so, include/omds_test.h) or, in experiment
+// builds, by the environment (OMDS_TAIL_SEL_ROWS = 4 | 16 | 32, OMDS_TAIL_ROWS = 16 | 32): every shape computes the same bits, and
+// the tests say so by running them against each other.  The release library has neither: 0 = the launcher's own choice.
+#ifdef OMDS_TEST_HOOKS
+static std::atomic<int> g_force_sel_rows{0}, g_force_tail_rows{0};
 void omds_force_tile_rows(int tail_sel_rows, int tail_rows) {
     g_force_sel_rows.store(tail_sel_rows);
     g_force_tail_rows.store(tail_rows);
 }
-static int forced_rows(std::atomic<int>& slot, const char* env) {
-    int f = slot.load();
-    if (f < 0) { const char* e = getenv(env); f = e ? atoi(e) : 0; slot.store(f); }
-    return f;
-}
+#define OMDS_FORCED_ROWS(slot, env) ((slot).load() > 0 ? (slot).load() : OMDS_EXP_ENV(env, 0))
+#else
+#define OMDS_FORCED_ROWS(slot, env) OMDS_EXP_ENV(env, 0)
+#endif
 static int tail_sel_rows(int N, int k, bool g4_ok) {
-    const int forced = forced_rows(g_force_sel_rows, "OMDS_TAIL_SEL_ROWS");
+    const int forced = OMDS_FORCED_ROWS(g_force_sel_rows, "OMDS_TAIL_SEL_ROWS");
     if (k > 16) return 32;
     if (forced == 4 && g4_ok && k <= 20) return 4;
     if (forced == 16 || forced == 32) return forced;
@@ -441,8 +442,7 @@ void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Bpre, con
     a.ldF = ldF;
     a.t_begin = 0; a.t_end = st.N;
     a.slot0 = 0; a.n_slots = 0;
-    static int stop = -1;
-    if (stop < 0) { const char* e = getenv("OMDS_TAIL_SEL_STOP"); stop = e ? atoi(e) : 0; }
+    static const int stop = OMDS_EXP_ENV("OMDS_TAIL_SEL_STOP", 0);
     a.dbg_stop = stop;
     a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Dmin = nullptr; a.Apre = Apre; a.ApreOut = Apre; a.dscr = nullptr; a.O = O; a.st = st;
     a.rowlist = rowlist; a.range = range; a.ex = ex;
@@ -477,7 +477,7 @@ bool omds_tail_supported(int n_dof, int k) { return (n_dof == 7 || n_dof == 2) &
 
 // 16-row tiles when 32-row tiles would leave most CUs without a workgroup (OMDS_TAIL_ROWS=16|32 forces one)
 int omds_tail_rows(int N, int k) {
-    const int forced = forced_rows(g_force_tail_rows, "OMDS_TAIL_ROWS");
+    const int forced = OMDS_FORCED_ROWS(g_force_tail_rows, "OMDS_TAIL_ROWS");
     if (k > 16) return 32;
     if (forced == 16 || forced == 32) return forced;
     const int RW32 = 32 / k;
@@ -502,8 +502,7 @@ void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const f
     a.t_begin = t_begin; a.t_end = t_end;          // t_begin must be a multiple of RW
     a.slot0 = t_begin / RW;
     a.n_slots = (st.N + RW - 1) / RW;
-    static int stop = -1;
-    if (stop < 0) { const char* e = getenv("OMDS_TAIL_STOP"); stop = e ? atoi(e) : 0; }
+    static const int stop = OMDS_EXP_ENV("OMDS_TAIL_STOP", 0);
     a.dbg_stop = stop;
     a.rowlist = nullptr; a.range = guard_range; a.ex = ExactOut{}; a.e_bound = e_bound; a.viol = viol;
     a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Dmin = Dmin; a.Apre = Apre; a.ApreOut = ApreOut ? ApreOut : Apre; a.dscr = dscr; a.O = O; a.st = st;

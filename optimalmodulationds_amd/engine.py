@@ -11,8 +11,8 @@ from . import _lib as L
 
 
 class Engine:
-    def __init__(self, n_dof, n_traj, horizon, n_closest, max_obs, n_kernel_max=50, device=0, flags=0):
-        self.lib = L.load()
+    def __init__(self, n_dof, n_traj, horizon, n_closest, max_obs, n_kernel_max=50, device=0, flags=0, lib=None):
+        self.lib = lib or L.load()   # lib: another build of the library (tests: _lib.load_test_hooks())
         self.n, self.N, self.H, self.k = int(n_dof), int(n_traj), int(horizon), int(n_closest)
         self.max_obs, self.Kmax, self.device = int(max_obs), int(n_kernel_max), int(device)
         cfg = L.OmdsConfig(self.n, self.N, self.H, self.Kmax, self.max_obs, self.k, self.device, int(flags))
@@ -38,7 +38,7 @@ class Engine:
             pass
 
     def _ck(self, rc):
-        L.check(self.h, rc)
+        L.check(self.h, rc, self.lib)
 
     # ---- configuration ------------------------------------------------------------------------
     def set_mlp(self, weights, biases, act="relu", out_div=None, skip_after=()):
@@ -288,11 +288,13 @@ class Engine:
         self._ck(self.lib.omds_set_screening_sweep(self.h, int(every)))
 
     def screen_debug_corrupt(self, what, index, value=0.0):
-        """Test hook (omds.h): 0 = zero a weight fragment of the fp16 pack, 1 = shift an obstacle in the screening inputs."""
+        """Test hook (include/omds_test.h; needs ``lib=_lib.load_test_hooks()``): 0 = zero a weight fragment of the fp16 pack,
+        1 = shift an obstacle in the screening inputs."""
         self._ck(self.lib.omds_screen_debug_corrupt(self.h, int(what), int(index), float(value)))
 
     def debug_force_tile_rows(self, tail_sel_rows=0, tail_rows=0):
-        """Test hook (omds.h, process-wide): tile shape of the tail kernels; 0 = the launcher's own choice."""
+        """Test hook (include/omds_test.h; needs ``lib=_lib.load_test_hooks()``; wide to that library): tile shape of the tail
+        kernels; 0 = the launcher's own choice again."""
         self._ck(self.lib.omds_debug_force_tile_rows(int(tail_sel_rows), int(tail_rows)))
 
     def screen_mindist(self, q):

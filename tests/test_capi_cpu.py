@@ -12,8 +12,8 @@ from helpers import ROOT, SCENARIOS, assert_close, load
 from oracle import omds_oracle as orc
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "omds.h")).read()
+def _declared(header="omds.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     return sorted(set(re.findall(r"OMDS_API\s+[\w\s\*]+?\b(omds_\w+)\s*\(", src)))
 
 
@@ -35,6 +35,26 @@ def test_header_symbols_exported_and_bound(lib):
         assert nme in _lib.SIGNATURES, f"{nme} declared in omds.h but missing from the ctypes binding"
     assert set(_lib.SIGNATURES) == set(names)
     assert lib.omds_version() >= 100
+
+
+def test_test_hooks_live_in_the_test_library_only(lib):
+    """include/omds_test.h: the hooks that damage the screening inputs / force a tile shape are exported by
+    libomds_hip_test.so and NOT by the product library; and the product library reads no experiment environment variable
+    (only OMDS_SCREEN, OMDS_ROCTX, OMDS_RCCL_LIB appear among its strings)."""
+    from optimalmodulationds_amd import _lib
+    hooks = _declared("omds_test.h")
+    assert hooks == sorted(_lib.TEST_HOOK_SIGNATURES) and len(hooks) == 2
+    raw, raw_test = C.CDLL(_lib.LIB_PATH), C.CDLL(_lib.TEST_LIB_PATH)
+    for nme in hooks:
+        assert not hasattr(raw, nme), f"{nme} is a test hook and must not be exported by the product library"
+        assert hasattr(raw_test, nme)
+    for nme in _declared():
+        assert hasattr(raw_test, nme)
+    bound = _lib.load_test_hooks()
+    assert bound.omds_version() == lib.omds_version()
+    env_names = set(re.findall(rb"OMDS_[A-Z0-9_]+", open(_lib.LIB_PATH, "rb").read()))
+    knobs = {e for e in env_names if not re.match(rb"OMDS_(ERR|ACT|MAX|WIDTH|CPAD|FLAG|COST|VARIANT|OK|HIP|API|H$|TEST|EXP|DBG)", e)}
+    assert knobs <= {b"OMDS_SCREEN", b"OMDS_ROCTX", b"OMDS_RCCL_LIB"}, knobs
 
 
 def test_default_params_are_the_reference_constants(lib):

@@ -346,8 +346,11 @@ def test_every_tile_shape_computes_the_same_bits(kind, n, k, N):
     mu_c = (q0 + 0.3 * rng.standard_normal((K, n))).astype(np.float32)
     sg_c, al_c = np.full(K, 0.5, np.float32), rng.standard_normal((K, n)).astype(np.float32)
 
+    from optimalmodulationds_amd import _lib
+    hooks = _lib.load_test_hooks()   # libomds_hip_test.so: the product's objects + the hooks of include/omds_test.h
+
     def run(mode, sel_rows, tail_rows):
-        e = Engine(n, N, H, k, max_obs=1024)
+        e = Engine(n, N, H, k, max_obs=1024, lib=hooks)
         try:
             e.debug_force_tile_rows(sel_rows, tail_rows)
             e.set_mlp(m.W, m.b)
