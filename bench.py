@@ -40,10 +40,19 @@ WORKLOADS = {
     # (tools/make_golden.py) -- throughput does not depend on the values
     "franka_tanh_4096x32": dict(kind="franka_tanh", N=4096, H=32, dt=0.5, k=5, dst_thr=0.01, ker_thr=0.1, alpha_s=3.0,
                                 sigma=1.0, ignored=[0, 1, 2], act="tanh"),
-    # BASELINE configs[4] per GPU: the obstacle set is replaced every iteration (update_obstacles), kernel
-    # normals are re-evaluated (update_kernel_normal_bases) and kernel candidates are searched on the device
+    # BASELINE configs[4] per GPU, as frankaPlanner.py:129-163 runs it: the obstacle set is replaced every iteration
+    # (update_obstacles), kernel normals are re-evaluated (update_kernel_normal_bases), kernel candidates are searched on the
+    # device and ONE kernel is added per iteration while candidates exist (Policy.add_kernel): every timed block starts from an
+    # empty policy (Policy.reset_policy) at q0, so K grows from 0 inside the timed region and every iteration samples, evaluates
+    # and reduces another kernel count
     "franka_dynamic_1024x32": dict(kind="franka", N=1024, H=32, dt=0.5, k=5, dst_thr=0.01, ker_thr=0.1, alpha_s=3.0,
                                    sigma=1.0, ignored=[0, 1, 2], dynamic=True),
+    # BASELINE configs[3]'s shard: 32768 x 64 over 8 GPUs = 4096 x 64 per GPU
+    "franka_shelf_4096x64": dict(kind="franka", N=4096, H=64, dt=0.5, k=5, dst_thr=0.01, ker_thr=0.1, alpha_s=3.0,
+                                 sigma=1.0, ignored=[0, 1, 2]),
+    # BASELINE configs[4]'s rollout count on ONE GPU (8 shards' worth): static shelf, fixed K
+    "franka_shelf_8192x32": dict(kind="franka", N=8192, H=32, dt=0.5, k=5, dst_thr=0.01, ker_thr=0.1, alpha_s=3.0,
+                                 sigma=1.0, ignored=[0, 1, 2]),
 }
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 FLOP/clk
 MFMA_F16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (v_mfma_f32_32x32x16_f16), never the 2:1-sparsity figure
@@ -163,35 +172,80 @@ def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, di
     sg_c = np.full(K, w["sigma"], np.float32)
     al_c = rng.standard_normal((K, n)).astype(np.float32)
     q_cur = q0.copy()
+    dyn = bool(w.get("dynamic"))
+    Kmax = eng.Kmax
+    k_trace = []          # dynamic workload: K at the end of every timed block
+    pick = np.random.RandomState(99)
+
+    def reset_policy():   # Policy.reset_policy (policy.py:43-49) + the integrator back at q0: a timed block of the dynamic workload
+        nonlocal mu_c, sg_c, al_c, q_cur, K
+        K = 0
+        mu_c, sg_c, al_c = np.zeros((Kmax, n), np.float32), np.zeros(Kmax, np.float32), np.zeros((Kmax, n), np.float32)
+        q_cur = q0.copy()
+
+    def choose_candidate(cand_q, cand_th):
+        """frankaPlanner.py:149-161: the candidate closest to q_cur when it is within 0.1, else a random one; the rollout it came
+        from is read back for closests_dist_all[i, h] and norm_basis[i, h] (its row only, omds_get_rollout_rows)."""
+        d2 = np.linalg.norm(cand_q - q_cur, axis=1)
+        j = int(np.argmin(d2)) if d2.min() < 1e-1 else int(pick.randint(cand_q.shape[0]))
+        row = eng.get_rollout_rows([int(cand_th[j, 0])], want=("closest_dist_all", "normal"))
+        _gamma, _normal = row["closest_dist_all"][0, cand_th[j, 1]], row["normal"][0, cand_th[j, 1]]   # kernel_gammas / kernel_obstacle_bases
+        return cand_q[j].copy()
+
+    def add_kernel(qk):
+        """Policy.add_kernel (policy.py:129-151): centre = the candidate, sigma = nominal, alpha = the closest existing kernel's
+        (0 for the first)."""
+        nonlocal K
+        if K < Kmax:
+            mu_c[K], sg_c[K] = qk, w["sigma"]
+            al_c[K] = al_c[int(np.argmin(np.linalg.norm(mu_c[:K] - qk, axis=1)))] if K else 0.0
+            K += 1
 
     def iteration(it):
         nonlocal mu_c, sg_c, al_c, q_cur
-        if w.get("dynamic"):
+        if dyn:
             # shelf translated by a slow sinusoid (the obstacle streamer's mechanism, obstacleStreamer.py:120-142),
             # then distance/normal at the K kernel centres (MPPI.update_kernel_normal_bases, MPPI.py:284-304)
             moved = obs.copy()
             moved[:, 1] += 0.05 * np.sin(0.3 * it)
             eng.set_obstacles(moved)
             if K:
-                eng.dist_grad(mu_c)
+                eng.dist_grad(mu_c[:K])
         eng.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, w["alpha_s"], K, seed=1234 * 1000003 + it, rollout_offset=rank * N)
         eng.propagate(q_cur)
         eng.cost(fetch=False)
         # two tiny all-reduces (SURVEY 8e); the MINLOC gather for get_qdot('best') is not part of a planner iteration
         if use_dist and not native:   # --share-gpu: two ranks on ONE GPU cannot form a RCCL communicator; host-mediated gloo
-            mu_c, sg_c, al_c, mask, qd_w, _ = sharded_update(eng.cost_sum, eng.local_sums, K, n, H, 0.1, w["ker_thr"],
-                                                             mu_c, sg_c, al_c, want_best=False)
+            m2, s2, a2, mask, qd_w, _ = sharded_update(eng.cost_sum, eng.local_sums, K, n, H, 0.1, w["ker_thr"],
+                                                       mu_c[:K], sg_c[:K], al_c[:K], want_best=False)
         else:                         # library path: RCCL on the context stream (single shard: the same kernels, no collective)
-            mu_c, sg_c, al_c, mask, qd_w, _, _ = eng.weighted_update_sharded(0.1, w["ker_thr"], mu_c, sg_c, al_c)
+            m2, s2, a2, mask, qd_w, _, _ = eng.weighted_update_sharded(0.1, w["ker_thr"], mu_c, sg_c, al_c)
+        if dyn:   # the means live in Kmax-row arrays whose first K rows are active
+            mu_c[:K], sg_c[:K], al_c[:K] = m2, s2, a2
+        else:
+            mu_c, sg_c, al_c = m2, s2, a2
         q_cur = (q_cur + 0.1 * w["dt"] * qd_w).astype(np.float32)   # drift along the weighted rollout velocity: non-degenerate states
-        if w.get("dynamic"):   # Policy.check_traj_for_kernels on the device (policy.py:153-175); only candidates cross PCIe
-            eng.kernel_candidates(0.03 - w["dst_thr"], 0.3, -0.9, mu_c, sg_c, K, cap=256)
+        if dyn:   # Policy.check_traj_for_kernels on the device (policy.py:153-175); only candidates cross PCIe; then add_kernel
+            cq, cth, total = eng.kernel_candidates(0.03 - w["dst_thr"], 0.3, -0.9, mu_c, sg_c, K, cap=256)
+            chosen = choose_candidate(cq, cth) if (cq.shape[0] and rank == 0) else None
+            if use_dist:   # one planner decides (rank 0, whose shard holds the global rollout 0); every rank installs the same kernel,
+                           # so the kernel count -- and with it the size of the update's all-reduce -- stays identical across ranks
+                buf = torch.zeros(1 + n, dtype=torch.float32)
+                if chosen is not None:
+                    buf[0] = 1.0
+                    buf[1:] = torch.from_numpy(chosen)
+                dist.broadcast(buf, 0)
+                chosen = buf[1:].numpy().copy() if float(buf[0]) > 0 else None
+            if chosen is not None:
+                add_kernel(chosen)
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if dyn:
+        reset_policy()
     for it in range(warmup):
         iteration(it)
     # HIP events around every launch of the dominant kernel (keeps a batch on ONE stream).  An event record between two
@@ -201,6 +255,8 @@ def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, di
     eng.prof_reset()
     els = []
     for rep in range(reps):
+        if dyn:
+            reset_policy()
         barrier()
         t0 = time.perf_counter()
         for it in range(steps):
@@ -213,6 +269,7 @@ def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, di
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         els.append(el)
+        k_trace.append(int(K))
     el = float(np.median(els))
     p1_ms, p1_launches, p1_rows = eng.prof_read()
     _, _, p1_flops, p1_kernel = eng.prof_read_ex()
@@ -226,7 +283,7 @@ def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, di
 
     scr = eng.screen_stats()
     eng.close()
-    return dict(els=els, scr=scr, dh=dh, qmin=qmin, qmax=qmax, w=w, W=W, b=b, obs=obs, q0=q0, qf=qf, N=N, H=H, K=K, el=el, p1_ms=p1_ms, p1_launches=p1_launches,
+    return dict(els=els, scr=scr, k_trace=k_trace, dh=dh, qmin=qmin, qmax=qmax, w=w, W=W, b=b, obs=obs, q0=q0, qf=qf, N=N, H=H, K=K, el=el, p1_ms=p1_ms, p1_launches=p1_launches,
                 p1_rows=p1_rows, p1_flops=p1_flops, p1_kernel=p1_kernel, fetch_ms=fetch_ms)
 
 
@@ -280,7 +337,9 @@ def main():
                 "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, committed; not re-collected by this run)",
                 "launches": int(rr["p1_launches"]), "launch_sampling": f"HIP events around every {args.prof_stride}-th launch inside the timed blocks",
                 "avg_launch_ms": rr["p1_ms"] / max(rr["p1_launches"], 1),
-                "flops_per_launch": rr["p1_flops"] / max(rr["p1_launches"], 1)}
+                "flops_per_launch": rr["p1_flops"] / max(rr["p1_launches"], 1),
+                "profile": "profiles/r04_kernel_trace_stats%s.txt (rocprofv3 --kernel-trace --stats of this command%s)" %
+                           (("", "") if rr["p1_kernel"] != "k_pass1" else ("_fp32", " with the library's screening switched off"))}
 
     def rate(rr, steps):
         v = [world * rr["N"] * rr["H"] * steps / e for e in rr["els"]]
@@ -295,12 +354,14 @@ def main():
         r32 = measure(args, args.workload, args.steps, 1, rank, world, local_rank, use_dist, dist, torch, reps=3, screening=0)
         fp32 = dict(rate(r32, args.steps), roofline=roofline(r32, args.workload))
         also = []
-        for wl2, st2, rp2 in (("planar7_1024x32", 10, 5), ("franka_shelf_4096x32", 5, 3), ("franka_dynamic_1024x32", 10, 3),
-                              ("franka_tanh_4096x32", 5, 3)):
+        for wl2, st2, rp2 in (("planar7_1024x32", 10, 5), ("franka_shelf_4096x32", 5, 3), ("franka_dynamic_1024x32", 20, 3),
+                              ("franka_tanh_4096x32", 5, 3), ("franka_shelf_4096x64", 3, 3), ("franka_shelf_8192x32", 3, 3)):
             if wl2 == args.workload:
                 continue
             r2 = measure(args, wl2, st2, 1, rank, world, local_rank, use_dist, dist, torch, prof=False, reps=rp2)
             e2 = dict({"workload": wl2, "unit": "rollout-steps/s", "steps": st2}, **rate(r2, st2))
+            if WORKLOADS[wl2].get("dynamic"):
+                e2["kernels_at_block_end"] = r2["k_trace"]   # K grows from 0 inside every timed block (one add_kernel per iteration at most)
             e2["screening"] = {k2: r2["scr"][k2] for k2 in ("active", "eps", "candidates_per_rollout_step", "fallbacks", "audit_max_err",
                                                           "audit_rows_per_rollout_step", "calibrations", "suspended", "sweeps", "sweep_max_err")}
             also.append(e2)
@@ -314,7 +375,14 @@ def main():
             # that only feed the obstacle selection run in screen_dtype (fp16 inputs, fp32 accumulate); value_fp32_only is the
             # same run with every row in fp32
             "dtype": "f32", "screen_dtype": "f16" if r["scr"]["active"] else None, "data": "synthetic",
-            "config": {"workload": args.workload, "rollouts_per_gpu": N, "horizon": H, "obstacles": int(obs.shape[0]),
+            "config": {"workload": args.workload,
+                       # what the arithmetic is, in one sentence, where the driver's parser keeps it
+                       "precision": ("fp32 outputs (every distance, gradient, velocity and cost the step returns comes from fp32 kernels); the N x O "
+                                     "first-pass evaluations that only feed the obstacle selection are screened in f16 and the candidates re-evaluated "
+                                     "in fp32 -- identity with the all-fp32 step is conditional on a measured bound eps (profiles/r04_screen_error_hist.txt: "
+                                     "0 of > 1e10 unevaluated pairs above eps / 2); value_fp32_only / roofline.fp32_only = the same iterations with "
+                                     "every row in fp32") if r["scr"]["active"] else "fp32 throughout",
+                       "rollouts_per_gpu": N, "horizon": H, "obstacles": int(obs.shape[0]),
                        "n_closest": w["k"], "active_kernels": K, "network": "x".join(str(x.shape[1]) for x in W) + f"x{W[-1].shape[0]} {act} "
                        + ("(shipped reference weights)" if act == "relu" else "(seeded synthetic weights)"),
                        "parallelism": f"rollout-sharded x{world}", "collectives": (("gloo-host (--share-gpu test mode)" if args.share_gpu else "rccl") if use_dist else "none")},
@@ -323,6 +391,11 @@ def main():
         if fp32 is not None:
             out["value_fp32_only"] = fp32["value"]
             out["fp32_only"] = fp32
+            # the precision-matched figure where the driver's parser keeps it: the all-fp32 iteration and its dominant kernel
+            rf = fp32["roofline"]
+            out["roofline"]["fp32_only"] = {"kernel": rf["kernel"], "pipe": rf["pipe"], "frac": rf["frac"], "achieved": rf["achieved"], "peak": rf["peak"],
+                                            "avg_launch_ms": rf["avg_launch_ms"], "launches": rf["launches"], "value": fp32["value"],
+                                            "ms_per_step": fp32["ms_per_step"], "profile": rf["profile"]}
         out["screening"] = r["scr"]   # fp16 screening of pass 1 + exact fp32 re-selection + audit sample; inactive = fp32 pass 1
         if fetch_ms is not None:
             out["fetch_all_rollouts_ms"] = fetch_ms

@@ -168,6 +168,13 @@ OMDS_API int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout);
 OMDS_API int omds_get_rollouts(omds_ctx* ctx, float* all_traj, float* closest_dist_all, float* kernel_val_all,
                                float* dot_products, float* kernel_activations, float* qdot, float* normal);
 
+/* The same outputs for `count` chosen rollouts t[count] only: all_traj [count,H,n], ..., qdot [count,n], normal [count,H,n] (NULL =
+ * skip).  What the reference's planner loop reads per iteration is a few rollouts -- the best one for its FK payload, the one a new
+ * kernel centre came from (frankaPlanner.py:147-168: closests_dist_all[i, h], norm_basis[i, h], all_traj[best_idx]) -- so a driver
+ * need not move the N x H tensors across PCIe at all.                                                                     */
+OMDS_API int omds_get_rollout_rows(omds_ctx* ctx, const int32_t* t, int count, float* all_traj, float* closest_dist_all,
+                                   float* kernel_val_all, float* dot_products, float* kernel_activations, float* qdot, float* normal);
+
 /* MPPI.distance_repulsion_nn on an arbitrary batch (MPPI.py:227-282): q [B,n], B <= N.
  * Outputs (NULL = skip): distance [B], nn_grad [B,n], mindist [B,O] (pass-1 matrix),
  * closest_idx [B,k] (ascending distance).  Also serves update_kernel_normal_bases (:284-304). */
@@ -268,7 +275,10 @@ OMDS_API int omds_apply_update(int n_kernels, int n_dof, int horizon, const floa
  *     sample (another one every step) of the pairs that are not candidates, re-evaluated in fp32 by one launch at the end
  *     of the horizon loop (k_audit); the slack of every rollout (tau - exact k-th smallest >= eps).
  *   - every 32nd screened propagate (omds_set_screening_sweep): a SWEEP -- all N x O pairs of the propagate's last horizon
- *     step in fp32 beside all their screening values, max |Da - D| over every one of them.
+ *     step (soak runs: of EVERY horizon step) in fp32 beside all their screening values, max |Da - D| over every one of them,
+ *     and the distribution of Da - D over the pairs that were not candidates (omds_screen_sweep_hist): the quantity the
+ *     selection rule's assumption is about, counted exhaustively instead of sampled.  profiles/r04_screen_error_hist.txt
+ *     holds that distribution over > 1e10 pairs (tools/sweep_soak.py).
  * A propagate is accepted only while all these maxima stay <= eps / 2 and no slack check failed; otherwise it is redone with the
  * fp32 pass 1 (its results are then the fp32 ones by construction) and eps is widened; three fallbacks in a row suspend
  * screening until the next calibration.  A row outside the audit sample whose error exceeds eps can still go unseen in
@@ -283,10 +293,26 @@ OMDS_API int omds_apply_update(int n_kernels, int n_dof, int horizon, const floa
  * seen since the last calibration, suspended flag, calibrations run since creation.                                   */
 OMDS_API int omds_set_screening(omds_ctx* ctx, int mode, float eps);
 OMDS_API int omds_set_screening_audit(omds_ctx* ctx, int one_in);
-/* every = 0: no sweeps; default 32.  Stats: the setting, sweeps run since creation, largest |Da - D| a sweep saw since the last
- * calibration (NULL = skip). */
-OMDS_API int omds_set_screening_sweep(omds_ctx* ctx, int every);
+/* every = 0: no sweeps; default 32.  all_steps = 0: a sweeping propagate checks its last horizon step (0.5 % of the run at the
+ * default period); 1: every horizon step (a soak / qualification mode: each step then also runs the fp32 pass 1, so the propagate
+ * is slower than the unscreened one).  Stats: the setting, sweeps (swept steps) run since creation, largest |Da - D| a sweep saw
+ * since the last calibration (NULL = skip).
+ * omds_screen_sweep_hist: what all sweeps since creation (or the last reset != 0) have counted, OMDS_SWEEP_HIST_WORDS 64-bit words:
+ *   [0] pairs swept  [1] of them NOT candidates (never re-evaluated by the step: the population the bound eps is about)
+ *   [2] non-candidates with Da - D > eps / 2 (the acceptance margin)  [3] with Da - D > eps (a possible miss)
+ *   [4] non-candidates with a non-finite difference  [5] largest Da - D over the non-candidates (float bits)
+ *   [6] largest |Da - D| over all pairs (float bits)  [7] steps swept
+ *   [8 .. 8 + L)     non-candidates with Da - D >= 0 by magnitude: bin b holds 2^(b - L) <= |x| < 2^(b + 1 - L) (bin 0 also zero
+ *                    and everything smaller, bin L - 1 everything >= 1/2), L = OMDS_SWEEP_HIST_LOG_BINS
+ *   [8 + L .. 8 + 2L)   the same for Da - D < 0 (the harmless side: the pair is even farther than its screening value said)
+ *   [8 + 2L .. 8 + 2L + R)  non-candidates with Da - D > 0 by (Da - D) / eps in R = OMDS_SWEEP_HIST_RATIO_BINS linear bins over [0, 1)
+ *                    (the last bin also holds everything >= 1), eps = the bound in use when the step was swept.            */
+#define OMDS_SWEEP_HIST_LOG_BINS 32
+#define OMDS_SWEEP_HIST_RATIO_BINS 128
+#define OMDS_SWEEP_HIST_WORDS (8 + 2 * OMDS_SWEEP_HIST_LOG_BINS + OMDS_SWEEP_HIST_RATIO_BINS)
+OMDS_API int omds_set_screening_sweep(omds_ctx* ctx, int every, int all_steps);
 OMDS_API int omds_screen_sweep_stats(omds_ctx* ctx, int32_t* every, int64_t* sweeps, float* sweep_max_err);
+OMDS_API int omds_screen_sweep_hist(omds_ctx* ctx, uint64_t* words, int n_words, int reset);
 OMDS_API int omds_screen_audit_stats(omds_ctx* ctx, int32_t* one_in, double* audit_rows_per_rollout_step, float* audit_max_err,
                                      int32_t* suspended, int64_t* calibrations);
 /* (The two test hooks that damage the screening inputs / force a tile shape are NOT part of this library: they are declared in

@@ -15,6 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OMDS_LIB") or os.path.join(_HERE, "csrc", "libomds_hip.so")
 
 OMDS_MAX_DOF = 7
+SWEEP_HIST_LOG_BINS, SWEEP_HIST_RATIO_BINS = 32, 128
+SWEEP_HIST_WORDS = 8 + 2 * SWEEP_HIST_LOG_BINS + SWEEP_HIST_RATIO_BINS    # omds.h: OMDS_SWEEP_HIST_WORDS
 # float* / int32_t* arguments are declared as plain addresses: numpy's ``a.ctypes.data_as(POINTER(c_float))`` goes through
 # ``ctypes.cast`` (~28 us per call: 0.8 ms of a planner iteration through the facade), ``a.ctypes.data`` is an attribute read
 F32P = C.c_void_p
@@ -68,6 +70,7 @@ SIGNATURES = {
     "omds_get_policy_samples": (C.c_int, [C.c_void_p, F32P, F32P, F32P]),
     "omds_propagate": (C.c_int, [C.c_void_p, F32P, C.c_int]),
     "omds_get_rollouts": (C.c_int, [C.c_void_p, F32P, F32P, F32P, F32P, F32P, F32P, F32P]),
+    "omds_get_rollout_rows": (C.c_int, [C.c_void_p, I32P, C.c_int, F32P, F32P, F32P, F32P, F32P, F32P, F32P]),
     "omds_dist_grad": (C.c_int, [C.c_void_p, F32P, C.c_int, F32P, F32P, F32P, I32P]),
     "omds_mlp_forward_vjp": (C.c_int, [C.c_void_p, F32P, C.c_int, F32P, F32P, I32P]),
     "omds_cost": (C.c_int, [C.c_void_p, F32P]),
@@ -92,7 +95,8 @@ SIGNATURES = {
     "omds_set_screening": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),
     "omds_set_screening_audit": (C.c_int, [C.c_void_p, C.c_int]),
     "omds_screen_audit_stats": (C.c_int, [C.c_void_p, I32P, C.POINTER(C.c_double), F32P, I32P, C.POINTER(C.c_int64)]),
-    "omds_set_screening_sweep": (C.c_int, [C.c_void_p, C.c_int]),
+    "omds_set_screening_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "omds_screen_sweep_hist": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int, C.c_int]),
     "omds_screen_sweep_stats": (C.c_int, [C.c_void_p, I32P, C.POINTER(C.c_int64), F32P]),
     "omds_screen_mindist": (C.c_int, [C.c_void_p, F32P, C.c_int, F32P]),
     "omds_screen_stats": (C.c_int, [C.c_void_p, I32P, F32P, F32P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

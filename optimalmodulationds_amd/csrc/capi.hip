@@ -120,7 +120,7 @@ static void free_all(omds_ctx* ctx) {
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
                     ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
                     ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
-                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP, ctx->d_seds, ctx->d_audit_rows, ctx->d_audit_da, ctx->d_ApreAll, ctx->d_featQAll, ctx->d_FqS, ctx->d_FpS, ctx->d_listDa, ctx->d_sinks, ctx->d_qcur};
+                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP, ctx->d_seds, ctx->d_audit_rows, ctx->d_audit_da, ctx->d_ApreAll, ctx->d_featQAll, ctx->d_FqS, ctx->d_FpS, ctx->d_listDa, ctx->d_sinks, ctx->d_qcur, ctx->d_sweepD, ctx->d_sweepDa, ctx->d_sweep_hist};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : ctx->mlp_allocs)
@@ -560,10 +560,15 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
 // the screening state survive.  Nothing of their old contents is needed: the caller is about to replace the scene.
 static int grow_obstacle_capacity(omds_ctx* ctx, int n_obs) {
     const size_t N = ctx->cfg.n_traj, k = ctx->cfg.n_closest, H = ctx->cfg.horizon, n = ctx->cfg.n_dof, Km = ctx->cfg.n_kernel_max;
-    const size_t Om = (size_t)std::max(2 * n_obs, 64), rows2 = N * k;
-    REQUIRE((long long)N * (long long)Om < (1LL << 31), OMDS_ERR_INVALID_ARG,
-            "omds_set_obstacles: n_traj * (grown obstacle capacity) must stay below 2^31");
+    // twice the new count, but never past what 32-bit pair indices allow: a count that fits is not rejected for its doubling
+    const long long Omax = ((1LL << 31) - 1) / (long long)N;
+    REQUIRE(n_obs <= Omax, OMDS_ERR_INVALID_ARG, "omds_set_obstacles: n_traj * n_obs must stay below 2^31");
+    const size_t Om = (size_t)std::min<long long>(std::max(2LL * n_obs, 64LL), Omax), rows2 = N * k;
     CK(hipStreamSynchronize(ctx->stream));
+    // Until every replacement exists the context holds NO scene: if an allocation below fails, check_ready refuses to run
+    // (n_obs == 0) and the next omds_set_obstacles starts the growth again (max_obs == 0) instead of touching freed buffers
+    ctx->n_obs = 0;
+    ctx->cfg.max_obs = 0;
     void** olds[] = {(void**)&ctx->d_obs, (void**)&ctx->d_Bpre, (void**)&ctx->d_radius, (void**)&ctx->d_FpH, (void**)&ctx->d_Dmin,
                      (void**)&ctx->d_rowlist, (void**)&ctx->d_listDa, (void**)&ctx->d_featP, (void**)&ctx->d_FpS};
     const bool had_featP = ctx->d_featP != nullptr, had_FpS = ctx->d_FpS != nullptr;
@@ -590,17 +595,19 @@ static int grow_obstacle_capacity(omds_ctx* ctx, int n_obs) {
     if (stage > ctx->stage_bytes) {
         (void)hipFree(ctx->d_stage);
         ctx->d_stage = nullptr;
+        ctx->stage_bytes = 0;
         CK(hipMalloc(&ctx->d_stage, stage));
         ctx->stage_bytes = stage;
     }
     const int ex_cap = (int)std::min<size_t>(N * Om, N * 32);
     if (ex_cap > ctx->ex_cap) {
         for (void** o : {(void**)&ctx->d_exD, (void**)&ctx->d_exDr, (void**)&ctx->d_exMin, (void**)&ctx->d_exMask}) { if (*o) (void)hipFree(*o); *o = nullptr; }
-        ctx->ex_cap = ex_cap;
+        ctx->ex_cap = 0;
         CK(hipMalloc(&ctx->d_exD, (size_t)ex_cap * 4));
         CK(hipMalloc(&ctx->d_exDr, (size_t)ex_cap * 4));
         CK(hipMalloc(&ctx->d_exMin, (size_t)ex_cap * 4));
         CK(hipMalloc(&ctx->d_exMask, (size_t)ex_cap * (OMDS_MAX_HIDDEN + 1) * 8 * 4));
+        ctx->ex_cap = ex_cap;
     }
     ctx->cfg.max_obs = (int)Om;
     ctx->n_obs = 0;
@@ -974,6 +981,38 @@ static int prepare_audit(omds_ctx* ctx, SelectSink& sk) {
     return OMDS_OK;
 }
 
+// Buffers of a sweep (allocated at the first one): the fp32 values and the screening values of all pairs of ONE step, and the
+// statistics every sweep adds to.
+static int prepare_sweep(omds_ctx* ctx) {
+    const size_t pairs = (size_t)ctx->cfg.n_traj * ctx->cfg.max_obs;
+    if (pairs > ctx->sweep_cap) {
+        CK(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_sweepD) (void)hipFree(ctx->d_sweepD);
+        if (ctx->d_sweepDa) (void)hipFree(ctx->d_sweepDa);
+        ctx->d_sweepD = nullptr; ctx->d_sweepDa = nullptr; ctx->sweep_cap = 0;
+        CK(hipMalloc(&ctx->d_sweepD, pairs * 4));
+        CK(hipMalloc(&ctx->d_sweepDa, pairs * 4));
+        ctx->sweep_cap = pairs;
+    }
+    if (!ctx->d_sweep_hist) {
+        CK(hipMalloc(&ctx->d_sweep_hist, OMDS_SWEEP_HIST_WORDS * 8));
+        CK(hipMemsetAsync(ctx->d_sweep_hist, 0, OMDS_SWEEP_HIST_WORDS * 8, ctx->stream));
+    }
+    return OMDS_OK;
+}
+
+// One step swept: ALL N x O pairs in fp32 (k_pass1 on the step's layer-1 halves) beside all N x O screening values (k_screen in
+// matrix mode on the step's fp16 inputs), compared against the tau the step's selection used (d_range): max |Da - D| ->
+// d_scerr[3], the distribution of Da - D over the non-candidates -> d_sweep_hist.  Must be enqueued between the step's selection
+// and its tail (the tail overwrites the fp16 inputs with the next step's states).
+static void enqueue_sweep_of_step(omds_ctx* ctx, const float* apre_step, int N) {
+    omds_launch_pass1(ctx->stream, ctx->mlp, apre_step, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N, ctx->prm.ignored_links, ctx->d_sweepD);
+    omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_FqH, ctx->cfg.n_traj, ctx->d_FpH, ctx->cfg.max_obs, ctx->d_radius, ctx->n_obs, N,
+                       ctx->prm.ignored_links, ctx->d_sweepDa);
+    omds_launch_sweep_hist(ctx->stream, ctx->d_sweepD, ctx->d_sweepDa, ctx->d_range, N, ctx->n_obs, ctx->screen_eps, ctx->d_sweep_hist, ctx->d_scerr + 3);
+    ctx->sweep_steps_now++;
+}
+
 static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) {
     const int N = a.N, H = a.H, n = a.n;
     int rc;
@@ -1032,6 +1071,14 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
             }
             CK(hipMemcpyAsync(d_sinks, hs, (size_t)H * sizeof(SelectSink), hipMemcpyHostToDevice, ctx->stream));
         }
+        // Every sweep_every-th screened propagate carries a SWEEP: a complete fp32 check of its last horizon step -- or, in the soak
+        // mode, of every step (omds_set_screening_sweep).  The audit sample sees every step thinly, a sweep sees a step whole.
+        ctx->sweep_now = false;
+        ctx->sweep_steps_now = 0;
+        if (screen && ctx->sweep_every > 0 && (ctx->screen_propagates++ % ctx->sweep_every) == 0) {
+            if ((rc = prepare_sweep(ctx))) return rc;
+            ctx->sweep_now = true;
+        }
         omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, apre0, screen ? ctx->d_FqH : nullptr, N);
         for (int i = 1; i <= H; ++i) {
             float* apre_i = apre0 + (size_t)(i - 1) * apre_slab;
@@ -1052,6 +1099,10 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
                                       ctx->prm.ignored_links, ctx->d_Dmin);
                     if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs))) return rc;
                 }
+            }
+            if (ctx->sweep_now && (ctx->sweep_all_steps || i == H)) {
+                RoctxRange r4("screening sweep (all pairs of this step in fp32)");
+                enqueue_sweep_of_step(ctx, apre_i, N);
             }
             RoctxRange r2("TAG: evaluate NN_3-5 + Modulation-propagation");
             a.step = i;
@@ -1077,19 +1128,6 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
             }
             omds_launch_audit(ctx->stream, ma, ctx->d_ApreAll, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, ctx->prm.ignored_links,
                               sink.audit_rows, sink.audit_da, sink.audit_total, sink.audit_cap, ctx->d_scerr);
-        }
-        ctx->sweep_now = false;
-        if (screen && ctx->sweep_every > 0 && (ctx->screen_propagates++ % ctx->sweep_every) == 0) {
-            // Every sweep_every-th screened propagate: a COMPLETE check of one horizon step -- the last one, whose inputs are
-            // still in place (layer-1 halves, fp16 tables) -- all N x O pairs in fp32 (k_pass1) beside all N x O screening
-            // values: max |Da - D| -> d_scerr[3].  The audit sample sees every step thinly, the sweep sees one step whole.
-            RoctxRange r4("screening sweep (all pairs of the last step in fp32)");
-            float* apre_last = apre0 + (size_t)(H - 1) * apre_slab;
-            omds_launch_pass1(ctx->stream, ctx->mlp, apre_last, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N, ctx->prm.ignored_links, ctx->d_Dmin);
-            omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_FqH, ctx->cfg.n_traj, ctx->d_FpH, ctx->cfg.max_obs, ctx->d_radius, ctx->n_obs, N,
-                               ctx->prm.ignored_links, ctx->d_stage);
-            omds_launch_max_abs_diff(ctx->stream, ctx->d_Dmin, ctx->d_stage, (long long)N * ctx->n_obs, ctx->d_scerr + 3);
-            ctx->sweep_now = true;
         }
     } else {
         for (int i = 1; i <= H; ++i) {   // MPPI.py:101: H network evaluations, the last velocity is not integrated
@@ -1159,7 +1197,7 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
         // Accepted only while both errors keep a 2x margin to eps and no slack check failed; otherwise redone in fp32.
         //   serr  = (every sweep_every-th propagate) max |Da - D| over ALL pairs of the last horizon step.
         const float err = ctx->h_red[0], aerr = ctx->h_red[2], serr = ctx->sweep_now ? ctx->h_red[3] : 0.f;
-        if (ctx->sweep_now) { ctx->screen_sweeps++; if (serr > ctx->screen_sweep_err_seen || serr != serr) ctx->screen_sweep_err_seen = serr; }
+        if (ctx->sweep_now) { ctx->screen_sweeps += ctx->sweep_steps_now; if (serr > ctx->screen_sweep_err_seen || serr != serr) ctx->screen_sweep_err_seen = serr; }
         if (err > ctx->screen_err_seen || err != err) ctx->screen_err_seen = err;
         if (aerr > ctx->screen_audit_err_seen || aerr != aerr) ctx->screen_audit_err_seen = aerr;
         const int32_t* tot = reinterpret_cast<const int32_t*>(ctx->h_red + 4);
@@ -1215,6 +1253,40 @@ int omds_get_rollouts(omds_ctx* ctx, float* all_traj, float* closest_dist_all, f
         CK(hipMemcpyAsync(qdot, ctx->d_stage, (size_t)N * n * 4, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
     }
+    return OMDS_OK;
+}
+
+// The rows of a few rollouts (reference layouts): what a planner loop reads per iteration -- the best rollout for its FK
+// payload, the rollout a new kernel's centre came from (frankaPlanner.py:147-168) -- without moving the N x H tensors.
+int omds_get_rollout_rows(omds_ctx* ctx, const int32_t* t, int count, float* all_traj, float* closest_dist_all, float* kernel_val_all,
+                          float* dot_products, float* kernel_activations, float* qdot, float* normal) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    const int N = ctx->cfg.n_traj, H = ctx->cfg.horizon, n = ctx->cfg.n_dof, K = ctx->n_kernels, Km = ctx->cfg.n_kernel_max;
+    REQUIRE(t && count >= 1 && count <= N, OMDS_ERR_INVALID_ARG, "omds_get_rollout_rows: need 1 <= count <= n_traj and a non-null index array");
+    for (int r = 0; r < count; ++r) REQUIRE(t[r] >= 0 && t[r] < N, OMDS_ERR_INVALID_ARG, "omds_get_rollout_rows: rollout index out of range");
+    REQUIRE(ctx->have_rollouts, OMDS_ERR_NOT_INITIALISED, "omds_get_rollout_rows: no rollouts yet (omds_propagate)");
+    CK(hipSetDevice(ctx->dev));
+    const size_t per = (size_t)H * (2 * n + 3 + K) + n;   // floats per rollout over all seven outputs
+    REQUIRE((per * count + count) * 4 <= ctx->stage_bytes, OMDS_ERR_INVALID_ARG, "omds_get_rollout_rows: too many rollouts for the staging buffer");
+    int* d_t = reinterpret_cast<int*>(ctx->d_stage + per * count);
+    CK(hipMemcpyAsync(d_t, t, (size_t)count * 4, hipMemcpyHostToDevice, ctx->stream));
+    struct Out { const float* src; float* dst; int Hh, X, Xld; };
+    const Out outs[] = {{ctx->d_trajT, all_traj, H, n, n}, {ctx->d_distT, closest_dist_all, H, 1, 1}, {ctx->d_kvalT, kernel_val_all, H, K, Km},
+                        {ctx->d_dotT, dot_products, H, 1, 1}, {ctx->d_actT, kernel_activations, H, 1, 1}, {ctx->d_qdotT, qdot, 1, n, n},
+                        {ctx->d_normalT, normal, H, n, n}};
+    size_t off = 0, offs[7];
+    for (int i = 0; i < 7; ++i) {
+        offs[i] = off;
+        if (!outs[i].dst || outs[i].X == 0) continue;
+        omds_launch_gather_rows(ctx->stream, outs[i].src, ctx->d_stage + off, d_t, count, outs[i].Hh, outs[i].X, N, outs[i].Xld);
+        off += (size_t)count * outs[i].Hh * outs[i].X;
+    }
+    CK(hipGetLastError());
+    std::vector<float> host(off);
+    if (off) CK(hipMemcpyAsync(host.data(), ctx->d_stage, off * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 7; ++i)
+        if (outs[i].dst && outs[i].X) std::memcpy(outs[i].dst, host.data() + offs[i], (size_t)count * outs[i].Hh * outs[i].X * 4);
     return OMDS_OK;
 }
 
@@ -1507,10 +1579,23 @@ int omds_set_screening_audit(omds_ctx* ctx, int one_in) {
     ctx->audit_one_in = one_in;
     return OMDS_OK;
 }
-int omds_set_screening_sweep(omds_ctx* ctx, int every) {
+int omds_set_screening_sweep(omds_ctx* ctx, int every, int all_steps) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    REQUIRE(every >= 0, OMDS_ERR_INVALID_ARG, "omds_set_screening_sweep: every >= 0 (0 = no sweeps)");
+    REQUIRE(every >= 0 && (all_steps == 0 || all_steps == 1), OMDS_ERR_INVALID_ARG, "omds_set_screening_sweep: every >= 0 (0 = no sweeps), all_steps in {0, 1}");
     ctx->sweep_every = every;
+    ctx->sweep_all_steps = all_steps != 0;
+    return OMDS_OK;
+}
+int omds_screen_sweep_hist(omds_ctx* ctx, uint64_t* words, int n_words, int reset) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(words && n_words == OMDS_SWEEP_HIST_WORDS, OMDS_ERR_INVALID_ARG, "omds_screen_sweep_hist: words must hold OMDS_SWEEP_HIST_WORDS entries");
+    CK(hipSetDevice(ctx->dev));
+    std::memset(words, 0, (size_t)n_words * 8);
+    if (!ctx->d_sweep_hist) return OMDS_OK;   // no sweep has run yet
+    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipMemcpy(words, ctx->d_sweep_hist, (size_t)n_words * 8, hipMemcpyDeviceToHost));
+    words[OMDS_HIST_STEPS] = (uint64_t)ctx->screen_sweeps;
+    if (reset) { CK(hipMemset(ctx->d_sweep_hist, 0, (size_t)n_words * 8)); ctx->screen_sweeps = 0; }
     return OMDS_OK;
 }
 int omds_screen_sweep_stats(omds_ctx* ctx, int32_t* every, int64_t* sweeps, float* sweep_max_err) {

@@ -154,10 +154,16 @@ struct omds_ctx {
     int audit_one_in = 128;              // a non-candidate pair is audited with probability 1 / audit_one_in (power of two; 0 = no audit)
     unsigned audit_counter = 0;          // feeds the audit hash: another sample every step of every propagate
     int sweep_every = 32;                // every sweep_every-th screened propagate checks ALL pairs of its last step in fp32 (0 = never)
+    bool sweep_all_steps = false;        // ... of EVERY horizon step (soak runs: omds_set_screening_sweep(every, 1))
+    float* d_sweepD = nullptr;           // [N*max_obs] fp32 values / screening values of the step being swept (allocated at the first sweep)
+    float* d_sweepDa = nullptr;
+    size_t sweep_cap = 0;                // pairs the two buffers hold
+    unsigned long long* d_sweep_hist = nullptr;   // [OMDS_SWEEP_HIST_WORDS] accumulated statistics of every sweep since creation / the last reset
     long long screen_propagates = 0;     // screened propagates since creation
     long long screen_sweeps = 0;         // sweeps run since creation
     float screen_sweep_err_seen = 0.f;   // largest |Da - D| a sweep saw since the last calibration
     bool sweep_now = false;              // the propagate being finished carried a sweep (d_scerr[3] is valid)
+    int sweep_steps_now = 0;             // ... of this many steps
     std::vector<float> obs_cal;          // the obstacle set the bound was calibrated against (omds_set_obstacles compares)
     std::vector<float> obs_now;          // host copy of the current obstacle set
     bool have_rollouts = false;          // d_trajT holds the rollouts of a finished propagate (calibration draws states from them)
@@ -337,6 +343,13 @@ void omds_launch_audit(hipStream_t s, const MlpDev& m, const float* ApreAll, con
 void omds_launch_calib_states(hipStream_t s, float* qT, int B, int n, const float* lo, const float* hi, const float* center,
                               const float* trajT, int N, int H, unsigned seed);
 void omds_launch_max_abs_diff(hipStream_t s, const float* x, const float* y, long long n, unsigned* out_bits);
+// sweep statistics (omds.h: omds_screen_sweep_hist), word indices of the 64-bit histogram buffer
+constexpr int OMDS_HIST_LOG_BINS = OMDS_SWEEP_HIST_LOG_BINS, OMDS_HIST_RATIO_BINS = OMDS_SWEEP_HIST_RATIO_BINS;
+constexpr int OMDS_HIST_PAIRS = 0, OMDS_HIST_NONCAND = 1, OMDS_HIST_ABOVE_HALF = 2, OMDS_HIST_ABOVE_EPS = 3, OMDS_HIST_NONFINITE = 4,
+              OMDS_HIST_MAX_POS = 5, OMDS_HIST_MAX_ABS = 6, OMDS_HIST_STEPS = 7, OMDS_HIST_BINS0 = 8;
+static_assert(OMDS_HIST_BINS0 + 2 * OMDS_HIST_LOG_BINS + OMDS_HIST_RATIO_BINS == OMDS_SWEEP_HIST_WORDS, "omds.h: OMDS_SWEEP_HIST_WORDS");
+void omds_launch_sweep_hist(hipStream_t s, const float* D, const float* Da, const int* range, int N, int O, float eps,
+                            unsigned long long* hist, unsigned* maxabs_bits);
 void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius, int O,
                        int B, uint32_t ignored, float* Dmin, const int* rowlist, const int* total, unsigned* maxerr_bits,
                        const ExactOut& ex);
@@ -411,4 +424,5 @@ void omds_launch_broadcast_q(hipStream_t s, const float* q_host_vals, int n, int
 // layout conversions between reference (AoS) and device (SoA) orders
 void omds_launch_transpose(hipStream_t s, const float* src, float* dst, int rows, int cols);  // dst[c][r] = src[r][c]
 void omds_launch_permute_hxn_to_nhx(hipStream_t s, const float* srcT, float* dst, int H, int X, int N, int Xld);
+void omds_launch_gather_rows(hipStream_t s, const float* srcT, float* dst, const int* tlist, int count, int H, int X, int N, int Xld);
 

@@ -506,3 +506,17 @@ void omds_launch_permute_hxn_to_nhx(hipStream_t s, const float* srcT, float* dst
     if (total == 0) return;
     hipLaunchKernelGGL(k_permute, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, srcT, dst, H, X, N, Xld);
 }
+
+// dst[r][h][x] = srcT[(h*Xld + x)*N + tlist[r]]  for x < X: the rows of a few rollouts in the reference layout (omds_get_rollout_rows)
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ srcT, float* __restrict__ dst, const int* __restrict__ tlist,
+                                                     int count, int H, int X, int N, int Xld) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count * H * X) return;
+    const int x = e % X, rh = e / X, h = rh % H, r = rh / H;
+    dst[e] = srcT[((size_t)h * Xld + x) * N + tlist[r]];
+}
+void omds_launch_gather_rows(hipStream_t s, const float* srcT, float* dst, const int* tlist, int count, int H, int X, int N, int Xld) {
+    const int total = count * H * X;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(k_gather_rows, dim3((total + 255) / 256), dim3(256), 0, s, srcT, dst, tlist, count, H, X, N, Xld);
+}

@@ -790,6 +790,73 @@ void omds_launch_max_abs_diff(hipStream_t s, const float* x, const float* y, lon
     hipLaunchKernelGGL(k_max_abs_diff, dim3(grid), dim3(256), 0, s, x, y, n, out_bits);
 }
 
+// Sweep statistics (omds.h, omds_screen_sweep_hist): one step's N x O screening values Da beside its N x O fp32 values D and the
+// tau of every rollout (range[4 t + 2], what the selection of that step used).  x = Da - D over the pairs that are NOT candidates
+// -- the population the selection rule's assumption "x <= eps" is about -- goes into histograms; max |x| over ALL pairs into
+// *maxabs_bits (a non-finite difference counts as +inf) like k_max_abs_diff.  Counters are 64-bit and accumulate across launches.
+__global__ __launch_bounds__(256) void k_sweep_hist(const float* __restrict__ D, const float* __restrict__ Da, const int* __restrict__ range,
+                                                    int N, int O, OmdsDivisor od, float eps, unsigned long long* __restrict__ hist, unsigned* maxabs_bits) {
+    __shared__ unsigned bins[OMDS_HIST_LOG_BINS * 2 + OMDS_HIST_RATIO_BINS];
+    __shared__ unsigned cnt[8];
+    for (int i = threadIdx.x; i < OMDS_HIST_LOG_BINS * 2 + OMDS_HIST_RATIO_BINS; i += blockDim.x) bins[i] = 0;
+    if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const long long total = (long long)N * O;
+    float mabs = 0.f, mpos = 0.f;
+    unsigned n_all = 0, n_non = 0, n_half = 0, n_eps = 0, n_bad = 0;
+    const float inv_eps = eps > 0.f ? 1.f / eps : 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const float d = D[i], da = Da[i];
+        const int t = (int)od.div((unsigned)i);
+        const float tau = __builtin_bit_cast(float, range[4 * t + 2]);
+        const float x = da - d, e = fabsf(x);
+        ++n_all;
+        if (!(e <= mabs)) mabs = (e < __builtin_inff()) ? e : __builtin_inff();
+        const bool cand = !(da > tau) || !(da < __builtin_inff());   // select_rollout's is_cand
+        if (cand) continue;
+        ++n_non;
+        if (!(e < __builtin_inff())) { ++n_bad; continue; }          // a finite Da beside a non-finite D: cannot happen with finite weights
+        if (x > mpos) mpos = x;
+        if (x > 0.5f * eps) ++n_half;
+        if (x > eps) ++n_eps;
+        // log2 bins: bin b holds 2^(b - OMDS_HIST_LOG_BINS) <= |x| < 2^(b + 1 - OMDS_HIST_LOG_BINS); bin 0 also everything smaller
+        // (zero included), the last bin everything >= 1/2
+        int b = (e > 0.f ? ilogbf(e) : -1000) + OMDS_HIST_LOG_BINS;
+        b = b < 0 ? 0 : (b > OMDS_HIST_LOG_BINS - 1 ? OMDS_HIST_LOG_BINS - 1 : b);
+        atomicAdd(&bins[(x < 0.f ? OMDS_HIST_LOG_BINS : 0) + b], 1u);
+        if (x > 0.f) {   // x / eps in OMDS_HIST_RATIO_BINS linear bins over [0, 1); the last bin also everything >= 1
+            int r = (int)(x * inv_eps * OMDS_HIST_RATIO_BINS);
+            r = r > OMDS_HIST_RATIO_BINS - 1 ? OMDS_HIST_RATIO_BINS - 1 : r;
+            atomicAdd(&bins[2 * OMDS_HIST_LOG_BINS + r], 1u);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { mabs = fmaxf(mabs, __shfl_xor(mabs, off)); mpos = fmaxf(mpos, __shfl_xor(mpos, off)); }
+    atomicAdd(&cnt[0], n_all); atomicAdd(&cnt[1], n_non); atomicAdd(&cnt[2], n_half); atomicAdd(&cnt[3], n_eps); atomicAdd(&cnt[4], n_bad);
+    if ((threadIdx.x & 63) == 0) {
+        if (mabs > 0.f) atomicMax(maxabs_bits, __builtin_bit_cast(unsigned, mabs));
+        if (mpos > 0.f) atomicMax(&hist[OMDS_HIST_MAX_POS], (unsigned long long)__builtin_bit_cast(unsigned, mpos));
+        if (mabs > 0.f) atomicMax(&hist[OMDS_HIST_MAX_ABS], (unsigned long long)__builtin_bit_cast(unsigned, mabs));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&hist[OMDS_HIST_PAIRS], (unsigned long long)cnt[0]);
+        atomicAdd(&hist[OMDS_HIST_NONCAND], (unsigned long long)cnt[1]);
+        atomicAdd(&hist[OMDS_HIST_ABOVE_HALF], (unsigned long long)cnt[2]);
+        atomicAdd(&hist[OMDS_HIST_ABOVE_EPS], (unsigned long long)cnt[3]);
+        atomicAdd(&hist[OMDS_HIST_NONFINITE], (unsigned long long)cnt[4]);
+    }
+    for (int i = threadIdx.x; i < OMDS_HIST_LOG_BINS * 2 + OMDS_HIST_RATIO_BINS; i += blockDim.x)
+        if (bins[i]) atomicAdd(&hist[OMDS_HIST_BINS0 + i], (unsigned long long)bins[i]);
+}
+void omds_launch_sweep_hist(hipStream_t s, const float* D, const float* Da, const int* range, int N, int O, float eps,
+                            unsigned long long* hist, unsigned* maxabs_bits) {
+    const long long n = (long long)N * O;
+    if (n <= 0) return;
+    const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_sweep_hist, dim3(grid), dim3(256), 0, s, D, Da, range, N, O, OmdsDivisor::make((unsigned)O), eps, hist, maxabs_bits);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------

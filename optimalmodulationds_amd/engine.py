@@ -152,6 +152,19 @@ class Engine:
         self._ck(self.lib.omds_get_rollouts(self.h, *ptrs))
         return {k: v for k, v in out.items() if v is not None}
 
+    def get_rollout_rows(self, t, want=("all_traj", "closest_dist_all", "kernel_val_all", "dot_products", "kernel_activations",
+                                        "qdot", "normal")):
+        """The same tensors for the rollouts ``t`` (indices) only: [len(t), H, ...] -- a few KB instead of the N x H tensors."""
+        t = np.ascontiguousarray(np.atleast_1d(np.asarray(t)).astype(np.int32))
+        R, H, n, K = t.shape[0], self.H, self.n, self.K
+        shapes = {"all_traj": (R, H, n), "closest_dist_all": (R, H), "kernel_val_all": (R, H, K), "dot_products": (R, H),
+                  "kernel_activations": (R, H), "qdot": (R, n), "normal": (R, H, n)}
+        out = {k: (np.zeros(shapes[k], np.float32) if k in want else None) for k in shapes}
+        order = ["all_traj", "closest_dist_all", "kernel_val_all", "dot_products", "kernel_activations", "qdot", "normal"]
+        ptrs = [L.fptr(out[k]) if (out[k] is not None and out[k].size) else None for k in order]
+        self._ck(self.lib.omds_get_rollout_rows(self.h, L.iptr(t), R, *ptrs))
+        return {k: v for k, v in out.items() if v is not None}
+
     def dist_grad(self, q, want_mindist=False, want_idx=False):
         q = L.f32(q).reshape(-1, self.n)
         B = q.shape[0]
@@ -283,9 +296,23 @@ class Engine:
         """Audit sample of the pairs the screened step does not re-evaluate: 1 in ``one_in`` (power of two), 0 = none."""
         self._ck(self.lib.omds_set_screening_audit(self.h, int(one_in)))
 
-    def set_screening_sweep(self, every=32):
-        """Every ``every``-th screened propagate checks ALL pairs of its last horizon step in fp32 (0 = never)."""
-        self._ck(self.lib.omds_set_screening_sweep(self.h, int(every)))
+    def set_screening_sweep(self, every=32, all_steps=False):
+        """Every ``every``-th screened propagate checks ALL pairs of its last horizon step in fp32 (0 = never); with
+        ``all_steps`` of every horizon step (soak / qualification runs)."""
+        self._ck(self.lib.omds_set_screening_sweep(self.h, int(every), 1 if all_steps else 0))
+
+    def sweep_hist(self, reset=False):
+        """What all sweeps so far have counted (omds.h: omds_screen_sweep_hist), as a dict: pair counts, the largest
+        ``Da - D`` over the pairs that were NOT candidates, and its distribution in log2 bins (``pos`` / ``neg``: bin b holds
+        2^(b-32) <= |x| < 2^(b-31)) and in 128 linear bins of ``(Da - D) / eps`` over [0, 1) (``ratio``)."""
+        w = (C.c_uint64 * L.SWEEP_HIST_WORDS)()
+        self._ck(self.lib.omds_screen_sweep_hist(self.h, w, L.SWEEP_HIST_WORDS, 1 if reset else 0))
+        a = np.frombuffer(w, dtype=np.uint64).copy()
+        f = lambda bits: float(np.array([bits & 0xffffffff], np.uint32).view(np.float32)[0])
+        Lb, Rb = L.SWEEP_HIST_LOG_BINS, L.SWEEP_HIST_RATIO_BINS
+        return dict(pairs=int(a[0]), non_candidates=int(a[1]), above_half_eps=int(a[2]), above_eps=int(a[3]), non_finite=int(a[4]),
+                    max_pos=f(int(a[5])), max_abs=f(int(a[6])), steps=int(a[7]), pos=a[8:8 + Lb].astype(np.int64),
+                    neg=a[8 + Lb:8 + 2 * Lb].astype(np.int64), ratio=a[8 + 2 * Lb:8 + 2 * Lb + Rb].astype(np.int64))
 
     def screen_debug_corrupt(self, what, index, value=0.0):
         """Test hook (include/omds_test.h; needs ``lib=_lib.load_test_hooks()``): 0 = zero a weight fragment of the fp16 pack,

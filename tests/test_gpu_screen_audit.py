@@ -265,6 +265,41 @@ def test_sweep_checks_every_pair_of_a_step_and_catches_what_a_disabled_audit_mis
         e.close()
 
 
+def test_all_steps_sweep_counts_every_unevaluated_pair_of_1e8():
+    """The soak mode of tools/sweep_soak.py at test size: EVERY horizon step of every propagate swept -- all N x O pairs in fp32
+    beside their screening values -- over > 1e8 (rollout, obstacle) pairs on the moving shelf at 1024 x 32.  The assumption of the
+    selection rule (omds.h) is about the pairs that are NOT re-evaluated: Da - D <= eps.  Here that population is counted
+    exhaustively, not sampled: none above eps / 2 (the acceptance margin), none above eps (a possible miss), none non-finite; and
+    every propagate is bit-identical to the fp32 step, as the proof says it must be under that condition."""
+    from optimalmodulationds_amd import scenes
+    N, H = 1024, 32
+    shelf = scenes.shelf_scene()
+    engines = _pair(N, H, shelf)
+    engines[1].set_screening_sweep(1, all_steps=True)
+    pol = _policy()
+    q = scenes.FRANKA_Q0.copy()
+    rng = np.random.RandomState(3)
+    for it in range(11):
+        moved = shelf.copy()
+        moved[:, 1] += 0.05 * np.sin(0.3 * it)
+        for e in engines:
+            e.set_obstacles(moved)
+        r = _step_both(engines, q, pol, 900 + it, f"swept iteration {it}")
+        q = (q + 0.05 * r["qdot"][0] + 0.01 * rng.standard_normal(7)).astype(np.float32)
+    st, hs = engines[1].screen_stats(), engines[1].sweep_hist()
+    print({k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in hs.items()}, st)
+    assert hs["steps"] == 11 * H and hs["pairs"] == 11 * H * N * shelf.shape[0] and hs["pairs"] > 1e8, hs
+    cand = st["candidates_per_rollout_step"] * N * H * 11
+    assert abs((hs["pairs"] - hs["non_candidates"]) - cand) <= 1e-6 * hs["pairs"], (hs, cand)   # the sweep's candidate test = the selection's
+    assert hs["above_half_eps"] == 0 and hs["above_eps"] == 0 and hs["non_finite"] == 0, hs
+    assert 0.0 < hs["max_pos"] <= 0.5 * st["eps"] and hs["max_abs"] <= 0.5 * st["eps"], (hs, st)
+    assert hs["max_abs"] == pytest.approx(st["sweep_max_err"]) and st["fallbacks"] == 0, (hs, st)
+    assert int(hs["pos"].sum() + hs["neg"].sum()) == hs["non_candidates"], hs
+    assert int(hs["ratio"][len(hs["ratio"]) // 2:].sum()) == 0, hs                     # nothing in the upper half of [0, eps)
+    for e in engines:
+        e.close()
+
+
 def test_large_radii_and_in_collision_rollouts():
     """Spheres of radius 0.1 .. 0.3 m scattered through the arm's workspace: most rollouts spend steps in collision (negative
     thresholded distance, the in-collision branch of the modulation) and the pass-1 values are dominated by the radii."""
