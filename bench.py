@@ -81,13 +81,16 @@ def setup(wl, rank):
 
 
 def pmc_traffic(workload, kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this workload
-    (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md)."""
+    """(HBM bytes per launch of the dominant kernel, the round whose profiles/ file holds it) from the committed rocprofv3 PMC
+    summary of this workload (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md;
+    tools/profile_refresh.sh).  The all-fp32 step's passes are filed under <workload>_fp32."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)[workload][kernel]["traffic_bytes"]
+            t = json.load(f)
+        key = workload + "_fp32" if (kernel == "k_pass1" and workload + "_fp32" in t) else workload
+        return t[key][kernel]["traffic_bytes"], t.get("_round", "r03")
     except Exception:
-        return None
+        return None, None
 
 
 def flops_per_row(W):
@@ -302,6 +305,8 @@ def main():
                          "launches idles the GPU for a few us: every launch costs 2.4 %% of value at 190 us per step, every 8th 0.2 %%)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="test mode for a 1-GPU box: all ranks use GPU 0 and exchange through the host (gloo); never a scaling number")
+    ap.add_argument("--screening", type=int, default=-1, choices=(-1, 0, 1),
+                    help="-1: the library's own choice (default); 0: the all-fp32 step as the primary measurement (omds_set_screening(0)); 1: forced on")
     ap.add_argument("--time-fetch", action="store_true", help="also report the cost of fetching all rollout tensors to the host")
     args = ap.parse_args()
 
@@ -325,16 +330,18 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     r = measure(args, args.workload, args.steps, args.warmup, rank, world, local_rank, use_dist, dist, torch, args.time_fetch,
-                reps=max(1, args.reps))
+                reps=max(1, args.reps), screening=args.screening)
     w, W, b, obs, q0, qf, N, H, K, el = (r[k] for k in ("w", "W", "b", "obs", "q0", "qf", "N", "H", "K", "el"))
     p1_ms, p1_launches, p1_rows, fetch_ms = r["p1_ms"], r["p1_launches"], r["p1_rows"], r["fetch_ms"]
 
     def roofline(rr, workload):
         ach = rr["p1_flops"] / (rr["p1_ms"] * 1e-3) / 1e12 if rr["p1_ms"] > 0 else 0.0
         pipe, peak = PEAK_OF.get(rr["p1_kernel"], PEAK_OF["k_pass1"])
+        traffic, traffic_round = pmc_traffic(workload, rr["p1_kernel"])
         return {"bound": "mfma", "kernel": rr["p1_kernel"], "pipe": pipe, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                "frac": ach / peak, "traffic": pmc_traffic(workload, rr["p1_kernel"]),
-                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, committed; not re-collected by this run)",
+                "frac": ach / peak, "traffic": traffic,
+                "traffic_source": f"profiles/pmc_traffic.json = profiles/{traffic_round}_pmc_hbm*.txt (rocprofv3 --pmc passes of this workload, "
+                                  f"collected in round {traffic_round} by tools/profile_refresh.sh and committed; not re-collected by this run)",
                 "launches": int(rr["p1_launches"]), "launch_sampling": f"HIP events around every {args.prof_stride}-th launch inside the timed blocks",
                 "avg_launch_ms": rr["p1_ms"] / max(rr["p1_launches"], 1),
                 "flops_per_launch": rr["p1_flops"] / max(rr["p1_launches"], 1),

@@ -315,6 +315,11 @@ OMDS_API int omds_screen_sweep_stats(omds_ctx* ctx, int32_t* every, int64_t* swe
 OMDS_API int omds_screen_sweep_hist(omds_ctx* ctx, uint64_t* words, int n_words, int reset);
 OMDS_API int omds_screen_audit_stats(omds_ctx* ctx, int32_t* one_in, double* audit_rows_per_rollout_step, float* audit_max_err,
                                      int32_t* suspended, int64_t* calibrations);
+/* What tripped the fp32 fallbacks since creation (NULL = skip): a measured error above eps / 2 (candidates, audit sample or sweep);
+ * a rollout whose exact k-th smallest candidate came within eps of tau (slack guard); a step whose candidate list outgrew the
+ * per-entry buffers (32 candidates per rollout on average: near-flat distance fields); and how often three in a row (or a
+ * non-finite error) suspended screening until the next calibration.                                                      */
+OMDS_API int omds_screen_fallback_stats(omds_ctx* ctx, int64_t* by_error, int64_t* by_slack, int64_t* by_overflow, int64_t* suspensions);
 /* (The two test hooks that damage the screening inputs / force a tile shape are NOT part of this library: they are declared in
  * include/omds_test.h and exported by libomds_hip_test.so only.)                                                           */
 /* Diagnostic: the fp16 screening network alone on q [B,n] -> mindist [B,O] (the values the candidate selection sees). */

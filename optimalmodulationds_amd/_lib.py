@@ -95,6 +95,7 @@ SIGNATURES = {
     "omds_set_screening": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),
     "omds_set_screening_audit": (C.c_int, [C.c_void_p, C.c_int]),
     "omds_screen_audit_stats": (C.c_int, [C.c_void_p, I32P, C.POINTER(C.c_double), F32P, I32P, C.POINTER(C.c_int64)]),
+    "omds_screen_fallback_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "omds_set_screening_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "omds_screen_sweep_hist": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int, C.c_int]),
     "omds_screen_sweep_stats": (C.c_int, [C.c_void_p, I32P, C.POINTER(C.c_int64), F32P]),

@@ -45,6 +45,12 @@ struct RoctxRange {
 }  // namespace
 
 #define CK(expr) OMDS_HIP_CHECK(ctx, expr)
+// first line of every entry point that reads, overwrites or reports on what the last propagate produced (omds_internal.h: pending)
+#define RESOLVE(ctx)                                   \
+    do {                                               \
+        const int _rrc = omds_resolve_pending(ctx);    \
+        if (_rrc) return _rrc;                         \
+    } while (0)
 #define REQUIRE(cond, code, msg)            \
     do {                                    \
         if (!(cond)) {                      \
@@ -126,6 +132,10 @@ static void free_all(omds_ctx* ctx) {
     for (void* p : ctx->mlp_allocs)
         if (p) (void)hipFree(p);
     if (ctx->h_red) (void)hipHostFree(ctx->h_red);
+    if (ctx->h_verdict) (void)hipHostFree(ctx->h_verdict);
+    if (ctx->ev_steps) (void)hipEventDestroy(ctx->ev_steps);
+    if (ctx->ev_verdict) (void)hipEventDestroy(ctx->ev_verdict);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->h_sinks) (void)hipHostFree(ctx->h_sinks);
     if (ctx->h_in) (void)hipHostFree(ctx->h_in);
     if (ctx->ev_in_q) (void)hipEventDestroy(ctx->ev_in_q);
@@ -178,7 +188,15 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
         if (_e != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(_e), OMDS_ERR_HIP); \
     } while (0)
     CKC(hipSetDevice(ctx->dev));
-    CKC(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    {   // the main stream at the highest priority the device offers, the audit stream at the lowest: when both have workgroups
+        // ready, the rollouts' kernels are dispatched first
+        int prio_lo = 0, prio_hi = 0;
+        CKC(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        CKC(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi));
+        CKC(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_lo));
+    }
+    CKC(hipEventCreateWithFlags(&ctx->ev_steps, hipEventDisableTiming));
+    CKC(hipEventCreateWithFlags(&ctx->ev_verdict, hipEventDisableTiming));
     const size_t N = cfg->n_traj, H = cfg->horizon, n = cfg->n_dof, Km = cfg->n_kernel_max, Om = cfg->max_obs,
                  k = cfg->n_closest, d = n + 3;
     const size_t rows2 = N * k;
@@ -231,6 +249,7 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
     const size_t redn = std::max<size_t>((size_t)omds_red_size((int)Km, (int)n) + 8, 2 * H + 16);   // also the screening counters of a propagate (4 + 2 (H + 1))
     CKC(hipMalloc(&ctx->d_red, redn * 4));
     CKC(hipHostMalloc(&ctx->h_red, redn * 4));
+    CKC(hipHostMalloc(&ctx->h_verdict, (H + 8) * 4));
     CKC(hipHostMalloc(&ctx->h_in, (Km * (2 * n + 1) + OMDS_MAX_DOF) * 4));   // pinned staging of the small per-iteration inputs
     CKC(hipEventCreateWithFlags(&ctx->ev_in_q, hipEventDisableTiming));
     CKC(hipEventCreateWithFlags(&ctx->ev_in_means, hipEventDisableTiming));
@@ -253,12 +272,15 @@ void omds_destroy(omds_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->dev);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     free_all(ctx);
     delete ctx;
 }
 
 int omds_sync(omds_ctx* ctx) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    int rc;
+    if ((rc = omds_resolve_pending(ctx))) return rc;
     CK(hipStreamSynchronize(ctx->stream));
     return OMDS_OK;
 }
@@ -285,6 +307,7 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
 int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const int32_t* out_dims, const float* const* W,
                     const float* const* b, int act, float out_div, int n_skips, const int32_t* skip_after) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     REQUIRE(in_dims && out_dims && W && b && n_linear >= 2, OMDS_ERR_INVALID_ARG, "omds_set_mlp: null argument or fewer than 2 Linear layers");
     REQUIRE(n_skips == 0 || skip_after, OMDS_ERR_INVALID_ARG, "omds_set_mlp_ex: n_skips > 0 needs skip_after");
     const int n = ctx->cfg.n_dof;
@@ -632,6 +655,7 @@ static bool scene_differs_from_calibration(const omds_ctx* ctx, const float* xyz
 
 int omds_set_obstacles(omds_ctx* ctx, const float* xyzr, int n_obs) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     REQUIRE(xyzr && n_obs >= 1, OMDS_ERR_INVALID_ARG, "omds_set_obstacles: need n_obs >= 1 and a non-null [O,4] array");
     REQUIRE(n_obs >= ctx->cfg.n_closest, OMDS_ERR_INVALID_ARG, "omds_set_obstacles: fewer obstacles than n_closest");
     CK(hipSetDevice(ctx->dev));
@@ -659,6 +683,7 @@ static void refresh_goal_fk(omds_ctx* ctx) {
 
 int omds_set_ds(omds_ctx* ctx, const float* q_goal) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     REQUIRE(q_goal, OMDS_ERR_INVALID_ARG, "omds_set_ds: null q_goal");
     std::memcpy(ctx->qf, q_goal, ctx->cfg.n_dof * sizeof(float));
     ctx->have_ds = true;
@@ -708,6 +733,7 @@ int omds_set_ds_seds(omds_ctx* ctx, const float* q_goal, int G, const float* mu_
 
 int omds_set_params(omds_ctx* ctx, const omds_params* p) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     REQUIRE(p, OMDS_ERR_INVALID_ARG, "omds_set_params: null params");
     REQUIRE(p->rbf_p > 0.f, OMDS_ERR_INVALID_ARG, "omds_set_params: rbf_p must be positive");
     REQUIRE((p->cost_terms & ~OMDS_COST_ALL) == 0 && (p->variant & ~3u) == 0, OMDS_ERR_INVALID_ARG,
@@ -723,6 +749,7 @@ int omds_set_params(omds_ctx* ctx, const omds_params* p) {
 
 int omds_set_cost(omds_ctx* ctx, const float* dh_params, const float* q_min, const float* q_max) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     REQUIRE(dh_params && q_min && q_max, OMDS_ERR_INVALID_ARG, "omds_set_cost: null argument");
     const int n = ctx->cfg.n_dof;
     std::memcpy(ctx->dh, dh_params, (size_t)(n + 1) * 4 * sizeof(float));
@@ -736,6 +763,7 @@ int omds_set_cost(omds_ctx* ctx, const float* dh_params, const float* q_min, con
 // ---- policy samples -------------------------------------------------------------------------------
 int omds_set_policy_samples(omds_ctx* ctx, const float* mu, const float* sigma, const float* alpha, int K) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     REQUIRE(K >= 0 && K <= ctx->cfg.n_kernel_max, OMDS_ERR_INVALID_ARG, "omds_set_policy_samples: 0 <= n_kernels <= n_kernel_max");
     CK(hipSetDevice(ctx->dev));
     ctx->n_kernels = K;
@@ -758,6 +786,7 @@ int omds_set_policy_samples(omds_ctx* ctx, const float* mu, const float* sigma, 
 int omds_sample_policy(omds_ctx* ctx, const float* mu_c, const float* sigma_c, const float* alpha_c, float mu_s,
                        float sigma_s, float alpha_s, int K, uint64_t seed, int64_t rollout_offset) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     REQUIRE(K >= 0 && K <= ctx->cfg.n_kernel_max, OMDS_ERR_INVALID_ARG, "omds_sample_policy: 0 <= n_kernels <= n_kernel_max");
     CK(hipSetDevice(ctx->dev));
     ctx->n_kernels = K;
@@ -781,6 +810,7 @@ int omds_sample_policy(omds_ctx* ctx, const float* mu_c, const float* sigma_c, c
 
 int omds_get_policy_samples(omds_ctx* ctx, float* mu, float* sigma, float* alpha) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     CK(hipSetDevice(ctx->dev));
     const int N = ctx->cfg.n_traj, n = ctx->cfg.n_dof, K = ctx->n_kernels;
     if (K == 0) return OMDS_OK;
@@ -803,6 +833,7 @@ int omds_get_policy_samples(omds_ctx* ctx, float* mu, float* sigma, float* alpha
 }
 
 // ---- distance network on a batch: Apre -> pass 1 -> top-k -> pass 2 ---------------------------------
+static int prof_collect(omds_ctx* ctx);
 static int prof_begin(omds_ctx* ctx) {
     if (!ctx->prof_on) return OMDS_OK;
     // an event record between two kernels costs ~5.7 us of idle GPU (tools/gap_probe.py: back-to-back launches
@@ -810,6 +841,7 @@ static int prof_begin(omds_ctx* ctx) {
     ctx->prof_open = (ctx->prof_seen++ % ctx->prof_stride) == 0;
     if (!ctx->prof_open) return OMDS_OK;
     ProfEvents& p = ctx->prof;
+    if (p.used >= 4096) { int rc = prof_collect(ctx); if (rc) return rc; }   // elapsed times are read lazily (omds_prof_read); bound the open events
     if (p.used == p.start.size()) {
         hipEvent_t a, b;
         CK(hipEventCreate(&a));
@@ -1116,18 +1148,30 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
                 omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, ctx->d_Apre,
                                  ctx->d_dscr, ctx->n_obs, a, 0, N);
         }
-        if (screen && sink.audit_rows) {
-            // The audit sample of this propagate in one throughput-shaped launch: k_audit on the recorded pairs against the
-            // kept layer-1 slabs of all horizon steps -> d_scerr[2] = max (Da - D)
-            RoctxRange r3("screening audit sample (fp32 re-evaluation of unevaluated pairs)");
-            MlpDev ma = ctx->mlp;
-            if (ma.featQ) {   // skip-connection networks: the encoded joint inputs of every step's states, rebuilt from the stored
-                              // rollouts (trajT [H][n][N] as H slabs; the same kernel, so ApreAll is rewritten with the same bits)
-                ma.featQ = ctx->d_featQAll;
-                omds_launch_rollout_layer1(ctx->stream, ma, ctx->d_trajT, N, H * N, ctx->d_ApreAll, nullptr, 0, N);
+        if (screen) {
+            // Off the rollouts' stream from here: the audit sample of this propagate in one throughput-shaped launch (k_audit on
+            // the recorded pairs against the kept layer-1 slabs of all horizon steps -> d_scerr[2] = max (Da - D)) and the copies
+            // of what the propagate measured, on the low-priority stream2 behind the last horizon step.  The caller's next launches
+            // (cost, the update's reductions) run beside it on the main stream; omds_resolve_pending waits for ev_verdict before
+            // anything is published.
+            hipStream_t s2 = ctx->stream2;
+            CK(hipEventRecord(ctx->ev_steps, ctx->stream));
+            CK(hipStreamWaitEvent(s2, ctx->ev_steps, 0));
+            if (sink.audit_rows) {
+                RoctxRange r3("screening audit sample (fp32 re-evaluation of unevaluated pairs)");
+                MlpDev ma = ctx->mlp;
+                if (ma.featQ) {   // skip-connection networks: the encoded joint inputs of every step's states, rebuilt from the stored
+                                  // rollouts (trajT [H][n][N] as H slabs; the same kernel, so ApreAll is rewritten with the same bits)
+                    ma.featQ = ctx->d_featQAll;
+                    omds_launch_rollout_layer1(s2, ma, ctx->d_trajT, N, H * N, ctx->d_ApreAll, nullptr, 0, N);
+                }
+                omds_launch_audit(s2, ma, ctx->d_ApreAll, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, ctx->prm.ignored_links,
+                                  sink.audit_rows, sink.audit_da, sink.audit_total, sink.audit_cap, ctx->d_scerr);
             }
-            omds_launch_audit(ctx->stream, ma, ctx->d_ApreAll, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, ctx->prm.ignored_links,
-                              sink.audit_rows, sink.audit_da, sink.audit_total, sink.audit_cap, ctx->d_scerr);
+            CK(hipGetLastError());
+            CK(hipMemcpyAsync(ctx->h_verdict, ctx->d_scerr, 16, hipMemcpyDeviceToHost, s2));
+            CK(hipMemcpyAsync(ctx->h_verdict + 4, ctx->d_sctotal, (size_t)(H + 2) * 4, hipMemcpyDeviceToHost, s2));
+            CK(hipEventRecord(ctx->ev_verdict, s2));
         }
     } else {
         for (int i = 1; i <= H; ++i) {   // MPPI.py:101: H network evaluations, the last velocity is not integrated
@@ -1142,6 +1186,7 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
 int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
     RoctxRange range("TAG: general propagation");
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     REQUIRE(q_cur, OMDS_ERR_INVALID_ARG, "omds_propagate: null q_cur");
     int rc;
     if ((rc = check_ready(ctx, true))) return rc;
@@ -1177,61 +1222,89 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
     bool screen = tail && screen_wanted(ctx);
     if (screen && !ctx->screen_cal && (rc = calibrate_screen(ctx, q_cur))) return rc;
     screen = screen && ctx->screen_ok && !ctx->screen_suspended && ctx->screen_eps > 0.f;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        if ((rc = enqueue_rollouts(ctx, a, tail, screen))) return rc;
-        CK(hipGetLastError());
-        ctx->have_cost_vals = false;
-        if (screen) {
-            CK(hipMemcpyAsync(ctx->h_red, ctx->d_scerr, 16, hipMemcpyDeviceToHost, ctx->stream));
-            CK(hipMemcpyAsync(ctx->h_red + 4, ctx->d_sctotal, (size_t)(H + 2) * 4, hipMemcpyDeviceToHost, ctx->stream));
-        }
-        CK(hipStreamSynchronize(ctx->stream));
-        ctx->have_rollouts = true;
-        if (!screen) break;
-        // What this propagate MEASURED about the screening values it relied on:
-        //   err   = max |Da - D| over every candidate pair (the rows nearest the decision threshold, all re-evaluated);
-        //   aerr  = max (Da - D) over the audit sample, a uniform pseudo-random 1 in audit_one_in (another one every step) of
-        //           the pairs that were NOT re-evaluated -- the population the selection rule's assumption is about --
-        //           evaluated in fp32 by k_audit at the end of the horizon loop;
-        //   slack = rollouts whose exact k-th smallest candidate came within eps of tau.
-        // Accepted only while both errors keep a 2x margin to eps and no slack check failed; otherwise redone in fp32.
-        //   serr  = (every sweep_every-th propagate) max |Da - D| over ALL pairs of the last horizon step.
-        const float err = ctx->h_red[0], aerr = ctx->h_red[2], serr = ctx->sweep_now ? ctx->h_red[3] : 0.f;
-        if (ctx->sweep_now) { ctx->screen_sweeps += ctx->sweep_steps_now; if (serr > ctx->screen_sweep_err_seen || serr != serr) ctx->screen_sweep_err_seen = serr; }
-        if (err > ctx->screen_err_seen || err != err) ctx->screen_err_seen = err;
-        if (aerr > ctx->screen_audit_err_seen || aerr != aerr) ctx->screen_audit_err_seen = aerr;
-        const int32_t* tot = reinterpret_cast<const int32_t*>(ctx->h_red + 4);
-        const uint32_t slack_viol = reinterpret_cast<const uint32_t*>(ctx->h_red)[1];
-        bool overflow = false;   // a step listed more rows than k_exact's per-entry outputs hold: redo in fp32
-        for (int i = 0; i < H; ++i) { ctx->screen_rows += tot[i]; overflow = overflow || tot[i] > ctx->ex_cap; }
-        ctx->screen_audit_rows += std::min<double>(tot[H + 1], ctx->audit_cap);   // entries k_audit evaluated
-        ctx->screen_steps += (double)N * H;
-        static const int noguard = OMDS_EXP_ENV("OMDS_SCREEN_NOGUARD", 0);   // experiment builds only: the release library cannot switch the guard off
-        const float worst = (err != err || aerr != aerr || serr != serr) ? __builtin_inff() : std::max({err, aerr, serr});
-        if ((!overflow && worst <= 0.5f * ctx->screen_eps && slack_viol == 0) || noguard) {
-            // accepted.  Keep the bound at >= 4x the largest error seen, so that states drifting into regions where the fp16
-            // network is less accurate widen it gradually instead of tripping the fallback
-            if (!noguard && 4.f * worst > ctx->screen_eps) ctx->screen_eps = 4.f * worst;
-            ctx->screen_consec = 0;
-            break;
-        }
-        // the bound lost its margin on live data (or the list outgrew its buffers): this propagate is redone in fp32 -- its
-        // results are the fp32 ones by construction -- and the bound is widened.  Three in a row: the screening network is
-        // not usable on this scene (out of its fp16 range, a scene far from the calibration batch, corrupted weights); the
-        // context stays on the fp32 step until the next calibration (omds_set_obstacles with a changed scene, omds_set_mlp,
-        // omds_set_screening(mode, eps < 0))
-        ctx->screen_fallbacks++;
-        if (!overflow && worst < 3.0e38f) ctx->screen_eps = std::max(ctx->screen_eps, 4.f * worst);
-        if (++ctx->screen_consec >= 3 || !(worst < 3.0e38f)) ctx->screen_suspended = true;
-        screen = false;
-    }
-    if (ctx->prof_on && (rc = prof_collect(ctx))) return rc;
+    if ((rc = enqueue_rollouts(ctx, a, tail, screen))) return rc;
+    CK(hipGetLastError());
+    ctx->have_cost_vals = false;
+    ctx->have_rollouts = true;
+    // Not synchronised: the launches are enqueued, and every entry point that reads (or overwrites) what they produce resolves
+    // the propagate first (omds_resolve_pending) -- for a screened propagate that includes its verdict.
+    ctx->pending = true;
+    ctx->pending_screen = screen;
+    ctx->pending_tail = tail;
+    ctx->pending_args = a;
     return OMDS_OK;
 }
+
+}  // extern "C"
+
+static int enqueue_cost(omds_ctx* ctx);
+
+// What a screened propagate MEASURED about the screening values it relied on (read from the pinned verdict words):
+//   err   = max |Da - D| over every candidate pair (the rows nearest the decision threshold, all re-evaluated);
+//   aerr  = max (Da - D) over the audit sample, a uniform pseudo-random 1 in audit_one_in (another one every step) of
+//           the pairs that were NOT re-evaluated -- the population the selection rule's assumption is about --
+//           evaluated in fp32 by k_audit (on stream2, beside whatever the caller enqueued behind the rollouts);
+//   slack = rollouts whose exact k-th smallest candidate came within eps of tau;
+//   serr  = (every sweep_every-th propagate) max |Da - D| over ALL pairs of the swept horizon step(s).
+// Accepted only while the errors keep a 2x margin to eps and no slack check failed; otherwise the propagate is redone with
+// the fp32 pass 1 -- its results are then the fp32 ones by construction -- before anything of it has been published.
+int omds_resolve_pending(omds_ctx* ctx, bool* redone) {
+    if (redone) *redone = false;
+    if (!ctx->pending) return OMDS_OK;
+    ctx->pending = false;
+    CK(hipSetDevice(ctx->dev));
+    const int N = ctx->cfg.n_traj, H = ctx->cfg.horizon;
+    if (!ctx->pending_screen) {
+        CK(hipStreamSynchronize(ctx->stream));
+        return OMDS_OK;
+    }
+    CK(hipEventSynchronize(ctx->ev_verdict));   // behind ev_steps on the main stream: the rollouts themselves are complete too
+    const float* hv = ctx->h_verdict;
+    const float err = hv[0], aerr = hv[2], serr = ctx->sweep_now ? hv[3] : 0.f;
+    if (ctx->sweep_now) { ctx->screen_sweeps += ctx->sweep_steps_now; if (serr > ctx->screen_sweep_err_seen || serr != serr) ctx->screen_sweep_err_seen = serr; }
+    if (err > ctx->screen_err_seen || err != err) ctx->screen_err_seen = err;
+    if (aerr > ctx->screen_audit_err_seen || aerr != aerr) ctx->screen_audit_err_seen = aerr;
+    const int32_t* tot = reinterpret_cast<const int32_t*>(hv + 4);
+    const uint32_t slack_viol = reinterpret_cast<const uint32_t*>(hv)[1];
+    bool overflow = false;   // a step listed more rows than k_exact's per-entry outputs hold: redo in fp32
+    for (int i = 0; i < H; ++i) { ctx->screen_rows += tot[i]; overflow = overflow || tot[i] > ctx->ex_cap; }
+    ctx->screen_audit_rows += std::min<double>(tot[H + 1], ctx->audit_cap);   // entries k_audit evaluated
+    ctx->screen_steps += (double)N * H;
+    static const int noguard = OMDS_EXP_ENV("OMDS_SCREEN_NOGUARD", 0);   // experiment builds only: the release library cannot switch the guard off
+    const float worst = (err != err || aerr != aerr || serr != serr) ? __builtin_inff() : std::max({err, aerr, serr});
+    if ((!overflow && worst <= 0.5f * ctx->screen_eps && slack_viol == 0) || noguard) {
+        // accepted.  Keep the bound at >= 4x the largest error seen, so that states drifting into regions where the fp16
+        // network is less accurate widen it gradually instead of tripping the fallback
+        if (!noguard && 4.f * worst > ctx->screen_eps) ctx->screen_eps = 4.f * worst;
+        ctx->screen_consec = 0;
+        return OMDS_OK;
+    }
+    // the bound lost its margin on live data (or the list outgrew its buffers): this propagate is redone in fp32 and the bound
+    // is widened.  Three in a row: the screening network is not usable on this scene (out of its fp16 range, a scene far from
+    // the calibration batch, corrupted weights); the context stays on the fp32 step until the next calibration
+    // (omds_set_obstacles with a changed scene, omds_set_mlp, omds_set_screening(mode, eps < 0))
+    ctx->screen_fallbacks++;
+    if (overflow) ctx->screen_fb_overflow++;
+    else if (!(worst <= 0.5f * ctx->screen_eps)) ctx->screen_fb_error++;
+    else ctx->screen_fb_slack++;
+    if (!overflow && worst < 3.0e38f) ctx->screen_eps = std::max(ctx->screen_eps, 4.f * worst);
+    if (++ctx->screen_consec >= 3 || !(worst < 3.0e38f)) { if (!ctx->screen_suspended) ctx->screen_suspensions++; ctx->screen_suspended = true; }
+    int rc;
+    CK(hipStreamSynchronize(ctx->stream));   // whatever the caller enqueued on the rejected rollouts
+    if ((rc = enqueue_rollouts(ctx, ctx->pending_args, ctx->pending_tail, false))) return rc;   // from trajT[0], which no step overwrites
+    CK(hipGetLastError());
+    if (ctx->have_cost_vals && (rc = enqueue_cost(ctx))) return rc;   // a cost had been evaluated on the rejected rollouts
+    CK(hipStreamSynchronize(ctx->stream));
+    if (redone) *redone = true;
+    return OMDS_OK;
+}
+
+extern "C" {
 
 int omds_get_rollouts(omds_ctx* ctx, float* all_traj, float* closest_dist_all, float* kernel_val_all, float* dot_products,
                       float* kernel_activations, float* qdot, float* normal) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     CK(hipSetDevice(ctx->dev));
     const int N = ctx->cfg.n_traj, H = ctx->cfg.horizon, n = ctx->cfg.n_dof, K = ctx->n_kernels, Km = ctx->cfg.n_kernel_max;
     auto fetch = [&](const float* srcT, float* dst, int X, int Xld) -> int {
@@ -1261,6 +1334,7 @@ int omds_get_rollouts(omds_ctx* ctx, float* all_traj, float* closest_dist_all, f
 int omds_get_rollout_rows(omds_ctx* ctx, const int32_t* t, int count, float* all_traj, float* closest_dist_all, float* kernel_val_all,
                           float* dot_products, float* kernel_activations, float* qdot, float* normal) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     const int N = ctx->cfg.n_traj, H = ctx->cfg.horizon, n = ctx->cfg.n_dof, K = ctx->n_kernels, Km = ctx->cfg.n_kernel_max;
     REQUIRE(t && count >= 1 && count <= N, OMDS_ERR_INVALID_ARG, "omds_get_rollout_rows: need 1 <= count <= n_traj and a non-null index array");
     for (int r = 0; r < count; ++r) REQUIRE(t[r] >= 0 && t[r] < N, OMDS_ERR_INVALID_ARG, "omds_get_rollout_rows: rollout index out of range");
@@ -1293,6 +1367,7 @@ int omds_get_rollout_rows(omds_ctx* ctx, const int32_t* t, int count, float* all
 int omds_dist_grad(omds_ctx* ctx, const float* q, int B, float* distance, float* nn_grad, float* mindist,
                    int32_t* closest_idx) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     REQUIRE(q && B >= 1 && B <= ctx->cfg.n_traj, OMDS_ERR_INVALID_ARG, "omds_dist_grad: need 1 <= batch <= n_traj and non-null q");
     int rc;
     if ((rc = check_ready(ctx, false))) return rc;
@@ -1308,12 +1383,12 @@ int omds_dist_grad(omds_ctx* ctx, const float* q, int B, float* distance, float*
     if (mindist) CK(hipMemcpyAsync(mindist, ctx->d_Dmin, (size_t)B * O * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (closest_idx) CK(hipMemcpyAsync(closest_idx, ctx->d_idx, (size_t)B * k * 4, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
-    if (ctx->prof_on && (rc = prof_collect(ctx))) return rc;
     return OMDS_OK;
 }
 
 int omds_mlp_forward_vjp(omds_ctx* ctx, const float* x, int B, float* y, float* grad, int32_t* min_idx) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     const int n = ctx->cfg.n_dof;
     const int cap = ctx->cfg.n_traj * ctx->cfg.n_closest;
     REQUIRE(x && B >= 1 && B <= cap, OMDS_ERR_INVALID_ARG, "omds_mlp_forward_vjp: need 1 <= batch <= n_traj*n_closest and non-null x");
@@ -1384,6 +1459,8 @@ int omds_cost(omds_ctx* ctx, float* cost_out) {
     REQUIRE(ctx->have_ds && ctx->have_cost, OMDS_ERR_NOT_INITIALISED, "omds_cost: call omds_set_ds and omds_set_cost first");
     CK(hipSetDevice(ctx->dev));
     int rc;
+    if (cost_out) RESOLVE(ctx);   // publishing costs: the propagate's verdict first.  Without a fetch the kernel is only enqueued
+                                  // (beside the audit of a screened propagate); a rejected propagate re-evaluates it (omds_resolve_pending)
     if ((rc = enqueue_cost(ctx))) return rc;
     if (cost_out) {
         CK(hipMemcpyAsync(cost_out, ctx->d_cost, (size_t)ctx->cfg.n_traj * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1397,6 +1474,7 @@ int omds_cost(omds_ctx* ctx, float* cost_out) {
 int omds_cost_eval(omds_ctx* ctx, const float* all_traj, const float* closest_dist_all, int B, float* cost_out) {
     RoctxRange range("TAG: cost calculation");
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     REQUIRE(all_traj && closest_dist_all && cost_out && B >= 1 && B <= ctx->cfg.n_traj, OMDS_ERR_INVALID_ARG,
             "omds_cost_eval: need 1 <= batch <= n_traj and non-null arrays");
     REQUIRE(ctx->have_ds && ctx->have_cost, OMDS_ERR_NOT_INITIALISED, "omds_cost_eval: call omds_set_ds and omds_set_cost first");
@@ -1430,6 +1508,7 @@ int omds_cost_eval(omds_ctx* ctx, const float* all_traj, const float* closest_di
 // Local [sum(cost), N] of this shard.
 int omds_cost_sum(omds_ctx* ctx, float* out2) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     REQUIRE(out2, OMDS_ERR_INVALID_ARG, "omds_cost_sum: null output");
     REQUIRE(ctx->have_cost_vals, OMDS_ERR_NOT_INITIALISED, "no cost available: call omds_cost after omds_propagate");
     CK(hipSetDevice(ctx->dev));
@@ -1449,6 +1528,7 @@ int omds_red_count(const omds_ctx* ctx) { return ctx ? omds_red_size(ctx->n_kern
 // Packed partial sums of this shard for the GLOBAL beta = (sum_cost / n_total) / 50.
 int omds_local_sums(omds_ctx* ctx, float sum_cost, float n_total, int include_rollout0, float* red_out) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     REQUIRE(red_out && n_total > 0.f, OMDS_ERR_INVALID_ARG, "omds_local_sums: null output or n_total <= 0");
     REQUIRE(ctx->have_cost_vals, OMDS_ERR_NOT_INITIALISED, "no cost available: call omds_cost after omds_propagate");
     CK(hipSetDevice(ctx->dev));
@@ -1524,6 +1604,7 @@ int omds_get_qdot(omds_ctx* ctx, int mode, float* out) {
 int omds_kernel_candidates(omds_ctx* ctx, float thr_dist, float thr_kernel, float thr_dot, const float* mu_c,
                            const float* sigma_c, int K, int cap, float* cand_q, int32_t* cand_th, int32_t* count) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     REQUIRE(count && cap >= 0 && K >= 0 && K <= ctx->cfg.n_kernel_max, OMDS_ERR_INVALID_ARG,
             "omds_kernel_candidates: bad arguments");
     REQUIRE(K == 0 || (mu_c && sigma_c), OMDS_ERR_INVALID_ARG, "omds_kernel_candidates: null kernel means");
@@ -1560,6 +1641,7 @@ int omds_kernel_candidates(omds_ctx* ctx, float thr_dist, float thr_kernel, floa
 // ---- screening controls ------------------------------------------------------------------------------
 int omds_set_screening(omds_ctx* ctx, int mode, float eps) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     REQUIRE(mode >= -1 && mode <= 1 && eps == eps, OMDS_ERR_INVALID_ARG, "omds_set_screening: mode in {-1, 0, 1}, eps not NaN");
     ctx->screen_mode = mode;
     if (eps > 0.f) {            // the caller's bound instead of a calibration (the run-time checks still widen it when they must)
@@ -1574,6 +1656,7 @@ int omds_set_screening(omds_ctx* ctx, int mode, float eps) {
 }
 int omds_set_screening_audit(omds_ctx* ctx, int one_in) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     REQUIRE(one_in >= 0 && one_in <= (1 << 20) && (one_in & (one_in - 1)) == 0, OMDS_ERR_INVALID_ARG,
             "omds_set_screening_audit: one_in must be 0 (no audit rows) or a power of two <= 2^20");
     ctx->audit_one_in = one_in;
@@ -1581,6 +1664,7 @@ int omds_set_screening_audit(omds_ctx* ctx, int one_in) {
 }
 int omds_set_screening_sweep(omds_ctx* ctx, int every, int all_steps) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     REQUIRE(every >= 0 && (all_steps == 0 || all_steps == 1), OMDS_ERR_INVALID_ARG, "omds_set_screening_sweep: every >= 0 (0 = no sweeps), all_steps in {0, 1}");
     ctx->sweep_every = every;
     ctx->sweep_all_steps = all_steps != 0;
@@ -1588,6 +1672,7 @@ int omds_set_screening_sweep(omds_ctx* ctx, int every, int all_steps) {
 }
 int omds_screen_sweep_hist(omds_ctx* ctx, uint64_t* words, int n_words, int reset) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     REQUIRE(words && n_words == OMDS_SWEEP_HIST_WORDS, OMDS_ERR_INVALID_ARG, "omds_screen_sweep_hist: words must hold OMDS_SWEEP_HIST_WORDS entries");
     CK(hipSetDevice(ctx->dev));
     std::memset(words, 0, (size_t)n_words * 8);
@@ -1600,14 +1685,25 @@ int omds_screen_sweep_hist(omds_ctx* ctx, uint64_t* words, int n_words, int rese
 }
 int omds_screen_sweep_stats(omds_ctx* ctx, int32_t* every, int64_t* sweeps, float* sweep_max_err) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     if (every) *every = ctx->sweep_every;
     if (sweeps) *sweeps = ctx->screen_sweeps;
     if (sweep_max_err) *sweep_max_err = ctx->screen_sweep_err_seen;
     return OMDS_OK;
 }
+int omds_screen_fallback_stats(omds_ctx* ctx, int64_t* by_error, int64_t* by_slack, int64_t* by_overflow, int64_t* suspensions) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
+    if (by_error) *by_error = ctx->screen_fb_error;
+    if (by_slack) *by_slack = ctx->screen_fb_slack;
+    if (by_overflow) *by_overflow = ctx->screen_fb_overflow;
+    if (suspensions) *suspensions = ctx->screen_suspensions;
+    return OMDS_OK;
+}
 int omds_screen_audit_stats(omds_ctx* ctx, int32_t* one_in, double* audit_rows_per_rollout_step, float* audit_max_err,
                             int32_t* suspended, int64_t* calibrations) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     if (one_in) *one_in = ctx->audit_one_in;
     if (audit_rows_per_rollout_step) *audit_rows_per_rollout_step = ctx->screen_steps > 0 ? ctx->screen_audit_rows / ctx->screen_steps : 0.0;
     if (audit_max_err) *audit_max_err = ctx->screen_audit_err_seen;
@@ -1630,6 +1726,7 @@ int omds_debug_force_tile_rows(int tail_sel_rows, int tail_rows) {
 
 int omds_screen_debug_corrupt(omds_ctx* ctx, int what, int index, float value) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     REQUIRE(ctx->screen_ok, OMDS_ERR_UNSUPPORTED, "omds_screen_debug_corrupt: no screening network for this model");
     CK(hipSetDevice(ctx->dev));
     CK(hipStreamSynchronize(ctx->stream));
@@ -1653,6 +1750,7 @@ int omds_screen_debug_corrupt(omds_ctx* ctx, int what, int index, float value) {
 // Diagnostic: the screening network alone on a batch (what k_select sees), for tests and for measuring eps.
 int omds_screen_mindist(omds_ctx* ctx, const float* q, int B, float* mindist) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     REQUIRE(q && mindist && B >= 1 && B <= ctx->cfg.n_traj, OMDS_ERR_INVALID_ARG, "omds_screen_mindist: need 1 <= batch <= n_traj and non-null arrays");
     int rc;
     if ((rc = check_ready(ctx, false))) return rc;
@@ -1671,6 +1769,7 @@ int omds_screen_mindist(omds_ctx* ctx, const float* q, int B, float* mindist) {
 int omds_screen_stats(omds_ctx* ctx, int32_t* active, float* eps, float* max_err_seen, double* cand_per_rollout_step,
                       int64_t* fallbacks) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     if (active) *active = (ctx->screen_ok && screen_wanted(ctx)) ? 1 : 0;
     if (eps) *eps = ctx->screen_eps;
     if (max_err_seen) *max_err_seen = ctx->screen_err_seen;
@@ -1688,6 +1787,7 @@ int omds_prof_enable(omds_ctx* ctx, int on) {
 }
 int omds_prof_reset(omds_ctx* ctx) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
     ctx->prof.ms = 0.0;
     ctx->prof_seen = 0;
     ctx->prof.launches = 0;
@@ -1701,6 +1801,8 @@ int omds_prof_reset(omds_ctx* ctx) {
 }
 int omds_prof_read_ex(omds_ctx* ctx, double* ms, int64_t* launches, double* flops, const char** kernel) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
+    { const int rc = prof_collect(ctx); if (rc) return rc; }
     if (ms) *ms = ctx->prof.ms;
     if (launches) *launches = ctx->prof.launches;
     if (flops) *flops = ctx->prof.flops;
@@ -1709,6 +1811,8 @@ int omds_prof_read_ex(omds_ctx* ctx, double* ms, int64_t* launches, double* flop
 }
 int omds_prof_read(omds_ctx* ctx, double* pass1_ms, int64_t* pass1_launches, int64_t* pass1_rows) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    RESOLVE(ctx);
+    { const int rc = prof_collect(ctx); if (rc) return rc; }
     if (pass1_ms) *pass1_ms = ctx->prof.ms;
     if (pass1_launches) *pass1_launches = ctx->prof.launches;
     if (pass1_rows) *pass1_rows = ctx->prof.rows;

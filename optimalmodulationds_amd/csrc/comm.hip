@@ -128,6 +128,7 @@ int omds_comm_unique_id(uint8_t* out128) {
 
 int omds_comm_init_rank(omds_ctx* ctx, const uint8_t* id128, int rank, int world) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    { const int rrc = omds_resolve_pending(ctx); if (rrc) return rrc; }
     REQUIRE(id128 && world >= 1 && rank >= 0 && rank < world, OMDS_ERR_INVALID_ARG,
             "omds_comm_init_rank: need a 128-byte id and 0 <= rank < world");
     REQUIRE(rccl().ok(), OMDS_ERR_RCCL, rccl().err);
@@ -148,6 +149,7 @@ int omds_comm_init_rank(omds_ctx* ctx, const uint8_t* id128, int rank, int world
 
 int omds_comm_destroy(omds_ctx* ctx) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
+    { const int rrc = omds_resolve_pending(ctx); if (rrc) return rrc; }
     CK(hipSetDevice(ctx->dev));
     CK(hipStreamSynchronize(ctx->stream));
     omds_comm_release(ctx);
@@ -183,19 +185,36 @@ int omds_update_impl(omds_ctx* ctx, bool use_comm, float rate, float ker_thr, fl
     const int world = comm ? ctx->comm_world : 1;
     const int rs = omds_red_size(K, n), n_sum = rs - (1 + n);
     float* red2 = ctx->d_red + rs;   // [sum cost, N] lives behind the packed buffer
-    omds_launch_cost_sum(ctx->stream, ctx->d_cost, N, red2);
-    if (comm) CKN(rccl().AllReduce(red2, red2, 2, ncclFloat, ncclSum, comm, ctx->stream));
-    omds_launch_weights(ctx->stream, ctx->d_cost, N, red2, ctx->d_w, nullptr);
-    omds_launch_policy_sums(ctx->stream, N, n, K, ctx->d_w, ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_maxact,
-                            ctx->d_phisum0, ctx->d_qdotT, ctx->d_cost, (!comm || ctx->comm_rank == 0) ? 1 : 0, ctx->d_red);
-    CK(hipGetLastError());
-    if (comm) CKN(rccl().AllReduce(ctx->d_red, ctx->d_red, (size_t)n_sum, ncclFloat, ncclSum, comm, ctx->stream));
     const bool gather = comm && qdot_best && world > 1;
-    if (gather) {
-        CKN(rccl().AllGather(ctx->d_red + n_sum, ctx->d_gather, (size_t)(1 + n), ncclFloat, comm, ctx->stream));
-        CK(hipMemcpyAsync(ctx->h_gather, ctx->d_gather, (size_t)world * (1 + n) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    auto enqueue = [&]() -> int {
+        omds_launch_cost_sum(ctx->stream, ctx->d_cost, N, red2);
+        if (comm) CKN(rccl().AllReduce(red2, red2, 2, ncclFloat, ncclSum, comm, ctx->stream));
+        omds_launch_weights(ctx->stream, ctx->d_cost, N, red2, ctx->d_w, nullptr);
+        omds_launch_policy_sums(ctx->stream, N, n, K, ctx->d_w, ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_maxact,
+                                ctx->d_phisum0, ctx->d_qdotT, ctx->d_cost, (!comm || ctx->comm_rank == 0) ? 1 : 0, ctx->d_red);
+        CK(hipGetLastError());
+        if (comm) CKN(rccl().AllReduce(ctx->d_red, ctx->d_red, (size_t)n_sum, ncclFloat, ncclSum, comm, ctx->stream));
+        if (gather) {
+            CKN(rccl().AllGather(ctx->d_red + n_sum, ctx->d_gather, (size_t)(1 + n), ncclFloat, comm, ctx->stream));
+            CK(hipMemcpyAsync(ctx->h_gather, ctx->d_gather, (size_t)world * (1 + n) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        CK(hipMemcpyAsync(ctx->h_red, ctx->d_red, (size_t)(rs + 2) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        return OMDS_OK;
+    };
+    int erc;
+    if (comm && world > 1) {
+        // several ranks: the verdict of this rank's propagate BEFORE the first collective -- a rank that had to redo its rollouts
+        // after its collectives were enqueued would have to repeat them alone
+        if ((erc = omds_resolve_pending(ctx))) return erc;
+        if ((erc = enqueue())) return erc;
+    } else {
+        // one shard: the reductions run on the main stream beside the audit of a screened propagate (stream2); the verdict is
+        // awaited afterwards, and a rejected propagate (redone in fp32, its cost re-evaluated) gets the reductions again
+        if ((erc = enqueue())) return erc;
+        bool redone = false;
+        if ((erc = omds_resolve_pending(ctx, &redone))) return erc;
+        if (redone && (erc = enqueue())) return erc;
     }
-    CK(hipMemcpyAsync(ctx->h_red, ctx->d_red, (size_t)(rs + 2) * 4, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     const float* red = ctx->h_red;
     const float n_total = red[rs + 1];

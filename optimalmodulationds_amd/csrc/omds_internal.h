@@ -108,12 +108,40 @@ struct ProfEvents {
     const char* kernel = "k_pass1";
 };
 
+__host__ __device__ inline int omds_seds_stride(int n) { return 2 * n + 2 + 2 * n * n; }
+struct StepArgs {
+    int N, H, n, K, Kmax, k, d, step;   // step = i in 1..H
+    float* trajT; float* distT; float* dotT; float* actT; float* normalT; float* kvalT; float* qdotT;
+    float* maxact; float* phisum0;
+    const float* muT; const float* sigmaT; const float* alphaT;
+    const float* gradx; const float* drow;
+    float qf[OMDS_MAX_DOF];
+    const float* A;   // [n][n] nominal DS matrix of MPPI_toy (velocity = (q - qf) @ A), nullptr = LinDS
+    const float* seds;   // SEDS components [G][omds_seds_stride(n)]: mu_in[n], b[n], prior, den, sigma_inv[n][n], A[n][n]; nullptr = not SEDS
+    int seds_G;
+    float seds_lin_thr, seds_thr;
+    omds_params prm;
+};
+
 struct omds_ctx {
     omds_config cfg{};
     omds_params prm{};
     int dev = 0;
     hipStream_t stream = nullptr;
     std::string err;
+    // A propagate returns once its launches are enqueued; every entry point that reads or overwrites what it produced first calls
+    // omds_resolve_pending.  A SCREENED propagate additionally carries a verdict (omds.h: accepted only while every error it measured
+    // keeps its margin): its audit sample is evaluated by k_audit on a second, low-priority stream next to whatever the caller enqueues
+    // behind the rollouts (cost, the update's reductions), the four error words + the list totals come back through pinned memory, and
+    // a rejected propagate is redone with the fp32 pass 1 (and the cost with it) before anything of it is published.
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_steps = nullptr;       // main stream: the horizon loop of the pending propagate is enqueued up to here
+    hipEvent_t ev_verdict = nullptr;     // stream2: k_audit and the copies into h_verdict are done
+    float* h_verdict = nullptr;          // pinned [4 + H + 2]: d_scerr, d_sctotal of the pending propagate
+    bool pending = false;                // a propagate has been enqueued and not resolved yet
+    bool pending_screen = false;         // ... and it was a screened one (a verdict is due)
+    bool pending_tail = false;
+    StepArgs pending_args{};
     // network
     bool have_mlp = false;
     MlpDev mlp{};
@@ -145,6 +173,8 @@ struct omds_ctx {
     double screen_steps = 0.0;
     double screen_audit_rows = 0.0;
     long long screen_fallbacks = 0;      // since creation
+    long long screen_fb_error = 0, screen_fb_slack = 0, screen_fb_overflow = 0;   // ... by what tripped them (omds_screen_fallback_stats)
+    long long screen_suspensions = 0;    // times three fallbacks in a row (or a non-finite error) suspended screening
     long long screen_recals = 0;         // calibrations run since creation
     float screen_err_seen = 0.f;         // largest |Da - D| seen on candidates since the last calibration
     float screen_audit_err_seen = 0.f;   // largest Da - D seen on audit rows since the last calibration
@@ -263,6 +293,10 @@ struct omds_ctx {
         }                                                                                 \
     } while (0)
 
+// capi.hip: waits for the pending propagate (and, for a screened one, its verdict: a rejected propagate is redone in fp32 here,
+// its cost re-evaluated when one had been enqueued on it).  *redone (optional) tells the caller that what it enqueued behind the
+// rollouts in the meantime was computed from rejected rollouts.  No-op when nothing is pending.
+int omds_resolve_pending(omds_ctx* ctx, bool* redone = nullptr);
 // comm.hip: releases the communicator and its buffers (called by omds_destroy)
 void omds_comm_release(omds_ctx* ctx);
 // the cost-weighted update on the context stream (one host sync); use_comm = reduce over the communicator's shards
@@ -355,20 +389,6 @@ void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const 
                        const ExactOut& ex);
 
 // ---- launchers implemented in rollout_kernels.hip ---------------------------------------------
-__host__ __device__ inline int omds_seds_stride(int n) { return 2 * n + 2 + 2 * n * n; }
-struct StepArgs {
-    int N, H, n, K, Kmax, k, d, step;   // step = i in 1..H
-    float* trajT; float* distT; float* dotT; float* actT; float* normalT; float* kvalT; float* qdotT;
-    float* maxact; float* phisum0;
-    const float* muT; const float* sigmaT; const float* alphaT;
-    const float* gradx; const float* drow;
-    float qf[OMDS_MAX_DOF];
-    const float* A;   // [n][n] nominal DS matrix of MPPI_toy (velocity = (q - qf) @ A), nullptr = LinDS
-    const float* seds;   // SEDS components [G][omds_seds_stride(n)]: mu_in[n], b[n], prior, den, sigma_inv[n][n], A[n][n]; nullptr = not SEDS
-    int seds_G;
-    float seds_lin_thr, seds_thr;
-    omds_params prm;
-};
 void omds_launch_modulate(hipStream_t s, const StepArgs& a);
 // fused per-step tail (tail_kernel.hip): top-k + pass 2 + blend + modulation + next-step layer-1 half
 bool omds_tail_supported(int n_dof, int k);

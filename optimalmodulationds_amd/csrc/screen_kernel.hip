@@ -853,7 +853,7 @@ void omds_launch_sweep_hist(hipStream_t s, const float* D, const float* Da, cons
                             unsigned long long* hist, unsigned* maxabs_bits) {
     const long long n = (long long)N * O;
     if (n <= 0) return;
-    const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 2048);
+    const unsigned grid = (unsigned)std::min<long long>((n + 2047) / 2048, 512);   // few workgroups: each ends with ~200 64-bit atomics
     hipLaunchKernelGGL(k_sweep_hist, dim3(grid), dim3(256), 0, s, D, Da, range, N, O, OmdsDivisor::make((unsigned)O), eps, hist, maxabs_bits);
 }
 

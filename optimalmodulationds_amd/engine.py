@@ -341,7 +341,10 @@ class Engine:
                                                   C.byref(susp), C.byref(ncal)))
         sw_every, sw_n, sw_err = C.c_int32(), C.c_int64(), C.c_float()
         self._ck(self.lib.omds_screen_sweep_stats(self.h, C.byref(sw_every), C.byref(sw_n), C.byref(sw_err)))
-        return dict(active=bool(act.value), eps=eps.value, max_err_seen=err.value, candidates_per_rollout_step=cand.value,
+        fe, fs, fo, ns = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        self._ck(self.lib.omds_screen_fallback_stats(self.h, C.byref(fe), C.byref(fs), C.byref(fo), C.byref(ns)))
+        return dict(fallbacks_by_error=fe.value, fallbacks_by_slack=fs.value, fallbacks_by_overflow=fo.value, suspensions=ns.value,
+                    active=bool(act.value), eps=eps.value, max_err_seen=err.value, candidates_per_rollout_step=cand.value,
                     fallbacks=fb.value, audit_one_in=one_in.value, audit_rows_per_rollout_step=arows.value,
                     audit_max_err=aerr.value, suspended=bool(susp.value), calibrations=ncal.value,
                     sweep_every=sw_every.value, sweeps=sw_n.value, sweep_max_err=sw_err.value)

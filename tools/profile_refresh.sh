@@ -2,7 +2,7 @@
 # Regenerates the rocprofv3 summaries committed under profiles/ (run on the GPU box through gpurun from the repo root).
 # Every rocprofv3 call has python3 directly after "--"; counters are collected in their own passes.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 OUT=$PWD/gpurun_out/prof_$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -10,7 +10,12 @@ B="bench.py --steps 5 --warmup 1 --reps 1 --no-cpu-baseline --no-secondary"
 P="bench.py --steps 2 --warmup 1 --reps 1 --no-cpu-baseline --no-secondary"
 python3 bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
 finddb() { find "$1" -name '*_results.db' | head -1; }
-for wl in franka_shelf_1024x32 franka_shelf_4096x32 planar7_1024x32 franka_tanh_4096x32 franka_dynamic_1024x32; do
+# the all-fp32 step (omds_set_screening(0)): the precision-matched figure of the bench line (roofline.fp32_only), k_pass1 + k_tail
+rocprofv3 --kernel-trace --stats -d "$OUT/kt_fp32" -- python3 $B --screening 0 > "$OUT/kt_fp32.log" 2>&1
+python3 tools/rocprof_summary.py stats "$(finddb "$OUT/kt_fp32")" > "$OUT/stats_fp32.txt"
+tail -1 "$OUT/kt_fp32.log" | grep '^{' > "$OUT/bench_profiled_fp32.json"
+rm -rf "$OUT/kt_fp32"
+for wl in franka_shelf_1024x32 franka_shelf_4096x32 planar7_1024x32 franka_tanh_4096x32 franka_dynamic_1024x32 franka_shelf_4096x64 franka_shelf_8192x32; do
   rocprofv3 --kernel-trace --stats -d "$OUT/kt_$wl" -- python3 $B --workload $wl > "$OUT/kt_$wl.log" 2>&1
   python3 tools/rocprof_summary.py stats "$(finddb "$OUT/kt_$wl")" > "$OUT/stats_$wl.txt"
   tail -1 "$OUT/kt_$wl.log" | grep '^{' > "$OUT/bench_profiled_$wl.json"
@@ -20,6 +25,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d "$OUT/pmc_$c" -- python3 $P > "$OUT/pmc_$c.log" 2>&1
   python3 tools/rocprof_summary.py pmc "$(finddb "$OUT/pmc_$c")" > "$OUT/pmc_$c.txt"
   rm -rf "$OUT/pmc_$c"
+  rocprofv3 --pmc $c -d "$OUT/pmc_fp32_$c" -- python3 $P --screening 0 > "$OUT/pmc_fp32_$c.log" 2>&1
+  python3 tools/rocprof_summary.py pmc "$(finddb "$OUT/pmc_fp32_$c")" > "$OUT/pmc_fp32_$c.txt"
+  rm -rf "$OUT/pmc_fp32_$c"
   rocprofv3 --pmc $c -d "$OUT/pmc_p7_$c" -- python3 $P --workload planar7_1024x32 > "$OUT/pmc_p7_$c.log" 2>&1
   python3 tools/rocprof_summary.py pmc "$(finddb "$OUT/pmc_p7_$c")" > "$OUT/pmc_p7_$c.txt"
   rm -rf "$OUT/pmc_p7_$c"
@@ -28,7 +36,7 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_
 python3 tools/rocprof_summary.py pmc "$(finddb "$OUT/pmc_sq")" > "$OUT/pmc_sq.txt"
 rm -rf "$OUT/pmc_sq"
 # HBM bytes per launch of each workload's kernels -> profiles/pmc_traffic.json (read by bench.py for roofline.traffic)
-python3 - "$OUT" <<'PY'
+python3 - "$OUT" "$R" <<'PY'
 import json, re, sys
 out = sys.argv[1]
 def table(path):
@@ -38,9 +46,9 @@ def table(path):
         if m and m.group(2) in ("FETCH_SIZE", "WRITE_SIZE"):
             t[m.group(1).strip()] = float(m.group(4))
     return t
-res = {"_doc": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024 from separate rocprofv3 --pmc passes of "
+res = {"_round": sys.argv[2] if len(sys.argv) > 2 else "?", "_doc": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024 from separate rocprofv3 --pmc passes of "
                "bench.py --workload <workload> (FETCH_SIZE doubled: gfx950 correction of MI355X_MICROARCH.md)"}
-for wl, tag in (("franka_shelf_1024x32", ""), ("planar7_1024x32", "_p7")):
+for wl, tag in (("franka_shelf_1024x32", ""), ("franka_shelf_1024x32_fp32", "_fp32"), ("planar7_1024x32", "_p7")):
     f, w = table(out + "/pmc%s_FETCH_SIZE.txt" % tag), table(out + "/pmc%s_WRITE_SIZE.txt" % tag)
     res[wl] = {}
     for name in f:

@@ -71,6 +71,8 @@ def run_leg(name, e, n_iter, obs_of=None, uniform_starts=False, seed=0):
         e.cost(fetch=False)
         mu_c, sg_c, al_c, _, qd_w, _, _ = e.weighted_update_sharded(0.1, 0.1, mu_c, sg_c, al_c)
         q = (q + 0.05 * qd_w + 0.02 * rng.standard_normal(7)).astype(np.float32)
+        if e.screen_stats()["suspended"]:    # three fallbacks in a row: what a driver would do -- calibrate again (counted in the report)
+            e.set_screening(1, -1.0)
         if it % 16 == 15:      # a fresh start somewhere between the two ends, so that the legs do not sit in one region
             q = (q0 + rng.uniform(0, 1) * (qf - q0) + 0.3 * rng.standard_normal(7)).astype(np.float32)
             q = np.clip(q, lo, hi)
@@ -89,7 +91,7 @@ def report(legs, out=sys.stdout):
     w("The selection rule (omds.h) is exact while every such x <= eps; a propagate is accepted only while the largest error it\n")
     w("measured stays <= eps / 2.  Every horizon step of every propagate below was swept: all N x O pairs in fp32.\n\n")
     w(f"{'leg':38s} {'iters':>5s} {'pairs':>14s} {'non-candidates':>15s} {'eps [m]':>10s} {'max x [m]':>10s} {'max x/eps':>9s} {'max|x| all':>10s} "
-      f"{'> eps/2':>7s} {'> eps':>5s} {'nonfin':>6s} {'fallb.':>6s} {'calib.':>6s} {'cand/step':>9s} {'s':>6s}\n")
+      f"{'> eps/2':>7s} {'> eps':>5s} {'nonfin':>6s} {'fallb. e/s/o':>12s} {'susp.':>5s} {'calib.':>6s} {'cand/step':>9s} {'s':>6s}\n")
     worst_ratio = 0.0
     for lg in legs:
         h, st = lg["hist"], lg["stats"]
@@ -98,9 +100,12 @@ def report(legs, out=sys.stdout):
         pos += h["pos"]; neg += h["neg"]; ratio += h["ratio"]
         r = h["max_pos"] / st["eps"] if st["eps"] > 0 else float("nan")
         worst_ratio = max(worst_ratio, r)
+        fb = f"{st['fallbacks_by_error']}/{st['fallbacks_by_slack']}/{st['fallbacks_by_overflow']}"
         w(f"{lg['name']:38s} {lg['iterations']:5d} {h['pairs']:14d} {h['non_candidates']:15d} {st['eps']:10.3e} {h['max_pos']:10.3e} {r:9.3f} "
-          f"{h['max_abs']:10.3e} {h['above_half_eps']:7d} {h['above_eps']:5d} {h['non_finite']:6d} {st['fallbacks']:6d} {st['calibrations']:6d} "
+          f"{h['max_abs']:10.3e} {h['above_half_eps']:7d} {h['above_eps']:5d} {h['non_finite']:6d} {fb:>12s} {st['suspensions']:5d} {st['calibrations']:6d} "
           f"{st['candidates_per_rollout_step']:9.2f} {lg['seconds']:6.1f}\n")
+    w("(fallb. e/s/o: propagates redone in fp32 because a measured error exceeded eps / 2, because a rollout's slack guard failed, because a\n"
+      " candidate list outgrew its buffers; susp.: times screening was suspended after three in a row -- a suspended leg is unscreened, and unswept, from there on)\n")
     w(f"\nTOTAL: {tot['pairs']:.4e} pairs in {tot['steps']} swept steps, {tot['non_candidates']:.4e} of them not candidates; "
       f"above eps/2: {tot['above_half_eps']}, above eps: {tot['above_eps']}, non-finite: {tot['non_finite']}; largest x / eps of any leg: {worst_ratio:.3f}\n")
     w("\nDistribution of x over the non-candidates, all legs (log2 bins of |x| in metres; the network's outputs are <= ~1 m):\n")
