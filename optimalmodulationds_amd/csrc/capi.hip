@@ -192,8 +192,13 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
         // ready, the rollouts' kernels are dispatched first
         int prio_lo = 0, prio_hi = 0;
         CKC(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        CKC(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi));
-        CKC(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_lo));
+        if (OMDS_EXP_ENV("OMDS_AB_PRIO", 1)) {
+            CKC(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi));
+            CKC(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_lo));
+        } else {
+            CKC(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+            CKC(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        }
     }
     CKC(hipEventCreateWithFlags(&ctx->ev_steps, hipEventDisableTiming));
     CKC(hipEventCreateWithFlags(&ctx->ev_verdict, hipEventDisableTiming));
@@ -1154,9 +1159,12 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
             // of what the propagate measured, on the low-priority stream2 behind the last horizon step.  The caller's next launches
             // (cost, the update's reductions) run beside it on the main stream; omds_resolve_pending waits for ev_verdict before
             // anything is published.
-            hipStream_t s2 = ctx->stream2;
-            CK(hipEventRecord(ctx->ev_steps, ctx->stream));
-            CK(hipStreamWaitEvent(s2, ctx->ev_steps, 0));
+            static const int ab = OMDS_EXP_ENV("OMDS_AB", 2);   // experiment builds: 0 = the audit on the main stream (round 3)
+            hipStream_t s2 = (ab == 0 || ab == 3) ? ctx->stream : ctx->stream2;
+            if (ab != 0 && ab != 3) {
+                CK(hipEventRecord(ctx->ev_steps, ctx->stream));
+                CK(hipStreamWaitEvent(s2, ctx->ev_steps, 0));
+            }
             if (sink.audit_rows) {
                 RoctxRange r3("screening audit sample (fp32 re-evaluation of unevaluated pairs)");
                 MlpDev ma = ctx->mlp;
@@ -1232,6 +1240,7 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
     ctx->pending_screen = screen;
     ctx->pending_tail = tail;
     ctx->pending_args = a;
+    if (OMDS_EXP_ENV("OMDS_AB", 2) < 2) return omds_resolve_pending(ctx);   // experiment builds: the verdict before returning (round 3)
     return OMDS_OK;
 }
 
