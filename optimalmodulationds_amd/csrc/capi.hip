@@ -45,12 +45,6 @@ struct RoctxRange {
 }  // namespace
 
 #define CK(expr) OMDS_HIP_CHECK(ctx, expr)
-// first line of every entry point that reads, overwrites or reports on what the last propagate produced (omds_internal.h: pending)
-#define RESOLVE(ctx)                                   \
-    do {                                               \
-        const int _rrc = omds_resolve_pending(ctx);    \
-        if (_rrc) return _rrc;                         \
-    } while (0)
 #define REQUIRE(cond, code, msg)            \
     do {                                    \
         if (!(cond)) {                      \
@@ -133,9 +127,6 @@ static void free_all(omds_ctx* ctx) {
         if (p) (void)hipFree(p);
     if (ctx->h_red) (void)hipHostFree(ctx->h_red);
     if (ctx->h_verdict) (void)hipHostFree(ctx->h_verdict);
-    if (ctx->ev_steps) (void)hipEventDestroy(ctx->ev_steps);
-    if (ctx->ev_verdict) (void)hipEventDestroy(ctx->ev_verdict);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->h_sinks) (void)hipHostFree(ctx->h_sinks);
     if (ctx->h_in) (void)hipHostFree(ctx->h_in);
     if (ctx->ev_in_q) (void)hipEventDestroy(ctx->ev_in_q);
@@ -188,20 +179,7 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
         if (_e != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(_e), OMDS_ERR_HIP); \
     } while (0)
     CKC(hipSetDevice(ctx->dev));
-    {   // the main stream at the highest priority the device offers, the audit stream at the lowest: when both have workgroups
-        // ready, the rollouts' kernels are dispatched first
-        int prio_lo = 0, prio_hi = 0;
-        CKC(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        if (OMDS_EXP_ENV("OMDS_AB_PRIO", 1)) {
-            CKC(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi));
-            CKC(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_lo));
-        } else {
-            CKC(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-            CKC(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-        }
-    }
-    CKC(hipEventCreateWithFlags(&ctx->ev_steps, hipEventDisableTiming));
-    CKC(hipEventCreateWithFlags(&ctx->ev_verdict, hipEventDisableTiming));
+    CKC(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     const size_t N = cfg->n_traj, H = cfg->horizon, n = cfg->n_dof, Km = cfg->n_kernel_max, Om = cfg->max_obs,
                  k = cfg->n_closest, d = n + 3;
     const size_t rows2 = N * k;
@@ -277,15 +255,12 @@ void omds_destroy(omds_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->dev);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     free_all(ctx);
     delete ctx;
 }
 
 int omds_sync(omds_ctx* ctx) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    int rc;
-    if ((rc = omds_resolve_pending(ctx))) return rc;
     CK(hipStreamSynchronize(ctx->stream));
     return OMDS_OK;
 }
@@ -312,7 +287,6 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
 int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const int32_t* out_dims, const float* const* W,
                     const float* const* b, int act, float out_div, int n_skips, const int32_t* skip_after) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     REQUIRE(in_dims && out_dims && W && b && n_linear >= 2, OMDS_ERR_INVALID_ARG, "omds_set_mlp: null argument or fewer than 2 Linear layers");
     REQUIRE(n_skips == 0 || skip_after, OMDS_ERR_INVALID_ARG, "omds_set_mlp_ex: n_skips > 0 needs skip_after");
     const int n = ctx->cfg.n_dof;
@@ -660,7 +634,6 @@ static bool scene_differs_from_calibration(const omds_ctx* ctx, const float* xyz
 
 int omds_set_obstacles(omds_ctx* ctx, const float* xyzr, int n_obs) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     REQUIRE(xyzr && n_obs >= 1, OMDS_ERR_INVALID_ARG, "omds_set_obstacles: need n_obs >= 1 and a non-null [O,4] array");
     REQUIRE(n_obs >= ctx->cfg.n_closest, OMDS_ERR_INVALID_ARG, "omds_set_obstacles: fewer obstacles than n_closest");
     CK(hipSetDevice(ctx->dev));
@@ -688,7 +661,6 @@ static void refresh_goal_fk(omds_ctx* ctx) {
 
 int omds_set_ds(omds_ctx* ctx, const float* q_goal) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     REQUIRE(q_goal, OMDS_ERR_INVALID_ARG, "omds_set_ds: null q_goal");
     std::memcpy(ctx->qf, q_goal, ctx->cfg.n_dof * sizeof(float));
     ctx->have_ds = true;
@@ -738,7 +710,6 @@ int omds_set_ds_seds(omds_ctx* ctx, const float* q_goal, int G, const float* mu_
 
 int omds_set_params(omds_ctx* ctx, const omds_params* p) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     REQUIRE(p, OMDS_ERR_INVALID_ARG, "omds_set_params: null params");
     REQUIRE(p->rbf_p > 0.f, OMDS_ERR_INVALID_ARG, "omds_set_params: rbf_p must be positive");
     REQUIRE((p->cost_terms & ~OMDS_COST_ALL) == 0 && (p->variant & ~3u) == 0, OMDS_ERR_INVALID_ARG,
@@ -754,7 +725,6 @@ int omds_set_params(omds_ctx* ctx, const omds_params* p) {
 
 int omds_set_cost(omds_ctx* ctx, const float* dh_params, const float* q_min, const float* q_max) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     REQUIRE(dh_params && q_min && q_max, OMDS_ERR_INVALID_ARG, "omds_set_cost: null argument");
     const int n = ctx->cfg.n_dof;
     std::memcpy(ctx->dh, dh_params, (size_t)(n + 1) * 4 * sizeof(float));
@@ -768,7 +738,6 @@ int omds_set_cost(omds_ctx* ctx, const float* dh_params, const float* q_min, con
 // ---- policy samples -------------------------------------------------------------------------------
 int omds_set_policy_samples(omds_ctx* ctx, const float* mu, const float* sigma, const float* alpha, int K) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     REQUIRE(K >= 0 && K <= ctx->cfg.n_kernel_max, OMDS_ERR_INVALID_ARG, "omds_set_policy_samples: 0 <= n_kernels <= n_kernel_max");
     CK(hipSetDevice(ctx->dev));
     ctx->n_kernels = K;
@@ -791,7 +760,6 @@ int omds_set_policy_samples(omds_ctx* ctx, const float* mu, const float* sigma, 
 int omds_sample_policy(omds_ctx* ctx, const float* mu_c, const float* sigma_c, const float* alpha_c, float mu_s,
                        float sigma_s, float alpha_s, int K, uint64_t seed, int64_t rollout_offset) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     REQUIRE(K >= 0 && K <= ctx->cfg.n_kernel_max, OMDS_ERR_INVALID_ARG, "omds_sample_policy: 0 <= n_kernels <= n_kernel_max");
     CK(hipSetDevice(ctx->dev));
     ctx->n_kernels = K;
@@ -815,7 +783,6 @@ int omds_sample_policy(omds_ctx* ctx, const float* mu_c, const float* sigma_c, c
 
 int omds_get_policy_samples(omds_ctx* ctx, float* mu, float* sigma, float* alpha) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     CK(hipSetDevice(ctx->dev));
     const int N = ctx->cfg.n_traj, n = ctx->cfg.n_dof, K = ctx->n_kernels;
     if (K == 0) return OMDS_OK;
@@ -1154,32 +1121,26 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
                                  ctx->d_dscr, ctx->n_obs, a, 0, N);
         }
         if (screen) {
-            // Off the rollouts' stream from here: the audit sample of this propagate in one throughput-shaped launch (k_audit on
-            // the recorded pairs against the kept layer-1 slabs of all horizon steps -> d_scerr[2] = max (Da - D)) and the copies
-            // of what the propagate measured, on the low-priority stream2 behind the last horizon step.  The caller's next launches
-            // (cost, the update's reductions) run beside it on the main stream; omds_resolve_pending waits for ev_verdict before
-            // anything is published.
-            static const int ab = OMDS_EXP_ENV("OMDS_AB", 2);   // experiment builds: 0 = the audit on the main stream (round 3)
-            hipStream_t s2 = (ab == 0 || ab == 3) ? ctx->stream : ctx->stream2;
-            if (ab != 0 && ab != 3) {
-                CK(hipEventRecord(ctx->ev_steps, ctx->stream));
-                CK(hipStreamWaitEvent(s2, ctx->ev_steps, 0));
-            }
+            // The audit sample of this propagate in one throughput-shaped launch: k_audit on the recorded pairs against the kept
+            // layer-1 slabs of all horizon steps -> d_scerr[2] = max (Da - D); then everything the propagate measured about its
+            // screening values comes back through pinned memory.  (Measured and rejected in round 4: k_audit on a second,
+            // low-priority stream with the verdict deferred to the next call that publishes results, so that the cost and update
+            // kernels run beside it -- 5.92-5.97 ms per iteration against 5.86 ms for this form on the same box,
+            // profiles/r04_audit_stream_ab.txt: the cross-stream dependency costs more than the 0.07 ms of kernels it overlaps.)
             if (sink.audit_rows) {
                 RoctxRange r3("screening audit sample (fp32 re-evaluation of unevaluated pairs)");
                 MlpDev ma = ctx->mlp;
                 if (ma.featQ) {   // skip-connection networks: the encoded joint inputs of every step's states, rebuilt from the stored
                                   // rollouts (trajT [H][n][N] as H slabs; the same kernel, so ApreAll is rewritten with the same bits)
                     ma.featQ = ctx->d_featQAll;
-                    omds_launch_rollout_layer1(s2, ma, ctx->d_trajT, N, H * N, ctx->d_ApreAll, nullptr, 0, N);
+                    omds_launch_rollout_layer1(ctx->stream, ma, ctx->d_trajT, N, H * N, ctx->d_ApreAll, nullptr, 0, N);
                 }
-                omds_launch_audit(s2, ma, ctx->d_ApreAll, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, ctx->prm.ignored_links,
+                omds_launch_audit(ctx->stream, ma, ctx->d_ApreAll, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, ctx->prm.ignored_links,
                                   sink.audit_rows, sink.audit_da, sink.audit_total, sink.audit_cap, ctx->d_scerr);
             }
             CK(hipGetLastError());
-            CK(hipMemcpyAsync(ctx->h_verdict, ctx->d_scerr, 16, hipMemcpyDeviceToHost, s2));
-            CK(hipMemcpyAsync(ctx->h_verdict + 4, ctx->d_sctotal, (size_t)(H + 2) * 4, hipMemcpyDeviceToHost, s2));
-            CK(hipEventRecord(ctx->ev_verdict, s2));
+            CK(hipMemcpyAsync(ctx->h_verdict, ctx->d_scerr, 16, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipMemcpyAsync(ctx->h_verdict + 4, ctx->d_sctotal, (size_t)(H + 2) * 4, hipMemcpyDeviceToHost, ctx->stream));
         }
     } else {
         for (int i = 1; i <= H; ++i) {   // MPPI.py:101: H network evaluations, the last velocity is not integrated
@@ -1191,10 +1152,10 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
     return OMDS_OK;
 }
 
+static int screened_verdict(omds_ctx* ctx, StepArgs& a, bool tail);
 int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
     RoctxRange range("TAG: general propagation");
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     REQUIRE(q_cur, OMDS_ERR_INVALID_ARG, "omds_propagate: null q_cur");
     int rc;
     if ((rc = check_ready(ctx, true))) return rc;
@@ -1233,41 +1194,26 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
     if ((rc = enqueue_rollouts(ctx, a, tail, screen))) return rc;
     CK(hipGetLastError());
     ctx->have_cost_vals = false;
+    CK(hipStreamSynchronize(ctx->stream));
     ctx->have_rollouts = true;
-    // Not synchronised: the launches are enqueued, and every entry point that reads (or overwrites) what they produce resolves
-    // the propagate first (omds_resolve_pending) -- for a screened propagate that includes its verdict.
-    ctx->pending = true;
-    ctx->pending_screen = screen;
-    ctx->pending_tail = tail;
-    ctx->pending_args = a;
-    if (OMDS_EXP_ENV("OMDS_AB", 2) < 2) return omds_resolve_pending(ctx);   // experiment builds: the verdict before returning (round 3)
+    if (screen && (rc = screened_verdict(ctx, a, tail))) return rc;
     return OMDS_OK;
 }
 
 }  // extern "C"
 
-static int enqueue_cost(omds_ctx* ctx);
-
-// What a screened propagate MEASURED about the screening values it relied on (read from the pinned verdict words):
+// What a screened propagate MEASURED about the screening values it relied on (the pinned verdict words, complete once the stream
+// has been synchronised):
 //   err   = max |Da - D| over every candidate pair (the rows nearest the decision threshold, all re-evaluated);
 //   aerr  = max (Da - D) over the audit sample, a uniform pseudo-random 1 in audit_one_in (another one every step) of
 //           the pairs that were NOT re-evaluated -- the population the selection rule's assumption is about --
-//           evaluated in fp32 by k_audit (on stream2, beside whatever the caller enqueued behind the rollouts);
+//           evaluated in fp32 by k_audit at the end of the horizon loop;
 //   slack = rollouts whose exact k-th smallest candidate came within eps of tau;
 //   serr  = (every sweep_every-th propagate) max |Da - D| over ALL pairs of the swept horizon step(s).
 // Accepted only while the errors keep a 2x margin to eps and no slack check failed; otherwise the propagate is redone with
-// the fp32 pass 1 -- its results are then the fp32 ones by construction -- before anything of it has been published.
-int omds_resolve_pending(omds_ctx* ctx, bool* redone) {
-    if (redone) *redone = false;
-    if (!ctx->pending) return OMDS_OK;
-    ctx->pending = false;
-    CK(hipSetDevice(ctx->dev));
+// the fp32 pass 1 -- its results are then the fp32 ones by construction -- before omds_propagate returns.
+static int screened_verdict(omds_ctx* ctx, StepArgs& a, bool tail) {
     const int N = ctx->cfg.n_traj, H = ctx->cfg.horizon;
-    if (!ctx->pending_screen) {
-        CK(hipStreamSynchronize(ctx->stream));
-        return OMDS_OK;
-    }
-    CK(hipEventSynchronize(ctx->ev_verdict));   // behind ev_steps on the main stream: the rollouts themselves are complete too
     const float* hv = ctx->h_verdict;
     const float err = hv[0], aerr = hv[2], serr = ctx->sweep_now ? hv[3] : 0.f;
     if (ctx->sweep_now) { ctx->screen_sweeps += ctx->sweep_steps_now; if (serr > ctx->screen_sweep_err_seen || serr != serr) ctx->screen_sweep_err_seen = serr; }
@@ -1299,12 +1245,9 @@ int omds_resolve_pending(omds_ctx* ctx, bool* redone) {
     if (!overflow && worst < 3.0e38f) ctx->screen_eps = std::max(ctx->screen_eps, 4.f * worst);
     if (++ctx->screen_consec >= 3 || !(worst < 3.0e38f)) { if (!ctx->screen_suspended) ctx->screen_suspensions++; ctx->screen_suspended = true; }
     int rc;
-    CK(hipStreamSynchronize(ctx->stream));   // whatever the caller enqueued on the rejected rollouts
-    if ((rc = enqueue_rollouts(ctx, ctx->pending_args, ctx->pending_tail, false))) return rc;   // from trajT[0], which no step overwrites
+    if ((rc = enqueue_rollouts(ctx, a, tail, false))) return rc;   // from trajT[0], which no step overwrites
     CK(hipGetLastError());
-    if (ctx->have_cost_vals && (rc = enqueue_cost(ctx))) return rc;   // a cost had been evaluated on the rejected rollouts
     CK(hipStreamSynchronize(ctx->stream));
-    if (redone) *redone = true;
     return OMDS_OK;
 }
 
@@ -1313,7 +1256,6 @@ extern "C" {
 int omds_get_rollouts(omds_ctx* ctx, float* all_traj, float* closest_dist_all, float* kernel_val_all, float* dot_products,
                       float* kernel_activations, float* qdot, float* normal) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     CK(hipSetDevice(ctx->dev));
     const int N = ctx->cfg.n_traj, H = ctx->cfg.horizon, n = ctx->cfg.n_dof, K = ctx->n_kernels, Km = ctx->cfg.n_kernel_max;
     auto fetch = [&](const float* srcT, float* dst, int X, int Xld) -> int {
@@ -1343,7 +1285,6 @@ int omds_get_rollouts(omds_ctx* ctx, float* all_traj, float* closest_dist_all, f
 int omds_get_rollout_rows(omds_ctx* ctx, const int32_t* t, int count, float* all_traj, float* closest_dist_all, float* kernel_val_all,
                           float* dot_products, float* kernel_activations, float* qdot, float* normal) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     const int N = ctx->cfg.n_traj, H = ctx->cfg.horizon, n = ctx->cfg.n_dof, K = ctx->n_kernels, Km = ctx->cfg.n_kernel_max;
     REQUIRE(t && count >= 1 && count <= N, OMDS_ERR_INVALID_ARG, "omds_get_rollout_rows: need 1 <= count <= n_traj and a non-null index array");
     for (int r = 0; r < count; ++r) REQUIRE(t[r] >= 0 && t[r] < N, OMDS_ERR_INVALID_ARG, "omds_get_rollout_rows: rollout index out of range");
@@ -1376,7 +1317,6 @@ int omds_get_rollout_rows(omds_ctx* ctx, const int32_t* t, int count, float* all
 int omds_dist_grad(omds_ctx* ctx, const float* q, int B, float* distance, float* nn_grad, float* mindist,
                    int32_t* closest_idx) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     REQUIRE(q && B >= 1 && B <= ctx->cfg.n_traj, OMDS_ERR_INVALID_ARG, "omds_dist_grad: need 1 <= batch <= n_traj and non-null q");
     int rc;
     if ((rc = check_ready(ctx, false))) return rc;
@@ -1397,7 +1337,6 @@ int omds_dist_grad(omds_ctx* ctx, const float* q, int B, float* distance, float*
 
 int omds_mlp_forward_vjp(omds_ctx* ctx, const float* x, int B, float* y, float* grad, int32_t* min_idx) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     const int n = ctx->cfg.n_dof;
     const int cap = ctx->cfg.n_traj * ctx->cfg.n_closest;
     REQUIRE(x && B >= 1 && B <= cap, OMDS_ERR_INVALID_ARG, "omds_mlp_forward_vjp: need 1 <= batch <= n_traj*n_closest and non-null x");
@@ -1468,8 +1407,6 @@ int omds_cost(omds_ctx* ctx, float* cost_out) {
     REQUIRE(ctx->have_ds && ctx->have_cost, OMDS_ERR_NOT_INITIALISED, "omds_cost: call omds_set_ds and omds_set_cost first");
     CK(hipSetDevice(ctx->dev));
     int rc;
-    if (cost_out) RESOLVE(ctx);   // publishing costs: the propagate's verdict first.  Without a fetch the kernel is only enqueued
-                                  // (beside the audit of a screened propagate); a rejected propagate re-evaluates it (omds_resolve_pending)
     if ((rc = enqueue_cost(ctx))) return rc;
     if (cost_out) {
         CK(hipMemcpyAsync(cost_out, ctx->d_cost, (size_t)ctx->cfg.n_traj * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1483,7 +1420,6 @@ int omds_cost(omds_ctx* ctx, float* cost_out) {
 int omds_cost_eval(omds_ctx* ctx, const float* all_traj, const float* closest_dist_all, int B, float* cost_out) {
     RoctxRange range("TAG: cost calculation");
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     REQUIRE(all_traj && closest_dist_all && cost_out && B >= 1 && B <= ctx->cfg.n_traj, OMDS_ERR_INVALID_ARG,
             "omds_cost_eval: need 1 <= batch <= n_traj and non-null arrays");
     REQUIRE(ctx->have_ds && ctx->have_cost, OMDS_ERR_NOT_INITIALISED, "omds_cost_eval: call omds_set_ds and omds_set_cost first");
@@ -1517,7 +1453,6 @@ int omds_cost_eval(omds_ctx* ctx, const float* all_traj, const float* closest_di
 // Local [sum(cost), N] of this shard.
 int omds_cost_sum(omds_ctx* ctx, float* out2) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     REQUIRE(out2, OMDS_ERR_INVALID_ARG, "omds_cost_sum: null output");
     REQUIRE(ctx->have_cost_vals, OMDS_ERR_NOT_INITIALISED, "no cost available: call omds_cost after omds_propagate");
     CK(hipSetDevice(ctx->dev));
@@ -1537,7 +1472,6 @@ int omds_red_count(const omds_ctx* ctx) { return ctx ? omds_red_size(ctx->n_kern
 // Packed partial sums of this shard for the GLOBAL beta = (sum_cost / n_total) / 50.
 int omds_local_sums(omds_ctx* ctx, float sum_cost, float n_total, int include_rollout0, float* red_out) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     REQUIRE(red_out && n_total > 0.f, OMDS_ERR_INVALID_ARG, "omds_local_sums: null output or n_total <= 0");
     REQUIRE(ctx->have_cost_vals, OMDS_ERR_NOT_INITIALISED, "no cost available: call omds_cost after omds_propagate");
     CK(hipSetDevice(ctx->dev));
@@ -1613,7 +1547,6 @@ int omds_get_qdot(omds_ctx* ctx, int mode, float* out) {
 int omds_kernel_candidates(omds_ctx* ctx, float thr_dist, float thr_kernel, float thr_dot, const float* mu_c,
                            const float* sigma_c, int K, int cap, float* cand_q, int32_t* cand_th, int32_t* count) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     REQUIRE(count && cap >= 0 && K >= 0 && K <= ctx->cfg.n_kernel_max, OMDS_ERR_INVALID_ARG,
             "omds_kernel_candidates: bad arguments");
     REQUIRE(K == 0 || (mu_c && sigma_c), OMDS_ERR_INVALID_ARG, "omds_kernel_candidates: null kernel means");
@@ -1650,7 +1583,6 @@ int omds_kernel_candidates(omds_ctx* ctx, float thr_dist, float thr_kernel, floa
 // ---- screening controls ------------------------------------------------------------------------------
 int omds_set_screening(omds_ctx* ctx, int mode, float eps) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     REQUIRE(mode >= -1 && mode <= 1 && eps == eps, OMDS_ERR_INVALID_ARG, "omds_set_screening: mode in {-1, 0, 1}, eps not NaN");
     ctx->screen_mode = mode;
     if (eps > 0.f) {            // the caller's bound instead of a calibration (the run-time checks still widen it when they must)
@@ -1665,7 +1597,6 @@ int omds_set_screening(omds_ctx* ctx, int mode, float eps) {
 }
 int omds_set_screening_audit(omds_ctx* ctx, int one_in) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     REQUIRE(one_in >= 0 && one_in <= (1 << 20) && (one_in & (one_in - 1)) == 0, OMDS_ERR_INVALID_ARG,
             "omds_set_screening_audit: one_in must be 0 (no audit rows) or a power of two <= 2^20");
     ctx->audit_one_in = one_in;
@@ -1673,7 +1604,6 @@ int omds_set_screening_audit(omds_ctx* ctx, int one_in) {
 }
 int omds_set_screening_sweep(omds_ctx* ctx, int every, int all_steps) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     REQUIRE(every >= 0 && (all_steps == 0 || all_steps == 1), OMDS_ERR_INVALID_ARG, "omds_set_screening_sweep: every >= 0 (0 = no sweeps), all_steps in {0, 1}");
     ctx->sweep_every = every;
     ctx->sweep_all_steps = all_steps != 0;
@@ -1681,7 +1611,6 @@ int omds_set_screening_sweep(omds_ctx* ctx, int every, int all_steps) {
 }
 int omds_screen_sweep_hist(omds_ctx* ctx, uint64_t* words, int n_words, int reset) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     REQUIRE(words && n_words == OMDS_SWEEP_HIST_WORDS, OMDS_ERR_INVALID_ARG, "omds_screen_sweep_hist: words must hold OMDS_SWEEP_HIST_WORDS entries");
     CK(hipSetDevice(ctx->dev));
     std::memset(words, 0, (size_t)n_words * 8);
@@ -1694,7 +1623,6 @@ int omds_screen_sweep_hist(omds_ctx* ctx, uint64_t* words, int n_words, int rese
 }
 int omds_screen_sweep_stats(omds_ctx* ctx, int32_t* every, int64_t* sweeps, float* sweep_max_err) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     if (every) *every = ctx->sweep_every;
     if (sweeps) *sweeps = ctx->screen_sweeps;
     if (sweep_max_err) *sweep_max_err = ctx->screen_sweep_err_seen;
@@ -1702,7 +1630,6 @@ int omds_screen_sweep_stats(omds_ctx* ctx, int32_t* every, int64_t* sweeps, floa
 }
 int omds_screen_fallback_stats(omds_ctx* ctx, int64_t* by_error, int64_t* by_slack, int64_t* by_overflow, int64_t* suspensions) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     if (by_error) *by_error = ctx->screen_fb_error;
     if (by_slack) *by_slack = ctx->screen_fb_slack;
     if (by_overflow) *by_overflow = ctx->screen_fb_overflow;
@@ -1712,7 +1639,6 @@ int omds_screen_fallback_stats(omds_ctx* ctx, int64_t* by_error, int64_t* by_sla
 int omds_screen_audit_stats(omds_ctx* ctx, int32_t* one_in, double* audit_rows_per_rollout_step, float* audit_max_err,
                             int32_t* suspended, int64_t* calibrations) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     if (one_in) *one_in = ctx->audit_one_in;
     if (audit_rows_per_rollout_step) *audit_rows_per_rollout_step = ctx->screen_steps > 0 ? ctx->screen_audit_rows / ctx->screen_steps : 0.0;
     if (audit_max_err) *audit_max_err = ctx->screen_audit_err_seen;
@@ -1735,7 +1661,6 @@ int omds_debug_force_tile_rows(int tail_sel_rows, int tail_rows) {
 
 int omds_screen_debug_corrupt(omds_ctx* ctx, int what, int index, float value) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     REQUIRE(ctx->screen_ok, OMDS_ERR_UNSUPPORTED, "omds_screen_debug_corrupt: no screening network for this model");
     CK(hipSetDevice(ctx->dev));
     CK(hipStreamSynchronize(ctx->stream));
@@ -1759,7 +1684,6 @@ int omds_screen_debug_corrupt(omds_ctx* ctx, int what, int index, float value) {
 // Diagnostic: the screening network alone on a batch (what k_select sees), for tests and for measuring eps.
 int omds_screen_mindist(omds_ctx* ctx, const float* q, int B, float* mindist) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     REQUIRE(q && mindist && B >= 1 && B <= ctx->cfg.n_traj, OMDS_ERR_INVALID_ARG, "omds_screen_mindist: need 1 <= batch <= n_traj and non-null arrays");
     int rc;
     if ((rc = check_ready(ctx, false))) return rc;
@@ -1778,7 +1702,6 @@ int omds_screen_mindist(omds_ctx* ctx, const float* q, int B, float* mindist) {
 int omds_screen_stats(omds_ctx* ctx, int32_t* active, float* eps, float* max_err_seen, double* cand_per_rollout_step,
                       int64_t* fallbacks) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     if (active) *active = (ctx->screen_ok && screen_wanted(ctx)) ? 1 : 0;
     if (eps) *eps = ctx->screen_eps;
     if (max_err_seen) *max_err_seen = ctx->screen_err_seen;
@@ -1796,7 +1719,6 @@ int omds_prof_enable(omds_ctx* ctx, int on) {
 }
 int omds_prof_reset(omds_ctx* ctx) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     ctx->prof.ms = 0.0;
     ctx->prof_seen = 0;
     ctx->prof.launches = 0;
@@ -1810,7 +1732,6 @@ int omds_prof_reset(omds_ctx* ctx) {
 }
 int omds_prof_read_ex(omds_ctx* ctx, double* ms, int64_t* launches, double* flops, const char** kernel) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     { const int rc = prof_collect(ctx); if (rc) return rc; }
     if (ms) *ms = ctx->prof.ms;
     if (launches) *launches = ctx->prof.launches;
@@ -1820,7 +1741,6 @@ int omds_prof_read_ex(omds_ctx* ctx, double* ms, int64_t* launches, double* flop
 }
 int omds_prof_read(omds_ctx* ctx, double* pass1_ms, int64_t* pass1_launches, int64_t* pass1_rows) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    RESOLVE(ctx);
     { const int rc = prof_collect(ctx); if (rc) return rc; }
     if (pass1_ms) *pass1_ms = ctx->prof.ms;
     if (pass1_launches) *pass1_launches = ctx->prof.launches;

@@ -128,7 +128,6 @@ int omds_comm_unique_id(uint8_t* out128) {
 
 int omds_comm_init_rank(omds_ctx* ctx, const uint8_t* id128, int rank, int world) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    { const int rrc = omds_resolve_pending(ctx); if (rrc) return rrc; }
     REQUIRE(id128 && world >= 1 && rank >= 0 && rank < world, OMDS_ERR_INVALID_ARG,
             "omds_comm_init_rank: need a 128-byte id and 0 <= rank < world");
     REQUIRE(rccl().ok(), OMDS_ERR_RCCL, rccl().err);
@@ -149,7 +148,6 @@ int omds_comm_init_rank(omds_ctx* ctx, const uint8_t* id128, int rank, int world
 
 int omds_comm_destroy(omds_ctx* ctx) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    { const int rrc = omds_resolve_pending(ctx); if (rrc) return rrc; }
     CK(hipSetDevice(ctx->dev));
     CK(hipStreamSynchronize(ctx->stream));
     omds_comm_release(ctx);
@@ -201,20 +199,7 @@ int omds_update_impl(omds_ctx* ctx, bool use_comm, float rate, float ker_thr, fl
         CK(hipMemcpyAsync(ctx->h_red, ctx->d_red, (size_t)(rs + 2) * 4, hipMemcpyDeviceToHost, ctx->stream));
         return OMDS_OK;
     };
-    int erc;
-    if (comm && world > 1) {
-        // several ranks: the verdict of this rank's propagate BEFORE the first collective -- a rank that had to redo its rollouts
-        // after its collectives were enqueued would have to repeat them alone
-        if ((erc = omds_resolve_pending(ctx))) return erc;
-        if ((erc = enqueue())) return erc;
-    } else {
-        // one shard: the reductions run on the main stream beside the audit of a screened propagate (stream2); the verdict is
-        // awaited afterwards, and a rejected propagate (redone in fp32, its cost re-evaluated) gets the reductions again
-        if ((erc = enqueue())) return erc;
-        bool redone = false;
-        if ((erc = omds_resolve_pending(ctx, &redone))) return erc;
-        if (redone && (erc = enqueue())) return erc;
-    }
+    { const int erc = enqueue(); if (erc) return erc; }
     CK(hipStreamSynchronize(ctx->stream));
     const float* red = ctx->h_red;
     const float n_total = red[rs + 1];

@@ -129,19 +129,7 @@ struct omds_ctx {
     int dev = 0;
     hipStream_t stream = nullptr;
     std::string err;
-    // A propagate returns once its launches are enqueued; every entry point that reads or overwrites what it produced first calls
-    // omds_resolve_pending.  A SCREENED propagate additionally carries a verdict (omds.h: accepted only while every error it measured
-    // keeps its margin): its audit sample is evaluated by k_audit on a second, low-priority stream next to whatever the caller enqueues
-    // behind the rollouts (cost, the update's reductions), the four error words + the list totals come back through pinned memory, and
-    // a rejected propagate is redone with the fp32 pass 1 (and the cost with it) before anything of it is published.
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_steps = nullptr;       // main stream: the horizon loop of the pending propagate is enqueued up to here
-    hipEvent_t ev_verdict = nullptr;     // stream2: k_audit and the copies into h_verdict are done
-    float* h_verdict = nullptr;          // pinned [4 + H + 2]: d_scerr, d_sctotal of the pending propagate
-    bool pending = false;                // a propagate has been enqueued and not resolved yet
-    bool pending_screen = false;         // ... and it was a screened one (a verdict is due)
-    bool pending_tail = false;
-    StepArgs pending_args{};
+    float* h_verdict = nullptr;          // pinned [4 + H + 2]: d_scerr, d_sctotal of the propagate being finished
     // network
     bool have_mlp = false;
     MlpDev mlp{};
@@ -293,10 +281,6 @@ struct omds_ctx {
         }                                                                                 \
     } while (0)
 
-// capi.hip: waits for the pending propagate (and, for a screened one, its verdict: a rejected propagate is redone in fp32 here,
-// its cost re-evaluated when one had been enqueued on it).  *redone (optional) tells the caller that what it enqueued behind the
-// rollouts in the meantime was computed from rejected rollouts.  No-op when nothing is pending.
-int omds_resolve_pending(omds_ctx* ctx, bool* redone = nullptr);
 // comm.hip: releases the communicator and its buffers (called by omds_destroy)
 void omds_comm_release(omds_ctx* ctx);
 // the cost-weighted update on the context stream (one host sync); use_comm = reduce over the communicator's shards
