@@ -197,6 +197,14 @@ OMDS_API int omds_cost_eval(omds_ctx* ctx, const float* all_traj, const float* c
  * kernels; mask_out [K] (1 = updated); weights_out [N] (normalised MPPI weights) or NULL.   */
 OMDS_API int omds_weighted_update(omds_ctx* ctx, float rate, float ker_thr, float* mu_c, float* sigma_c,
                                   float* alpha_c, int32_t* mask_out, float* weights_out);
+/* The same update on caller-supplied tensors (MPPI.shift_policy_means reads self.cost, self.kernel_val_all and
+ * self.kernel_activations, MPPI.py:333-341), the way omds_cost_eval serves Cost.evaluate_costs: cost [N], kernel_val_all [N,H,K],
+ * kernel_activations [N,H] in the reference layouts (K = the kernel count of the policy samples the context holds; they are the
+ * theta_tmp of the update).  The context's own rollouts, cost and running maxima stay untouched.  Teacher-forced parity: the
+ * reference's own rollout tensors in, its updated means out.                                                              */
+OMDS_API int omds_weighted_update_eval(omds_ctx* ctx, const float* cost, const float* kernel_val_all, const float* kernel_activations,
+                                       float rate, float ker_thr, float* mu_c, float* sigma_c, float* alpha_c, int32_t* mask_out,
+                                       float* weights_out);
 /* MPPI.get_qdot (MPPI.py:319-329): mode 0 = 'best', 1 = 'weighted'; out [n]. */
 OMDS_API int omds_get_qdot(omds_ctx* ctx, int mode, float* out);
 

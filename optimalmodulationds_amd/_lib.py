@@ -76,6 +76,7 @@ SIGNATURES = {
     "omds_cost": (C.c_int, [C.c_void_p, F32P]),
     "omds_cost_eval": (C.c_int, [C.c_void_p, F32P, F32P, C.c_int, F32P]),
     "omds_weighted_update": (C.c_int, [C.c_void_p, C.c_float, C.c_float, F32P, F32P, F32P, I32P, F32P]),
+    "omds_weighted_update_eval": (C.c_int, [C.c_void_p, F32P, F32P, F32P, C.c_float, C.c_float, F32P, F32P, F32P, I32P, F32P]),
     "omds_get_qdot": (C.c_int, [C.c_void_p, C.c_int, F32P]),
     "omds_kernel_candidates": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, F32P, F32P, C.c_int, C.c_int,
                                          F32P, I32P, I32P]),

@@ -120,7 +120,7 @@ static void free_all(omds_ctx* ctx) {
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
                     ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
                     ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
-                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP, ctx->d_seds, ctx->d_audit_rows, ctx->d_audit_da, ctx->d_ApreAll, ctx->d_featQAll, ctx->d_FqS, ctx->d_FpS, ctx->d_listDa, ctx->d_sinks, ctx->d_qcur, ctx->d_sweepD, ctx->d_sweepDa, ctx->d_sweep_hist};
+                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP, ctx->d_seds, ctx->d_audit_rows, ctx->d_audit_da, ctx->d_ApreAll, ctx->d_featQAll, ctx->d_FqS, ctx->d_FpS, ctx->d_listDa, ctx->d_sinks, ctx->d_qcur, ctx->d_sweepD, ctx->d_sweepDa, ctx->d_sweep_hist, ctx->d_uev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : ctx->mlp_allocs)
@@ -1521,6 +1521,46 @@ int omds_weighted_update(omds_ctx* ctx, float rate, float ker_thr, float* mu_c, 
     if ((rc = omds_update_impl(ctx, false, rate, ker_thr, mu_c, sigma_c, alpha_c, mask_out, nullptr, nullptr, nullptr))) return rc;
     if (weights_out) {
         const int N = ctx->cfg.n_traj;
+        std::vector<float> w(N);
+        CK(hipMemcpy(w.data(), ctx->d_w, (size_t)N * 4, hipMemcpyDeviceToHost));
+        for (int t = 0; t < N; ++t) weights_out[t] = w[t] / ctx->h_red[0];
+    }
+    return OMDS_OK;
+}
+
+// MPPI.shift_policy_means + TensorPolicyMPPI.update_policy (MPPI.py:331-345, policy.py:88-113) on caller-supplied tensors, the way
+// omds_cost_eval serves Cost.evaluate_costs: cost [N], kernel_val_all [N,H,K], kernel_activations [N,H] in the reference layouts, against
+// the policy samples the context holds.  The context's own rollouts, cost values and running maxima are not touched.
+int omds_weighted_update_eval(omds_ctx* ctx, const float* cost, const float* kernel_val_all, const float* kernel_activations, float rate,
+                              float ker_thr, float* mu_c, float* sigma_c, float* alpha_c, int32_t* mask_out, float* weights_out) {
+    RoctxRange range("shift_policy_means");
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    const int N = ctx->cfg.n_traj, H = ctx->cfg.horizon, n = ctx->cfg.n_dof, K = ctx->n_kernels, Km = ctx->cfg.n_kernel_max;
+    REQUIRE(cost && kernel_activations && (K == 0 || (kernel_val_all && mu_c && sigma_c && alpha_c)), OMDS_ERR_INVALID_ARG,
+            "omds_weighted_update_eval: null argument");
+    CK(hipSetDevice(ctx->dev));
+    if (!ctx->d_uev) CK(hipMalloc(&ctx->d_uev, ((size_t)N + (size_t)Km * N + Km + (size_t)N * H) * 4));
+    float* d_costv = ctx->d_uev;
+    float* d_maxact = d_costv + N;
+    float* d_phisum0 = d_maxact + (size_t)Km * N;
+    float* d_act = d_phisum0 + Km;
+    CK(hipMemcpyAsync(d_costv, cost, (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipMemcpyAsync(d_act, kernel_activations, (size_t)N * H * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (K > 0) {
+        CK(hipMemcpyAsync(ctx->d_stage, kernel_val_all, (size_t)N * H * K * 4, hipMemcpyHostToDevice, ctx->stream));   // stage_bytes >= N*H*Kmax*4
+        omds_launch_update_inputs(ctx->stream, ctx->d_stage, d_act, N, H, K, (ctx->prm.variant & OMDS_VARIANT_KVAL_TIMES_ACT) ? 1 : 0, d_maxact, d_phisum0);
+    }
+    const int rs = omds_red_size(K, n);
+    float* red2 = ctx->d_red + rs;
+    omds_launch_cost_sum(ctx->stream, d_costv, N, red2);
+    omds_launch_weights(ctx->stream, d_costv, N, red2, ctx->d_w, nullptr);
+    omds_launch_policy_sums(ctx->stream, N, n, K, ctx->d_w, ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, d_maxact, d_phisum0, ctx->d_qdotT, d_costv, 1, ctx->d_red);
+    CK(hipGetLastError());
+    CK(hipMemcpyAsync(ctx->h_red, ctx->d_red, (size_t)(rs + 2) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    const int rc = omds_apply_update(K, n, H, ctx->h_red, ctx->h_red[rs + 1], rate, ker_thr, ctx->prm.variant, mu_c, sigma_c, alpha_c, mask_out);
+    if (rc) { ctx->err = "omds_apply_update: invalid argument"; return rc; }
+    if (weights_out) {
         std::vector<float> w(N);
         CK(hipMemcpy(w.data(), ctx->d_w, (size_t)N * 4, hipMemcpyDeviceToHost));
         for (int t = 0; t < N; ++t) weights_out[t] = w[t] / ctx->h_red[0];

@@ -238,6 +238,7 @@ struct omds_ctx {
     float* d_dscr = nullptr;     // tanh only: [hidden layers][N*k padded to 32][256] activation derivatives
     float* d_dist = nullptr;     // [N]
     float* d_nngrad = nullptr;   // [N][n]
+    float* d_uev = nullptr;      // omds_weighted_update_eval scratch (first use): cost [N], maxact [Kmax][N], phisum0 [Kmax], act [N][H]
     float* d_evalT = nullptr;    // omds_cost_eval scratch (first use): caller tensors in SoA + their cost
     float* d_vjp_xyzr = nullptr; // omds_mlp_forward_vjp scratch (first use): per-row points, their layer-1 halves, zero radii
     float* d_vjp_B = nullptr;
@@ -428,5 +429,7 @@ void omds_launch_broadcast_q(hipStream_t s, const float* q_host_vals, int n, int
 // layout conversions between reference (AoS) and device (SoA) orders
 void omds_launch_transpose(hipStream_t s, const float* src, float* dst, int rows, int cols);  // dst[c][r] = src[r][c]
 void omds_launch_permute_hxn_to_nhx(hipStream_t s, const float* srcT, float* dst, int H, int X, int N, int Xld);
+void omds_launch_update_inputs(hipStream_t s, const float* kval, const float* act, int N, int H, int K, int kval_is_product, float* maxact,
+                               float* phisum0);
 void omds_launch_gather_rows(hipStream_t s, const float* srcT, float* dst, const int* tlist, int count, int H, int X, int N, int Xld);
 

@@ -520,3 +520,27 @@ void omds_launch_gather_rows(hipStream_t s, const float* srcT, float* dst, const
     if (total <= 0) return;
     hipLaunchKernelGGL(k_gather_rows, dim3((total + 255) / 256), dim3(256), 0, s, srcT, dst, tlist, count, H, X, N, Xld);
 }
+
+// What the horizon loop accumulates for the update (step_device.h: maxact, phisum0), from caller-supplied tensors in the reference
+// layouts (omds_weighted_update_eval): maxact[kk][t] = max_h(phi * act) with the loop's NaN rule, phisum0[kk] = sum_h phi of rollout 0
+// in the loop's order.  kval_is_product: OMDS_VARIANT_KVAL_TIMES_ACT (the stored kernel values already hold phi * act).
+__global__ __launch_bounds__(256) void k_update_inputs(const float* __restrict__ kval, const float* __restrict__ act, int N, int H, int K,
+                                                       int kval_is_product, float* __restrict__ maxact, float* __restrict__ phisum0) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * K) return;
+    const int t = e / K, kk = e % K;
+    float m = 0.f, s = 0.f;
+    for (int h = 0; h < H; ++h) {
+        const float phi = kval[((size_t)t * H + h) * K + kk];
+        const float pa = kval_is_product ? phi : phi * act[(size_t)t * H + h];
+        m = (h == 0) ? pa : ((m != m || pa != pa) ? __builtin_nanf("") : fmaxf(m, pa));
+        s = (h == 0 ? 0.f : s) + phi;
+    }
+    maxact[(size_t)kk * N + t] = m;
+    if (t == 0) phisum0[kk] = s;
+}
+void omds_launch_update_inputs(hipStream_t s, const float* kval, const float* act, int N, int H, int K, int kval_is_product, float* maxact,
+                               float* phisum0) {
+    if (N * K <= 0) return;
+    hipLaunchKernelGGL(k_update_inputs, dim3((N * K + 255) / 256), dim3(256), 0, s, kval, act, N, H, K, kval_is_product, maxact, phisum0);
+}

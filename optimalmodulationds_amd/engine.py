@@ -212,6 +212,22 @@ class Engine:
                                                L.iptr(mask), L.fptr(w)))
         return mu, sg, al, mask.astype(bool), w
 
+    def weighted_update_eval(self, cost, kernel_val_all, kernel_activations, rate, ker_thr, mu_c, sigma_c, alpha_c, want_weights=False):
+        """shift_policy_means on caller-supplied tensors (cost [N], kernel_val_all [N,H,K], kernel_activations [N,H]) against the
+        policy samples the context holds; the context's own rollouts and cost stay untouched."""
+        K = self.K
+        c = L.f32(cost).reshape(self.N)
+        kv = np.ascontiguousarray(L.f32(kernel_val_all).reshape(self.N, self.H, -1)[:, :, :K]) if K else None
+        ka = L.f32(kernel_activations).reshape(self.N, self.H)
+        mu = np.array(np.asarray(mu_c, dtype=np.float32)[:K], dtype=np.float32, order="C", copy=True).reshape(K, self.n)
+        sg = np.array(np.asarray(sigma_c, dtype=np.float32)[:K], dtype=np.float32, order="C", copy=True).reshape(K)
+        al = np.array(np.asarray(alpha_c, dtype=np.float32)[:K], dtype=np.float32, order="C", copy=True).reshape(K, self.n)
+        mask = np.zeros(K, np.int32)
+        w = np.zeros(self.N, np.float32) if want_weights else None
+        self._ck(self.lib.omds_weighted_update_eval(self.h, L.fptr(c), L.fptr(kv), L.fptr(ka), float(rate), float(ker_thr),
+                                                    L.fptr(mu), L.fptr(sg), L.fptr(al), L.iptr(mask), L.fptr(w)))
+        return mu, sg, al, mask.astype(bool), w
+
     def get_qdot(self, mode="best"):
         out = np.zeros(self.n, np.float32)
         self._ck(self.lib.omds_get_qdot(self.h, 0 if mode == "best" else 1, L.fptr(out)))

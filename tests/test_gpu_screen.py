@@ -93,27 +93,37 @@ def test_screened_propagate_is_bit_identical(N, H, iters):
 
 
 def test_screened_teacher_forced_fixture():
-    """The reference-captured Franka shelf fixture through the screened path (per-rollout start states)."""
+    """The reference-captured Franka shelf fixture through the screened path (per-rollout start states): the screened step
+    returns the bits of the all-fp32 step -- with the tile shapes each launcher picks for this small batch (N = 64: different
+    heights for the two steps) and with both forced to 32-row tiles (omds_debug_force_tile_rows), not merely equal to rounding."""
     fx = load("franka_shelf_K6")
+    from optimalmodulationds_amd import _lib
     from optimalmodulationds_amd.engine import Engine
     m = orc.Mlp.from_npz(weights_path("franka"))
     N, H, K = int(fx["N"]), int(fx["H"]), int(fx["K"])
-    outs = []
-    for mode in (0, 1):
-        e = Engine(7, N, H, int(fx["k"]), max_obs=512)
-        e.set_mlp(m.W, m.b)
-        e.set_obstacles(fx["obs"])
-        e.params.dt, e.params.dst_thr = float(fx["dt"]), float(fx["dst_thr"])
-        e.params.ignored_links = sum(1 << int(l) for l in fx["ignored_links"])
-        e.push_params()
-        e.set_ds(fx["qf"])
-        e.set_screening(mode)
-        e.set_policy_samples(fx["it0_mu_tmp"][:, :K], fx["it0_sigma_tmp"][:, :K], fx["it0_alpha_tmp"][:, :K])
-        e.propagate(fx["it0_q_cur"])
-        outs.append(e.get_rollouts())
-        e.close()
-    for key in KEYS:   # N = 64: the unscreened step runs 16-row pass-2 tiles, the screened one 32-row tiles -> equal to fp32 rounding
-        assert np.abs(outs[0][key] - outs[1][key]).max() <= 2e-4 * max(1.0, float(np.abs(outs[0][key]).max())), key
+    hooks = _lib.load_test_hooks()
+    for forced in ((0, 0), (32, 32)):
+        outs = []
+        for mode in (0, 1):
+            e = Engine(7, N, H, int(fx["k"]), max_obs=512, lib=hooks)
+            try:
+                e.debug_force_tile_rows(*forced)
+                e.set_mlp(m.W, m.b)
+                e.set_obstacles(fx["obs"])
+                e.params.dt, e.params.dst_thr = float(fx["dt"]), float(fx["dst_thr"])
+                e.params.ignored_links = sum(1 << int(l) for l in fx["ignored_links"])
+                e.push_params()
+                e.set_ds(fx["qf"])
+                e.set_screening(mode)
+                e.set_policy_samples(fx["it0_mu_tmp"][:, :K], fx["it0_sigma_tmp"][:, :K], fx["it0_alpha_tmp"][:, :K])
+                e.propagate(fx["it0_q_cur"])
+                outs.append(e.get_rollouts())
+                assert e.screen_stats()["fallbacks"] == 0
+            finally:
+                e.debug_force_tile_rows(0, 0)
+                e.close()
+        for key in KEYS:
+            assert np.array_equal(outs[0][key], outs[1][key]), (forced, key, float(np.nanmax(np.abs(outs[0][key] - outs[1][key]))))
 
 
 def test_guards_trip_on_a_bound_that_is_too_small():

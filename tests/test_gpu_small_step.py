@@ -105,7 +105,12 @@ def test_fused_small_step_against_the_oracle():
     assert_close(r["kernel_val_all"][tt, hh], st["phi"], RTOL, "rbf")
     nxt = (hh + 1 < H) & ok
     vel = (r["all_traj"][tt[nxt], hh[nxt] + 1] - q[nxt]) / np.float32(0.3)
-    assert np.abs(vel - st["u"][nxt]).max() <= 2e-4 * max(1.0, float(np.abs(st["u"]).max()))
+    # inside the envelope the oracle's modulation spans when the network distance moves by +-DIST_ULP x its scale (helpers), for
+    # the oracle's and the device's own normal -- the bar of every other full-size test, not the 2e-4 this test held until round 3
+    from helpers import assert_velocity_in_envelope
+    prm = orc.Params(dst_thr=0.25)
+    assert_velocity_in_envelope(vel, q[nxt], qf, d[nxt], (g[nxt], r["normal"][tt, hh][nxt]), mu[tt][nxt], sg[tt][nxt], al[tt][nxt], prm,
+                                float(np.abs(d).max()), "integrated velocity", pad=4e-6 * max(1.0, float(np.abs(q).max())) / 0.3)
     e.close()
 
 
