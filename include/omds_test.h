@@ -23,6 +23,13 @@ OMDS_API int omds_screen_debug_corrupt(omds_ctx* ctx, int what, int index, float
  * for the unscreened one; 0 = the launcher chooses again.  Every shape computes the same bits per row: the tests run them against
  * each other.                                                                                                             */
 OMDS_API int omds_debug_force_tile_rows(int tail_sel_rows, int tail_rows);
+/* The HOST half of omds_set_mlp_ex alone: argument validation, zero-padding to the kernels' width and every MFMA fragment pack
+ * (fp32 forward / backward, 16-row, 4-row-group, fp16 screening slices), with no device and no context -- the sanitizer build
+ * (`make asan`) runs it on the CPU (tests/test_asan_cpu.py).  *checksum = FNV-1a over all packs, *bytes = their total size (NULL =
+ * skip); the message of a failure through omds_last_error(NULL).                                                          */
+OMDS_API int omds_test_pack_mlp(int n_dof, int n_linear, const int32_t* in_dims, const int32_t* out_dims, const float* const* W,
+                                const float* const* b, int act, float out_div, int n_skips, const int32_t* skip_after,
+                                uint64_t* checksum, int64_t* bytes);
 
 #ifdef __cplusplus
 }

@@ -284,34 +284,48 @@ int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* 
     return omds_set_mlp_ex(ctx, n_linear, dims, dims + 1, W, b, act, out_div, 0, nullptr);
 }
 
-int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const int32_t* out_dims, const float* const* W,
-                    const float* const* b, int act, float out_div, int n_skips, const int32_t* skip_after) {
-    if (!ctx) return OMDS_ERR_INVALID_ARG;
-    REQUIRE(in_dims && out_dims && W && b && n_linear >= 2, OMDS_ERR_INVALID_ARG, "omds_set_mlp: null argument or fewer than 2 Linear layers");
-    REQUIRE(n_skips == 0 || skip_after, OMDS_ERR_INVALID_ARG, "omds_set_mlp_ex: n_skips > 0 needs skip_after");
-    const int n = ctx->cfg.n_dof;
-    REQUIRE(in_dims[0] == 3 * (n + 3) || in_dims[0] == 3 * (n + 2), OMDS_ERR_INVALID_ARG,
-            "omds_set_mlp: dims[0] must be 3*(n_dof+3), or 3*(n_dof+2) for planar obstacle points (NeRF encoding [x, sin x, cos x])");
+// Everything omds_set_mlp_ex derives from the caller's weights on the HOST: validation, zero-padding to the kernels' width, and the
+// MFMA fragment packs.  No device, no context: the sanitizer build runs it on the CPU (tests/test_asan_cpu.py through
+// omds_test_pack_mlp).
+struct MlpPacks {
+    int nhh = 0, C = 0, d = 0, act = 0;
+    float out_div = 1.f;
+    uint32_t skip_mask = 0;
+    uint8_t skip_col[OMDS_MAX_HIDDEN + 1] = {0};
+    std::vector<float4> wf, wb, wf16, wb16, wb4, wl, w1b, w1b16;
+    std::vector<float> bh, bl, wlraw, whraw, w1t, b1, sbias;
+    std::vector<uint16_t> wh;
+    double f_fwd = 0.0, f_bwd = 0.0;
+};
+#define PREQ(cond, code, msg) do { if (!(cond)) { err = (msg); return (code); } } while (0)
+static int build_mlp_packs(int n, int n_linear, const int32_t* in_dims, const int32_t* out_dims, const float* const* W,
+                           const float* const* b, int act, float out_div, int n_skips, const int32_t* skip_after, MlpPacks& pk,
+                           std::string& err) {
+    PREQ(in_dims && out_dims && W && b && n_linear >= 2, OMDS_ERR_INVALID_ARG, "omds_set_mlp: null argument or fewer than 2 Linear layers");
+    PREQ(n_skips == 0 || skip_after, OMDS_ERR_INVALID_ARG, "omds_set_mlp_ex: n_skips > 0 needs skip_after");
+    PREQ(in_dims[0] == 3 * (n + 3) || in_dims[0] == 3 * (n + 2), OMDS_ERR_INVALID_ARG,
+         "omds_set_mlp: dims[0] must be 3*(n_dof+3), or 3*(n_dof+2) for planar obstacle points (NeRF encoding [x, sin x, cos x])");
     const int d = in_dims[0] / 3;
-    REQUIRE(3 * d <= 32, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: 3*(n_dof+3) > 32 not supported");
+    PREQ(3 * d <= 32, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: 3*(n_dof+3) > 32 not supported");
     const int nhid = n_linear - 1;
-    REQUIRE(nhid <= OMDS_MAX_HIDDEN, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: too many hidden layers");
+    PREQ(nhid <= OMDS_MAX_HIDDEN, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: too many hidden layers");
     uint32_t skip_mask = 0;   // bit i: the encoded input is concatenated behind the activations of Linear i (network_macros_mod.py:142-146)
     for (int s = 0; s < n_skips; ++s) {
-        REQUIRE(skip_after[s] >= 0 && skip_after[s] < nhid, OMDS_ERR_INVALID_ARG,
-                "omds_set_mlp_ex: skip_after entries must name a hidden Linear layer (0 .. n_linear-2)");
+        PREQ(skip_after[s] >= 0 && skip_after[s] < nhid, OMDS_ERR_INVALID_ARG,
+             "omds_set_mlp_ex: skip_after entries must name a hidden Linear layer (0 .. n_linear-2)");
         skip_mask |= 1u << skip_after[s];
     }
     for (int i = 0; i < nhid; ++i)
-        REQUIRE(out_dims[i] >= 1 && out_dims[i] + (((skip_mask >> i) & 1u) ? 3 * d : 0) <= OMDS_WIDTH, OMDS_ERR_UNSUPPORTED,
-                "omds_set_mlp: hidden widths (plus a concatenated input) above 256 are not supported by the MFMA kernels (narrower layers are zero-padded to width 256)");
+        PREQ(out_dims[i] >= 1 && out_dims[i] + (((skip_mask >> i) & 1u) ? 3 * d : 0) <= OMDS_WIDTH, OMDS_ERR_UNSUPPORTED,
+             "omds_set_mlp: hidden widths (plus a concatenated input) above 256 are not supported by the MFMA kernels (narrower layers are zero-padded to width 256)");
     for (int i = 1; i < n_linear; ++i)
-        REQUIRE(in_dims[i] == out_dims[i - 1] + (((skip_mask >> (i - 1)) & 1u) ? 3 * d : 0), OMDS_ERR_INVALID_ARG,
-                "omds_set_mlp: the input width of a Linear layer must be the previous output width (+ 3*(n_dof+3) behind a skip concatenation)");
+        PREQ(in_dims[i] == out_dims[i - 1] + (((skip_mask >> (i - 1)) & 1u) ? 3 * d : 0), OMDS_ERR_INVALID_ARG,
+             "omds_set_mlp: the input width of a Linear layer must be the previous output width (+ 3*(n_dof+3) behind a skip concatenation)");
     const int C = out_dims[n_linear - 1];
-    REQUIRE(C >= 1 && C <= OMDS_CPAD, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: 1 <= out_channels <= 16 required");
-    REQUIRE(act == OMDS_ACT_RELU || act == OMDS_ACT_TANH, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: act must be OMDS_ACT_RELU or OMDS_ACT_TANH");
-    REQUIRE(out_div != 0.f, OMDS_ERR_INVALID_ARG, "omds_set_mlp: out_div must be non-zero");
+    PREQ(C >= 1 && C <= OMDS_CPAD, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: 1 <= out_channels <= 16 required");
+    PREQ(act == OMDS_ACT_RELU || act == OMDS_ACT_TANH, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: act must be OMDS_ACT_RELU or OMDS_ACT_TANH");
+    PREQ(out_div != 0.f, OMDS_ERR_INVALID_ARG, "omds_set_mlp: out_div must be non-zero");
+    for (int i = 0; i < n_linear; ++i) PREQ(W[i] && b[i], OMDS_ERR_INVALID_ARG, "omds_set_mlp: null weight or bias array");
     // Narrower hidden layers (the reference also ships 128-wide nets) are zero-padded to the kernels' width:
     // padded units have zero weights and biases on both sides, so relu/tanh(0) = 0 feeds nothing forward and
     // receives no gradient -- outputs and gradients are unchanged (the padded MFMA work is wasted, not wrong).
@@ -332,40 +346,21 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
     }
     W = Wp.data();
     b = bp.data();
-    CK(hipSetDevice(ctx->dev));
-    CK(hipStreamSynchronize(ctx->stream));
-    for (void* p : ctx->mlp_allocs) (void)hipFree(p);
-    ctx->mlp_allocs.clear();
-    ctx->have_mlp = false;
-    MlpDev m{};
-    m.nhh = nhid - 1;
-    m.C = C;
-    m.d = d;
-    m.n_dof = n;
-    m.out_div = out_div;
-    m.act = act;
-    m.skip_mask = skip_mask;
-    for (int i = 0; i < nhid; ++i) m.skip_col[i] = (uint8_t)(((skip_mask >> i) & 1u) ? out_dims[i] : 0);
-    if (skip_mask) {   // encoded-input tables beside Apre / Bpre, written by the layer-1 kernels (zero in the other operand's slots)
-        const size_t rowsA = (size_t)ctx->cfg.n_traj * ctx->cfg.n_closest, rowsB = (size_t)ctx->cfg.max_obs;
-        if (!ctx->d_featQ) CK(hipMalloc(&ctx->d_featQ, rowsA * 32 * 4));
-        if (!ctx->d_featP) CK(hipMalloc(&ctx->d_featP, rowsB * 32 * 4));
-        CK(hipMemsetAsync(ctx->d_featQ, 0, rowsA * 32 * 4, ctx->stream));
-        CK(hipMemsetAsync(ctx->d_featP, 0, rowsB * 32 * 4, ctx->stream));
-        m.featQ = ctx->d_featQ;
-        m.featP = ctx->d_featP;
-    }
-    if (ctx->d_dscr) { (void)hipFree(ctx->d_dscr); ctx->d_dscr = nullptr; }
-    if (act == OMDS_ACT_TANH) {   // pass 2 keeps 1 - h^2 of every hidden layer for the backward (ReLU uses LDS bit masks)
-        const size_t rows = std::max(((size_t)ctx->cfg.n_traj * ctx->cfg.n_closest + 31) / 32 * 32,
-                                     (size_t)omds_tail_scratch_rows(ctx->cfg.n_traj, ctx->cfg.n_closest));
-        CK(hipMalloc(&ctx->d_dscr, (size_t)nhid * rows * OMDS_WIDTH * 4));
-    }
+    pk.nhh = nhid - 1;
+    pk.C = C;
+    pk.d = d;
+    pk.out_div = out_div;
+    pk.act = act;
+    pk.skip_mask = skip_mask;
+    for (int i = 0; i < nhid; ++i) pk.skip_col[i] = (uint8_t)(((skip_mask >> i) & 1u) ? out_dims[i] : 0);
+    const int nhh = pk.nhh;
     const int Wd = OMDS_WIDTH;
     // hidden->hidden: forward and transposed (backward) fragment packs
-    std::vector<float4> wf((size_t)std::max(m.nhh, 1) * OMDS_NCB * 32 * 64), wb(wf.size());
-    std::vector<float> bh((size_t)std::max(m.nhh, 1) * Wd, 0.f);
-    for (int l = 0; l < m.nhh; ++l) {
+    std::vector<float4>&wf = pk.wf, &wb = pk.wb;
+    wf.assign((size_t)std::max(nhh, 1) * OMDS_NCB * 32 * 64, make_float4(0, 0, 0, 0));
+    wb.assign(wf.size(), make_float4(0, 0, 0, 0));
+    pk.bh.assign((size_t)std::max(nhh, 1) * Wd, 0.f);
+    for (int l = 0; l < nhh; ++l) {
         const float* Wl = W[l + 1];
         for (int cb = 0; cb < OMDS_NCB; ++cb)
             for (int c = 0; c < 32; ++c)
@@ -375,14 +370,16 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
                     wf[o] = make_float4(Wl[j * Wd + k0], Wl[j * Wd + k0 + 1], Wl[j * Wd + k0 + 2], Wl[j * Wd + k0 + 3]);
                     wb[o] = make_float4(Wl[(k0)*Wd + j], Wl[(k0 + 1) * Wd + j], Wl[(k0 + 2) * Wd + j], Wl[(k0 + 3) * Wd + j]);
                 }
-        std::memcpy(&bh[(size_t)l * Wd], b[l + 1], Wd * sizeof(float));
+        std::memcpy(&pk.bh[(size_t)l * Wd], b[l + 1], Wd * sizeof(float));
     }
     // 16-row packs (v_mfma_f32_16x16x4): the four k of lane group g in steps 0..3 of chunk c are
     // 16c + pa[g] + {0, 2, 8, 10}, pa = {0, 4, 1, 5} -- the k SEQUENCE of the 32-row kernels (8c'+{0,4,1,5,2,6,3,7}), so a
     // 16-row tile is bit-identical to a 32-row tile (both MFMAs are fmaf chains in k order, tools/ubench/mfma_order.hip)
     auto k16 = [](int c, int g, int mm) { return 16 * c + ((g >> 1) + 4 * (g & 1)) + 8 * (mm >> 1) + 2 * (mm & 1); };
-    std::vector<float4> wf16(wf.size()), wb16(wf.size());
-    for (int l = 0; l < m.nhh; ++l) {
+    std::vector<float4>&wf16 = pk.wf16, &wb16 = pk.wb16;
+    wf16.assign(wf.size(), make_float4(0, 0, 0, 0));
+    wb16.assign(wf.size(), make_float4(0, 0, 0, 0));
+    for (int l = 0; l < nhh; ++l) {
         const float* Wl = W[l + 1];
         for (int cb = 0; cb < 16; ++cb)
             for (int c = 0; c < 16; ++c)
@@ -396,8 +393,9 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
     }
     // backward pack for the 4-row-group GEMM (v_mfma_f32_4x4x1, mlp_device.h gemm4): the gradient at a layer's inputs is
     // sum_k G[row][k] W[k][j] (W [out = k][in = j]); lane l of column block cb holds W[4 kq .. 4 kq + 3][64 cb + l]
-    std::vector<float4> wb4((size_t)std::max(m.nhh, 1) * 4 * 64 * 64);
-    for (int l = 0; l < m.nhh; ++l) {
+    std::vector<float4>& wb4 = pk.wb4;
+    wb4.assign((size_t)std::max(nhh, 1) * 4 * 64 * 64, make_float4(0, 0, 0, 0));
+    for (int l = 0; l < nhh; ++l) {
         const float* Wl = W[l + 1];
         for (int cb = 0; cb < 4; ++cb)
             for (int kq = 0; kq < 64; ++kq)
@@ -409,7 +407,8 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
     }
     // last layer: 16x16x4 B-fragments, channels padded to 16
     const float* WL = W[n_linear - 1];
-    std::vector<float4> wl(16 * 64);
+    std::vector<float4>& wl = pk.wl;
+    wl.assign(16 * 64, make_float4(0, 0, 0, 0));
     for (int c = 0; c < 16; ++c)
         for (int lane = 0; lane < 64; ++lane) {
             const int j = lane & 15, k0 = 16 * c + 4 * (lane >> 4);
@@ -418,16 +417,19 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
                 for (int mm = 0; mm < 4; ++mm) v[mm] = WL[j * Wd + k0 + mm];
             wl[c * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
         }
-    std::vector<float> bl(OMDS_CPAD, 0.f), wlraw((size_t)C * Wd);
-    std::memcpy(bl.data(), b[n_linear - 1], C * sizeof(float));
-    std::memcpy(wlraw.data(), WL, (size_t)C * Wd * sizeof(float));
+    pk.bl.assign(OMDS_CPAD, 0.f);
+    pk.wlraw.assign((size_t)C * Wd, 0.f);
+    std::memcpy(pk.bl.data(), b[n_linear - 1], C * sizeof(float));
+    std::memcpy(pk.wlraw.data(), WL, (size_t)C * Wd * sizeof(float));
     // first layer: transposed copy + backward pack over the 3d features (padded to 32 columns)
     const int F = 3 * d;
-    std::vector<float> w1t((size_t)F * Wd), b1(Wd);
+    pk.w1t.assign((size_t)F * Wd, 0.f);
+    pk.b1.assign(Wd, 0.f);
     for (int c = 0; c < Wd; ++c)
-        for (int f = 0; f < F; ++f) w1t[(size_t)f * Wd + c] = W[0][c * F + f];
-    std::memcpy(b1.data(), b[0], Wd * sizeof(float));
-    std::vector<float4> w1b(32 * 64);
+        for (int f = 0; f < F; ++f) pk.w1t[(size_t)f * Wd + c] = W[0][c * F + f];
+    std::memcpy(pk.b1.data(), b[0], Wd * sizeof(float));
+    std::vector<float4>& w1b = pk.w1b;
+    w1b.assign(32 * 64, make_float4(0, 0, 0, 0));
     for (int c = 0; c < 32; ++c)
         for (int lane = 0; lane < 64; ++lane) {
             const int f = lane & 31, k0 = 8 * c + 4 * (lane >> 5);
@@ -436,7 +438,8 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
                 for (int mm = 0; mm < 4; ++mm) v[mm] = W[0][(k0 + mm) * F + f];
             w1b[c * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
         }
-    std::vector<float4> w1b16(16 * 2 * 64);
+    std::vector<float4>& w1b16 = pk.w1b16;
+    w1b16.assign(16 * 2 * 64, make_float4(0, 0, 0, 0));
     for (int c = 0; c < 16; ++c)
         for (int jb = 0; jb < 2; ++jb)
             for (int lane = 0; lane < 64; ++lane) {
@@ -446,19 +449,10 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
                     for (int mm = 0; mm < 4; ++mm) v[mm] = W[0][k16(c, g, mm) * F + f];
                 w1b16[(c * 2 + jb) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
             }
+    pk.whraw.assign((size_t)std::max(nhh, 1) * Wd * Wd, 0.f);
+    for (int l = 0; l < nhh; ++l) std::memcpy(&pk.whraw[(size_t)l * Wd * Wd], W[l + 1], (size_t)Wd * Wd * sizeof(float));
     // fp16 screening network: slices of 32 output rows x 256 k in A-fragment order of v_mfma_f32_32x32x16_f16, with the k
     // order permuted to the C layout of the previous layer (chunk cc, lane-half h, slot j <-> feature 16cc + 8(j>>2) + 4h + (j&3))
-    ctx->screen = ScreenDev{};
-    // the input tables keep zeros in the slots the other operand owns; the slot assignment depends on the network's d
-    CK(hipMemsetAsync(ctx->d_FpH, 0, (size_t)ctx->cfg.max_obs * 32 * 2, ctx->stream));
-    CK(hipMemsetAsync(ctx->d_FqH, 0, (size_t)ctx->cfg.n_traj * 32 * 2, ctx->stream));
-    ctx->screen_ok = false;
-    ctx->screen_cal = false;
-    if (!ctx->screen_eps_fixed) ctx->screen_eps = 0.f;
-    ctx->screen_suspended = false;
-    ctx->screen_consec = 0;
-    std::vector<uint16_t> wh;
-    std::vector<float> sbias;
     // Behind a skip concatenation (level L = output of Linear L) the consuming layer's input columns are packed in a VIRTUAL
     // order: its own c0 = out_dims[L] columns first, the 3d concatenated input columns LAST (virtual 256 - 3d .. 255 = k-chunks
     // 14 and 15 whatever c0 is -- the K order of a dot product is free), zeros in between: omds_screen_sidx puts the inputs there
@@ -470,10 +464,11 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
         if (v >= Wd - F) return c0 + (v - (Wd - F));
         return -1;
     };
-    if ((act == OMDS_ACT_RELU || act == OMDS_ACT_TANH) && m.nhh >= 1 && m.nhh <= 4) {
-        const int nsl = m.nhh * 8 + 2;
+    if ((act == OMDS_ACT_RELU || act == OMDS_ACT_TANH) && nhh >= 1 && nhh <= 4) {
+        std::vector<uint16_t>& wh = pk.wh;
+        const int nsl = nhh * 8 + 2;
         wh.assign((size_t)nsl * 16 * 64 * 8, 0);
-        sbias.assign((size_t)(m.nhh + 2) * Wd, 0.f);
+        pk.sbias.assign((size_t)(nhh + 2) * Wd, 0.f);
         // slice 0: layer 1, fragment 2 fb + cc = rows 32 fb .. +31 x inputs 16 cc .. +15 (slot j of lane-half h = input 16cc + 8h + j)
         for (int fb = 0; fb < 8; ++fb)
             for (int cc = 0; cc < 2; ++cc)
@@ -496,15 +491,68 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
                         wh[(((size_t)sl * 16 + cc) * 64 + lane) * 8 + j] = f32_to_f16_bits(v);
                     }
         }
-        std::memcpy(&sbias[0], b[0], Wd * sizeof(float));
-        for (int l = 0; l < m.nhh; ++l) std::memcpy(&sbias[(size_t)(l + 1) * Wd], b[l + 1], Wd * sizeof(float));
-        std::memcpy(&sbias[(size_t)(m.nhh + 1) * Wd], b[n_linear - 1], C * sizeof(float));
+        std::memcpy(&pk.sbias[0], b[0], Wd * sizeof(float));
+        for (int l = 0; l < nhh; ++l) std::memcpy(&pk.sbias[(size_t)(l + 1) * Wd], b[l + 1], Wd * sizeof(float));
+        std::memcpy(&pk.sbias[(size_t)(nhh + 1) * Wd], b[n_linear - 1], C * sizeof(float));
     }
+    pk.f_fwd = 0.0;
+    for (int i = 0; i < n_linear; ++i) pk.f_fwd += 2.0 * in_dims[i] * out_dims[i];   // algorithmic: un-padded
+    pk.f_bwd = pk.f_fwd - 2.0 * in_dims[n_linear - 1] * out_dims[n_linear - 1];   // no weight-gradient, no last-layer GEMM
+    return OMDS_OK;
+}
+#undef PREQ
+
+int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const int32_t* out_dims, const float* const* W,
+                    const float* const* b, int act, float out_div, int n_skips, const int32_t* skip_after) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    const int n = ctx->cfg.n_dof;
+    MlpPacks pk;
     int rc;
-    if (!wh.empty()) {
+    if ((rc = build_mlp_packs(n, n_linear, in_dims, out_dims, W, b, act, out_div, n_skips, skip_after, pk, ctx->err))) return rc;
+    const int nhid = n_linear - 1;
+    const uint32_t skip_mask = pk.skip_mask;
+    CK(hipSetDevice(ctx->dev));
+    CK(hipStreamSynchronize(ctx->stream));
+    for (void* p : ctx->mlp_allocs) (void)hipFree(p);
+    ctx->mlp_allocs.clear();
+    ctx->have_mlp = false;
+    MlpDev m{};
+    m.nhh = pk.nhh;
+    m.C = pk.C;
+    m.d = pk.d;
+    m.n_dof = n;
+    m.out_div = out_div;
+    m.act = act;
+    m.skip_mask = skip_mask;
+    std::memcpy(m.skip_col, pk.skip_col, sizeof(m.skip_col));
+    if (skip_mask) {   // encoded-input tables beside Apre / Bpre, written by the layer-1 kernels (zero in the other operand's slots)
+        const size_t rowsA = (size_t)ctx->cfg.n_traj * ctx->cfg.n_closest, rowsB = (size_t)ctx->cfg.max_obs;
+        if (!ctx->d_featQ) CK(hipMalloc(&ctx->d_featQ, rowsA * 32 * 4));
+        if (!ctx->d_featP) CK(hipMalloc(&ctx->d_featP, rowsB * 32 * 4));
+        CK(hipMemsetAsync(ctx->d_featQ, 0, rowsA * 32 * 4, ctx->stream));
+        CK(hipMemsetAsync(ctx->d_featP, 0, rowsB * 32 * 4, ctx->stream));
+        m.featQ = ctx->d_featQ;
+        m.featP = ctx->d_featP;
+    }
+    if (ctx->d_dscr) { (void)hipFree(ctx->d_dscr); ctx->d_dscr = nullptr; }
+    if (act == OMDS_ACT_TANH) {   // pass 2 keeps 1 - h^2 of every hidden layer for the backward (ReLU uses LDS bit masks)
+        const size_t rows = std::max(((size_t)ctx->cfg.n_traj * ctx->cfg.n_closest + 31) / 32 * 32,
+                                     (size_t)omds_tail_scratch_rows(ctx->cfg.n_traj, ctx->cfg.n_closest));
+        CK(hipMalloc(&ctx->d_dscr, (size_t)nhid * rows * OMDS_WIDTH * 4));
+    }
+    ctx->screen = ScreenDev{};
+    // the input tables keep zeros in the slots the other operand owns; the slot assignment depends on the network's d
+    CK(hipMemsetAsync(ctx->d_FpH, 0, (size_t)ctx->cfg.max_obs * 32 * 2, ctx->stream));
+    CK(hipMemsetAsync(ctx->d_FqH, 0, (size_t)ctx->cfg.n_traj * 32 * 2, ctx->stream));
+    ctx->screen_ok = false;
+    ctx->screen_cal = false;
+    if (!ctx->screen_eps_fixed) ctx->screen_eps = 0.f;
+    ctx->screen_suspended = false;
+    ctx->screen_consec = 0;
+    if (!pk.wh.empty()) {
         const uint16_t* dwh = nullptr;
-        if ((rc = upload(ctx, wh, &dwh))) return rc;
-        if ((rc = upload(ctx, sbias, &ctx->screen.bias))) return rc;
+        if ((rc = upload(ctx, pk.wh, &dwh))) return rc;
+        if ((rc = upload(ctx, pk.sbias, &ctx->screen.bias))) return rc;
         ctx->screen.Wh = dwh;
         ctx->screen_ok = true;
         if (skip_mask) {   // the concatenation operands of the screening kernel (omds_screen_sidx), beside FqH / FpH
@@ -517,24 +565,20 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
             m.scrP = ctx->d_FpS;
         }
     }
-    if ((rc = upload(ctx, wf16, &m.Wf16))) return rc;
-    if ((rc = upload(ctx, wb16, &m.Wb16))) return rc;
-    if ((rc = upload(ctx, wb4, &m.Wb4))) return rc;
-    if ((rc = upload(ctx, w1b16, &m.W1b16))) return rc;
-    if ((rc = upload(ctx, wf, &m.Wf))) return rc;
-    if ((rc = upload(ctx, wb, &m.Wb))) return rc;
-    if ((rc = upload(ctx, bh, &m.bh))) return rc;
-    if ((rc = upload(ctx, wl, &m.Wl))) return rc;
-    if ((rc = upload(ctx, bl, &m.bl))) return rc;
-    if ((rc = upload(ctx, wlraw, &m.Wlraw))) return rc;
-    {
-        std::vector<float> whraw((size_t)std::max(m.nhh, 1) * Wd * Wd, 0.f);
-        for (int l = 0; l < m.nhh; ++l) std::memcpy(&whraw[(size_t)l * Wd * Wd], W[l + 1], (size_t)Wd * Wd * sizeof(float));
-        if ((rc = upload(ctx, whraw, &m.Whraw))) return rc;
-    }
-    if ((rc = upload(ctx, w1t, &m.W1t))) return rc;
-    if ((rc = upload(ctx, b1, &m.b1))) return rc;
-    if ((rc = upload(ctx, w1b, &m.W1b))) return rc;
+    if ((rc = upload(ctx, pk.wf16, &m.Wf16))) return rc;
+    if ((rc = upload(ctx, pk.wb16, &m.Wb16))) return rc;
+    if ((rc = upload(ctx, pk.wb4, &m.Wb4))) return rc;
+    if ((rc = upload(ctx, pk.w1b16, &m.W1b16))) return rc;
+    if ((rc = upload(ctx, pk.wf, &m.Wf))) return rc;
+    if ((rc = upload(ctx, pk.wb, &m.Wb))) return rc;
+    if ((rc = upload(ctx, pk.bh, &m.bh))) return rc;
+    if ((rc = upload(ctx, pk.wl, &m.Wl))) return rc;
+    if ((rc = upload(ctx, pk.bl, &m.bl))) return rc;
+    if ((rc = upload(ctx, pk.wlraw, &m.Wlraw))) return rc;
+    if ((rc = upload(ctx, pk.whraw, &m.Whraw))) return rc;
+    if ((rc = upload(ctx, pk.w1t, &m.W1t))) return rc;
+    if ((rc = upload(ctx, pk.b1, &m.b1))) return rc;
+    if ((rc = upload(ctx, pk.w1b, &m.W1b))) return rc;
 #ifdef OMDS_TIMELINE
     {
         static unsigned long long* tl = nullptr;
@@ -545,9 +589,8 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
 #endif
     ctx->mlp = m;
     ctx->act = act;
-    ctx->f_fwd = 0.0;
-    for (int i = 0; i < n_linear; ++i) ctx->f_fwd += 2.0 * in_dims[i] * out_dims[i];   // algorithmic: un-padded
-    ctx->f_bwd = ctx->f_fwd - 2.0 * in_dims[n_linear - 1] * out_dims[n_linear - 1];   // no weight-gradient, no last-layer GEMM
+    ctx->f_fwd = pk.f_fwd;
+    ctx->f_bwd = pk.f_bwd;
     ctx->have_mlp = true;
     if (ctx->n_obs > 0) {  // re-derive the obstacle half of layer 1 for the new weights
         omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, ctx->n_obs, ctx->d_Bpre, ctx->d_radius, ctx->d_FpH, ctx->cfg.max_obs, ctx->mlp.featP);
@@ -556,6 +599,35 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
     }
     return OMDS_OK;
 }
+
+#ifdef OMDS_TEST_HOOKS
+// Test hook (include/omds_test.h): the host half of omds_set_mlp_ex alone -- validation, padding, every fragment pack -- with no
+// device and no context, so that the sanitizer build can run it on the CPU.  *checksum = FNV-1a over all packs in upload order,
+// *bytes = their total size; message of a failure through omds_last_error(NULL).
+int omds_test_pack_mlp(int n_dof, int n_linear, const int32_t* in_dims, const int32_t* out_dims, const float* const* W,
+                       const float* const* b, int act, float out_div, int n_skips, const int32_t* skip_after, uint64_t* checksum,
+                       int64_t* bytes) {
+    MlpPacks pk;
+    const int rc = build_mlp_packs(n_dof, n_linear, in_dims, out_dims, W, b, act, out_div, n_skips, skip_after, pk, g_create_err);
+    if (rc) return rc;
+    uint64_t h = 1469598103934665603ull;
+    int64_t total = 0;
+    auto mix = [&](const void* p, size_t nb) {
+        const unsigned char* c = static_cast<const unsigned char*>(p);
+        for (size_t i = 0; i < nb; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+        total += (int64_t)nb;
+    };
+    mix(pk.wh.data(), pk.wh.size() * 2); mix(pk.sbias.data(), pk.sbias.size() * 4);
+    mix(pk.wf16.data(), pk.wf16.size() * 16); mix(pk.wb16.data(), pk.wb16.size() * 16); mix(pk.wb4.data(), pk.wb4.size() * 16);
+    mix(pk.w1b16.data(), pk.w1b16.size() * 16); mix(pk.wf.data(), pk.wf.size() * 16); mix(pk.wb.data(), pk.wb.size() * 16);
+    mix(pk.bh.data(), pk.bh.size() * 4); mix(pk.wl.data(), pk.wl.size() * 16); mix(pk.bl.data(), pk.bl.size() * 4);
+    mix(pk.wlraw.data(), pk.wlraw.size() * 4); mix(pk.whraw.data(), pk.whraw.size() * 4); mix(pk.w1t.data(), pk.w1t.size() * 4);
+    mix(pk.b1.data(), pk.b1.size() * 4); mix(pk.w1b.data(), pk.w1b.size() * 16);
+    if (checksum) *checksum = h;
+    if (bytes) *bytes = total;
+    return OMDS_OK;
+}
+#endif
 
 // The obstacle buffers grow on demand (MPPI.update_obstacles takes any obstacle count at any time, MPPI.py:347-350): everything
 // sized by max_obs is re-allocated at twice the new count; the handle, the network, the policy samples, the communicator and
