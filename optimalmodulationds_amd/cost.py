@@ -35,7 +35,7 @@ class Cost:
             raise RuntimeError("Cost.evaluate_costs needs an owning MPPI (its device context evaluates the cost)")
         o = self._owner
         own = (all_traj is None and closest_dist_all is None) or \
-              (all_traj is o.all_traj and closest_dist_all is o.closest_dist_all and bool(o._cache))
+              (all_traj is o.all_traj and closest_dist_all is o.closest_dist_all and o._generation > 0)
         if own:
             return o.get_cost()
         tr = torch.as_tensor(all_traj, dtype=torch.float32)

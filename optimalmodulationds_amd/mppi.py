@@ -11,6 +11,7 @@ import torch
 
 from .cost import Cost
 from .engine import Engine
+from .lazy import LazyRollout
 from .policy import TensorPolicyMPPI
 
 
@@ -36,18 +37,18 @@ class _LazyBasis:
     any other index (or ``.tensor()``) materialises the selection."""
 
     def __init__(self, normals):
-        self._g = normals                                   # [N, H, n]
-        self.shape = normals.shape + (normals.shape[-1],)
+        self._g = normals                                   # [N, H, n]: a LazyRollout (row fetches) or an array
+        self.shape = tuple(normals.shape) + (normals.shape[-1],)
 
     def __getitem__(self, idx):
         if not isinstance(idx, tuple):
             idx = (idx,)
         lead = tuple(int(i) if isinstance(i, torch.Tensor) and i.ndim == 0 else i for i in idx[:2])
-        out = _qr_complete(np.asarray(self._g[lead]))
+        out = _qr_complete(np.asarray(self._g[lead], dtype=np.float32))
         return out[(Ellipsis,) + tuple(idx[2:])] if len(idx) > 2 else out
 
     def tensor(self):
-        return _qr_complete(self._g)
+        return _qr_complete(np.asarray(self._g, dtype=np.float32))
 
     def __torch_function__(self, func, types, args=(), kwargs=None):
         args = tuple(a.tensor() if isinstance(a, _LazyBasis) else a for a in args)
@@ -95,6 +96,9 @@ class MPPI:
         self.Cost = Cost(self.qf, self.dh_params, owner=self)
         self.cur_cost = None
         self._cache = {}
+        self._generation = 0          # propagate() calls so far (LazyRollout tensors belong to one of them)
+        self._pushed = None           # what the device context last received (_push skips an unchanged set)
+        self._qdot_cache = {}         # get_qdot values of the current cost (filled by shift_policy_means)
         self.all_traj = torch.zeros(N_traj, dt_H, self.n_dof)
         self.closest_dist_all = 100 + torch.zeros(N_traj, dt_H)
         self.qdot = torch.zeros(N_traj, self.n_dof)
@@ -127,25 +131,33 @@ class MPPI:
 
     # ---- parameters -> device ----------------------------------------------------------------------
     def _push(self):
+        """The mutable attributes the reference's callers poke (dt, dst_thr, ignored_links, Policy.p, DS, Cost limits) -> the
+        device context; skipped while nothing changed since the last call (three ctypes calls per use otherwise)."""
         e = self._engine
-        p = e.params
-        p.dt = float(self.dt)
-        p.dst_thr = float(self.dst_thr)
-        p.lin_thr = float(self.DS.lin_thr)
-        p.rbf_p = float(self.Policy.p)
         mask = 0
         for l in self.ignored_links:
             mask |= 1 << int(l)
-        p.ignored_links = mask
+        qf, dh, qmin, qmax = _np(self.qf), _np(self.dh_params), _np(self.Cost.q_min), _np(self.Cost.q_max)
+        sig = (float(self.dt), float(self.dst_thr), float(self.DS.lin_thr), float(self.Policy.p), mask, id(self.DS), qf.tobytes(),
+               dh.tobytes(), qmin.tobytes(), qmax.tobytes(), e.params.variant, e.params.cost_terms)
+        if sig == self._pushed:
+            return
+        p = e.params
+        p.dt, p.dst_thr, p.lin_thr, p.rbf_p, p.ignored_links = sig[0], sig[1], sig[2], sig[3], mask
         e.push_params()
         if hasattr(self.DS, "device_params"):       # SEDS nominal DS (seds.py)
-            e.set_ds_seds(_np(self.qf), *self.DS.device_params(), lin_thr=float(self.DS.lin_thr), seds_thr=float(self.DS.seds_thr))
+            e.set_ds_seds(qf, *self.DS.device_params(), lin_thr=float(self.DS.lin_thr), seds_thr=float(self.DS.seds_thr))
         else:
-            e.set_ds(_np(self.qf))
-        e.set_cost(_np(self.dh_params), _np(self.Cost.q_min), _np(self.Cost.q_max))
+            e.set_ds(qf)
+        e.set_cost(dh, qmin, qmax)
+        self._pushed = sig
 
     # ---- rollouts (MPPI.py:97-224) -------------------------------------------------------------------
-    def propagate(self, fetch=True):
+    def propagate(self, fetch=False):
+        """MPPI.py:97-224.  Returns the reference's 5-tuple (all_traj, closest_dist_all, kernel_val_all[:, :, :K], dot_products,
+        kernel_activations) and sets the same attributes -- as LazyRollout tensors (lazy.py): they stay on the GPU until read,
+        single rollouts are fetched as rows, and the candidate search / cost / update work on the device-resident copies.
+        ``fetch=True`` materialises everything at once (torch CPU tensors, what rounds 1-3 returned)."""
         self._push()
         if self._engine.K != self.Policy.n_kernels:
             # like the reference, propagate() consumes whatever sample tensors exist; with a changed
@@ -154,24 +166,33 @@ class MPPI:
         self._engine.propagate(_np(self.q_cur))
         self._cache = {}
         self.cur_cost = None
-        if not fetch:
-            return None
-        r = self._fetch()
-        return (self.all_traj, self.closest_dist_all, r["kernel_val_all"], r["dot_products"], r["kernel_activations"])
+        self._qdot_cache = {}
+        self._generation += 1
+        N, H, n, K = self.N_traj, self.dt_H, self.n_dof, self.Policy.n_kernels
+        lz = lambda key, shape: LazyRollout(self, key, shape, self._generation)
+        self.all_traj = lz("all_traj", (N, H, n))
+        self.closest_dist_all = lz("closest_dist_all", (N, H))
+        self.kernel_val_all = lz("kernel_val_all", (N, H, K))
+        self.dot_products = lz("dot_products", (N, H))
+        self.kernel_activations = lz("kernel_activations", (N, H))
+        self.qdot = lz("qdot", (N, n))
+        self.normal_dirs = lz("normal", (N, H, n))      # norm_basis[..., 0]
+        if fetch:
+            self._fetch()
+            return (self.all_traj.tensor(), self.closest_dist_all.tensor(), self.kernel_val_all.tensor(), self.dot_products.tensor(),
+                    self.kernel_activations.tensor())
+        return (self.all_traj, self.closest_dist_all, self.kernel_val_all, self.dot_products, self.kernel_activations)
 
     def _fetch(self):
+        """All rollout tensors of the last propagate as torch CPU tensors (one omds_get_rollouts), cached until the next one."""
         if not self._cache:
-            r = {k: torch.from_numpy(v) for k, v in self._engine.get_rollouts().items()}
-            self._cache = r
-            self.all_traj = r["all_traj"]
-            self.closest_dist_all = r["closest_dist_all"]
-            self.kernel_val_all = r["kernel_val_all"]
-            self.dot_products = r["dot_products"]
-            self.kernel_activations = r["kernel_activations"]
-            self.qdot = r["qdot"]
-            self.normal_dirs = r["normal"]              # norm_basis[..., 0]
-            self.ker_w = r["kernel_val_all"][:, -1:, :].transpose(1, 2) if r["kernel_val_all"].numel() else None
+            self._cache = {k: torch.from_numpy(v) for k, v in self._engine.get_rollouts().items()}
         return self._cache
+
+    @property
+    def ker_w(self):
+        kv = self._fetch()["kernel_val_all"]
+        return kv[:, -1:, :].transpose(1, 2) if kv.numel() else None
 
     @property
     def norm_basis(self):
@@ -180,7 +201,7 @@ class MPPI:
         (geqrf/orgqr via numpy), evaluated lazily and only for the entries a caller indexes -- nothing
         on the rollout path reads it (M v uses the closed form), the drivers read ONE entry per
         iteration (frankaPlanner.py:162)."""
-        return _LazyBasis(self._fetch()["normal"].numpy())
+        return _LazyBasis(self.normal_dirs)
 
     # ---- distance + gradient on arbitrary states (MPPI.py:227-282) ------------------------------------
     def distance_repulsion_nn(self, q_prev, aot=False):
@@ -212,6 +233,7 @@ class MPPI:
     def get_cost(self):
         self._push()
         self.cur_cost = torch.from_numpy(self._engine.cost())
+        self._qdot_cache = {}
         return self.cur_cost
 
     def init_comm(self, group=None):
@@ -223,14 +245,21 @@ class MPPI:
         return init_native_comm(self._engine, group)
 
     def get_qdot(self, mode='best'):
+        """MPPI.py:319-329.  After ``shift_policy_means()`` this is a local read, as in the reference: the update's reduction already
+        produced both velocities (over ALL shards when a communicator exists) and they are kept until the next propagate / cost.
+        Called BEFORE ``shift_policy_means()`` on a sharded context it has to run that reduction itself, which is a COLLECTIVE:
+        then every rank must call it (a driver in which only rank 0 asks for the velocity would hang inside RCCL)."""
         if self.cur_cost is None:
             self.get_cost()
-        if self._engine.comm_info()[1] > 1:      # sharded: the arg-min / weighted mean over the rollouts of every rank
+        if mode in self._qdot_cache:
+            return self._qdot_cache[mode].clone()
+        if self._engine.comm_info()[1] > 1:      # sharded: the arg-min / weighted mean over the rollouts of every rank (collective)
             K = self.Policy.n_kernels
             P = self.Policy
             _, _, _, _, qw, qb, _ = self._engine.weighted_update_sharded(0.0, self.ker_thr, P.mu_c.numpy()[:K], P.sigma_c.numpy()[:K],
-                                                                         P.alpha_c.numpy()[:K], want_best=(mode == 'best'))
-            return torch.from_numpy(qb if mode == 'best' else qw)
+                                                                         P.alpha_c.numpy()[:K], want_best=True)
+            self._qdot_cache = {'weighted': torch.from_numpy(qw), 'best': torch.from_numpy(qb)}
+            return self._qdot_cache[mode].clone()
         return torch.from_numpy(self._engine.get_qdot(mode))
 
     def shift_policy_means(self):
@@ -240,12 +269,14 @@ class MPPI:
             self.get_cost()
         P = self.Policy
         K = P.n_kernels
-        mu, sg, al, mask, qw, _, _ = self._engine.weighted_update_sharded(self.policy_upd_rate, self.ker_thr, P.mu_c.numpy(),
-                                                                          P.sigma_c.numpy(), P.alpha_c.numpy())
+        mu, sg, al, mask, qw, qb, _ = self._engine.weighted_update_sharded(self.policy_upd_rate, self.ker_thr, P.mu_c.numpy(),
+                                                                           P.sigma_c.numpy(), P.alpha_c.numpy(), want_best=True)
         if K > 0:
             P.mu_c[:K] = torch.from_numpy(mu)
             P.sigma_c[:K] = torch.from_numpy(sg)
             P.alpha_c[:K] = torch.from_numpy(al)
         self.update_mask = torch.from_numpy(mask)
         self.qdot_weighted = torch.from_numpy(qw)
+        # get_qdot() of this cost is a local read from here on (the reduction above is the same one, over every shard)
+        self._qdot_cache = {'weighted': torch.from_numpy(qw.copy()), 'best': torch.from_numpy(qb.copy())}
         return 0, int(mask.sum())

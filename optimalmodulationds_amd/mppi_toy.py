@@ -62,7 +62,7 @@ class MPPI(_MPPI):
         super()._push()
         self._engine.set_ds_matrix(_np(self.qf), _np(self.A))
 
-    def propagate(self, fetch=True):
+    def propagate(self, fetch=False):
         r = super().propagate(fetch)
         return None if r is None else r[:4]
 

@@ -39,12 +39,10 @@ class TensorPolicyMPPI:
 
     # ---- state -------------------------------------------------------------------------------
     def reset_policy(self):
+        """policy.py:43-49: forget every kernel."""
         self.n_kernels = 0
-        self.mu_c *= 0
-        self.sigma_c *= 0
-        self.alpha_c *= 0
-        self.kernel_gammas *= 0
-        self.kernel_obstacle_bases *= 0
+        for t in (self.mu_c, self.sigma_c, self.alpha_c, self.kernel_gammas, self.kernel_obstacle_bases):
+            t.zero_()
 
     def _need_engine(self):
         if self._engine is None:
@@ -94,36 +92,34 @@ class TensorPolicyMPPI:
         self.alpha_c[:K] = (1 - u[:, None]) * self.alpha_c[:K] + u[:, None] * torch.from_numpy((w[:, None, None] * al).sum(0))
 
     def update_with_data(self, data):
-        """policy.py:115-127: install a policy dict received from the planner process."""
+        """policy.py:115-127: install a policy dict received from the planner process (keys n_kernels, mu_c, alpha_c, sigma_c,
+        norm_basis: payloads.planner_payload); rows past the received kernel count are cleared."""
         if data is None:
             return
-        K = self.n_kernels = int(data["n_kernels"])
-        self.mu_c[0:K] = torch.as_tensor(data["mu_c"])
-        self.alpha_c[0:K] = torch.as_tensor(data["alpha_c"])
-        self.sigma_c[0:K] = torch.as_tensor(data["sigma_c"])
-        self.kernel_obstacle_bases[0:K] = torch.as_tensor(data["norm_basis"])
-        self.mu_c[K:] *= 0
-        self.alpha_c[K:] *= 0
-        self.sigma_c[K:] *= 0
-        self.kernel_obstacle_bases[K:] *= 0
+        K = int(data["n_kernels"])
+        for dst, key in ((self.mu_c, "mu_c"), (self.alpha_c, "alpha_c"), (self.sigma_c, "sigma_c"), (self.kernel_obstacle_bases, "norm_basis")):
+            dst[:K] = torch.as_tensor(data[key], dtype=dst.dtype)
+            dst[K:].zero_()
+        self.n_kernels = K
 
     def add_kernel(self, q, kernel_gamma, kernel_obstacle_basis):
-        """policy.py:129-151 (host bookkeeping on the K x n means)."""
-        if self.n_kernels < self.N_KERNEL_MAX:
-            K = self.n_kernels
-            q = torch.as_tensor(q, dtype=torch.float32)
-            self.mu_c[K, :] = q
-            self.sigma_c[K] = self.sigma_c_nominal
-            if K > 0:
-                _, idx = torch.min(torch.norm(self.mu_c[0:K, :] - q, 2, 1), 0)
-                self.alpha_c[K, :] = self.alpha_c[idx, :]
-            else:
-                self.alpha_c[K, :] = 0
-            self.kernel_gammas[K] = float(kernel_gamma)
-            self.kernel_obstacle_bases[K] = torch.as_tensor(kernel_obstacle_basis, dtype=torch.float32)
-            self.n_kernels += 1
+        """policy.py:129-151: a new kernel centred at q with the nominal width; its weights start as those of the nearest existing
+        kernel (zero for the first one).  Host bookkeeping on the K x n means; a full policy is reported and left unchanged."""
+        K = self.n_kernels
+        if K >= self.N_KERNEL_MAX:
+            print(f"kernel not added at {q}: the policy already holds N_KERNEL_MAX = {self.N_KERNEL_MAX} kernels")
+            return
+        q = torch.as_tensor(q, dtype=torch.float32).reshape(self.n_dof)
+        if K:
+            nearest = torch.linalg.vector_norm(self.mu_c[:K] - q, ord=2, dim=1).argmin()
+            self.alpha_c[K] = self.alpha_c[nearest]
         else:
-            print('Not adding new kernel at: maximum number of kernels reached', q)
+            self.alpha_c[K].zero_()
+        self.mu_c[K] = q
+        self.sigma_c[K] = float(self.sigma_c_nominal)
+        self.kernel_gammas[K] = float(kernel_gamma)
+        self.kernel_obstacle_bases[K] = torch.as_tensor(kernel_obstacle_basis, dtype=torch.float32)
+        self.n_kernels = K + 1
 
     def check_traj_for_kernels(self, all_traj, closests_dist_all, dotproducts_all, thr_dist, thr_kernel, thr_dot):
         """policy.py:153-175: candidate kernel centres.  When the tensors are the owner MPPI's current
@@ -133,29 +129,33 @@ class TensorPolicyMPPI:
         own = getattr(self, "_owner", None)
         if own is not None and all_traj is own.all_traj and closests_dist_all is own.closest_dist_all \
                 and dotproducts_all is own.dot_products and self._engine is not None:
-            self._engine.params.rbf_p = float(self.p)
-            self._engine.push_params()
+            own._push()     # Policy.p (the RBF norm order) and the other mutable attributes, when they changed
             q, th, total = self._engine.kernel_candidates(thr_dist, thr_kernel, thr_dot, self.mu_c.numpy(),
                                                           self.sigma_c.numpy(), self.n_kernels)
             self.last_candidate_index = torch.from_numpy(th.astype(np.int64))   # (t, h) of every candidate
             return torch.from_numpy(q)
-        all_traj = torch.as_tensor(all_traj)
-        idx_close = torch.as_tensor(closests_dist_all) < thr_dist
-        idx_dot = torch.as_tensor(dotproducts_all) < thr_dot
-        cand = all_traj[idx_close & idx_dot].view(-1, self.n_dof)
-        if self.n_kernels > 0:
-            rbf = eval_rbf_simple(cand, self.mu_c[0:self.n_kernels], self.sigma_c[0:self.n_kernels], self.p)
-            cand = cand[torch.max(rbf, -1)[0] < thr_kernel] if cand.shape[0] else cand
+        # foreign tensors: the same selection on the host
+        states = torch.as_tensor(all_traj, dtype=torch.float32)
+        near = (torch.as_tensor(closests_dist_all) < thr_dist) & (torch.as_tensor(dotproducts_all) < thr_dot)
+        cand = states[near].reshape(-1, self.n_dof)
+        K = self.n_kernels
+        if K and cand.shape[0]:
+            uncovered = eval_rbf_simple(cand, self.mu_c[:K], self.sigma_c[:K], self.p).amax(dim=-1) < thr_kernel   # NaN: not a candidate, like torch
+            cand = cand[uncovered]
         return cand
 
 
+def _rbf(q, mu, sigma, p):
+    """exp(-sigma * ||q - mu||_p^2) with q [B, n] against mu [B, K, n] (per-row kernels) or [K, n] (shared kernels) -> [B, K]."""
+    return torch.exp(-sigma * torch.linalg.vector_norm(q.unsqueeze(-2) - mu, ord=p, dim=-1) ** 2)
+
+
 def eval_rbf(q, mu, sigma, p=2):
-    """policy.py:186-199 (host helper; the rollouts evaluate it inside k_modulate)."""
-    numerator = torch.norm(q[:, None, :] - mu, p=p, dim=2, keepdim=True) ** 2
-    return torch.exp(-sigma.unsqueeze(2) * numerator)
+    """policy.py:186-199: per-rollout kernels mu [N, K, n], sigma [N, K] -> [N, K, 1] (host helper; the rollouts evaluate it inside
+    the step kernels)."""
+    return _rbf(q, mu, sigma, p).unsqueeze(2)
 
 
 def eval_rbf_simple(q, mu, sigma, p=2):
-    """policy.py:201-214."""
-    numerator = torch.norm(q[:, None, :] - mu, p, -1) ** 2
-    return torch.exp(-sigma * numerator)
+    """policy.py:201-214: shared kernels mu [K, n], sigma [K] -> [B, K]."""
+    return _rbf(q, mu, sigma, p)

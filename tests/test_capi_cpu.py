@@ -195,3 +195,29 @@ def test_stale_library_version_is_reported(tmp_path, lib):
     )
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "RAISED" in r.stdout and f"ABI version {_lib.ABI_VERSION}" in r.stdout and "rebuild" in r.stdout, r.stdout + r.stderr
+
+
+def test_example_driver_accepts_the_reference_config_keys():
+    """examples/franka_planner_loop.py --config: the reference's YAML keys (ds_mppi/config.yaml, read at frankaPlanner.py:20-21,
+    43-88, 129).  examples/config.yaml carries every key the loop reads; in the build container the reference's own config files
+    are parsed too and must define every one of those keys (so that the loop takes them unchanged)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("franka_planner_loop", os.path.join(ROOT, "examples", "franka_planner_loop.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cfg = mod.load_config(os.path.join(ROOT, "examples", "config.yaml"))
+    for sec, keys in mod.DEFAULTS.items():
+        assert set(keys) <= set(cfg[sec]), sec
+    assert cfg["planner"]["n_trajectories"] == 40 and cfg["planner"]["kernel_adding_dotproduct_thr"] == -0.9
+    assert mod.load_config(None) == {k: dict(v) for k, v in mod.DEFAULTS.items()}
+    assert os.path.exists(mod.weights_file(cfg["collision_model"]["fname"]))
+    for ref in ("config.yaml", "config_real.yaml"):
+        path = os.path.join("/root/reference/python_scripts/ds_mppi", ref)
+        if not os.path.exists(path):      # the GPU box has no reference tree
+            continue
+        import yaml
+        raw = yaml.safe_load(open(path))
+        for sec, keys in mod.DEFAULTS.items():
+            assert set(keys) <= set(raw[sec]), (ref, sec, set(keys) - set(raw[sec]))
+        got = mod.load_config(path)
+        assert got["planner"]["horizon"] == raw["planner"]["horizon"] and got["general"]["q_f"] == raw["general"]["q_f"]
