@@ -344,7 +344,11 @@ OMDS_API int omds_screen_stats(omds_ctx* ctx, int32_t* active, float* eps, float
  * (tools/train_sdf_hip.py).  A trainer is its own object (no omds_ctx needed); dims[n_linear + 1] = {3 d, hidden ..., C}; W[i] is
  * [dims[i+1], dims[i]] row-major like torch.  omds_trainer_set_weights also resets the optimizer state and step count.
  * omds_trainer_step returns the loss BEFORE the update (what train_sdf.py prints as train loss); omds_trainer_eval runs the
- * forward + loss on the current data set without an update (pred_out [B, C] or NULL).                                   */
+ * forward + loss with the current weights, no update, on the training set (which = 0) or on the validation set of
+ * omds_trainer_set_val_data (which = 1: train_sdf.py:84-86, 117-121; no weight copy, the optimizer state untouched); pred_out
+ * [B, C] or NULL.  omds_trainer_get / set_optimizer_state: torch.optim.Adam's exp_avg (m) and exp_avg_sq (v) of every weight and
+ * bias and the step count -- what train_sdf.py:130-138 saves as optimizer.state_dict() and a resumed run restores (arrays shaped
+ * like the weights; get: a NULL array or entry is skipped).                                                               */
 typedef struct omds_trainer omds_trainer;
 OMDS_API int omds_trainer_create(int device, int n_linear, const int32_t* dims, int act, omds_trainer** out);
 OMDS_API void omds_trainer_destroy(omds_trainer* tr);
@@ -353,7 +357,12 @@ OMDS_API int omds_trainer_set_weights(omds_trainer* tr, const float* const* W, c
 OMDS_API int omds_trainer_get_weights(omds_trainer* tr, float* const* W, float* const* b);
 OMDS_API int omds_trainer_set_data(omds_trainer* tr, const float* x, const float* y, int batch);
 OMDS_API int omds_trainer_step(omds_trainer* tr, float lr, float beta1, float beta2, float eps, float* loss_out);
-OMDS_API int omds_trainer_eval(omds_trainer* tr, float* mse_out, float* pred_out);
+OMDS_API int omds_trainer_set_val_data(omds_trainer* tr, const float* x, const float* y, int batch);
+OMDS_API int omds_trainer_eval(omds_trainer* tr, int which, float* mse_out, float* pred_out);
+OMDS_API int omds_trainer_get_optimizer_state(omds_trainer* tr, float* const* mW, float* const* mb, float* const* vW, float* const* vb,
+                                              int64_t* step);
+OMDS_API int omds_trainer_set_optimizer_state(omds_trainer* tr, const float* const* mW, const float* const* mb, const float* const* vW,
+                                              const float* const* vb, int64_t step);
 
 /* Measurement: when enabled, launches of the dominant kernel (k_pass1) are bracketed by HIP events on the
  * context stream -- every launch for on == 1, every on-th launch for on > 1 (an event record between two

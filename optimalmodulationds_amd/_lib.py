@@ -109,7 +109,11 @@ SIGNATURES = {
     "omds_trainer_get_weights": (C.c_int, [C.c_void_p, C.POINTER(F32P), C.POINTER(F32P)]),
     "omds_trainer_set_data": (C.c_int, [C.c_void_p, F32P, F32P, C.c_int]),
     "omds_trainer_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, F32P]),
-    "omds_trainer_eval": (C.c_int, [C.c_void_p, F32P, F32P]),
+    "omds_trainer_set_val_data": (C.c_int, [C.c_void_p, F32P, F32P, C.c_int]),
+    "omds_trainer_eval": (C.c_int, [C.c_void_p, C.c_int, F32P, F32P]),
+    "omds_trainer_get_optimizer_state": (C.c_int, [C.c_void_p, C.POINTER(F32P), C.POINTER(F32P), C.POINTER(F32P), C.POINTER(F32P),
+                                                   C.POINTER(C.c_int64)]),
+    "omds_trainer_set_optimizer_state": (C.c_int, [C.c_void_p, C.POINTER(F32P), C.POINTER(F32P), C.POINTER(F32P), C.POINTER(F32P), C.c_int64]),
     "omds_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "omds_prof_reset": (C.c_int, [C.c_void_p]),
     "omds_prof_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     __shared__ float As[TK][TM + 32];   // [k][m]; row stride 160 floats: the two k rows a wave reads at once fall into disjoint banks
     __shared__ float Bs[TK][TN + 32];   // [k][n]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;   // the batch dimension on grid.x: its limit is 2^31 - 1 tiles, grid.y stops at 65535
     const int k_begin = blockIdx.z * kchunk, k_end = min(K, k_begin + kchunk);
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     f32x16 acc[2][2];
@@ -177,8 +177,10 @@ struct omds_trainer {
     int L = 0, act = 0, d = 0;
     std::vector<int> dims;                 // [L + 1]: 3 d, hidden ..., C
     std::vector<float*> W, b, gW, gb, mW, mb, vW, vb;
-    int B = 0, cap = 0;                    // rows of the current data set, rows the activation buffers hold
+    int B = 0, cap = 0;                    // rows of the training set, rows the activation / gradient buffers hold
     float* x = nullptr; float* y = nullptr;
+    int Bv = 0, xcap = 0, vcap = 0;        // rows of the validation set (omds_trainer_set_val_data); rows x / y and xv / yv hold
+    float* xv = nullptr; float* yv = nullptr;
     std::vector<float*> H;                 // [L + 1] activations: H[0] = encoded input ... H[L] = prediction
     float* G[2] = {nullptr, nullptr};      // gradient ping-pong [cap x max width]
     float* partial = nullptr;              // split-K partials of the weight gradient / column-sum partials
@@ -194,35 +196,53 @@ static thread_local std::string g_train_err;
         if (_e != hipSuccess) { tr->err = std::string(#expr) + ": " + hipGetErrorString(_e); return OMDS_ERR_HIP; } \
     } while (0)
 
-static void trainer_free_data(omds_trainer* tr) {
-    for (float* p : {tr->x, tr->y, tr->G[0], tr->G[1]}) if (p) (void)hipFree(p);
-    tr->x = tr->y = tr->G[0] = tr->G[1] = nullptr;
+static void trainer_free_buffers(omds_trainer* tr) {   // activations and gradient ping-pong (sized by the larger data set)
+    for (float* p : {tr->G[0], tr->G[1]}) if (p) (void)hipFree(p);
+    tr->G[0] = tr->G[1] = nullptr;
     for (float*& p : tr->H) { if (p) (void)hipFree(p); p = nullptr; }
     tr->cap = 0;
+}
+static void trainer_free_data(omds_trainer* tr) {
+    for (float* p : {tr->x, tr->y, tr->xv, tr->yv}) if (p) (void)hipFree(p);
+    tr->x = tr->y = tr->xv = tr->yv = nullptr;
+    tr->B = tr->Bv = tr->xcap = tr->vcap = 0;
+    trainer_free_buffers(tr);
+}
+static int trainer_reserve(omds_trainer* tr, int rows) {
+    if (rows <= tr->cap) return OMDS_OK;
+    trainer_free_buffers(tr);
+    int wmax = 0;
+    for (int v : tr->dims) wmax = std::max(wmax, v);
+    for (int i = 0; i <= tr->L; ++i) TCK(hipMalloc(&tr->H[i], (size_t)rows * tr->dims[i] * 4));
+    for (int i = 0; i < 2; ++i) TCK(hipMalloc(&tr->G[i], (size_t)rows * wmax * 4));
+    tr->cap = rows;
+    return OMDS_OK;
 }
 
 template <bool TA, bool TB, int EPI>
 static void launch_gemm(hipStream_t s, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
                         int splits, int kchunk, size_t cstride, const float* aux = nullptr, int act = -1) {
-    const dim3 grid((N + TN - 1) / TN, (M + TM - 1) / TM, splits);
+    const dim3 grid((M + TM - 1) / TM, (N + TN - 1) / TN, splits);   // M may be the batch (millions of rows): grid.x
     hipLaunchKernelGGL((k_gemm<TA, TB, EPI>), grid, dim3(256), 0, s, A, lda, Bm, ldb, C, ldc, M, N, K, kchunk, cstride, aux, act);
 }
 
-static int forward(omds_trainer* tr, int B) {
+static int forward(omds_trainer* tr, int B, const float* x) {
     hipStream_t s = tr->stream;
     const int d = tr->d;
-    hipLaunchKernelGGL(k_encode, dim3((unsigned)(((size_t)B * d + 255) / 256)), dim3(256), 0, s, tr->x, B, d, tr->H[0]);
+    hipLaunchKernelGGL(k_encode, dim3((unsigned)(((size_t)B * d + 255) / 256)), dim3(256), 0, s, x, B, d, tr->H[0]);
     for (int i = 0; i < tr->L; ++i) {
         const int in = tr->dims[i], out = tr->dims[i + 1];
         launch_gemm<false, true, 1>(s, tr->H[i], in, tr->W[i], in, tr->H[i + 1], out, B, out, in, 1, in, 0, tr->b[i], i + 1 < tr->L ? tr->act : -1);
     }
+    TCK(hipGetLastError());   // an invalid launch configuration must not go on as a loss computed from stale buffers
     return OMDS_OK;
 }
 
-static int mse(omds_trainer* tr, int B, float* G, double* loss) {
+static int mse(omds_trainer* tr, int B, const float* y, float* G, double* loss) {
     const size_t n = (size_t)B * tr->dims[tr->L];
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 1024);
-    hipLaunchKernelGGL(k_mse, dim3(blocks), dim3(256), 0, tr->stream, tr->H[tr->L], tr->y, n, 2.f / (float)n, G, tr->lossp);
+    hipLaunchKernelGGL(k_mse, dim3(blocks), dim3(256), 0, tr->stream, tr->H[tr->L], y, n, 2.f / (float)n, G, tr->lossp);
+    TCK(hipGetLastError());
     TCK(hipMemcpyAsync(tr->h_lossp, tr->lossp, (size_t)blocks * 8, hipMemcpyDeviceToHost, tr->stream));
     TCK(hipStreamSynchronize(tr->stream));
     double sum = 0.0;
@@ -330,33 +350,92 @@ int omds_trainer_set_data(omds_trainer* tr, const float* x, const float* y, int 
     if (!x || !y || batch < 1) { tr->err = "omds_trainer_set_data: need batch >= 1 and non-null x [B, d], y [B, C]"; return OMDS_ERR_INVALID_ARG; }
     TCK(hipSetDevice(tr->dev));
     TCK(hipStreamSynchronize(tr->stream));
-    if (batch > tr->cap) {
-        trainer_free_data(tr);
-        int wmax = 0;
-        for (int v : tr->dims) wmax = std::max(wmax, v);
+    if (batch > tr->xcap) {
+        for (float* p : {tr->x, tr->y}) if (p) (void)hipFree(p);
+        tr->x = tr->y = nullptr; tr->xcap = 0; tr->B = 0;
         TCK(hipMalloc(&tr->x, (size_t)batch * tr->d * 4));
         TCK(hipMalloc(&tr->y, (size_t)batch * tr->dims[tr->L] * 4));
-        for (int i = 0; i <= tr->L; ++i) TCK(hipMalloc(&tr->H[i], (size_t)batch * tr->dims[i] * 4));
-        for (int i = 0; i < 2; ++i) TCK(hipMalloc(&tr->G[i], (size_t)batch * wmax * 4));
-        tr->cap = batch;
+        tr->xcap = batch;
     }
+    int rc;
+    if ((rc = trainer_reserve(tr, batch))) return rc;
     TCK(hipMemcpy(tr->x, x, (size_t)batch * tr->d * 4, hipMemcpyHostToDevice));
     TCK(hipMemcpy(tr->y, y, (size_t)batch * tr->dims[tr->L] * 4, hipMemcpyHostToDevice));
     tr->B = batch;
     return OMDS_OK;
 }
 
-// forward + F.mse_loss on the current data set, no update (train_sdf.py:117-121 on the validation split)
-int omds_trainer_eval(omds_trainer* tr, float* mse_out, float* pred_out) {
+// The validation split (train_sdf.py:84-86, 117-121) beside the training set: evaluated by omds_trainer_eval(which = 1) with the
+// trainer's current weights -- no weight copy, no second trainer, the optimizer state untouched.
+int omds_trainer_set_val_data(omds_trainer* tr, const float* x, const float* y, int batch) {
     if (!tr) return OMDS_ERR_INVALID_ARG;
-    if (tr->B < 1) { tr->err = "omds_trainer_eval: no data set (omds_trainer_set_data)"; return OMDS_ERR_NOT_INITIALISED; }
+    if (!x || !y || batch < 1) { tr->err = "omds_trainer_set_val_data: need batch >= 1 and non-null x [B, d], y [B, C]"; return OMDS_ERR_INVALID_ARG; }
+    TCK(hipSetDevice(tr->dev));
+    TCK(hipStreamSynchronize(tr->stream));
+    if (batch > tr->vcap) {
+        for (float* p : {tr->xv, tr->yv}) if (p) (void)hipFree(p);
+        tr->xv = tr->yv = nullptr; tr->vcap = 0; tr->Bv = 0;
+        TCK(hipMalloc(&tr->xv, (size_t)batch * tr->d * 4));
+        TCK(hipMalloc(&tr->yv, (size_t)batch * tr->dims[tr->L] * 4));
+        tr->vcap = batch;
+    }
+    int rc;
+    if ((rc = trainer_reserve(tr, std::max(batch, tr->B)))) return rc;
+    TCK(hipMemcpy(tr->xv, x, (size_t)batch * tr->d * 4, hipMemcpyHostToDevice));
+    TCK(hipMemcpy(tr->yv, y, (size_t)batch * tr->dims[tr->L] * 4, hipMemcpyHostToDevice));
+    tr->Bv = batch;
+    return OMDS_OK;
+}
+
+// forward + F.mse_loss with the current weights, no update: which = 0 the training set, 1 the validation set (train_sdf.py:117-121)
+int omds_trainer_eval(omds_trainer* tr, int which, float* mse_out, float* pred_out) {
+    if (!tr) return OMDS_ERR_INVALID_ARG;
+    if (which != 0 && which != 1) { tr->err = "omds_trainer_eval: which must be 0 (training set) or 1 (validation set)"; return OMDS_ERR_INVALID_ARG; }
+    const int B = which ? tr->Bv : tr->B;
+    if (B < 1) { tr->err = which ? "omds_trainer_eval: no validation set (omds_trainer_set_val_data)" : "omds_trainer_eval: no data set (omds_trainer_set_data)"; return OMDS_ERR_NOT_INITIALISED; }
     TCK(hipSetDevice(tr->dev));
     int rc;
-    if ((rc = forward(tr, tr->B))) return rc;
+    if ((rc = trainer_reserve(tr, B))) return rc;
+    if ((rc = forward(tr, B, which ? tr->xv : tr->x))) return rc;
     double loss = 0.0;
-    if ((rc = mse(tr, tr->B, nullptr, &loss))) return rc;
+    if ((rc = mse(tr, B, which ? tr->yv : tr->y, nullptr, &loss))) return rc;
     if (mse_out) *mse_out = (float)loss;
-    if (pred_out) TCK(hipMemcpy(pred_out, tr->H[tr->L], (size_t)tr->B * tr->dims[tr->L] * 4, hipMemcpyDeviceToHost));
+    if (pred_out) TCK(hipMemcpy(pred_out, tr->H[tr->L], (size_t)B * tr->dims[tr->L] * 4, hipMemcpyDeviceToHost));
+    return OMDS_OK;
+}
+
+// torch.optim.Adam's state (exp_avg, exp_avg_sq per parameter, the step count), for checkpoints in the reference's format
+// (train_sdf.py:130-138 saves optimizer.state_dict()) and for resuming: arrays like omds_trainer_get_weights (NULL array = skip).
+int omds_trainer_get_optimizer_state(omds_trainer* tr, float* const* mW, float* const* mb, float* const* vW, float* const* vb, int64_t* step) {
+    if (!tr) return OMDS_ERR_INVALID_ARG;
+    TCK(hipSetDevice(tr->dev));
+    TCK(hipStreamSynchronize(tr->stream));
+    for (int i = 0; i < tr->L; ++i) {
+        const size_t nw = (size_t)tr->dims[i] * tr->dims[i + 1] * 4, nb = (size_t)tr->dims[i + 1] * 4;
+        if (mW && mW[i]) TCK(hipMemcpy(mW[i], tr->mW[i], nw, hipMemcpyDeviceToHost));
+        if (vW && vW[i]) TCK(hipMemcpy(vW[i], tr->vW[i], nw, hipMemcpyDeviceToHost));
+        if (mb && mb[i]) TCK(hipMemcpy(mb[i], tr->mb[i], nb, hipMemcpyDeviceToHost));
+        if (vb && vb[i]) TCK(hipMemcpy(vb[i], tr->vb[i], nb, hipMemcpyDeviceToHost));
+    }
+    if (step) *step = tr->step;
+    return OMDS_OK;
+}
+int omds_trainer_set_optimizer_state(omds_trainer* tr, const float* const* mW, const float* const* mb, const float* const* vW,
+                                     const float* const* vb, int64_t step) {
+    if (!tr) return OMDS_ERR_INVALID_ARG;
+    if (!mW || !mb || !vW || !vb || step < 0) { tr->err = "omds_trainer_set_optimizer_state: null argument or negative step"; return OMDS_ERR_INVALID_ARG; }
+    for (int i = 0; i < tr->L; ++i)
+        if (!mW[i] || !mb[i] || !vW[i] || !vb[i]) { tr->err = "omds_trainer_set_optimizer_state: null array"; return OMDS_ERR_INVALID_ARG; }
+    TCK(hipSetDevice(tr->dev));
+    TCK(hipStreamSynchronize(tr->stream));
+    for (int i = 0; i < tr->L; ++i) {
+        const size_t nw = (size_t)tr->dims[i] * tr->dims[i + 1] * 4, nb = (size_t)tr->dims[i + 1] * 4;
+        TCK(hipMemcpy(tr->mW[i], mW[i], nw, hipMemcpyHostToDevice));
+        TCK(hipMemcpy(tr->vW[i], vW[i], nw, hipMemcpyHostToDevice));
+        TCK(hipMemcpy(tr->mb[i], mb[i], nb, hipMemcpyHostToDevice));
+        TCK(hipMemcpy(tr->vb[i], vb[i], nb, hipMemcpyHostToDevice));
+    }
+    tr->step = step;
     return OMDS_OK;
 }
 
@@ -368,11 +447,12 @@ int omds_trainer_step(omds_trainer* tr, float lr, float beta1, float beta2, floa
     hipStream_t s = tr->stream;
     const int B = tr->B, L = tr->L;
     int rc;
-    if ((rc = forward(tr, B))) return rc;
+    if ((rc = trainer_reserve(tr, B))) return rc;
+    if ((rc = forward(tr, B, tr->x))) return rc;
     double loss = 0.0;
     float* G = tr->G[0];
     float* Gn = tr->G[1];
-    if ((rc = mse(tr, B, G, &loss))) return rc;
+    if ((rc = mse(tr, B, tr->y, G, &loss))) return rc;
     if (loss_out) *loss_out = (float)loss;
     for (int i = L - 1; i >= 0; --i) {
         const int in = tr->dims[i], out = tr->dims[i + 1];

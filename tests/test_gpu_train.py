@@ -139,3 +139,54 @@ def test_trained_weights_round_trip_through_the_reference_checkpoint_format(tmp_
     assert np.abs(yy - pred[:200]).max() <= 1e-5 * max(1.0, float(np.abs(pred).max()))
     eng.close()
     tr.close()
+
+
+def test_validation_split_and_optimizer_state_round_trip():
+    """(a) One trainer holds the training and the validation split (train_sdf.py:84-86, 117-121): ``eval(val=True)`` equals a second
+    trainer given the same weights and the validation rows as its data.  (b) The optimizer state leaves and re-enters in
+    torch.optim.Adam's own state_dict() shape: a run interrupted after 5 epochs, saved as the reference's checkpoint dictionary and
+    resumed in a NEW trainer continues bit for bit like the uninterrupted one; torch's Adam accepts the dictionary."""
+    import torch
+    from optimalmodulationds_amd.trainer import SdfTrainer, checkpoint_dict
+    rng = np.random.RandomState(4)
+    dims = [15, 64, 64, 2]
+    W0 = [(0.3 * rng.standard_normal((dims[i + 1], dims[i]))).astype(np.float32) for i in range(3)]
+    b0 = [(0.1 * rng.standard_normal(dims[i + 1])).astype(np.float32) for i in range(3)]
+    x, y = rng.uniform(-2, 2, (3000, 5)).astype(np.float32), rng.uniform(0, 3, (3000, 2)).astype(np.float32)
+    xv, yv = rng.uniform(-2, 2, (5000, 5)).astype(np.float32), rng.uniform(0, 3, (5000, 2)).astype(np.float32)   # larger than the training set
+    a = SdfTrainer(dims, "relu")
+    a.set_weights(W0, b0)
+    a.set_data(x, y)
+    a.set_val_data(xv, yv)
+    losses_a = [a.step(lr=1e-3) for _ in range(5)]
+    v_a, pred_a = a.eval(want_pred=True, val=True)
+    ref = SdfTrainer(dims, "relu")
+    ref.set_weights(*a.get_weights())
+    ref.set_data(xv, yv)
+    v_ref, pred_ref = ref.eval(want_pred=True)
+    assert v_a == v_ref and np.array_equal(pred_a, pred_ref) and pred_a.shape == (5000, 2)
+    assert a.eval() == pytest.approx(losses_a[-1], rel=0.2)                  # the training set is still in place
+    # interrupted after 5 epochs -> checkpoint -> a new trainer
+    ck = checkpoint_dict(5, *a.get_weights(), 5, 2, a.optimizer_state_dict())
+    st = ck["optimizer_state_dict"]
+    assert sorted(st["state"]) == list(range(6)) and float(st["state"][0]["step"]) == 5.0 and st["param_groups"][0]["lr"] == 1e-3
+    params = [torch.nn.Parameter(torch.from_numpy(p.copy())) for pair in zip(*a.get_weights()) for p in pair]   # weight 0, bias 0, weight 1, ...
+    torch.optim.Adam(params, lr=1e-3).load_state_dict(st)                    # torch takes it as its own
+    b_ = SdfTrainer(dims, "relu")
+    b_.set_weights([ck["model_state_dict"][f"layers.0.{i}.0.weight"].numpy() for i in range(3)],
+                   [ck["model_state_dict"][f"layers.0.{i}.0.bias"].numpy() for i in range(3)])
+    b_.load_optimizer_state_dict(st)
+    b_.set_data(x, y)
+    cont_a = [a.step(lr=1e-3) for _ in range(5)]
+    cont_b = [b_.step(lr=1e-3) for _ in range(5)]
+    assert cont_a == cont_b
+    for wa, wb in zip(a.get_weights()[0] + a.get_weights()[1], b_.get_weights()[0] + b_.get_weights()[1]):
+        assert np.array_equal(wa, wb)
+    fresh = SdfTrainer(dims, "relu")                                          # without the state the resumed run differs (bias correction restarts)
+    fresh.set_weights([ck["model_state_dict"][f"layers.0.{i}.0.weight"].numpy() for i in range(3)],
+                      [ck["model_state_dict"][f"layers.0.{i}.0.bias"].numpy() for i in range(3)])
+    fresh.set_data(x, y)
+    fresh.step(lr=1e-3)
+    assert not np.array_equal(fresh.get_weights()[0][0], np.zeros(1)) and fresh.optimizer_state_dict()["state"][0]["step"] == 1.0
+    for t in (a, b_, ref, fresh):
+        t.close()

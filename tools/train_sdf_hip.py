@@ -59,10 +59,10 @@ def main():
     else:                                                                        # torch's default nn.Linear initialisation
         lin = [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)]
         W, b = [l.weight.detach().numpy() for l in lin], [l.bias.detach().numpy() for l in lin]
-    train, val = SdfTrainer(dims, "relu"), SdfTrainer(dims, "relu")
+    train = SdfTrainer(dims, "relu")          # ONE trainer holds both splits: the validation pass needs no weight copy
     train.set_weights(W, b)
     train.set_data(x_tr, y_tr)
-    val.set_data(x_va, y_va)
+    train.set_val_data(x_va, y_va)
     sched = ReduceLROnPlateau(args.lr, factor=0.5, patience=5000, threshold=0.01, eps=1e-4)   # train_sdf.py:85-87
     min_loss, e_notsaved, t_dev = None, 0, 0.0
     close = y_va[:, -1] < 1
@@ -70,9 +70,7 @@ def main():
         t0 = time.time()
         train_loss = train.step(lr=sched.lr)
         t_dev += time.time() - t0
-        Wc, bc = train.get_weights()
-        val.set_weights(Wc, bc)
-        val_loss, pred = val.eval(want_pred=True)
+        val_loss, pred = train.eval(want_pred=True, val=True)
         l1_close = float(np.abs(pred[close, -1] - y_va[close, -1]).mean()) if close.any() else float("nan")
         if e == 0:
             min_loss = val_loss
@@ -81,7 +79,8 @@ def main():
         if val_loss < min_loss and e > 100 and e_notsaved > 100:                 # train_sdf.py:127
             e_notsaved, min_loss = 0, val_loss
             if args.out:
-                torch.save(checkpoint_dict(e, Wc, bc, d, C), args.out)
+                Wc, bc = train.get_weights()
+                torch.save(checkpoint_dict(e, Wc, bc, d, C, train.optimizer_state_dict()), args.out)   # train_sdf.py:130-138
                 print("saving model", val_loss)
         if e % 20 == 0 or e == args.epochs - 1:
             print("Epoch: %d (Saved at %d), Train Loss: %4.3f, Validation Loss: %4.3f (%4.3f), Epoch time: %4.4f s, LR = %4.8f" % (
