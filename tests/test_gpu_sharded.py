@@ -90,6 +90,57 @@ def test_two_contexts_sum_to_one(N, H, K):
         e.close()
 
 
+def test_eight_shards_of_1024_reproduce_one_context_of_8192x32():
+    """BASELINE configs[4]'s shape -- 8192 rollouts x 32 steps over 8 GPUs -- emulated on one: eight contexts of 1024 rollouts (the
+    per-GPU shard, rollout_offset = rank * 1024, the moving shelf re-sent before the propagate like the dynamic workload does) and
+    ONE context holding all 8192.  Every shard's rollouts are the corresponding rows of the big context bit for bit (both shapes
+    take the screened step); the host-mediated sums over the eight (what the two all-reduces and the MINLOC gather do) reproduce
+    the single context's update: identical mask, means and weighted velocity to 1e-6, the same best rollout."""
+    from optimalmodulationds_amd.engine import apply_update, red_layout
+    N, H, K, G = 8192, 32, 10, 8
+    m, obs, q0, qf, dh, qmin, qmax, make, mu_c, sg_c, al_c = _setup(N, H, K=K)
+    moved = obs.copy()
+    moved[:, 1] += 0.05 * np.sin(0.3 * 7)
+    one = make(N)
+    one.set_obstacles(moved)
+    one.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 3.0, K, seed=4242, rollout_offset=0)
+    one.propagate(q0)
+    r_one = one.get_rollouts(want=("all_traj", "closest_dist_all", "qdot"))
+    c_one = one.cost()
+    ref_mu, ref_sg, ref_al, ref_mask, ref_qw, ref_qb, nt = one.weighted_update_sharded(0.1, 0.1, mu_c, sg_c, al_c, want_best=True)
+    assert nt == N and one.screen_stats()["active"]
+    h = N // G
+    cs, shards = np.zeros(2, np.float64), []
+    for r in range(G):
+        e = make(h)
+        e.set_obstacles(moved)
+        e.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 3.0, K, seed=4242, rollout_offset=r * h)
+        e.propagate(q0)
+        rr = e.get_rollouts(want=("all_traj", "closest_dist_all", "qdot"))
+        for key in rr:
+            assert np.array_equal(rr[key], r_one[key][r * h:(r + 1) * h]), (r, key)
+        assert np.array_equal(e.cost(), c_one[r * h:(r + 1) * h])
+        st = e.screen_stats()      # a shard's first propagate may trip the guard of its fresh calibration once (redone in fp32: the same bits)
+        print(r, {k2: st[k2] for k2 in ("eps", "max_err_seen", "audit_max_err", "fallbacks_by_error", "fallbacks_by_slack", "fallbacks_by_overflow")})
+        assert st["active"] and not st["suspended"] and st["fallbacks"] <= 1, st
+        cs += e.cost_sum()                                            # all-reduce SUM #1 over the 8 shards
+        shards.append(e)
+    assert cs[1] == N
+    reds = [e.local_sums(np.float32(cs[0]), np.float32(cs[1]), include_rollout0=(r == 0)) for r, e in enumerate(shards)]
+    lay = red_layout(K, 7)
+    red = reds[0].copy()
+    red[:lay["n_sum"]] = np.sum([x[:lay["n_sum"]] for x in reds], axis=0, dtype=np.float32)   # all-reduce SUM #2
+    nmu, nsg, nal, mask = apply_update(K, 7, H, red, float(cs[1]), 0.1, 0.1, mu_c, sg_c, al_c)
+    assert np.array_equal(mask, ref_mask)
+    for a, b, what in ((nmu, ref_mu, "mu"), (nsg, ref_sg, "sigma"), (nal, ref_al, "alpha")):
+        assert np.abs(a - b).max() <= 1e-6 * max(1.0, np.abs(b).max()), what
+    assert np.abs(red[lay["qdot"]:lay["qdot"] + 7] / red[0] - ref_qw).max() <= 2e-6
+    best = np.stack([x[lay["n_sum"]:] for x in reds])                 # all-gather + MINLOC (lowest rank on ties)
+    assert np.array_equal(best[int(np.argmin(best[:, 0])), 1:], ref_qb)
+    for e in shards + [one]:
+        e.close()
+
+
 def test_native_rccl_single_rank_matches_local_update():
     """omds_comm_init_rank (world 1) + omds_weighted_update_sharded: the RCCL all-reduces / all-gather run on the
     context stream on device buffers; with one rank they must leave every number of the local update unchanged."""
