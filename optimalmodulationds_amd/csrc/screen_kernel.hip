@@ -455,6 +455,12 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
 #endif
         };
         auto slot_ptr = [&](int s) { return ring_lane + ((sigma0 + s) & (SC_RING - 1)) * SC_SLICE; };
+#ifdef OMDS_SC_EXPERIMENT   // OMDS_SCREEN_DBG 8: the partial last tile of a chunk is not multiplied at all (what its round costs)
+        if ((OMDS_DBG(a.dbg) & 8) && it == my_tiles - 1 && (my_pairs % SC_ROWS) != 0) {
+            for (int s = 0; s < S; ++s) sync_and_issue(s);
+            continue;
+        }
+#endif
         if (it * SC_ROWS + wave * SC_RB * 32 >= my_pairs) {
             // all pairs of this wave lie past the end of the chunk (the partial last tile of a chunk of whole rollouts): it keeps
             // the ring moving -- its DMA pieces, the barriers -- and issues no MFMA.  The matrix pipe is power-limited under this
