@@ -120,7 +120,7 @@ static void free_all(omds_ctx* ctx) {
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
                     ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
                     ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
-                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP, ctx->d_seds, ctx->d_audit_rows, ctx->d_audit_da, ctx->d_ApreAll, ctx->d_featQAll, ctx->d_FqS, ctx->d_FpS, ctx->d_listDa, ctx->d_sinks, ctx->d_qcur, ctx->d_sweepD, ctx->d_sweepDa, ctx->d_sweep_hist, ctx->d_uev};
+                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP, ctx->d_seds, ctx->d_audit_rows, ctx->d_audit_da, ctx->d_ApreAll, ctx->d_featQAll, ctx->d_FqS, ctx->d_FpS, ctx->d_listDa, ctx->d_sinks, ctx->d_qcur, ctx->d_sweepD, ctx->d_sweepDa, ctx->d_sweep_hist, ctx->d_uev, ctx->d_exDeriv};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : ctx->mlp_allocs)
@@ -535,10 +535,13 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
         m.featP = ctx->d_featP;
     }
     if (ctx->d_dscr) { (void)hipFree(ctx->d_dscr); ctx->d_dscr = nullptr; }
+    if (ctx->d_exDeriv) { (void)hipFree(ctx->d_exDeriv); ctx->d_exDeriv = nullptr; }
     if (act == OMDS_ACT_TANH) {   // pass 2 keeps 1 - h^2 of every hidden layer for the backward (ReLU uses LDS bit masks)
         const size_t rows = std::max(((size_t)ctx->cfg.n_traj * ctx->cfg.n_closest + 31) / 32 * 32,
                                      (size_t)omds_tail_scratch_rows(ctx->cfg.n_traj, ctx->cfg.n_closest));
         CK(hipMalloc(&ctx->d_dscr, (size_t)nhid * rows * OMDS_WIDTH * 4));
+        // the screened step's hand-over: the same derivatives for every candidate k_exact evaluates (1 KB per entry and hidden
+        // layer; 400 MB at 4096 rollouts -- HBM capacity is not a constraint here).  Allocated lazily at the first screened step.
     }
     ctx->screen = ScreenDev{};
     // the input tables keep zeros in the slots the other operand owns; the slot assignment depends on the network's d
@@ -675,7 +678,7 @@ static int grow_obstacle_capacity(omds_ctx* ctx, int n_obs) {
     }
     const int ex_cap = (int)std::min<size_t>(N * Om, N * 32);
     if (ex_cap > ctx->ex_cap) {
-        for (void** o : {(void**)&ctx->d_exD, (void**)&ctx->d_exDr, (void**)&ctx->d_exMin, (void**)&ctx->d_exMask}) { if (*o) (void)hipFree(*o); *o = nullptr; }
+        for (void** o : {(void**)&ctx->d_exD, (void**)&ctx->d_exDr, (void**)&ctx->d_exMin, (void**)&ctx->d_exMask, (void**)&ctx->d_exDeriv}) { if (*o) (void)hipFree(*o); *o = nullptr; }   // (d_exDeriv: allocated again at the next screened tanh step)
         ctx->ex_cap = 0;
         CK(hipMalloc(&ctx->d_exD, (size_t)ex_cap * 4));
         CK(hipMalloc(&ctx->d_exDr, (size_t)ex_cap * 4));
@@ -1119,11 +1122,20 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
         size_t apre_slab = 0;
         SelectSink sink{};
         // ReLU networks: k_exact leaves masks and k_tail_sel runs the backward only; when a rollout's obstacles fit a
-        // workgroup's LDS, k_screen selects in its flush phase (no matrix, no k_select).  tanh networks: k_screen writes the
-        // matrix, k_exact puts the exact values of the candidates into it and k_tail works from the matrix as in the fp32 step
+        // workgroup's LDS, k_screen selects in its flush phase (no matrix, no k_select)
         const bool relu = ctx->mlp.act == OMDS_ACT_RELU;
+        // tanh networks: k_exact hands 1 - h^2 of every candidate's hidden units to k_tail_sel (ExactOut::deriv), so the step has
+        // the ReLU step's shape -- no matrix, no k_select, no second forward in the tail.  The buffer is allocated at the first
+        // screened tanh step; if that fails (an enormous batch) the step keeps the matrix route (k_exact mode 3 + k_tail)
+        if (screen && !relu && !ctx->d_exDeriv) {
+            static const int handover = OMDS_EXP_ENV("OMDS_TANH_HANDOVER", 1);   // experiment builds: 0 keeps the matrix route (A/B runs)
+            const size_t bytes = (size_t)(ctx->mlp.nhh + 1) * (size_t)ctx->ex_cap * OMDS_WIDTH * 4;
+            if (handover && hipMalloc(&ctx->d_exDeriv, bytes) != hipSuccess) { ctx->d_exDeriv = nullptr; (void)hipGetLastError(); }
+        }
+        const bool list_tail = relu || ctx->d_exDeriv != nullptr;   // k_tail_sel works from k_exact's per-entry outputs
+        ex.deriv = relu ? nullptr : ctx->d_exDeriv;
         static const int fuse_env = OMDS_EXP_ENV("OMDS_SCREEN_FUSE_SELECT", 1);   // experiment builds: 0 keeps k_select as its own launch (A/B runs)
-        const bool fuse_select = screen && relu && fuse_env != 0 && omds_screen_can_select(ctx->n_obs);
+        const bool fuse_select = screen && list_tail && fuse_env != 0 && omds_screen_can_select(ctx->n_obs);
         if (screen) {
             CK(hipMemsetAsync(ctx->d_sctotal, 0, (size_t)(H + 2) * 4, ctx->stream));
             CK(hipMemsetAsync(ctx->d_scerr, 0, 16, ctx->stream));
@@ -1182,7 +1194,7 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
             }
             RoctxRange r2("TAG: evaluate NN_3-5 + Modulation-propagation");
             a.step = i;
-            if (screen && relu)
+            if (screen && list_tail)
                 omds_launch_tail_sel(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, apre_next, ctx->n_obs, a,
                                      ctx->d_rowlist, ctx->d_range, ex, ctx->d_FqH, N, ctx->screen_eps, ctx->d_scerr + 1);
             else if (screen)

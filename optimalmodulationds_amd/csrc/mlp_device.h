@@ -338,7 +338,10 @@ struct OmdsDivisor {
 // arrays) and the masks stay in the tile's LDS block (maskS, behind rowIdx).  MODE 4 (audit sample, k_audit): rows as in
 // mode 1, the rollout index of a pair running over all horizon steps' states; no outputs but max (ex->Da[entry] - exact value)
 // into maxerr_bits[2].  MODE 3 (screened step of tanh networks): rows as in mode 1; the exact value overwrites the pair's
-// screening value in Dmin, max |screening - exact| goes to *maxerr_bits, nothing else is kept.
+// screening value in Dmin, max |screening - exact| goes to *maxerr_bits, nothing else is kept.  MODE 5 (screened step of tanh
+// networks with the derivative hand-over): mode 1 with the rows' activation derivatives 1 - h^2 of every hidden layer
+// (ex->deriv[(level * cap + entry) * 256 + column]: 1 KB per entry and layer, written row-wise from the tile) in place of the
+// ReLU masks -- what pass 2's forward would have left in its scratch, so that the tail runs the backward only (k_tail_sel).
 // The arithmetic of a row is the same in all forms and independent of the other rows of the tile: bit-identical results.
 template <int MT, int MR, int NR, int ACT, int MODE = 0>
 __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const float* __restrict__ Apre,
@@ -347,7 +350,9 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                                            const long long row0, const OmdsDivisor odiv,
                                            const int* __restrict__ rowlist = nullptr, unsigned* maxerr_bits = nullptr,
                                            const ExactOut* ex = nullptr) {
-    constexpr bool LIST = MODE == 1 || MODE == 3 || MODE == 4, EMIT = MODE == 1 || MODE == 2;
+    constexpr bool LIST = MODE == 1 || MODE == 3 || MODE == 4 || MODE == 5, EMIT = MODE == 1 || MODE == 2, DERIV = MODE == 5;
+    constexpr bool EMITY = EMIT || DERIV;   // pass 2's distance and arg-min link per row (ex->dr, ex->amin)
+    static_assert(!DERIV || MT == 16, "the derivative hand-over is written for the 16-row tiles of k_exact");
     using G = Geo<MT, MR, NR>;
     float* Hs = smem;                                           // [MT][LDH]
     float* rowRad = smem + MT * LDH;                            // [MT] obstacle radius of each row
@@ -356,6 +361,22 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
     const int nhid = m.nhh + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / G::WN, wn = wave % G::WN;
+    // MODE 5: the activation derivatives of the tile's rows at `level`, row-wise (a wave per row, one float4 per lane: 1 KB
+    // coalesced) from the activations the epilogue has just left in the tile; after the barrier behind the epilogue
+    [[maybe_unused]] auto emit_deriv = [&](int level) {
+        if constexpr (DERIV) {
+            for (int r = wave; r < MT; r += G::NW) {
+                const long long e_idx = row0 + r;
+                if (e_idx < total_rows && e_idx < ex->cap) {
+                    const float4 h = *reinterpret_cast<const float4*>(Hs + r * LDH + 4 * lane);
+                    float4 dv;
+                    dv.x = 1.f - h.x * h.x; dv.y = 1.f - h.y * h.y; dv.z = 1.f - h.z * h.z; dv.w = 1.f - h.w * h.w;
+                    *reinterpret_cast<float4*>(ex->deriv + ((size_t)level * ex->cap + (size_t)e_idx) * OMDS_WIDTH + 4 * lane) = dv;
+                }
+            }
+            if ((m.skip_mask >> level) & 1u) __syncthreads();   // the concatenated inputs are about to be written into these rows
+        }
+    };
     OMDS_TL(0);
 #ifdef OMDS_TIMELINE
     if (m.tl && threadIdx.x == 0)   // HW_ID and XCC_ID: which CU this workgroup landed on
@@ -462,6 +483,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
     OMDS_TL(9);
     __syncthreads();
     OMDS_TL(1);
+    emit_deriv(0);
     // skip-connection networks: the encoded input of each row goes behind the activations of `level` (MlpDev::skip_mask)
     auto inject = [&](int level) {
         const int c0 = m.skip_col[level], F = 3 * m.d;
@@ -514,6 +536,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
             for (int r = 0; r < 8; ++r)
                 Hs[(4 * (lane >> 4) + (r & 3)) * LDH + wave * 32 + 16 * (r >> 2) + (lane & 15)] = actf(acc[r >> 2][r & 3], ACT);
             __syncthreads();
+            emit_deriv(l + 1);
             if ((m.skip_mask >> (l + 1)) & 1u) inject(l + 1);
             OMDS_TL(2 + l);
         }
@@ -610,7 +633,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
         [[maybe_unused]] int yam[4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            if constexpr (EMIT) {   // pass 2's arg-min over ALL raw outputs (robot_sdf.py:155) and the distance of that link:
+            if constexpr (EMITY) {   // pass 2's arg-min over ALL raw outputs (robot_sdf.py:155) and the distance of that link:
                 // the minimum over the 16 link lanes by DPP, then the lowest lane holding it from a ballot (ties: lower link,
                 // as a compare-and-swap reduction by (value, index) would give; eight dependent cross-lane shuffles shorter)
                 const float yv = pad ? __builtin_inff() : acc[reg] + bj;
@@ -643,9 +666,9 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                         // candidates (MODE 1): |Da - D| -> maxerr_bits[0].  Audit sample (MODE 4: pairs that were NOT candidates):
                         // the one-sided Da - D the selection rule bounds by eps -> maxerr_bits[2]; a non-candidate whose
                         // screening value is too LOW is harmless, one too HIGH by more than eps could hide a top-k row
-                        const float e = MODE == 4 ? scr[reg] - y[reg] : fabsf(scr[reg] - y[reg]);
+                        const float e = MODE == 4 ? scr[reg] - y[reg] : fabsf(scr[reg] - y[reg]);   // (modes 1, 3, 5: candidates)
                         if (!(e <= me)) me = (e == e) ? e : __builtin_inff();   // a NaN screening value (fp16 overflow) counts as an infinite error
-                        if constexpr (MODE == 1) {
+                        if constexpr (MODE == 1 || MODE == 5) {
                             if (e_idx < ex->cap) { ex->D[e_idx] = y[reg]; ex->dr[e_idx] = ydr[reg]; ex->amin[e_idx] = yam[reg]; }
                         }
                         if constexpr (MODE == 3) Dmin[rowIdx[r4 + reg]] = y[reg];   // the exact value takes the screening value's place
@@ -742,6 +765,8 @@ struct P2Smem {
     int* rowT;        // [32] rollout of each row (-1: padding row)
     int* rowO;        // [32] obstacle of each row
     int* rowMin;      // [32] arg-min link of each row
+    const int* rowE = nullptr;   // tanh derivative hand-over (k_tail_sel): [32] list entry whose derivative rows each backward row reads
+                                 // (-1: padding row), dscr then being ExactOut::deriv with dlayer = cap * 256; nullptr: row S0 + r of dscr
 };
 
 // Geometry of the per-thread accumulator values of a pass-2 tile: ROWS = 32 uses the 32x32x2 MFMA (16 values per thread,
@@ -942,6 +967,14 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
     pass2_backward<ACT, ROWS>(m, sm, xyzr, R0, total_rows, qT, ldq, gradx, dbase, dscr, dlayer, S0, dbg);
 }
 
+// 1 - h^2 of (row, col) at one hidden level: from the workgroup's own scratch rows (pass 2 behind its own forward) or, with
+// sm.rowE, from the derivative rows k_exact left for the list entry of each backward row (a padding row multiplies by zero)
+__device__ __forceinline__ float p2_tanh_deriv(const P2Smem& sm, const float* __restrict__ dscr, size_t level_off, int S0, int row, int col) {
+    if (sm.rowE == nullptr) return dscr[level_off + (size_t)(S0 + row) * OMDS_WIDTH + col];
+    const int e = sm.rowE[row];
+    return e >= 0 ? dscr[level_off + (size_t)e * OMDS_WIDTH + col] : 0.f;
+}
+
 // The backward half of pass 2: from sm.rowMin (arg-min link of each row), the activation derivatives -- sm.maskL (ReLU:
 // 16 bits per thread and layer in the MFMA C layout) or dscr (tanh) -- and sm.rowT / sm.rowO to the input gradients
 // gradx[(dbase + row) * d + j].  pass2_body runs it behind its own forward; the screened step (k_tail_sel) runs it on masks
@@ -976,8 +1009,7 @@ __device__ __forceinline__ void pass2_backward(const MlpDev& m, const P2Smem& sm
             const int row = G::row(r, lane), col = G::col(r, wave, lane);
             const float g = m.Wlraw[(size_t)rowMin[row] * OMDS_WIDTH + col];
             if (cap && col >= c0 && col < c0 + F3) gf[row * 33 + col - c0] += g;
-            const float dv = relu ? (((bits >> r) & 1u) ? 1.f : 0.f)
-                                  : dscr[m.nhh * dlayer + (size_t)(S0 + row) * OMDS_WIDTH + col];
+            const float dv = relu ? (((bits >> r) & 1u) ? 1.f : 0.f) : p2_tanh_deriv(sm, dscr, m.nhh * dlayer, S0, row, col);
             Hs[row * LDH + col] = g * dv;
         }
     }
@@ -999,8 +1031,7 @@ __device__ __forceinline__ void pass2_backward(const MlpDev& m, const P2Smem& sm
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
             const int row = G::row(r, lane), col = G::col(r, wave, lane);
-            const float dv = relu ? (((bits >> r) & 1u) ? 1.f : 0.f)
-                                  : dscr[l * dlayer + (size_t)(S0 + row) * OMDS_WIDTH + col];
+            const float dv = relu ? (((bits >> r) & 1u) ? 1.f : 0.f) : p2_tanh_deriv(sm, dscr, l * dlayer, S0, row, col);
             if (cap && col >= c0 && col < c0 + F3) gf[row * 33 + col - c0] += acc[r];
             Hs[row * LDH + col] = acc[r] * dv;
         }

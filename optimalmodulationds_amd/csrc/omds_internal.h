@@ -149,6 +149,7 @@ struct omds_ctx {
     float* d_exDr = nullptr;
     int* d_exMin = nullptr;
     uint32_t* d_exMask = nullptr;
+    float* d_exDeriv = nullptr;  // tanh networks: [hidden layers][ex_cap][256] activation derivatives of the list entries (allocated by omds_set_mlp)
     int* d_sctotal = nullptr;    // [H+2]: candidate rows listed per horizon step; [H+1]: audit entries recorded in this propagate
     int* d_audit_rows = nullptr; // [audit_cap] audit sample of a propagate: pair rows into d_ApreAll's row space, their screening values
     float* d_audit_da = nullptr;
@@ -334,6 +335,7 @@ struct ExactOut {
     uint32_t* mask;    // [cap][nhid][8]
     int cap;           // entries the arrays hold (the list may be longer: the host then redoes the propagate in fp32)
     const float* Da = nullptr;   // audit list only (pass1_tile mode 4): [entries] screening value of each listed pair
+    float* deriv = nullptr;      // tanh networks (pass1_tile mode 5): [hidden layers][cap][256] 1 - h^2 of every entry's hidden units
 };
 
 // What the selection (k_select, or the flush phase of k_screen) produces per horizon step

@@ -995,9 +995,11 @@ void omds_launch_select(hipStream_t s, const float* Dmin, int B, int O, const Se
 }
 
 // ReLU networks: mode 1 -- per entry the exact value, pass 2's distance / arg-min link and the ReLU masks, for k_tail_sel.
-// tanh networks: mode 3 -- the exact value replaces the screening value in the matrix Dmin itself (candidates only); k_tail then
-// takes its top-k from the matrix (every non-candidate still holds a screening value > tau, above every row that matters) and
-// runs its own forward: a tanh backward needs 1 - h^2 of every unit, 3 KB per row instead of the 140 B of masks.
+// tanh networks: mode 5 -- the same with 1 - h^2 of every hidden unit (ex.deriv: 1 KB per entry and layer) in place of the masks, so
+// that k_tail_sel<..., tanh> runs the backward only (round 4; 3 KB per candidate row of HBM traffic against a second forward in
+// the tail).  Without ex.deriv (a matrix-mode step: rows too long for the selecting flush AND no derivative buffer), mode 3: the
+// exact value replaces the screening value in the matrix Dmin itself and k_tail takes its top-k from the matrix and runs its own
+// forward.
 void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius, int O,
                        int B, uint32_t ignored, float* Dmin, const int* rowlist, const int* total, unsigned* maxerr_bits,
                        const ExactOut& ex) {
@@ -1011,6 +1013,8 @@ void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const 
     const OmdsDivisor od = OmdsDivisor::make((unsigned)O);
     if (m.act == OMDS_ACT_RELU)
         hipLaunchKernelGGL((k_exact<OMDS_ACT_RELU, 1>), dim3(grid), dim3(512), lds, s, m, Apre, Bpre, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits, ex);
+    else if (ex.deriv)   // the derivative hand-over: k_tail_sel runs the backward on what this launch leaves per entry
+        hipLaunchKernelGGL((k_exact<OMDS_ACT_TANH, 5>), dim3(grid), dim3(512), lds, s, m, Apre, Bpre, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits, ex);
     else
         hipLaunchKernelGGL((k_exact<OMDS_ACT_TANH, 3>), dim3(grid), dim3(512), lds, s, m, Apre, Bpre, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits, ex);
 }

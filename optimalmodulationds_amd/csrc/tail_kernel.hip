@@ -152,10 +152,13 @@ static size_t tail_lds_bytes(int nhid);
 // pass-2 distance, the arg-min link and the ReLU masks per list entry.  This tail therefore needs no forward at all: top-k
 // by (D, obstacle index) over each rollout's few candidates, masks of the selected entries gathered into the MFMA C layout,
 // the pass-2 backward, then blend / modulation / Euler step / next-step layer 1 exactly as in k_tail.
+// tanh networks (ACT = OMDS_ACT_TANH, round 4): k_exact left 1 - h^2 of every hidden unit of every candidate instead of masks
+// (ExactOut::deriv, 1 KB per entry and layer); the backward reads the selected entries' rows through sm.rowE -- the same
+// numbers pass 2's own forward would have written to its scratch, so the tanh tail drops its forward too.
 // ------------------------------------------------------------------------------------------------
-template <int ND, int ROWS>
+template <int ND, int ROWS, int ACT = OMDS_ACT_RELU>
 __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
-    constexpr int ACT = OMDS_ACT_RELU;
+    static_assert(ACT == OMDS_ACT_RELU || ROWS != 4, "the 4-row-group backward works on ReLU masks");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const MlpDev& m = a.m;
     P2Smem sm;
@@ -252,6 +255,9 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
     __syncthreads();
     OMDS_TL_STAMP(2);
     if (OMDS_DBG(a.dbg_stop) == 1) return;   // OMDS_TAIL_SEL_STOP: timing experiments
+    if constexpr (ACT == OMDS_ACT_TANH) {
+        sm.rowE = sel;   // the backward gathers 1 - h^2 of row r from entry sel[r] of ExactOut::deriv (written by k_exact, mode 5)
+    } else {
     // ---- the selected entries' masks -> LDS -> 16 bits per thread and layer in the MFMA C layout (what pass 2's forward
     //      would have left in sm.maskL): thread (wave = 32-column block, lane) owns column wave*32 + (lane&31) of rows crow(r, lane)
     for (int i = tid; i < TROWS * nhid * 8; i += P2_NT) {
@@ -289,6 +295,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
         }
     }
     __syncthreads();
+    }
 
     OMDS_TL_STAMP(3);
     if (OMDS_DBG(a.dbg_stop) == 2) return;
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
         pass2_backward_hidden_g4<G4_NG>(m, sm);
         p2_backward_first<32>(m, sm, a.xyzr, t_base * k, N * k, qT, N, gx, 0);
     } else {
-        pass2_backward<ACT, ROWS>(m, sm, a.xyzr, t_base * k, N * k, qT, N, gx, 0, nullptr, 0, 0);
+        pass2_backward<ACT, ROWS>(m, sm, a.xyzr, t_base * k, N * k, qT, N, gx, 0, a.ex.deriv, (size_t)a.ex.cap * OMDS_WIDTH, 0);
     }
     __syncthreads();
     OMDS_TL_STAMP(9);
@@ -376,16 +383,16 @@ __global__ void k_tail_tl_dump(int nb) {
 }
 #endif
 
-template <int ND, int ROWS>
+template <int ND, int ROWS, int ACT = OMDS_ACT_RELU>
 static void launch_tail_sel_t(hipStream_t s, const TailArgs& a) {
     static std::atomic<uint64_t> configured{0};
     const size_t extra = 32 * 4;   // sel
     if (omds_first_use_on_device(configured)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail_sel<ND, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail_sel<ND, ROWS, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(tail_lds_bytes(OMDS_MAX_HIDDEN + 1) + extra));
     }
     const int RW = (ROWS == 4 ? 20 : ROWS) / a.st.k;
-    hipLaunchKernelGGL((k_tail_sel<ND, ROWS>), dim3((a.t_end - a.t_begin + RW - 1) / RW), dim3(P2_NT), tail_lds_bytes(a.m.nhh + 1) + extra, s, a);
+    hipLaunchKernelGGL((k_tail_sel<ND, ROWS, ACT>), dim3((a.t_end - a.t_begin + RW - 1) / RW), dim3(P2_NT), tail_lds_bytes(a.m.nhh + 1) + extra, s, a);
 #ifdef OMDS_TAIL_TL
     {
         static int seen = 0;
@@ -446,6 +453,12 @@ void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Bpre, con
     a.dbg_stop = stop;
     a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Dmin = nullptr; a.Apre = Apre; a.ApreOut = Apre; a.dscr = nullptr; a.O = O; a.st = st;
     a.rowlist = rowlist; a.range = range; a.ex = ex;
+    if (m.act == OMDS_ACT_TANH) {   // derivative rows instead of masks: 16- or 32-row tiles (the 4-row-group backward is a ReLU-mask form)
+        const int rows = tail_sel_rows(st.N, st.k, false);
+        if (st.n == 7) { if (rows == 16) launch_tail_sel_t<7, 16, OMDS_ACT_TANH>(s, a); else launch_tail_sel_t<7, 32, OMDS_ACT_TANH>(s, a); }
+        else { if (rows == 16) launch_tail_sel_t<2, 16, OMDS_ACT_TANH>(s, a); else launch_tail_sel_t<2, 32, OMDS_ACT_TANH>(s, a); }
+        return;
+    }
     const int rows = tail_sel_rows(st.N, st.k, m.skip_mask == 0 && m.nhh >= 1);
     if (st.n == 7) { if (rows == 4) launch_tail_sel_t<7, 4>(s, a); else if (rows == 16) launch_tail_sel_t<7, 16>(s, a); else launch_tail_sel_t<7, 32>(s, a); }
     else { if (rows == 4) launch_tail_sel_t<2, 4>(s, a); else if (rows == 16) launch_tail_sel_t<2, 16>(s, a); else launch_tail_sel_t<2, 32>(s, a); }
