@@ -465,6 +465,8 @@ static int build_mlp_packs(int n, int n_linear, const int32_t* in_dims, const in
         return -1;
     };
     if ((act == OMDS_ACT_RELU || act == OMDS_ACT_TANH) && nhh >= 1 && nhh <= 4) {
+        // tanh: every layer in front of an activation is scaled by 2 log2(e) (screen_kernel.hip: act_pk); the last layer is not
+        const float hs = act == OMDS_ACT_TANH ? OMDS_SCREEN_TANH_SCALE : 1.f;
         std::vector<uint16_t>& wh = pk.wh;
         const int nsl = nhh * 8 + 2;
         wh.assign((size_t)nsl * 16 * 64 * 8, 0);
@@ -476,7 +478,7 @@ static int build_mlp_packs(int n, int n_linear, const int32_t* in_dims, const in
                     for (int j = 0; j < 8; ++j) {
                         const int r = 32 * fb + (lane & 31), kk = 16 * cc + 8 * (lane >> 5) + j;
                         const float v = (kk < F) ? W[0][(size_t)r * F + kk] : 0.f;
-                        wh[(((size_t)(2 * fb + cc)) * 64 + lane) * 8 + j] = f32_to_f16_bits(v);
+                        wh[(((size_t)(2 * fb + cc)) * 64 + lane) * 8 + j] = f32_to_f16_bits(hs * v);
                     }
         for (int sl = 1; sl < nsl; ++sl) {
             const bool lastl = sl == nsl - 1;
@@ -488,11 +490,12 @@ static int build_mlp_packs(int n, int n_linear, const int32_t* in_dims, const in
                     for (int j = 0; j < 8; ++j) {
                         const int r = 32 * fb + (lane & 31), kk = real_col(lin, 16 * cc + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3));
                         const float v = (r < rows && kk >= 0) ? Wsrc[(size_t)r * Wd + kk] : 0.f;
-                        wh[(((size_t)sl * 16 + cc) * 64 + lane) * 8 + j] = f32_to_f16_bits(v);
+                        wh[(((size_t)sl * 16 + cc) * 64 + lane) * 8 + j] = f32_to_f16_bits(lastl ? v : hs * v);
                     }
         }
-        std::memcpy(&pk.sbias[0], b[0], Wd * sizeof(float));
-        for (int l = 0; l < nhh; ++l) std::memcpy(&pk.sbias[(size_t)(l + 1) * Wd], b[l + 1], Wd * sizeof(float));
+        for (int c = 0; c < Wd; ++c) pk.sbias[c] = hs * b[0][c];
+        for (int l = 0; l < nhh; ++l)
+            for (int c = 0; c < Wd; ++c) pk.sbias[(size_t)(l + 1) * Wd + c] = hs * b[l + 1][c];
         std::memcpy(&pk.sbias[(size_t)(nhh + 1) * Wd], b[n_linear - 1], C * sizeof(float));
     }
     pk.f_fwd = 0.0;

@@ -327,6 +327,9 @@ bool omds_screen_can_select(int O);
 // eps bounds the screening error of the rows that are NOT re-evaluated; the extra quarter absorbs the shift of the k-th row
 // itself (a re-evaluated row, whose error is measured: the slack guard of k_tail_sel checks tau - D*_k >= eps per rollout).
 constexpr float OMDS_SCREEN_WINDOW = 1.25f;
+// tanh screening networks: the pre-activations of every tanh layer are produced as 2 log2(e) x (fp16 weights and fp32 biases
+// scaled by this factor when they are packed), so that the kernel's tanh is 1 - 2 / (1 + exp2(.)) without a multiply
+constexpr float OMDS_SCREEN_TANH_SCALE = 2.885390081777927f;
 
 struct ExactOut {
     float* D;          // [cap] pass-1 value

@@ -137,7 +137,7 @@ __device__ __forceinline__ void wait_vm_barrier(int n) {
 
 // two fp32 pre-activations -> two fp16 activations (the next layer's B operand).  ReLU: convert, then one packed max.
 // tanh: 1 - 2 / (1 + exp(2x)) in fp32 (v_exp_f32 / v_rcp_f32: +inf and 0 give the saturated values, tanh(0) = 0 exactly), then
-// convert -- about 11 VALU instructions per pair against 2 (DESIGN.md 4.1b has what that costs beside the MFMAs)
+// convert -- 7 VALU instructions per pair against 2 (DESIGN.md 4.1b has what that costs beside the MFMAs)
 template <int ACT>
 __device__ __forceinline__ h2 act_pk(float a, float b) {
     if constexpr (ACT == OMDS_ACT_RELU) {
@@ -145,9 +145,15 @@ __device__ __forceinline__ h2 act_pk(float a, float b) {
         const h2 z = {(_Float16)0, (_Float16)0};
         return __builtin_elementwise_max(p, z);            // v_pk_max_f16
     } else {
-        const float ea = __builtin_amdgcn_exp2f(a * 2.885390081777927f), eb = __builtin_amdgcn_exp2f(b * 2.885390081777927f);
-        const float ta = __builtin_fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + ea), 1.f), tb = __builtin_fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + eb), 1.f);
-        return h2{(_Float16)ta, (_Float16)tb};
+        // a, b arrive as 2 log2(e) x: the host scales the fp16 weights and the biases of every tanh layer by that factor
+        // (build_mlp_packs, OMDS_SCREEN_TANH_SCALE), so tanh x = 1 - 2 / (1 + exp2(a)) needs no multiply here.  The add and the final
+        // multiply-add are packed fp32 instructions (v_pk_add_f32 / v_pk_fma_f32: one per pair), only exp and rcp run per element:
+        // 7 VALU instructions per pair (round 3: 11 -- scalar mul / add / fma; k_screen<2, tanh> 402 -> 382 us with the packed forms)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 e1 = f2{__builtin_amdgcn_exp2f(a), __builtin_amdgcn_exp2f(b)} + 1.f;
+        const f2 r = f2{__builtin_amdgcn_rcpf(e1[0]), __builtin_amdgcn_rcpf(e1[1])};
+        const f2 t = __builtin_elementwise_fma(f2{-2.f, -2.f}, r, f2{1.f, 1.f});
+        return h2{(_Float16)t[0], (_Float16)t[1]};
     }
 }
 
