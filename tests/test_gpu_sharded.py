@@ -301,16 +301,18 @@ def test_facade_shift_policy_means_uses_the_native_sharded_update():
         assert torch.equal(a, b)
 
 
-def test_bench_under_torchrun_single_rank_uses_rccl():
+@pytest.mark.parametrize("workload", ["franka_shelf_1024x32", "franka_dynamic_1024x32"])
+def test_bench_under_torchrun_single_rank_uses_rccl(workload):
     """The exact command line the driver uses for the scaling bench, at one rank: a child process started from here (the
-    launcher and the worker initialise the GPU themselves), rc 0, one JSON line, collectives = rccl."""
+    launcher and the worker initialise the GPU themselves), rc 0, one JSON line, collectives = rccl.  The dynamic workload also
+    runs its per-iteration kernel adding through the launcher's broadcast (rank 0 decides, every rank installs the same kernel)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--reps", "2",
-           "--no-cpu-baseline", "--no-secondary"]
+           "--master-port", "29533" if workload.startswith("franka_shelf") else "29534", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--reps", "2",
+           "--no-cpu-baseline", "--no-secondary", "--workload", workload]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
