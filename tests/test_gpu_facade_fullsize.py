@@ -490,3 +490,51 @@ def test_integrator_with_a_seds_nominal_ds():
     y = ds0.get_velocity(torch.tensor(mat["x"])).numpy()
     ok = np.abs(y - mat["y"]).max(axis=1) <= 5e-5 * max(1.0, float(np.abs(mat["y"]).max()))
     assert ok.mean() > 0.97     # a couple of states far outside the demonstrations are decided by denormal exponentials
+
+
+def test_lazy_rollout_tensors_fetch_rows_and_behave_like_tensors():
+    """``propagate()`` returns LazyRollout tensors (lazy.py): indexing by rollout fetches only those rows (omds_get_rollout_rows) and
+    equals the same index into the fully fetched tensor; every other use behaves like the torch tensor of ``propagate(fetch=True)``;
+    a tensor of an earlier propagate that was never read refuses to hand out the next propagate's numbers."""
+    from optimalmodulationds_amd.lazy import LazyRollout
+    mppi, _ = _franka_mppi()
+    N, H, n = 64, 6, 7
+    mppi.Policy.add_kernel(mppi.q_cur + 0.1, 0.0, torch.eye(7))
+    mppi.Policy.add_kernel(mppi.q_cur - 0.2, 0.0, torch.eye(7))
+    mppi.Policy.sample_policy()
+    out = mppi.propagate()
+    assert all(isinstance(x, LazyRollout) for x in out) and out[0] is mppi.all_traj and out[1] is mppi.closest_dist_all
+    all_traj, dist, kval, dots, acts = out
+    assert all_traj.shape == (N, H, n) and kval.shape == (N, H, 2) and len(dist) == N and all_traj.ndim == 3
+    # row fetches (nothing of size N x H has crossed PCIe yet)
+    i, h = torch.tensor(17), torch.tensor(3)
+    rows = dict(a=all_traj[5], b=all_traj[i, h], c=all_traj[-1, -1], d=dist[i, h], e=all_traj[60:64], f=mppi.qdot[0, :], g=kval[7, 2, 1],
+                nb=mppi.norm_basis[i, h], n2=mppi.normal_dirs[i, h])
+    assert all(x._full is None for x in out) and not mppi._cache
+    full = {k: v.clone() for k, v in mppi._fetch().items()}            # now everything, once
+    assert torch.equal(rows["a"], full["all_traj"][5]) and torch.equal(rows["b"], full["all_traj"][17, 3])
+    assert torch.equal(rows["c"], full["all_traj"][-1, -1]) and torch.equal(rows["d"], full["closest_dist_all"][17, 3])
+    assert torch.equal(rows["e"], full["all_traj"][60:64]) and torch.equal(rows["f"], full["qdot"][0])
+    assert torch.equal(rows["g"], full["kernel_val_all"][7, 2, 1]) and torch.equal(rows["n2"], full["normal"][17, 3])
+    assert torch.equal(rows["nb"][:, 0], full["normal"][17, 3]) and rows["nb"].shape == (7, 7)
+    # tensor look-alike: functions, arithmetic, comparisons, methods, numpy
+    assert torch.equal(torch.isfinite(all_traj), torch.isfinite(full["all_traj"]))
+    assert torch.equal((dist < 0.3) & (dots < 0.5), (full["closest_dist_all"] < 0.3) & (full["dot_products"] < 0.5))
+    assert torch.equal(all_traj[(dist < 0.3) & (dots < 0.5)], full["all_traj"][(full["closest_dist_all"] < 0.3) & (full["dot_products"] < 0.5)])
+    assert torch.equal(all_traj - 1.0, full["all_traj"] - 1.0) and torch.equal(2.0 * acts, 2.0 * full["kernel_activations"])
+    assert np.array_equal(np.asarray(dist), full["closest_dist_all"].numpy()) and np.array_equal(kval.numpy(), full["kernel_val_all"].numpy())
+    assert torch.equal(all_traj.view(-1, n), full["all_traj"].view(-1, n)) and float(dist.min()) == float(full["closest_dist_all"].min())
+    assert torch.equal(torch.cat((all_traj[:2], all_traj[2:4])), full["all_traj"][:4])
+    # the eager form
+    mppi.Policy.sample_policy()
+    eager = mppi.propagate(fetch=True)
+    assert all(isinstance(x, torch.Tensor) for x in eager)
+    # a tensor nobody read before the next propagate: refuses; one that was read keeps its numbers
+    mppi.Policy.sample_policy()
+    stale = mppi.propagate()
+    kept = stale[1].tensor().clone()
+    mppi.Policy.sample_policy()
+    mppi.propagate()
+    with pytest.raises(RuntimeError, match="earlier propagate"):
+        stale[0][0]
+    assert torch.equal(stale[1].tensor(), kept) and torch.equal(stale[1][3], kept[3])

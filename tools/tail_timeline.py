@@ -3,8 +3,8 @@
 (stdin or a file) and reports, over the workgroups of one launch, when each phase boundary is reached after the first
 workgroup's entry (median / max, microseconds at the measured shader clock) and the clock itself.
 
-    make -C optimalmodulationds_amd/csrc clean all CXXFLAGS="... -DOMDS_TAIL_TL"
-    OMDS_TAIL_TL_STEP=5 python bench.py --steps 4 --warmup 1 --reps 1 --no-cpu-baseline --no-secondary 2>&1 | python tools/tail_timeline.py
+    make -C optimalmodulationds_amd/csrc experiment VFLAGS=-DOMDS_TAIL_TL        # -> libomds_hip_exp.so (reads OMDS_TAIL_TL_STEP)
+    OMDS_LIB=optimalmodulationds_amd/csrc/libomds_hip_exp.so OMDS_TAIL_TL_STEP=5 python bench.py --steps 4 --warmup 1 --reps 1 --no-cpu-baseline --no-secondary 2>&1 | python tools/tail_timeline.py
 """
 import statistics
 import sys
