@@ -358,7 +358,11 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
     const long long p1e = p0 + (long long)(a.units_base + (wg < a.units_rem ? 1 : 0)) * a.unit;
     const long long p1 = p1e < a.total_rows ? p1e : a.total_rows;
     const int my_pairs = (int)(p1 - p0);
+#ifdef OMDS_SC_EXPERIMENT   // OMDS_SCREEN_DBG 16: the partial last tile of a chunk does not exist at all (neither its MFMAs nor its ring traffic)
+    const int my_tiles = (my_pairs + SC_ROWS - 1) / SC_ROWS - (((OMDS_DBG(a.dbg) & 16) && (my_pairs % SC_ROWS) != 0 && my_pairs > SC_ROWS) ? 1 : 0);
+#else
     const int my_tiles = (my_pairs + SC_ROWS - 1) / SC_ROWS;                    // >= 1: the grid never exceeds the chunks
+#endif
 
     // slice `sl` of the network -> ring slot `slot`; this wave moves fragments PW*w .. PW*w + PW-1
     const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.Wh) + (SC_PW * wave) * 1024;   // wave-uniform
