@@ -139,6 +139,13 @@ def cpu_baseline(w, W, b, obs, q0, qf, dh, qmin, qmax, K, H_full):
         out[label] = {"threads": int(T), "propagate_only": Ns * Hs / tp, "full_iteration": Ns * Hs / (tp + tr),
                       "full_iteration_at_workload_horizon": Ns * H_full / (H_full / Hs * tp + tr),
                       "t_propagate_s": tp, "t_rest_s": tr}
+    # is the per-rollout rate flat in N on this box?  The workload's own rollout count, ONE horizon step, at 8 threads
+    # (the extrapolation above scales a 256-rollout sample; this is the same path at N = 1024)
+    Nw = int(w["N"]) if int(w["N"]) <= 1024 else 1024
+    plw = TorchPlanner(m, obs, qf, dh, qmin, qmax, dt=w["dt"], k=w["k"], ignored_links=w["ignored"], prm=prm)
+    tpw, trw = time_iterations(plw, Nw, 1, q0, mu_c, sg_c, al_c, w["alpha_s"], w["ker_thr"], min(8, phys), warmup=2, timed=3)
+    out["at_workload_rollouts"] = {"threads": int(min(8, phys)), "rollouts": Nw, "steps": 1, "propagate_only": Nw / tpw, "t_propagate_s": tpw,
+                                   "t_rest_s": trw, "note": "the same path at the workload's rollout count, one horizon step: compare propagate_only with t8's"}
     best = max(("t8", "tall"), key=lambda l: out[l]["full_iteration_at_workload_horizon"])   # more threads are not always faster here
     out["value"] = out[best]["full_iteration_at_workload_horizon"]
     out["cores"] = out[best]["threads"]
