@@ -107,7 +107,11 @@ OMDS_API const char* omds_last_error(const omds_ctx* ctx);
  * C}; W[i] is [dims[i+1], dims[i]] row-major like torch, b[i] is [dims[i+1]].  act =
  * OMDS_ACT_*; out_div = 100 when C == 9 (cm -> m, MPPI.py:236-237) else 1.  dims[0] may also
  * be 3(n+2): the toy networks take planar obstacle points (in_channels = DOF+2,
- * scripts/standaloneToy2d.py:33); the z column of the obstacle array is then ignored.    */
+ * scripts/standaloneToy2d.py:33); the z column of the obstacle array is then ignored.
+ * Widths: hidden layers of up to 256 units (every network the reference ships: 256 and 128) run on the fused LDS-resident MFMA
+ * kernels (narrower ones zero-padded).  MLPRegression itself is width-agnostic (network_macros_mod.py:96-135): a network with a
+ * hidden layer of 257 .. 4096 units takes the unfused path of csrc/wide_kernels.hip -- the reference's own op sequence on exact-fp32
+ * MFMA GEMMs with the activations materialised in HBM; no screening, no skip concatenations there.  Same results contract.     */
 OMDS_API int omds_set_mlp(omds_ctx* ctx, int n_linear, const int32_t* dims, const float* const* W,
                           const float* const* b, int act, float out_div);
 /* The same for MLPRegression(..., skips=[...]) (network_macros_mod.py:113-146): behind the activations of

@@ -505,10 +505,96 @@ static int build_mlp_packs(int n, int n_linear, const int32_t* in_dims, const in
 }
 #undef PREQ
 
+// A network with a hidden layer wider than the fused kernels' 256 columns (MLPRegression is width-agnostic,
+// network_macros_mod.py:96-135): raw weights on the device and the buffers of the unfused GEMM path (wide_kernels.hip).
+static int set_mlp_wide(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const int32_t* out_dims, const float* const* W,
+                        const float* const* b, int act, float out_div, int n_skips) {
+    const int n = ctx->cfg.n_dof;
+    REQUIRE(n_skips == 0, OMDS_ERR_UNSUPPORTED, "omds_set_mlp_ex: skip concatenations are supported for hidden widths <= 256 only");
+    REQUIRE(in_dims[0] == 3 * (n + 3) || in_dims[0] == 3 * (n + 2), OMDS_ERR_INVALID_ARG,
+            "omds_set_mlp: dims[0] must be 3*(n_dof+3), or 3*(n_dof+2) for planar obstacle points (NeRF encoding [x, sin x, cos x])");
+    const int d = in_dims[0] / 3, C = out_dims[n_linear - 1];
+    REQUIRE(3 * d <= 32, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: 3*(n_dof+3) > 32 not supported");
+    REQUIRE(n_linear - 1 <= OMDS_MAX_HIDDEN, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: too many hidden layers");
+    REQUIRE(C >= 1 && C <= OMDS_CPAD, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: 1 <= out_channels <= 16 required");
+    REQUIRE(act == OMDS_ACT_RELU || act == OMDS_ACT_TANH, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: act must be OMDS_ACT_RELU or OMDS_ACT_TANH");
+    REQUIRE(out_div != 0.f, OMDS_ERR_INVALID_ARG, "omds_set_mlp: out_div must be non-zero");
+    int wmax = in_dims[0];
+    for (int i = 0; i < n_linear; ++i) {
+        REQUIRE(W[i] && b[i], OMDS_ERR_INVALID_ARG, "omds_set_mlp: null weight or bias array");
+        REQUIRE(out_dims[i] >= 1 && out_dims[i] <= 4096, OMDS_ERR_UNSUPPORTED, "omds_set_mlp: layer widths above 4096 are not supported");
+        REQUIRE(i == 0 || in_dims[i] == out_dims[i - 1], OMDS_ERR_INVALID_ARG,
+                "omds_set_mlp: the input width of a Linear layer must be the previous output width");
+        wmax = std::max(wmax, (int)out_dims[i]);
+    }
+    CK(hipSetDevice(ctx->dev));
+    CK(hipStreamSynchronize(ctx->stream));
+    for (void* p : ctx->mlp_allocs) (void)hipFree(p);
+    ctx->mlp_allocs.clear();
+    ctx->have_mlp = false;
+    ctx->screen = ScreenDev{};
+    ctx->screen_ok = false;
+    ctx->screen_cal = false;
+    ctx->screen_suspended = false;
+    if (ctx->d_dscr) { (void)hipFree(ctx->d_dscr); ctx->d_dscr = nullptr; }
+    if (ctx->d_exDeriv) { (void)hipFree(ctx->d_exDeriv); ctx->d_exDeriv = nullptr; }
+    WideNet w;
+    w.on = true;
+    w.d = d; w.act = act; w.out_div = out_div;
+    w.dims.assign(1, in_dims[0]);
+    for (int i = 0; i < n_linear; ++i) w.dims.push_back(out_dims[i]);
+    auto dalloc = [&](float** p, size_t floats) -> int {
+        void* q = nullptr;
+        CK(hipMalloc(&q, floats * sizeof(float)));
+        ctx->mlp_allocs.push_back(q);
+        *p = static_cast<float*>(q);
+        return OMDS_OK;
+    };
+    int rc;
+    for (int i = 0; i < n_linear; ++i) {
+        float *dw = nullptr, *db = nullptr;
+        const size_t nw = (size_t)in_dims[i] * out_dims[i];
+        if ((rc = dalloc(&dw, nw)) || (rc = dalloc(&db, out_dims[i]))) return rc;
+        CK(hipMemcpy(dw, W[i], nw * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(db, b[i], (size_t)out_dims[i] * 4, hipMemcpyHostToDevice));
+        w.W.push_back(dw);
+        w.b.push_back(db);
+    }
+    // pass 1 in chunks of ~256 MB per activation buffer; pass 2 keeps every layer's activation of its n_traj * n_closest rows
+    const long long pairs = (long long)ctx->cfg.n_traj * ctx->cfg.max_obs;
+    w.chunk_rows = (int)std::min<long long>(pairs, std::max<long long>(8192, std::min<long long>(262144, (1LL << 26) / wmax)));
+    w.rows2 = ctx->cfg.n_traj * ctx->cfg.n_closest;
+    if ((rc = dalloc(&w.X, (size_t)w.chunk_rows * in_dims[0])) || (rc = dalloc(&w.H[0], (size_t)w.chunk_rows * wmax)) ||
+        (rc = dalloc(&w.H[1], (size_t)w.chunk_rows * wmax)) || (rc = dalloc(&w.X2, (size_t)w.rows2 * in_dims[0])) ||
+        (rc = dalloc(&w.G[0], (size_t)w.rows2 * wmax)) || (rc = dalloc(&w.G[1], (size_t)w.rows2 * wmax)))
+        return rc;
+    for (int i = 0; i < n_linear; ++i) {
+        float* a = nullptr;
+        if ((rc = dalloc(&a, (size_t)w.rows2 * out_dims[i]))) return rc;
+        w.A.push_back(a);
+    }
+    MlpDev m{};   // the fields the stand-alone kernels around the network read (k_modulate, k_blend, the cost)
+    m.nhh = n_linear - 2; m.C = C; m.d = d; m.n_dof = n; m.out_div = out_div; m.act = act;
+    ctx->mlp = m;
+    ctx->wide = w;
+    ctx->act = act;
+    ctx->f_fwd = 0.0;
+    for (int i = 0; i < n_linear; ++i) ctx->f_fwd += 2.0 * in_dims[i] * out_dims[i];
+    ctx->f_bwd = ctx->f_fwd - 2.0 * in_dims[n_linear - 1] * out_dims[n_linear - 1];
+    ctx->have_mlp = true;
+    return OMDS_OK;
+}
+
 int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const int32_t* out_dims, const float* const* W,
                     const float* const* b, int act, float out_div, int n_skips, const int32_t* skip_after) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
     const int n = ctx->cfg.n_dof;
+    if (in_dims && out_dims && W && b && n_linear >= 2 && n_linear <= OMDS_MAX_HIDDEN + 1) {
+        bool is_wide = false;
+        for (int i = 0; i + 1 < n_linear; ++i) is_wide = is_wide || out_dims[i] > OMDS_WIDTH;
+        if (is_wide) return set_mlp_wide(ctx, n_linear, in_dims, out_dims, W, b, act, out_div, n_skips);
+    }
+    ctx->wide = WideNet{};
     MlpPacks pk;
     int rc;
     if ((rc = build_mlp_packs(n, n_linear, in_dims, out_dims, W, b, act, out_div, n_skips, skip_after, pk, ctx->err))) return rc;
@@ -725,7 +811,7 @@ int omds_set_obstacles(omds_ctx* ctx, const float* xyzr, int n_obs) {
         ctx->screen_consec = 0;
     }
     ctx->obs_now.assign(xyzr, xyzr + (size_t)n_obs * 4);
-    if (ctx->have_mlp) {
+    if (ctx->have_mlp && !ctx->wide.on) {
         omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, n_obs, ctx->d_Bpre, ctx->d_radius, ctx->d_FpH, ctx->cfg.max_obs, ctx->mlp.featP);
         CK(hipGetLastError());
     }
@@ -931,6 +1017,14 @@ static bool small_step_wanted(omds_ctx* ctx);
 static int enqueue_network(omds_ctx* ctx, const float* qT, int ldq, int B) {
     const MlpDev& m = ctx->mlp;
     const int O = ctx->n_obs, k = ctx->cfg.n_closest;
+    if (ctx->wide.on) {   // a hidden layer wider than 256: the unfused GEMM path (wide_kernels.hip)
+        int rcw;
+        if ((rcw = prof_begin(ctx))) return rcw;
+        if ((rcw = omds_wide_network(ctx, qT, ldq, B))) return rcw;
+        if ((rcw = prof_end(ctx, (int64_t)B * O, (double)B * O * ctx->f_fwd + (double)B * k * (ctx->f_fwd + ctx->f_bwd), "k_gemm (wide network)"))) return rcw;
+        CK(hipGetLastError());
+        return OMDS_OK;
+    }
     omds_launch_rollout_layer1(ctx->stream, m, qT, ldq, B, ctx->d_Apre);
     int rc;
     if (small_step_wanted(ctx)) {   // the arithmetic the step of this context uses: the batch entry point reproduces it bit for bit
@@ -1025,7 +1119,7 @@ static int calibrate_screen(omds_ctx* ctx, const float* q_center) {
 // two-kernel step's tail would sit on a fraction of the CUs (at R rollouts per workgroup; beyond ~3 rounds of workgroups
 // k_pass1 + the 16/32-row MFMA tail win back what the extra launch costs).
 static bool small_step_wanted(omds_ctx* ctx) {
-    if (ctx->cfg.flags & (OMDS_FLAG_UNFUSED_STEP | OMDS_FLAG_TWO_KERNEL_STEP)) return false;
+    if (ctx->wide.on || (ctx->cfg.flags & (OMDS_FLAG_UNFUSED_STEP | OMDS_FLAG_TWO_KERNEL_STEP))) return false;
     const int R = omds_step_small_rollouts(ctx->mlp, ctx->cfg.n_dof, ctx->n_obs, ctx->cfg.n_closest);
     if (R <= 0) return false;
     static const int env = OMDS_EXP_ENV("OMDS_SMALL_STEP", -1);   // experiment builds: 0 / 1 overrides the rule below
@@ -1274,7 +1368,7 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
     a.prm = ctx->prm;
     static const int fused = OMDS_EXP_ENV("OMDS_FUSED_TAIL", 1);   // experiment builds: 0 selects the five-kernel step (the release library: OMDS_FLAG_UNFUSED_STEP)
     // a SEDS nominal DS takes the step of stand-alone kernels: only k_modulate carries that branch (step_device.h)
-    const bool tail = fused && !(ctx->cfg.flags & OMDS_FLAG_UNFUSED_STEP) && omds_tail_supported(n, a.k) && ctx->seds_G == 0;
+    const bool tail = fused && !(ctx->cfg.flags & OMDS_FLAG_UNFUSED_STEP) && omds_tail_supported(n, a.k) && ctx->seds_G == 0 && !ctx->wide.on;
     bool screen = tail && screen_wanted(ctx);
     if (screen && !ctx->screen_cal && (rc = calibrate_screen(ctx, q_cur))) return rc;
     screen = screen && ctx->screen_ok && !ctx->screen_suspended && ctx->screen_eps > 0.f;
@@ -1430,6 +1524,22 @@ int omds_mlp_forward_vjp(omds_ctx* ctx, const float* x, int B, float* y, float* 
     REQUIRE(ctx->have_mlp, OMDS_ERR_NOT_INITIALISED, "distance network not set (omds_set_mlp)");
     const int d = ctx->mlp.d;
     CK(hipSetDevice(ctx->dev));
+    if (ctx->wide.on) {   // wide networks: the raw rows through the unfused GEMM path
+        int rcw;
+        CK(hipMemcpyAsync(ctx->d_stage, x, (size_t)B * d * 4, hipMemcpyHostToDevice, ctx->stream));
+        if ((rcw = omds_wide_vjp(ctx, ctx->d_stage, B))) return rcw;
+        CK(hipGetLastError());
+        CK(hipStreamSynchronize(ctx->stream));
+        if (y) {
+            std::vector<float> ypad((size_t)B * OMDS_CPAD);
+            CK(hipMemcpy(ypad.data(), ctx->d_yraw, ypad.size() * 4, hipMemcpyDeviceToHost));
+            for (int r = 0; r < B; ++r)
+                for (int c = 0; c < ctx->mlp.C; ++c) y[(size_t)r * ctx->mlp.C + c] = ypad[(size_t)r * OMDS_CPAD + c];
+        }
+        if (grad) CK(hipMemcpy(grad, ctx->d_gradx, (size_t)B * d * 4, hipMemcpyDeviceToHost));
+        if (min_idx) CK(hipMemcpy(min_idx, ctx->d_minidx, (size_t)B * 4, hipMemcpyDeviceToHost));
+        return OMDS_OK;
+    }
     // every row is its own (rollout, obstacle) pair: Apre from x[:, :n], Bpre from x[:, n:], radius 0
     std::vector<float> xyzr((size_t)B * 4, 0.f), qrow((size_t)B * n);
     std::vector<int32_t> ident(B);

@@ -99,6 +99,22 @@ inline bool omds_first_use_on_device(std::atomic<uint64_t>& mask) {
     return (mask.fetch_or(bit) & bit) == 0;
 }
 
+// A distance network with a hidden layer wider than OMDS_WIDTH (wide_kernels.hip): raw row-major weights, materialised activations
+struct WideNet {
+    bool on = false;
+    std::vector<int> dims;            // [L + 1]: 3 d, hidden ..., C
+    int d = 0, act = 0;
+    float out_div = 1.f;
+    std::vector<float*> W, b;         // device, torch layout [out][in]
+    int chunk_rows = 0;               // pass-1 rows per chunk
+    float* X = nullptr;               // [chunk_rows][3 d] encoded inputs of a pass-1 chunk
+    float* H[2] = {nullptr, nullptr}; // [chunk_rows][max width] activation ping-pong of pass 1
+    int rows2 = 0;                    // pass-2 row capacity (n_traj * n_closest)
+    float* X2 = nullptr;              // [rows2][3 d]
+    std::vector<float*> A;            // [L] activations of every layer of the pass-2 rows
+    float* G[2] = {nullptr, nullptr}; // [rows2][max width] gradient ping-pong
+};
+
 struct ProfEvents {
     std::vector<hipEvent_t> start, stop;
     size_t used = 0;
@@ -133,6 +149,7 @@ struct omds_ctx {
     // network
     bool have_mlp = false;
     MlpDev mlp{};
+    WideNet wide{};              // networks with a hidden layer wider than 256 (its buffers live in mlp_allocs)
     std::vector<void*> mlp_allocs;
     int act = OMDS_ACT_RELU;
     double f_fwd = 0.0, f_bwd = 0.0;   // algorithmic FLOPs of one network forward / backward row
@@ -308,6 +325,16 @@ void omds_launch_pass2(hipStream_t s, const MlpDev& m, const float* Apre, const 
                        float* gradx, float* drow, float* yraw, int32_t* minidx, float* dscr);
 void omds_launch_blend(hipStream_t s, const float* gradx, const float* drow, int B, int k, int d, int n,
                        float softmax_k, float* dist, float* nngrad);
+
+// ---- train.hip: the trainer's exact-fp32 MFMA GEMM, for callers outside the trainer (wide_kernels.hip) -------------------
+// Out [B][out] = act(H [B][in] . W^T + b), W [out][in] row-major like torch; act: OMDS_ACT_* or -1 (none)
+void omds_launch_linear_forward(hipStream_t s, const float* H, int in, const float* W, const float* b, float* Out, int out, int B, int act);
+// Gi [B][in] = (G [B][out] . W) * act'(Hact [B][in]); Hact == nullptr: no derivative factor
+void omds_launch_linear_inputgrad(hipStream_t s, const float* G, int out, const float* W, int in, float* Gi, int B, const float* Hact, int act);
+// ---- wide_kernels.hip ------------------------------------------------------------------------------
+struct omds_ctx;
+int omds_wide_network(omds_ctx* ctx, const float* qT, int ldq, int B);
+int omds_wide_vjp(omds_ctx* ctx, const float* d_x, int rows);
 
 // ---- launchers implemented in screen_kernel.hip -----------------------------------------------
 struct SelectSink;

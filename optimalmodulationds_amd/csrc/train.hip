@@ -488,3 +488,12 @@ int omds_trainer_step(omds_trainer* tr, float lr, float beta1, float beta2, floa
 }
 
 }  // extern "C"
+
+// The GEMM for callers outside the trainer (wide_kernels.hip: distance networks wider than the fused kernels' 256 columns)
+void omds_launch_linear_forward(hipStream_t s, const float* H, int in, const float* W, const float* b, float* Out, int out, int B, int act) {
+    launch_gemm<false, true, 1>(s, H, in, W, in, Out, out, B, out, in, 1, in, 0, b, act);
+}
+void omds_launch_linear_inputgrad(hipStream_t s, const float* G, int out, const float* W, int in, float* Gi, int B, const float* Hact, int act) {
+    if (Hact) launch_gemm<false, false, 2>(s, G, out, W, in, Gi, in, B, in, out, 1, out, 0, Hact, act);
+    else launch_gemm<false, false, 0>(s, G, out, W, in, Gi, in, B, in, out, 1, out, 0);
+}

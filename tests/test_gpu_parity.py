@@ -309,10 +309,8 @@ def test_error_paths():
     with pytest.raises(L.OmdsError, match="network not set"):
         eng.dist_grad(np.zeros((4, 7), np.float32))
     m = orc.Mlp.from_npz(weights_path("franka"))
-    wide = np.zeros((384, 384), np.float32)
-    with pytest.raises(L.OmdsError, match="above 256"):
-        eng.set_mlp([np.zeros((384, 30), np.float32), wide, np.zeros((9, 384), np.float32)],
-                    [np.zeros(384, np.float32), np.zeros(384, np.float32), np.zeros(9, np.float32)])
+    with pytest.raises(L.OmdsError, match="above 4096"):     # (256 < width <= 4096 runs on the unfused GEMM path: tests/test_gpu_wide.py)
+        eng.set_mlp([np.zeros((5000, 30), np.float32), np.zeros((9, 5000), np.float32)], [np.zeros(5000, np.float32), np.zeros(9, np.float32)])
     eng.set_mlp(m.W, m.b)
     eng.set_obstacles(np.zeros((9, 4), np.float32))         # beyond max_obs = 8: the context grows its obstacle buffers
     assert eng.max_obs >= 9
