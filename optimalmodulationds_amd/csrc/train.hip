@@ -48,8 +48,12 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int k0 = k_begin; k0 < k_end; k0 += TK) {
-        // stage the two operand tiles (zeros outside the matrices): 128 x 16 elements each, 8 per thread
+    // The two operand tiles of a k step (128 x 16 elements each, 8 per thread; zeros outside the matrices) travel global -> registers
+    // -> LDS.  The NEXT step's global loads are issued before this step's MFMAs and parked in registers, so their latency hides
+    // under 32 MFMAs per wave instead of standing between two barriers (round 4: the trainer's three GEMM shapes 64-71 -> see
+    // DESIGN.md 4.8; the arithmetic of an output element is unchanged: the same products in the same k order).
+    float ra[8], rb[8];
+    auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int idx = tid + 256 * e;
@@ -57,20 +61,32 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
                 int m, kk;
                 if (TA) { m = idx & 127; kk = idx >> 7; } else { kk = idx & 15; m = idx >> 4; }   // fastest index = the stored matrix's contiguous one
                 const int gm = m0 + m, gk = k0 + kk;
-                float v = 0.f;
-                if (gm < M && gk < k_end) v = TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
-                As[kk][m] = v;
+                ra[e] = (gm < M && gk < k_end) ? (TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk]) : 0.f;
             }
             {   // B tile
                 int n, kk;
                 if (TB) { kk = idx & 15; n = idx >> 4; } else { n = idx & 127; kk = idx >> 7; }
                 const int gn = n0 + n, gk = k0 + kk;
-                float v = 0.f;
-                if (gn < N && gk < k_end) v = TB ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn];
-                Bs[kk][n] = v;
+                rb[e] = (gn < N && gk < k_end) ? (TB ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn]) : 0.f;
             }
         }
-        __syncthreads();
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = tid + 256 * e;
+            { int m, kk; if (TA) { m = idx & 127; kk = idx >> 7; } else { kk = idx & 15; m = idx >> 4; } As[kk][m] = ra[e]; }
+            { int n, kk; if (TB) { kk = idx & 15; n = idx >> 4; } else { n = idx & 127; kk = idx >> 7; } Bs[kk][n] = rb[e]; }
+        }
+    };
+    if (k_begin < k_end) {
+        load_tiles(k_begin);
+        store_tiles();
+    }
+    __syncthreads();
+    for (int k0 = k_begin; k0 < k_end; k0 += TK) {
+        const bool more = k0 + TK < k_end;
+        if (more) load_tiles(k0 + TK);      // in flight across the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < TK; kk += 2) {
             const float a0 = As[kk + (lane >> 5)][wm + (lane & 31)], a1 = As[kk + (lane >> 5)][wm + 32 + (lane & 31)];
@@ -80,6 +96,8 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+        __syncthreads();                     // every wave has read this step's tiles
+        if (more) store_tiles();
         __syncthreads();
     }
     float* Cz = C + (size_t)blockIdx.z * cstride;
@@ -108,7 +126,15 @@ __global__ void k_sum_partials(const float* __restrict__ P, int S, size_t n, flo
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
-    for (int z = 0; z < S; ++z) s += P[(size_t)z * n + i];   // fixed order
+    int z = 0;
+    for (; z + 8 <= S; z += 8) {   // eight partials in flight, added in the fixed order z = 0, 1, 2, ...
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = P[(size_t)(z + u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < S; ++z) s += P[(size_t)z * n + i];
     out[i] = s;
 }
 
@@ -149,7 +175,15 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
     if (c >= N) return;
     const size_t r0 = (size_t)blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
     float s = 0.f;
-    for (size_t r = r0; r < r1; ++r) s += G[r * N + c];
+    size_t r = r0;
+    for (; r + 8 <= r1; r += 8) {   // eight rows in flight, added in row order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = G[(r + u) * N + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; r < r1; ++r) s += G[r * N + c];
     P[(size_t)blockIdx.y * N + c] = s;
 }
 
