@@ -35,8 +35,11 @@ template <bool TA, bool TB, int EPI>
 __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                               float* __restrict__ C, int ldc, int M, int N, int K, int kchunk, size_t cstride,
                                               const float* __restrict__ aux, int act) {
-    __shared__ float As[TK][TM + 32];   // [k][m]; row stride 160 floats: the two k rows a wave reads at once fall into disjoint banks
-    __shared__ float Bs[TK][TN + 32];   // [k][n]
+    // [k][m] / [k][n] tiles, row stride 132 floats: the MFMA operand reads (32 consecutive m of row k, lanes 32-63 row k + 1) are
+    // conflict-free in their lane groups, and so are the transposing stores of a k-contiguous operand (bank = 16 kq + m below)
+    constexpr int LDT = TM + 4;
+    __shared__ __attribute__((aligned(16))) float As[TK][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[TK][LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;   // the batch dimension on grid.x: its limit is 2^31 - 1 tiles, grid.y stops at 65535
     const int k_begin = blockIdx.z * kchunk, k_end = min(K, k_begin + kchunk);
@@ -52,32 +55,58 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     // -> LDS.  The NEXT step's global loads are issued before this step's MFMAs and parked in registers, so their latency hides
     // under 32 MFMAs per wave instead of standing between two barriers (round 4: the trainer's three GEMM shapes 64-71 -> see
     // DESIGN.md 4.8; the arithmetic of an output element is unchanged: the same products in the same k order).
-    float ra[8], rb[8];
-    auto load_tiles = [&](int k0) {
+    // Staging in 16-byte pieces (two per thread and operand): an operand stored with k contiguous (A of the forward and the input
+    // gradient, B = W of the forward) is read as float4 along k -- thread (row = idx >> 2, k quad = idx & 3) -- and transposed into the
+    // [k][row] tile by four scalar stores; an operand stored with its row index contiguous (G^T, H of the weight gradient, W of the
+    // input gradient) is read as float4 along the row and stored as one.  Pieces that straddle an edge, or operands whose row
+    // stride is not a multiple of four floats (the 3 d = 15 / 30 input features), fall back to guarded scalar loads.
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 ra[2], rb[2];
+    const bool a_vec = (lda & 3) == 0 && (reinterpret_cast<size_t>(A) & 15) == 0, b_vec = (ldb & 3) == 0 && (reinterpret_cast<size_t>(B) & 15) == 0;
+    auto load_op = [&](const float* __restrict__ P, int ld, int r0, int R, bool kcontig, bool vec, int k0, f4 (&r)[2]) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < 2; ++e) {
             const int idx = tid + 256 * e;
-            {   // A tile
-                int m, kk;
-                if (TA) { m = idx & 127; kk = idx >> 7; } else { kk = idx & 15; m = idx >> 4; }   // fastest index = the stored matrix's contiguous one
-                const int gm = m0 + m, gk = k0 + kk;
-                ra[e] = (gm < M && gk < k_end) ? (TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk]) : 0.f;
-            }
-            {   // B tile
-                int n, kk;
-                if (TB) { kk = idx & 15; n = idx >> 4; } else { n = idx & 127; kk = idx >> 7; }
-                const int gn = n0 + n, gk = k0 + kk;
-                rb[e] = (gn < N && gk < k_end) ? (TB ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn]) : 0.f;
+            if (kcontig) {
+                const int kq = idx & 3, row = idx >> 2, g = r0 + row, gk = k0 + 4 * kq;
+                if (vec && g < R && gk + 3 < k_end) {
+                    r[e] = *reinterpret_cast<const f4*>(P + (size_t)g * ld + gk);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) r[e][j] = (g < R && gk + j < k_end) ? P[(size_t)g * ld + gk + j] : 0.f;
+                }
+            } else {
+                const int rq = idx & 31, kk = idx >> 5, g = r0 + 4 * rq, gk = k0 + kk;
+                if (vec && gk < k_end && g + 3 < R) {
+                    r[e] = *reinterpret_cast<const f4*>(P + (size_t)gk * ld + g);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) r[e][j] = (gk < k_end && g + j < R) ? P[(size_t)gk * ld + g + j] : 0.f;
+                }
             }
         }
     };
-    auto store_tiles = [&]() {
+    auto store_op = [&](float (&T)[TK][LDT], bool kcontig, const f4 (&r)[2]) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < 2; ++e) {
             const int idx = tid + 256 * e;
-            { int m, kk; if (TA) { m = idx & 127; kk = idx >> 7; } else { kk = idx & 15; m = idx >> 4; } As[kk][m] = ra[e]; }
-            { int n, kk; if (TB) { kk = idx & 15; n = idx >> 4; } else { n = idx & 127; kk = idx >> 7; } Bs[kk][n] = rb[e]; }
+            if (kcontig) {
+                const int kq = idx & 3, row = idx >> 2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) T[4 * kq + j][row] = r[e][j];
+            } else {
+                const int rq = idx & 31, kk = idx >> 5;
+                *reinterpret_cast<f4*>(&T[kk][4 * rq]) = r[e];
+            }
         }
+    };
+    auto load_tiles = [&](int k0) {
+        load_op(A, lda, m0, M, !TA, a_vec, k0, ra);
+        load_op(B, ldb, n0, N, TB, b_vec, k0, rb);
+    };
+    auto store_tiles = [&]() {
+        store_op(As, !TA, ra);
+        store_op(Bs, TB, rb);
     };
     if (k_begin < k_end) {
         load_tiles(k_begin);
