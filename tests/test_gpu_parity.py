@@ -91,15 +91,16 @@ def _check_teacher_forced(name, flags):
       B  modulation: GPU step outputs vs oracle.modulation_step fed the GPU's own (distance, gradient) -- isolates the
                      per-rollout kernel                                        (1e-5)
       C  end to end: qdot / next state vs the reference's golden rollouts: inside the envelope the oracle's modulation
-                     spans when the reference's distance moves by +-DIST_ULP, widened by 1e-5 (rows whose gradient took
-                     another admissible mask assignment than the oracle's are covered by A + B only: which assignment
-                     the reference's BLAS happened to take is not recorded in its outputs)"""
+                     spans when the reference's distance moves by +-DIST_ULP, widened by 1e-5; for a row whose gradient
+                     took another admissible mask assignment than the oracle's: inside the UNION of those envelopes over
+                     every admissible assignment -- and so must the reference's own velocity be (which assignment its
+                     BLAS took is not recorded in its outputs, but it took one of them)"""
     fx = load(name)
     eng, m = _engine(fx, H=1, flags=flags)
     H, k, N = int(fx["H"]), int(fx["k"]), int(fx["N"])
     dt = np.float32(fx["dt"])
     prm = orc.Params(dst_thr=float(fx["dst_thr"]), lin_thr=float(fx["lin_thr"]), p=int(fx["p"]), seds=seds_of(fx))
-    n_alt_rows = n_rows = 0
+    n_alt_rows = n_rows = n_marginal_e2e = 0
     for it in range(int(fx["n_iter"])):
         pre = f"it{it}_"
         ref = fx[pre + "all_traj"]
@@ -163,11 +164,28 @@ def _check_teacher_forced(name, flags):
                 if i == 1:
                     uq = fx[pre + "qdot"][okc]
                     assert (uq >= lo[okc] - RTOL * uscale).all() and (uq <= hi[okc] + RTOL * uscale).all(), "C reference qdot outside its envelope"
+            # Rows whose gradient took another admissible mask assignment than the oracle's: the end-to-end bar is the UNION of the
+            # envelopes over every admissible assignment (each is a valid fp32 evaluation of the vjp; the reference's BLAS took one
+            # of them, the device's MFMA chain one of them) -- the device's velocity and the reference's own must both lie in it
+            for t in np.nonzero(~own & keep)[0]:
+                alts = orc.blended_gradient_alternatives(m, q[t], fx["obs"], oidx[t], MARGIN)
+                envs = [_velocity_envelope(q[t:t + 1], fx["qf"], d_ref_raw[t:t + 1], (a[None],), mu[t:t + 1], sg[t:t + 1], al[t:t + 1], prm, delta)
+                        for a in alts]
+                inside = lambda u, pad_: any(((u >= lo_[0] - pad_) & (u <= hi_[0] + pad_)).all() for lo_, hi_ in envs)
+                assert inside(r["qdot"][t], RTOL * uscale), f"C marginal row {t}, step {i}: device velocity in no admissible assignment's envelope"
+                if i == 1:
+                    assert inside(fx[pre + "qdot"][t], RTOL * uscale), f"C marginal row {t}: the reference's qdot in no admissible assignment's envelope"
+                if i < H:
+                    pad = 4e-6 * max(1.0, float(np.abs(ref).max())) / float(dt) + RTOL * uscale
+                    assert inside((ref[t, i, :] - q[t]) / dt, pad), f"C marginal row {t}, step {i}: the reference's step in no admissible assignment's envelope"
+                n_marginal_e2e += 1
             assert_close(r["closest_dist_all"][:, 0], fx[pre + "closest_dist_all"][:, i - 1], RTOL, f"C distance {i}", floor=dscale)
             if okc.any():
                 assert_close(r["normal"][okc, 0], fx[pre + "norm_basis_n"][okc, i - 1], 5e-5, f"C normal {i}")
                 assert_close(r["dot_products"][okc, 0], fx[pre + "dot_products"][okc, i - 1], 5e-5, f"C dot {i}")
             assert_close(r["kernel_val_all"][:, 0], fx[pre + "kernel_val_all"][:, i - 1], RTOL, f"C rbf {i}")
+    print(f"{name}: {n_rows} rows, {n_alt_rows} took another admissible mask assignment than the oracle's, {n_marginal_e2e} of them "
+          f"checked end to end against the union of admissible envelopes (the reference's velocity included)")
     eng.close()
 
 
