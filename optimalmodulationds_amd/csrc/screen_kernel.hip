@@ -659,7 +659,8 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
 
 // ------------------------------------------------------------------------------------------------
 // k_select: one wave per rollout (select_rollout above), for the steps whose k_screen writes the matrix: rows too long for a
-// workgroup's LDS, and the tanh / skip-less-tail path that needs the matrix (k_exact writes the exact values into it).
+// workgroup's LDS, and the matrix route of a tanh network whose derivative hand-over buffer could not be allocated (k_exact mode 3
+// writes the exact values into the matrix).
 // ------------------------------------------------------------------------------------------------
 struct SelectArgs {
     const float* Dmin;    // [N][O] screening values
