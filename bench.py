@@ -394,7 +394,7 @@ def main():
                        "precision": ("fp32 outputs (every distance, gradient, velocity and cost the step returns comes from fp32 kernels); the N x O "
                                      "first-pass evaluations that only feed the obstacle selection are screened in f16 and the candidates re-evaluated "
                                      "in fp32 -- identity with the all-fp32 step is conditional on a measured bound eps (profiles/r04_screen_error_hist.txt: "
-                                     "0 of > 1e10 unevaluated pairs above eps / 2); value_fp32_only / roofline.fp32_only = the same iterations with "
+                                     "0 of > 1e11 unevaluated pairs above eps / 2); value_fp32_only / roofline.fp32_only = the same iterations with "
                                      "every row in fp32") if r["scr"]["active"] else "fp32 throughout",
                        "rollouts_per_gpu": N, "horizon": H, "obstacles": int(obs.shape[0]),
                        "n_closest": w["k"], "active_kernels": K, "network": "x".join(str(x.shape[1]) for x in W) + f"x{W[-1].shape[0]} {act} "

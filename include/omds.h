@@ -290,14 +290,14 @@ OMDS_API int omds_apply_update(int n_kernels, int n_dof, int horizon, const floa
  *     step (soak runs: of EVERY horizon step) in fp32 beside all their screening values, max |Da - D| over every one of them,
  *     and the distribution of Da - D over the pairs that were not candidates (omds_screen_sweep_hist): the quantity the
  *     selection rule's assumption is about, counted exhaustively instead of sampled.  profiles/r04_screen_error_hist.txt
- *     holds that distribution over > 1e10 pairs (tools/sweep_soak.py).
+ *     holds that distribution over > 1e11 pairs (tools/sweep_soak.py).
  * A propagate is accepted only while all these maxima stay <= eps / 2 and no slack check failed; otherwise it is redone with the
  * fp32 pass 1 (its results are then the fp32 ones by construction) and eps is widened; three fallbacks in a row suspend
  * screening until the next calibration.  A row outside the audit sample whose error exceeds eps can still go unseen in
  * one propagate: at run time the identity is measured on a sample, not proven.  What the sample stands on: the exhaustive count of
- * tools/sweep_soak.py -- every horizon step of 1 550 propagates swept, 4.9e10 pairs over ten scene / network legs, none of the
- * 4.7e10 unevaluated pairs above eps / 2, the worst at 0.185 eps (profiles/r04_screen_error_hist.txt; the survival function of
- * (Da - D) / eps falls by half a decade per 1/128).  A caller who wants the reference's arithmetic on every row regardless calls
+ * tools/sweep_soak.py -- every horizon step of 5 183 propagates swept, 1.93e11 pairs over ten scene / network legs, none of the
+ * 1.87e11 unevaluated pairs above eps / 2, the worst at 0.197 eps (profiles/r04_screen_error_hist.txt; the survival function of
+ * (Da - D) / eps falls by half a decade or more per 1/128).  A caller who wants the reference's arithmetic on every row regardless calls
  * omds_set_screening(ctx, 0, 0).
  * mode: -1 auto (on for ReLU / tanh networks, with or without skip concatenations, when n_traj * n_obs >= 65536; env
  * OMDS_SCREEN=0|1 overrides), 0 off, 1 on.  eps > 0 sets the bound in place of a calibration (never recalibrated; the run-time checks
