@@ -188,6 +188,11 @@ OMDS_API int omds_dist_grad(omds_ctx* ctx, const float* q, int batch, float* dis
  * arg-min output (robot_sdf.py:153-158): x [B,n+3]; y [B,C], grad [B,n+3], min_idx [B]. B <= N*k. */
 OMDS_API int omds_mlp_forward_vjp(omds_ctx* ctx, const float* x, int batch, float* y, float* grad,
                                   int32_t* min_idx);
+/* RobotSdfCollisionNet.compute_signed_distance_wgrad with a column list (mlp_learn/sdf/robot_sdf.py:68-100): the Jacobian columns of
+ * the listed raw outputs, one backward per column as the reference's loop of .backward() calls does.  x [B,n+3]; cols [n_cols],
+ * 0 <= cols[k] < C, 1 <= n_cols <= 16; y [B,C] or NULL; jac [B, n+3, n_cols] (the reference's grads[:, :, k]). B <= N*k.   */
+OMDS_API int omds_mlp_jacobian(omds_ctx* ctx, const float* x, int batch, const int32_t* cols, int n_cols, float* y,
+                               float* jac);
 
 /* MPPI.get_cost -> Cost.evaluate_costs (MPPI.py:315-317, cost.py:13-22). cost_out [N] or NULL. */
 OMDS_API int omds_cost(omds_ctx* ctx, float* cost_out);

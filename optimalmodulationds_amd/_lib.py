@@ -73,6 +73,7 @@ SIGNATURES = {
     "omds_get_rollout_rows": (C.c_int, [C.c_void_p, I32P, C.c_int, F32P, F32P, F32P, F32P, F32P, F32P, F32P]),
     "omds_dist_grad": (C.c_int, [C.c_void_p, F32P, C.c_int, F32P, F32P, F32P, I32P]),
     "omds_mlp_forward_vjp": (C.c_int, [C.c_void_p, F32P, C.c_int, F32P, F32P, I32P]),
+    "omds_mlp_jacobian": (C.c_int, [C.c_void_p, F32P, C.c_int, I32P, C.c_int, F32P, F32P]),
     "omds_cost": (C.c_int, [C.c_void_p, F32P]),
     "omds_cost_eval": (C.c_int, [C.c_void_p, F32P, F32P, C.c_int, F32P]),
     "omds_weighted_update": (C.c_int, [C.c_void_p, C.c_float, C.c_float, F32P, F32P, F32P, I32P, F32P]),

@@ -1516,68 +1516,78 @@ int omds_dist_grad(omds_ctx* ctx, const float* q, int B, float* distance, float*
     return OMDS_OK;
 }
 
-int omds_mlp_forward_vjp(omds_ctx* ctx, const float* x, int B, float* y, float* grad, int32_t* min_idx) {
-    if (!ctx) return OMDS_ERR_INVALID_ARG;
+// the raw rows x [B][d] through the network and the vjp of one output per row: the arg-min one (seed_col < 0) or column seed_col
+static int mlp_rows_vjp(omds_ctx* ctx, const char* who, const float* x, int B, int seed_col, float* y, float* grad, int32_t* min_idx) {
     const int n = ctx->cfg.n_dof;
     const int cap = ctx->cfg.n_traj * ctx->cfg.n_closest;
-    REQUIRE(x && B >= 1 && B <= cap, OMDS_ERR_INVALID_ARG, "omds_mlp_forward_vjp: need 1 <= batch <= n_traj*n_closest and non-null x");
+    if (!(x && B >= 1 && B <= cap)) { ctx->err = std::string(who) + ": need 1 <= batch <= n_traj*n_closest and non-null x"; return OMDS_ERR_INVALID_ARG; }
     REQUIRE(ctx->have_mlp, OMDS_ERR_NOT_INITIALISED, "distance network not set (omds_set_mlp)");
     const int d = ctx->mlp.d;
     CK(hipSetDevice(ctx->dev));
     if (ctx->wide.on) {   // wide networks: the raw rows through the unfused GEMM path
         int rcw;
         CK(hipMemcpyAsync(ctx->d_stage, x, (size_t)B * d * 4, hipMemcpyHostToDevice, ctx->stream));
-        if ((rcw = omds_wide_vjp(ctx, ctx->d_stage, B))) return rcw;
-        CK(hipGetLastError());
-        CK(hipStreamSynchronize(ctx->stream));
-        if (y) {
-            std::vector<float> ypad((size_t)B * OMDS_CPAD);
-            CK(hipMemcpy(ypad.data(), ctx->d_yraw, ypad.size() * 4, hipMemcpyDeviceToHost));
-            for (int r = 0; r < B; ++r)
-                for (int c = 0; c < ctx->mlp.C; ++c) y[(size_t)r * ctx->mlp.C + c] = ypad[(size_t)r * OMDS_CPAD + c];
+        if ((rcw = omds_wide_vjp(ctx, ctx->d_stage, B, seed_col))) return rcw;
+    } else {
+        // every row is its own (rollout, obstacle) pair: Apre from x[:, :n], Bpre from x[:, n:], radius 0
+        std::vector<float> xyzr((size_t)B * 4, 0.f), qrow((size_t)B * n);
+        std::vector<int32_t> ident(B);
+        for (int r = 0; r < B; ++r) {
+            for (int j = 0; j < n; ++j) qrow[(size_t)r * n + j] = x[(size_t)r * d + j];
+            for (int j = 0; j < d - n; ++j) xyzr[(size_t)r * 4 + j] = x[(size_t)r * d + n + j];
+            ident[r] = r;
         }
-        if (grad) CK(hipMemcpy(grad, ctx->d_gradx, (size_t)B * d * 4, hipMemcpyDeviceToHost));
-        if (min_idx) CK(hipMemcpy(min_idx, ctx->d_minidx, (size_t)B * 4, hipMemcpyDeviceToHost));
-        return OMDS_OK;
+        // per-row "obstacle" buffers of this entry point, allocated on first use for the context's capacity and kept
+        if (!ctx->d_vjp_xyzr) {
+            CK(hipMalloc(&ctx->d_vjp_xyzr, (size_t)cap * 16));
+            CK(hipMalloc(&ctx->d_vjp_B, (size_t)cap * OMDS_WIDTH * 4));
+            CK(hipMalloc(&ctx->d_vjp_rad, (size_t)cap * 4));
+        }
+        float *d_xyzr = ctx->d_vjp_xyzr, *d_B = ctx->d_vjp_B, *d_rad = ctx->d_vjp_rad;
+        // pageable sources: the copies have read them when the calls return
+        CK(hipMemcpyAsync(d_xyzr, xyzr.data(), (size_t)B * 16, hipMemcpyHostToDevice, ctx->stream));
+        CK(hipMemcpyAsync(ctx->d_stage, qrow.data(), (size_t)B * n * 4, hipMemcpyHostToDevice, ctx->stream));
+        CK(hipMemcpyAsync(ctx->d_idx, ident.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+        omds_launch_transpose(ctx->stream, ctx->d_stage, ctx->d_qstage, B, n);
+        omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Apre);
+        omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, d_xyzr, B, d_B, d_rad);
+        omds_launch_pass2(ctx->stream, ctx->mlp, ctx->d_Apre, d_B, d_rad, d_xyzr, ctx->d_idx, B, 1, ctx->d_qstage, B,
+                          ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dscr, seed_col);
     }
-    // every row is its own (rollout, obstacle) pair: Apre from x[:, :n], Bpre from x[:, n:], radius 0
-    std::vector<float> xyzr((size_t)B * 4, 0.f), qrow((size_t)B * n);
-    std::vector<int32_t> ident(B);
-    for (int r = 0; r < B; ++r) {
-        for (int j = 0; j < n; ++j) qrow[(size_t)r * n + j] = x[(size_t)r * d + j];
-        for (int j = 0; j < d - n; ++j) xyzr[(size_t)r * 4 + j] = x[(size_t)r * d + n + j];
-        ident[r] = r;
-    }
-    // per-row "obstacle" buffers of this entry point, allocated on first use for the context's capacity and kept
-    if (!ctx->d_vjp_xyzr) {
-        CK(hipMalloc(&ctx->d_vjp_xyzr, (size_t)cap * 16));
-        CK(hipMalloc(&ctx->d_vjp_B, (size_t)cap * OMDS_WIDTH * 4));
-        CK(hipMalloc(&ctx->d_vjp_rad, (size_t)cap * 4));
-    }
-    float *d_xyzr = ctx->d_vjp_xyzr, *d_B = ctx->d_vjp_B, *d_rad = ctx->d_vjp_rad;
-    auto cleanup = [&]() {};
-    hipError_t e;
-#define CKL(expr) do { e = (expr); if (e != hipSuccess) { cleanup(); ctx->err = std::string(#expr) + ": " + hipGetErrorString(e); return OMDS_ERR_HIP; } } while (0)
-    CKL(hipMemcpyAsync(d_xyzr, xyzr.data(), (size_t)B * 16, hipMemcpyHostToDevice, ctx->stream));
-    CKL(hipMemcpyAsync(ctx->d_stage, qrow.data(), (size_t)B * n * 4, hipMemcpyHostToDevice, ctx->stream));
-    CKL(hipMemcpyAsync(ctx->d_idx, ident.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
-    omds_launch_transpose(ctx->stream, ctx->d_stage, ctx->d_qstage, B, n);
-    omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Apre);
-    omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, d_xyzr, B, d_B, d_rad);
-    omds_launch_pass2(ctx->stream, ctx->mlp, ctx->d_Apre, d_B, d_rad, d_xyzr, ctx->d_idx, B, 1, ctx->d_qstage, B,
-                      ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dscr);
-    CKL(hipGetLastError());
-    CKL(hipStreamSynchronize(ctx->stream));
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(ctx->stream));
     if (y) {
         std::vector<float> ypad((size_t)B * OMDS_CPAD);
-        CKL(hipMemcpy(ypad.data(), ctx->d_yraw, ypad.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(ypad.data(), ctx->d_yraw, ypad.size() * 4, hipMemcpyDeviceToHost));
         for (int r = 0; r < B; ++r)
             for (int c = 0; c < ctx->mlp.C; ++c) y[(size_t)r * ctx->mlp.C + c] = ypad[(size_t)r * OMDS_CPAD + c];
     }
-    if (grad) CKL(hipMemcpy(grad, ctx->d_gradx, (size_t)B * d * 4, hipMemcpyDeviceToHost));
-    if (min_idx) CKL(hipMemcpy(min_idx, ctx->d_minidx, (size_t)B * 4, hipMemcpyDeviceToHost));
-#undef CKL
-    cleanup();
+    if (grad) CK(hipMemcpy(grad, ctx->d_gradx, (size_t)B * d * 4, hipMemcpyDeviceToHost));
+    if (min_idx) CK(hipMemcpy(min_idx, ctx->d_minidx, (size_t)B * 4, hipMemcpyDeviceToHost));
+    return OMDS_OK;
+}
+
+int omds_mlp_forward_vjp(omds_ctx* ctx, const float* x, int B, float* y, float* grad, int32_t* min_idx) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    return mlp_rows_vjp(ctx, "omds_mlp_forward_vjp", x, B, -1, y, grad, min_idx);
+}
+
+int omds_mlp_jacobian(omds_ctx* ctx, const float* x, int B, const int32_t* cols, int n_cols, float* y, float* jac) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(ctx->have_mlp, OMDS_ERR_NOT_INITIALISED, "distance network not set (omds_set_mlp)");
+    REQUIRE(cols && jac && n_cols >= 1 && n_cols <= OMDS_CPAD, OMDS_ERR_INVALID_ARG, "omds_mlp_jacobian: need cols, jac and 1 <= n_cols <= 16");
+    for (int k = 0; k < n_cols; ++k)
+        REQUIRE(cols[k] >= 0 && cols[k] < ctx->mlp.C, OMDS_ERR_INVALID_ARG, "omds_mlp_jacobian: a column index is outside 0 .. out_channels - 1");
+    const int d = ctx->mlp.d;
+    std::vector<float> g;
+    for (int k = 0; k < n_cols; ++k) {   // one backward per column, like the reference's loop of .backward() calls (robot_sdf.py:94-100)
+        int rc = mlp_rows_vjp(ctx, "omds_mlp_jacobian", x, B, cols[k], k == 0 ? y : nullptr, nullptr, nullptr);
+        if (rc) return rc;
+        g.resize((size_t)B * d);
+        CK(hipMemcpy(g.data(), ctx->d_gradx, g.size() * 4, hipMemcpyDeviceToHost));
+        for (int r = 0; r < B; ++r)
+            for (int j = 0; j < d; ++j) jac[((size_t)r * d + j) * n_cols + k] = g[(size_t)r * d + j];
+    }
     return OMDS_OK;
 }
 

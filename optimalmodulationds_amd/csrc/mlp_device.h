@@ -821,7 +821,9 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
                                            const float* __restrict__ qT, int ldq, float* gradx, float* drow, int dbase,
                                            float* __restrict__ yraw, int32_t* __restrict__ minidx,
                                            float* __restrict__ dscr, size_t dlayer, int S0, int dbg = 0,
-                                           float* d1row = nullptr, uint32_t ignored = 0) {
+                                           float* d1row = nullptr, uint32_t ignored = 0, int seed_col = -1) {
+    // seed_col >= 0: the backward starts from that output column instead of the arg-min one (one Jacobian column,
+    // robot_sdf.py:92-100); minidx / drow then describe that column
     // d1row (optional, [ROWS]): the pass-1 value of each row, min over the un-ignored links of y / out_div - radius
     // (MPPI.py:236-242), computed from the same last-layer outputs -- bit-identical to pass1_tile's Dmin for 32-row tiles
     // dbg: timing experiments only (return after a stage).  S0 = first row of this workgroup's private slot in the tanh scratch
@@ -938,7 +940,7 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
             const int R = R0 + r;
             const float y = acc[reg] + bj;
             if (yraw != nullptr && R < total_rows) yraw[(size_t)R * OMDS_CPAD + j] = (j < m.C) ? y : 0.f;
-            float bv = (j < m.C) ? y : __builtin_inff();
+            float bv = (j < m.C && (seed_col < 0 || j == seed_col)) ? y : __builtin_inff();
             int bi = j;
 #pragma unroll
             for (int off = 1; off < 16; off <<= 1) {

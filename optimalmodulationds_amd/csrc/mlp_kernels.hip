@@ -151,7 +151,7 @@ __global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restri
                                                  int total_rows, int k, const float* __restrict__ qT, int ldq,
                                                  float* __restrict__ gradx, float* __restrict__ drow,
                                                  float* __restrict__ yraw, int32_t* __restrict__ minidx,
-                                                 float* __restrict__ dscr) {
+                                                 float* __restrict__ dscr, int seed_col) {
     // dscr (tanh only): [nhh+1][rows padded to 32][256] activation derivatives 1 - h^2, L2-resident scratch
     extern __shared__ __attribute__((aligned(16))) float smem[];
     P2Smem sm;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restri
     }
     __syncthreads();
     pass2_body<ACT, ROWS>(m, sm, Apre, Bpre, radius, xyzr, R0, total_rows, qT, ldq, gradx, drow, R0, yraw, minidx, dscr,
-                                 (size_t)gridDim.x * ROWS * OMDS_WIDTH, R0);
+                                 (size_t)gridDim.x * ROWS * OMDS_WIDTH, R0, 0, nullptr, 0, seed_col);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -284,7 +284,7 @@ void omds_launch_topk(hipStream_t s, const float* Dmin, int B, int O, int k, int
 
 void omds_launch_pass2(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
                        const float* xyzr, const int32_t* idx, int B, int k, const float* qT, int ldq, float* gradx,
-                       float* drow, float* yraw, int32_t* minidx, float* dscr) {
+                       float* drow, float* yraw, int32_t* minidx, float* dscr, int seed_col) {
     const int total = B * k;
     if (total <= 0) return;
     const size_t lds = ((size_t)P2_MT * LDH + P2_PSETS * 32 * 33 + 32 * 33) * 4 + (size_t)(m.nhh + 1) * P2_NT * 4 + 3 * P2_MT * 4;
@@ -300,7 +300,7 @@ void omds_launch_pass2(hipStream_t s, const MlpDev& m, const float* Apre, const 
     // reproduce the step path bit for bit
     const int rows = omds_tail_rows(B, k);
     const dim3 grid((total + rows - 1) / rows);
-#define OMDS_P2_LAUNCH(A, R) hipLaunchKernelGGL((k_pass2<A, R>), grid, dim3(P2_NT), lds, s, m, Apre, Bpre, radius, xyzr, idx, total, k, qT, ldq, gradx, drow, yraw, minidx, dscr)
+#define OMDS_P2_LAUNCH(A, R) hipLaunchKernelGGL((k_pass2<A, R>), grid, dim3(P2_NT), lds, s, m, Apre, Bpre, radius, xyzr, idx, total, k, qT, ldq, gradx, drow, yraw, minidx, dscr, seed_col)
     if (m.act == OMDS_ACT_RELU) { if (rows == 16) OMDS_P2_LAUNCH(OMDS_ACT_RELU, 16); else OMDS_P2_LAUNCH(OMDS_ACT_RELU, 32); }
     else { if (rows == 16) OMDS_P2_LAUNCH(OMDS_ACT_TANH, 16); else OMDS_P2_LAUNCH(OMDS_ACT_TANH, 32); }
 #undef OMDS_P2_LAUNCH

@@ -322,7 +322,7 @@ void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Apre, const 
 void omds_launch_topk(hipStream_t s, const float* Dmin, int B, int O, int k, int32_t* idx);
 void omds_launch_pass2(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
                        const float* xyzr, const int32_t* idx, int B, int k, const float* qT, int ldq,
-                       float* gradx, float* drow, float* yraw, int32_t* minidx, float* dscr);
+                       float* gradx, float* drow, float* yraw, int32_t* minidx, float* dscr, int seed_col = -1);
 void omds_launch_blend(hipStream_t s, const float* gradx, const float* drow, int B, int k, int d, int n,
                        float softmax_k, float* dist, float* nngrad);
 
@@ -334,7 +334,7 @@ void omds_launch_linear_inputgrad(hipStream_t s, const float* G, int out, const 
 // ---- wide_kernels.hip ------------------------------------------------------------------------------
 struct omds_ctx;
 int omds_wide_network(omds_ctx* ctx, const float* qT, int ldq, int B);
-int omds_wide_vjp(omds_ctx* ctx, const float* d_x, int rows);
+int omds_wide_vjp(omds_ctx* ctx, const float* d_x, int rows, int seed_col = -1);
 
 // ---- launchers implemented in screen_kernel.hip -----------------------------------------------
 struct SelectSink;

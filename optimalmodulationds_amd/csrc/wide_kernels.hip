@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_wide_min(const float* __restrict__ Y, c
 __global__ __launch_bounds__(256) void k_wide_seed(const float* __restrict__ Y, const float* __restrict__ Wlast, const float* __restrict__ Hlast,
                                                    const float* __restrict__ xyzr, const int32_t* __restrict__ obs_of_row, int rows, int C, int width,
                                                    int act, float out_div, float* __restrict__ drow, int32_t* __restrict__ minidx,
-                                                   float* __restrict__ yraw, float* __restrict__ G) {
+                                                   float* __restrict__ yraw, float* __restrict__ G, int seed_col) {
     const int r = blockIdx.x;
     if (r >= rows) return;
     __shared__ int s_min;
@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void k_wide_seed(const float* __restrict__ Y, 
         int bi = 0;
         float bv = Y[(size_t)r * C];
         for (int c = 1; c < C; ++c) { const float v = Y[(size_t)r * C + c]; if (v < bv) { bv = v; bi = c; } }
+        if (seed_col >= 0) { bi = seed_col; bv = Y[(size_t)r * C + seed_col]; }   // one Jacobian column (robot_sdf.py:92-100)
         s_min = bi;
         const float rad = obs_of_row ? xyzr[(size_t)obs_of_row[r] * 4 + 3] : 0.f;
         drow[r] = bv / out_div - rad;
@@ -137,7 +138,7 @@ int omds_wide_pass1(omds_ctx* ctx, const float* qT, int ldq, int B) {
 }
 
 // pass 2 on `rows` rows whose encoded inputs are in w.X2 (obs_of_row: their obstacles, or nullptr for radius 0) -> gradx [rows][d], drow
-int omds_wide_pass2_rows(omds_ctx* ctx, int rows, const int32_t* obs_of_row, float* gradx, float* drow, float* yraw, int32_t* minidx) {
+int omds_wide_pass2_rows(omds_ctx* ctx, int rows, const int32_t* obs_of_row, float* gradx, float* drow, float* yraw, int32_t* minidx, int seed_col = -1) {
     WideNet& w = ctx->wide;
     hipStream_t s = ctx->stream;
     const int d = w.d, L = (int)w.dims.size() - 1, C = w.dims[L];
@@ -148,7 +149,7 @@ int omds_wide_pass2_rows(omds_ctx* ctx, int rows, const int32_t* obs_of_row, flo
     }
     const int wl = w.dims[L - 1];
     hipLaunchKernelGGL(k_wide_seed, dim3(rows), dim3(256), 0, s, w.A[L - 1], w.W[L - 1], w.A[L - 2], ctx->d_obs, obs_of_row, rows, C, wl, w.act, w.out_div,
-                       drow, minidx, yraw, w.G[0]);
+                       drow, minidx, yraw, w.G[0], seed_col);
     float* G = w.G[0];
     float* Gn = w.G[1];
     for (int i = L - 2; i >= 1; --i) {   // gradient at the output of Linear i-1 through Linear i, times act'(h_{i-1})
@@ -174,8 +175,8 @@ int omds_wide_network(omds_ctx* ctx, const float* qT, int ldq, int B) {
 }
 
 // omds_mlp_forward_vjp on raw rows x [rows][d] (device pointer)
-int omds_wide_vjp(omds_ctx* ctx, const float* d_x, int rows) {
+int omds_wide_vjp(omds_ctx* ctx, const float* d_x, int rows, int seed_col) {
     WideNet& w = ctx->wide;
     hipLaunchKernelGGL(k_wide_encode_raw, dim3(blocks_of((long long)rows * w.d)), dim3(256), 0, ctx->stream, d_x, rows, w.d, w.X2);
-    return omds_wide_pass2_rows(ctx, rows, nullptr, ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx);
+    return omds_wide_pass2_rows(ctx, rows, nullptr, ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, seed_col);
 }

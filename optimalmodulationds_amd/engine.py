@@ -184,6 +184,16 @@ class Engine:
         self._ck(self.lib.omds_mlp_forward_vjp(self.h, L.fptr(x), B, L.fptr(y), L.fptr(g), L.iptr(mi)))
         return y, g, mi
 
+    def mlp_jacobian(self, x, cols):
+        """(y [B,C], jac [B,d,len(cols)]): Jacobian columns of the listed raw outputs (omds_mlp_jacobian)."""
+        x = L.f32(x).reshape(-1, self.d)
+        cols = np.ascontiguousarray(cols, dtype=np.int32).reshape(-1)
+        B = x.shape[0]
+        y = np.zeros((B, self.C), np.float32)
+        jac = np.zeros((B, self.d, cols.size), np.float32)
+        self._ck(self.lib.omds_mlp_jacobian(self.h, L.fptr(x), B, L.iptr(cols), int(cols.size), L.fptr(y), L.fptr(jac)))
+        return y, jac
+
     # ---- cost / update ------------------------------------------------------------------------
     def cost(self, fetch=True):
         c = np.zeros(self.N, np.float32) if fetch else None

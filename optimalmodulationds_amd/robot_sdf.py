@@ -78,6 +78,8 @@ class RobotSdfCollisionNet:
             chk = torch.load(f_name, map_location=torch.device("cpu"), weights_only=False)
             sd = chk["model_state_dict"]
             self.norm_dict = chk.get("norm")
+            if self.norm_dict is not None:          # robot_sdf.py:41-44 (.to(**tensor_args): the Franka checkpoint stores fp16)
+                self.norm_dict = {k: {kk: torch.as_tensor(vv).to(torch.float32) for kk, vv in v.items()} for k, v in self.norm_dict.items()}
             missing = [st for st in self.model.stems if st + ".weight" not in sd]
             if missing:
                 raise ValueError(f"checkpoint has no {missing[0]}.weight: it was not saved from a network with these layers / skips")
@@ -118,18 +120,80 @@ class RobotSdfCollisionNet:
     __call__ = forward
 
     def compute_signed_distance(self, q):
-        return self.forward(q)[:, self.order]
+        """robot_sdf.py:52-66; the reference scales through ``norm_dict`` here (checkpoints carry one)."""
+        if self.norm_dict is not None:
+            y = self._unscale(self.forward(self._scale(q)))
+        else:
+            y = self.forward(q)
+        return y[:, self.order]
+
+    # -- checkpoint normalisation (network_macros_mod.py:170-200) -------------------------------------------
+    def _scale(self, q):
+        q = torch.as_tensor(q, dtype=torch.float32)
+        s = torch.div(q - self.norm_dict["x"]["mean"], self.norm_dict["x"]["std"])
+        s[s != s] = 0.0
+        return s
+
+    def _unscale(self, y):
+        return torch.mul(y, self.norm_dict["y"]["std"]) + self.norm_dict["y"]["mean"]
+
+    @staticmethod
+    def _rows(q):
+        return np.asarray(q.detach().cpu() if isinstance(q, torch.Tensor) else q, dtype=np.float32)
+
+    def compute_signed_distance_wgrad(self, q, idx="all"):
+        """(dist [B,C] in ``self.order``, grads, minidx) -- robot_sdf.py:68-110.  ``idx`` a list (or 'all'): grads [B,in,len(idx)], one
+        Jacobian column per listed (re-ordered) output; any other value ('closest', 'mindist'): grads [B,in,1] of the arg-min output.
+        A single-output network takes the reference's scaled branch: grads [B,in] of the network-scale output w.r.t. the unscaled q."""
+        if idx == "all":
+            idx = list(range(self.out_channels))
+        if self.out_channels == 1:
+            qs = self._scale(q)
+            y, g, _ = self._eng(qs.shape[0]).mlp_forward_vjp(self._rows(qs))
+            grads = torch.from_numpy(g) / self.norm_dict["x"]["std"]
+            return self._unscale(torch.from_numpy(y)), grads, torch.zeros(qs.shape[0])
+        x = self._rows(q)
+        order = np.asarray(self.order, dtype=np.int64)
+        eng = self._eng(x.shape[0])
+        if isinstance(idx, list):
+            y, jac = eng.mlp_jacobian(x, order[np.asarray(idx, dtype=np.int64)])
+            mi = np.argmin(y[:, order], axis=1)
+            return torch.from_numpy(y[:, order]), torch.from_numpy(jac), torch.from_numpy(mi)
+        if order.size == self.out_channels and (order == np.arange(self.out_channels)).all():
+            y, g, mi = eng.mlp_forward_vjp(x)             # the arg-min of the raw outputs, found on the device
+            return torch.from_numpy(y), torch.from_numpy(g).unsqueeze(2), torch.from_numpy(mi.astype(np.int64))
+        # a link order of the caller's: the arg-min is over the re-ordered columns, the backward starts from that column
+        y = self._rows(self.forward(x))
+        dist = y[:, order]
+        mi = np.argmin(dist, axis=1)
+        need = np.unique(order[mi])
+        grads = np.zeros((x.shape[0], x.shape[1], 1), np.float32)
+        for c0 in range(0, need.size, 16):
+            cols = need[c0:c0 + 16]
+            _, jac = eng.mlp_jacobian(x, cols)
+            for k, c in enumerate(cols):
+                rows = order[mi] == c
+                grads[rows, :, 0] = jac[rows, :, k]
+        return torch.from_numpy(dist), torch.from_numpy(grads), torch.from_numpy(mi)
+
+    def compute_signed_distance_wgrad2(self, q):
+        """(dists, grads [B,in], minIdx) -- robot_sdf.py:144-151 (the vmap-of-vjp form of the same arg-min gradient)."""
+        return self.functorch_vjp(q)
 
     def dist_grad_closest(self, q):
-        """(dists [B,C], grads [B,in,1], minIdx [B]) -- robot_sdf.py:117-137."""
-        x = np.asarray(q.detach().cpu() if isinstance(q, torch.Tensor) else q, dtype=np.float32)
+        """(dists [B,C], grads [B,in,1], minIdx [B]) -- robot_sdf.py:117-137; like the reference, at most the
+        ``allocate_gradients`` row count is evaluated."""
+        x = self._rows(q)
+        if getattr(self, "maxInputSize", None):
+            x = x[:min(self.maxInputSize, x.shape[0])]
         y, g, mi = self._eng(x.shape[0]).mlp_forward_vjp(x)
         return torch.from_numpy(y), torch.from_numpy(g).unsqueeze(2), torch.from_numpy(mi.astype(np.int64))
 
     def functorch_vjp(self, points):
         """(dists, grads [B,in], minIdx) -- robot_sdf.py:153-158."""
-        y, g, mi = self.dist_grad_closest(points)
-        return y, g.squeeze(2), mi
+        x = self._rows(points)
+        y, g, mi = self._eng(x.shape[0]).mlp_forward_vjp(x)
+        return torch.from_numpy(y), torch.from_numpy(g), torch.from_numpy(mi.astype(np.int64))
 
     def dist_grad_closest_aot(self, q):
         return self.functorch_vjp(q)

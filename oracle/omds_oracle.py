@@ -78,10 +78,10 @@ def mlp_forward(m: Mlp, x):
     return (h @ m.W[-1].T + m.b[-1]).astype(F32)
 
 
-def mlp_vjp_argmin(m: Mlp, x):
+def mlp_vjp_argmin(m: Mlp, x, seed=None):
     """functorch_vjp (ML/robot_sdf.py:153-158): forward, minIdx = argmin over ALL raw outputs,
     gradient of y[b, minIdx[b]] w.r.t. the n+3 inputs, as an analytic backward (masks + PE chain
-    rule) instead of autograd."""
+    rule) instead of autograd.  ``seed`` [B]: differentiate those output columns instead (mlp_jacobian)."""
     x = np.asarray(x, dtype=F32)
     d = x.shape[1]
     feats = positional_encoding(x)
@@ -92,7 +92,7 @@ def mlp_vjp_argmin(m: Mlp, x):
         hs.append(_act(z, m.act))
         cur = np.concatenate((hs[-1], feats), axis=1) if i in m.skip_after else hs[-1]
     y = (cur @ m.W[-1].T + m.b[-1]).astype(F32)
-    min_idx = np.argmin(y, axis=1)
+    min_idx = np.argmin(y, axis=1) if seed is None else np.asarray(seed, dtype=np.int64)
     g = m.W[-1][min_idx]                                     # dy/d(input of the last layer)  [B, width]
     g_feat = np.zeros_like(feats)                            # direct paths into the encoded input (skip concatenations)
     for i in range(len(m.W) - 2, -1, -1):
@@ -104,6 +104,27 @@ def mlp_vjp_argmin(m: Mlp, x):
     g = g + g_feat
     grad = g[:, :d] + g[:, d:2 * d] * np.cos(x) - g[:, 2 * d:] * np.sin(x)
     return y, grad.astype(F32), min_idx
+
+
+def mlp_jacobian(m: Mlp, x, cols, order=None):
+    """compute_signed_distance_wgrad with a column list (ML/robot_sdf.py:88-100): dist = y[:, order], grads[:, :, k] = gradient of
+    dist[:, cols[k]] -- one backward per listed column of the RE-ORDERED outputs.  -> (dist [B,C'], grads [B,n+3,len(cols)])."""
+    x = np.asarray(x, dtype=F32)
+    order = list(range(m.W[-1].shape[0])) if order is None else list(order)
+    y = mlp_forward(m, x)
+    J = np.stack([mlp_vjp_argmin(m, x, seed=np.full(x.shape[0], order[c]))[1] for c in cols], axis=2)
+    return y[:, order], J.astype(F32)
+
+
+def mlp_closest_wgrad(m: Mlp, x, order=None):
+    """compute_signed_distance_wgrad(q, 'closest') (ML/robot_sdf.py:101-109): arg-min over the re-ordered outputs, the gradient of
+    that output.  -> (dist [B,C'], grads [B,n+3,1], minidx [B])."""
+    x = np.asarray(x, dtype=F32)
+    order = list(range(m.W[-1].shape[0])) if order is None else list(order)
+    dist = mlp_forward(m, x)[:, order]
+    mi = np.argmin(dist, axis=1)
+    g = mlp_vjp_argmin(m, x, seed=np.asarray(order)[mi])[1]
+    return dist, g[:, :, None], mi
 
 
 # ---------------------------------------------------------------------------------------------

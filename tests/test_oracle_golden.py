@@ -25,6 +25,42 @@ def test_mlp_forward_and_vjp(kind):
     assert_close(grad[safe], fx["grad"][safe], 2e-5, "vjp grad", floor=float(np.abs(fx["grad"]).max()))
 
 
+WGRAD_KINDS = ["franka", "planar7", "franka_tanh"]
+
+
+@pytest.mark.parametrize("kind", WGRAD_KINDS)
+def test_jacobian_columns_and_closest_gradient(kind):
+    """compute_signed_distance_wgrad / _wgrad2 / dist_grad_closest of the reference (tools/make_golden_wgrad.py) vs the oracle."""
+    fx = load("wgrad_" + kind)
+    m = orc.Mlp.from_npz(weights_path(kind))
+    x = fx["x"]
+    C = m.W[-1].shape[0]
+    safe = (fx["min_abs_preact"] > 1e-4) | (m.act != "relu")
+    assert safe.sum() > 0.8 * len(safe)
+    floor = float(np.abs(fx["all_grads"]).max())
+    d, J = orc.mlp_jacobian(m, x, list(range(C)))
+    assert_close(d, fx["all_dist"], RTOL, "distances")
+    assert_close(J[safe], fx["all_grads"][safe], 2e-5, "all Jacobian columns", floor=floor)
+    _, J = orc.mlp_jacobian(m, x, fx["cols"])
+    assert_close(J[safe], fx["cols_grads"][safe], 2e-5, "listed Jacobian columns", floor=floor)
+    d, g, mi = orc.mlp_closest_wgrad(m, x)
+    assert (mi == fx["closest_idx"]).all()
+    assert_close(g[safe], fx["closest_grads"][safe], 2e-5, "closest gradient", floor=floor)
+    if "w2_grads" in fx:
+        assert (mi == fx["w2_idx"]).all()
+        assert_close(g[safe, :, 0], fx["w2_grads"][safe], 2e-5, "wgrad2 gradient", floor=floor)
+    nb = fx["dgc_dist"].shape[0]                                   # dist_grad_closest evaluated maxInputSize rows only
+    assert (mi[:nb] == fx["dgc_idx"]).all()
+    assert_close(g[:nb][safe[:nb]], fx["dgc_grads"][safe[:nb]], 2e-5, "dist_grad_closest gradient", floor=floor)
+    # a permuted link order: columns, arg-min and Jacobian columns follow the re-ordered outputs
+    d, g, mi = orc.mlp_closest_wgrad(m, x, order=fx["order"])
+    assert_close(d, fx["ord_closest_dist"], RTOL, "re-ordered distances")
+    assert (mi == fx["ord_closest_idx"]).all()
+    assert_close(g[safe], fx["ord_closest_grads"][safe], 2e-5, "closest gradient, re-ordered", floor=floor)
+    _, J = orc.mlp_jacobian(m, x, fx["cols"], order=fx["order"])
+    assert_close(J[safe], fx["ord_cols_grads"][safe], 2e-5, "listed columns, re-ordered", floor=floor)
+
+
 def _model(fx):
     return orc.Mlp.from_npz(weights_path(str(fx["kind"])))
 
