@@ -56,6 +56,7 @@ WORKLOADS = {
 }
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 FLOP/clk
 MFMA_F16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (v_mfma_f32_32x32x16_f16), never the 2:1-sparsity figure
+RCCL_FAILURE = [""]     # set when a rank could not form the library's RCCL communicator (run_workload)
 PEAK_OF = {"k_pass1": ("f32 MFMA", MFMA_F32_PEAK_TFLOPS), "k_screen": ("f16 MFMA, f32 accumulate", MFMA_F16_PEAK_TFLOPS)}
 
 
@@ -172,9 +173,22 @@ def measure(args, workload, steps, warmup, rank, world, local_rank, use_dist, di
     eng.push_params()
     eng.set_ds(qf)
     eng.set_cost(dh, qmin, qmax)
-    native = use_dist and not args.share_gpu
-    if native:   # RCCL communicator owned by the library; raises (-> non-zero exit) if RCCL is unusable
-        init_native_comm(eng)
+    native = use_dist and (not args.share_gpu or args.try_rccl)
+    if native:   # RCCL communicator owned by the library (csrc/comm.hip)
+        err = ""
+        try:
+            init_native_comm(eng)
+        except Exception as e:   # OmdsError(OMDS_ERR_RCCL): RCCL not loadable / communicator not formed on this rank
+            err = f"rank {rank}: {e}"
+        # the ranks must agree on the path: if any of them has no communicator, all of them exchange the same two small buffers
+        # through the launcher's gloo group instead, and the JSON line says so (config.collectives) -- a labelled number, not a crash
+        errs = [None] * world
+        dist.all_gather_object(errs, err)
+        if any(errs):
+            native = False
+            RCCL_FAILURE[0] = "; ".join(e for e in errs if e)[:400]
+            if rank == 0:
+                print("bench.py: RCCL communicator unavailable, host-mediated sums over gloo instead: " + RCCL_FAILURE[0], file=sys.stderr)
     # policy means: K kernel centres near the q0 -> qf segment (SURVEY 8d "policy state for timing")
     rng = np.random.RandomState(1234)
     s = (np.arange(K) + 0.5) / max(K, 1)
@@ -306,6 +320,7 @@ def main():
     ap.add_argument("--kernels", type=int, default=10, help="active RBF navigation kernels K")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the all-fp32 figure and the other workloads reported under 'also'")
+    ap.add_argument("--try-rccl", action="store_true", help="with --share-gpu: attempt the RCCL communicator anyway (test of the failure path with OMDS_RCCL_LIB)")
     ap.add_argument("--reps", type=int, default=10, help="timed blocks of --steps iterations each; value = median block")
     ap.add_argument("--prof-stride", type=int, default=8,
                     help="HIP events around every n-th launch of the dominant kernel inside the timed region (an event record between two "
@@ -319,6 +334,7 @@ def main():
 
     import torch
     import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between processes on this driver
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -399,7 +415,7 @@ def main():
                        "rollouts_per_gpu": N, "horizon": H, "obstacles": int(obs.shape[0]),
                        "n_closest": w["k"], "active_kernels": K, "network": "x".join(str(x.shape[1]) for x in W) + f"x{W[-1].shape[0]} {act} "
                        + ("(shipped reference weights)" if act == "relu" else "(seeded synthetic weights)"),
-                       "parallelism": f"rollout-sharded x{world}", "collectives": (("gloo-host (--share-gpu test mode)" if args.share_gpu else "rccl") if use_dist else "none")},
+                       "parallelism": f"rollout-sharded x{world}", "collectives": (("gloo-host (RCCL unavailable: " + RCCL_FAILURE[0] + ")" if RCCL_FAILURE[0] else ("gloo-host (--share-gpu test mode)" if args.share_gpu else "rccl")) if use_dist else "none")},
             "roofline": roofline(r, args.workload),
         }
         if fp32 is not None:

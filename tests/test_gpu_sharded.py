@@ -319,3 +319,38 @@ def test_bench_under_torchrun_single_rank_uses_rccl(workload):
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["config"]["collectives"] == "rccl" and d["value"] > 1e5, d
     assert d["scaling"] == "weak" and d["steps"] == 3 and d["reps"] == 2
+
+
+@pytest.mark.parametrize("mode", ["share", "rccl_missing"])
+def test_bench_two_ranks_on_one_gpu(mode):
+    """World size 2 under the driver's launcher on a 1-GPU box: both ranks on GPU 0, sums through the launcher's gloo group (two
+    ranks on one GPU cannot form a RCCL communicator) -- the barrier, the max over ranks, the rank-0 kernel decision + broadcast of
+    the dynamic workload and the whole-job value all run.  'rccl_missing': the ranks attempt the RCCL communicator, cannot load the
+    library (OMDS_RCCL_LIB points nowhere), agree on the host-mediated path and say so in the line instead of crashing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    extra = []
+    if mode == "rccl_missing":
+        env["OMDS_RCCL_LIB"] = "/nonexistent/librccl.so"
+        extra = ["--try-rccl"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541" if mode == "share" else "29542", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--reps", "2", "--no-cpu-baseline", "--no-secondary", "--share-gpu", "--workload", "franka_dynamic_1024x32"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 alone prints the line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 1e5, d
+    assert d["config"]["parallelism"] == "rollout-sharded x2"
+    coll = d["config"]["collectives"]
+    if mode == "share":
+        assert coll.startswith("gloo-host (--share-gpu"), coll
+    else:
+        assert coll.startswith("gloo-host (RCCL unavailable: rank 0:"), coll
+        assert "RCCL communicator unavailable" in r.stderr, r.stderr[-2000:]
+    # whole-job value = both ranks' rollouts over the slowest rank's time
+    assert abs(d["value"] - 2 * 1024 * 32 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
