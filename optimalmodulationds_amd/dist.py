@@ -32,8 +32,15 @@ def init_native_comm(engine, group=None):
     no fallback.  Without an initialised process group: a single-rank communicator."""
     if dist.is_initialized():
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [engine.comm_unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box = [engine.comm_unique_id()]
+            except Exception as e:          # RCCL not loadable: the other ranks are waiting in the broadcast -- tell them
+                box = [e]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if isinstance(box[0], Exception):
+            raise box[0]
         uid = box[0]
     else:
         rank, world, uid = 0, 1, engine.comm_unique_id()

@@ -67,3 +67,44 @@ def test_two_rank_update_matches_single_process(tmp_path, name):
     assert_close(o["al"], fx["it0_alpha_c_new"], 1e-5, "alpha_c")
     assert_close(o["qw"], fx["it0_qdot_weighted"], 1e-5, "weighted qdot")
     assert_close(o["qb"], fx["it0_qdot_best"], 1e-6, "best qdot")
+
+
+def _worker_no_rccl(rank, world, port, outdir):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    os.environ["OMDS_RCCL_LIB"] = "/nonexistent/librccl-not-here.so"
+    import torch.distributed as dist
+    from optimalmodulationds_amd import _lib
+    from optimalmodulationds_amd.dist import init_native_comm
+    from optimalmodulationds_amd.engine import Engine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Ctx:                       # the two calls init_native_comm makes; no GPU context behind them
+        comm_unique_id = staticmethod(Engine.comm_unique_id)
+
+        def comm_init(self, uid, rank, world):
+            raise AssertionError("no id can exist without RCCL")
+
+    msg = ""
+    try:
+        init_native_comm(Ctx())
+    except _lib.OmdsError as e:
+        msg = str(e)
+    flags = [None] * world           # the agreement step bench.py runs behind the attempt
+    dist.all_gather_object(flags, bool(msg))
+    with open(os.path.join(outdir, f"r{rank}.txt"), "w") as f:
+        f.write(f"{flags}|{msg}")
+    dist.destroy_process_group()
+
+
+def test_a_missing_rccl_fails_on_every_rank_instead_of_hanging_the_others(tmp_path):
+    """Rank 0 cannot make the communicator id (librccl not loadable): the other ranks, waiting for it in the broadcast, must get
+    the same error -- not block until the launcher's timeout."""
+    import __graft_entry__ as g
+    g.build()
+    world = 2
+    mp.spawn(_worker_no_rccl, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        flags, msg = open(tmp_path / f"r{r}.txt").read().split("|", 1)
+        assert flags == "[True, True]" and "RCCL not available" in msg and "librccl-not-here" in msg, (r, flags, msg)

@@ -339,7 +339,7 @@ def test_bench_two_ranks_on_one_gpu(mode):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29541" if mode == "share" else "29542", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--reps", "2", "--no-cpu-baseline", "--no-secondary", "--share-gpu", "--workload", "franka_dynamic_1024x32"] + extra
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=root, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "rank 0 alone prints the line"
@@ -352,5 +352,6 @@ def test_bench_two_ranks_on_one_gpu(mode):
     else:
         assert coll.startswith("gloo-host (RCCL unavailable: rank 0:"), coll
         assert "RCCL communicator unavailable" in r.stderr, r.stderr[-2000:]
-    # whole-job value = both ranks' rollouts over the slowest rank's time
-    assert abs(d["value"] - 2 * 1024 * 32 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+    # whole-job value = both ranks' rollouts over the slowest rank's time (medians of two blocks: of the rates / of the times)
+    assert abs(d["value"] - 2 * 1024 * 32 / (d["ms_per_step"] * 1e-3)) < 5e-3 * d["value"]
+    assert d["value_min"] <= 2 * 1024 * 32 / (max(d["rep_ms_per_step"]) * 1e-3) * (1 + 1e-4)
