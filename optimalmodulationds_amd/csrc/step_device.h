@@ -3,6 +3,13 @@
 #pragma once
 #include "omds_internal.h"
 
+// phase stamps inside modulate_core for the k_tail_sel timeline build (-DOMDS_TAIL_TL, mlp_device.h); nothing otherwise
+#if defined(OMDS_TAIL_TL) && defined(OMDS_TL_STAMP)
+#define OMDS_MOD_STAMP(i) OMDS_TL_STAMP(i)
+#else
+#define OMDS_MOD_STAMP(i)
+#endif
+
 #define FLT_MAX_F 3.402823466e+38f
 
 __device__ __forceinline__ float nan_to_num_f(float x) {
@@ -128,6 +135,7 @@ __device__ __forceinline__ void modulate_core(const StepArgs& a, const int i, in
             v[j] = acc;
         }
     }
+    OMDS_MOD_STAMP(12);
     float vn2 = 0.f;
 #pragma unroll
     for (int j = 0; j < ND; ++j) vn2 += v[j] * v[j];
@@ -150,6 +158,7 @@ __device__ __forceinline__ void modulate_core(const StepArgs& a, const int i, in
 #pragma unroll
         for (int j = 0; j < ND; ++j) g[j] += gr[j] * w;
     }
+    OMDS_MOD_STAMP(13);
     const float distance = dr[0] - p.dst_thr;                               // MPPI.py:117
     if (sub == 0) a.distT[(size_t)(i - 1) * N + t] = distance;
     float gn2 = 0.f;
@@ -180,6 +189,7 @@ __device__ __forceinline__ void modulate_core(const StepArgs& a, const int i, in
     const float act = ca * va * ga;
     if (sub == 0) a.actT[(size_t)(i - 1) * N + t] = act;
 
+    OMDS_MOD_STAMP(14);
     // RBF policy (policy.py:186-199, MPPI.py:165-186) + running statistics for the update mask
 #pragma unroll
     for (int j = 0; j < ND; ++j) pol[j] = 0.f;
@@ -220,6 +230,7 @@ __device__ __forceinline__ void modulate_core(const StepArgs& a, const int i, in
 #pragma unroll
             for (int off = 1; off < NSUB; off <<= 1) pol[j] += __shfl_xor(pol[j], off);
     }
+    OMDS_MOD_STAMP(15);
     // total velocity, closed-form M v, normalisation, collision handling (MPPI.py:197-217)
     float gv = 0.f;
 #pragma unroll
@@ -252,5 +263,6 @@ __device__ __forceinline__ void modulate_core(const StepArgs& a, const int i, in
             for (int j = 0; j < ND; ++j) a.qdotT[(size_t)j * N + t] = u[j];
         }
     }
+    OMDS_MOD_STAMP(16);
 }
 

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
 __global__ void k_tail_tl_dump(int nb) {
     for (int b = 0; b < nb && b < 1024; ++b) {
         printf("TL %d", b);
-        for (int i = 0; i < 12; ++i) printf(" %llu", g_tail_tl[b][i]);
+        for (int i = 0; i < 17; ++i) printf(" %llu", g_tail_tl[b][i]);   // 12..16: inside modulate_core
         printf(" %llu\n", g_tail_tl[b][19]);
     }
 }
