@@ -369,7 +369,12 @@ def main():
                 "avg_launch_ms": rr["p1_ms"] / max(rr["p1_launches"], 1),
                 "flops_per_launch": rr["p1_flops"] / max(rr["p1_launches"], 1),
                 "profile": "profiles/r04_kernel_trace_stats%s.txt (rocprofv3 --kernel-trace --stats of this command%s)" %
-                           (("", "") if rr["p1_kernel"] != "k_pass1" else ("_fp32", " with the library's screening switched off"))}
+                           (("", "") if rr["p1_kernel"] != "k_pass1" else ("_fp32", " with the library's screening switched off")),
+                **({"flops_basis": "algorithmic: N x O pairs x the dense network.  k_screen does not issue the MFMAs of a k-chunk whose 16 hidden "
+                                   "units are zero for all 32 pairs of a wave (exact: it adds nothing); the library sorts the units by how often "
+                                   "they fire so that the silent ones of a trained ReLU network fill whole chunks (screening.unit_reorders, "
+                                   "screening.units_never_fired; SQ_INSTS_MFMA in profiles/r04_pmc_sq.txt is what the matrix pipe executed)"}
+                   if rr["p1_kernel"] == "k_screen" and rr["scr"].get("unit_reorders", 0) > 0 else {})}
 
     def rate(rr, steps):
         v = [world * rr["N"] * rr["H"] * steps / e for e in rr["els"]]

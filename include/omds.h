@@ -341,6 +341,15 @@ OMDS_API int omds_screen_audit_stats(omds_ctx* ctx, int32_t* one_in, double* aud
  * per-entry buffers (32 candidates per rollout on average: near-flat distance fields); and how often three in a row (or a
  * non-finite error) suspended screening until the next calibration.                                                      */
 OMDS_API int omds_screen_fallback_stats(omds_ctx* ctx, int64_t* by_error, int64_t* by_slack, int64_t* by_overflow, int64_t* suspensions);
+/* Unit order of the screening network.  k_screen does not issue the MFMAs of a k-chunk (16 hidden units) whose activations are zero
+ * for all 32 pairs of a wave -- exact: such a chunk adds nothing to any output.  Which units fire is a property of the trained
+ * weights (of the shipped Franka network's 1024 hidden units, 300 fire for no pair of the shelf scene), so behind every calibration the
+ * library sorts the hidden units of the fp16 pack by how often they fired on a uniform sample of the propagate's (rollout,
+ * obstacle) pairs (one k_exact launch, 8192 pairs), which puts the silent ones into whole chunks.  ReLU networks without skip
+ * concatenations; the fp32 kernels do not use this pack, so no returned number depends on the order.
+ * reorders: packs rebuilt since creation; never_fired [n_levels <= 9] (NULL = skip): per hidden level, units that fired in no
+ * sampled row at the last reorder.                                                                                          */
+OMDS_API int omds_screen_order_stats(omds_ctx* ctx, int64_t* reorders, int32_t* never_fired, int n_levels);
 /* (The two test hooks that damage the screening inputs / force a tile shape are NOT part of this library: they are declared in
  * include/omds_test.h and exported by libomds_hip_test.so only.)                                                           */
 /* Diagnostic: the fp16 screening network alone on q [B,n] -> mindist [B,O] (the values the candidate selection sees). */

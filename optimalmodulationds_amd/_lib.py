@@ -98,6 +98,7 @@ SIGNATURES = {
     "omds_set_screening_audit": (C.c_int, [C.c_void_p, C.c_int]),
     "omds_screen_audit_stats": (C.c_int, [C.c_void_p, I32P, C.POINTER(C.c_double), F32P, I32P, C.POINTER(C.c_int64)]),
     "omds_screen_fallback_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "omds_screen_order_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), I32P, C.c_int]),
     "omds_set_screening_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "omds_screen_sweep_hist": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int, C.c_int]),
     "omds_screen_sweep_stats": (C.c_int, [C.c_void_p, I32P, C.POINTER(C.c_int64), F32P]),
@@ -132,7 +133,7 @@ TEST_HOOK_SIGNATURES = {
 }
 TEST_LIB_PATH = os.path.join(_HERE, "csrc", "libomds_hip_test.so")
 
-ABI_VERSION = 400      # omds_version() of the library this binding was written against
+ABI_VERSION = 401      # omds_version() of the library this binding was written against
 _libs = {}             # path -> bound CDLL
 
 

@@ -87,7 +87,7 @@ static uint16_t f32_to_f16_bits(float f) {
 
 extern "C" {
 
-int omds_version(void) { return 400; }
+int omds_version(void) { return 401; }
 
 void omds_default_params(omds_params* p) {
     if (!p) return;
@@ -120,7 +120,7 @@ static void free_all(omds_ctx* ctx) {
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
                     ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
                     ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
-                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP, ctx->d_seds, ctx->d_audit_rows, ctx->d_audit_da, ctx->d_ApreAll, ctx->d_featQAll, ctx->d_FqS, ctx->d_FpS, ctx->d_listDa, ctx->d_sinks, ctx->d_qcur, ctx->d_sweepD, ctx->d_sweepDa, ctx->d_sweep_hist, ctx->d_uev, ctx->d_exDeriv};
+                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP, ctx->d_seds, ctx->d_audit_rows, ctx->d_audit_da, ctx->d_ApreAll, ctx->d_featQAll, ctx->d_FqS, ctx->d_FpS, ctx->d_listDa, ctx->d_sinks, ctx->d_qcur, ctx->d_sweepD, ctx->d_sweepDa, ctx->d_sweep_hist, ctx->d_uev, ctx->d_exDeriv, ctx->d_scr_tmp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : ctx->mlp_allocs)
@@ -296,7 +296,69 @@ struct MlpPacks {
     std::vector<float> bh, bl, wlraw, whraw, w1t, b1, sbias;
     std::vector<uint16_t> wh;
     double f_fwd = 0.0, f_bwd = 0.0;
+    // what build_screen_pack needs to build wh / sbias again in another unit order (ReLU / tanh networks the screening kernel takes)
+    std::vector<std::vector<float>> host_W, host_b;   // zero-padded to width 256
+    std::vector<int32_t> out_dims;
 };
+
+// fp16 screening network (screen_kernel.hip): slices of 32 output rows x 256 k in A-fragment order of v_mfma_f32_32x32x16_f16, with
+// the k order permuted to the C layout of the previous layer (chunk cc, lane-half h, slot j <-> position 16cc + 8(j>>2) + 4h + (j&3)).
+// Behind a skip concatenation (level L = output of Linear L) the consuming layer's input columns are packed in a VIRTUAL
+// order: its own c0 = out_dims[L] columns first, the 3d concatenated input columns LAST (virtual 256 - 3d .. 255 = k-chunks
+// 14 and 15 whatever c0 is -- the K order of a dot product is free), zeros in between: omds_screen_sidx puts the inputs there.
+// order (optional, [nhh + 1][256]): order[L][p] = the hidden unit of Linear L that sits at POSITION p of the screening network --
+// row p of that layer's slices, k position p of the layer behind it.  Any permutation computes the same function; the kernel
+// skips k-chunks whose 16 units are zero for all pairs of a wave, so the units that seldom or never fire are put together
+// (screen_reorder).  nullptr: the identity.
+static void build_screen_pack(MlpPacks& pk, const int32_t* order) {
+    const int nhh = pk.nhh, C = pk.C, Wd = OMDS_WIDTH, F = 3 * pk.d, n_linear = nhh + 2;
+    const uint32_t skip_mask = pk.skip_mask;
+    std::vector<const float*> Wv(n_linear), bv(n_linear);
+    for (int i = 0; i < n_linear; ++i) { Wv[i] = pk.host_W[i].data(); bv[i] = pk.host_b[i].data(); }
+    const float* const* W = Wv.data();
+    const float* const* b = bv.data();
+    auto unit = [&](int L, int p) -> int { return order ? order[(size_t)L * Wd + p] : p; };   // position p of Linear L's outputs
+    auto real_col = [&](int consumer, int v) -> int {   // virtual input position v of Linear `consumer` -> column of Wpad, -1 = zero
+        const int L = consumer - 1;
+        if (L < 0 || !((skip_mask >> L) & 1u)) return unit(L, v);
+        const int c0 = pk.out_dims[L];
+        if (v < c0) return v;
+        if (v >= Wd - F) return c0 + (v - (Wd - F));
+        return -1;
+    };
+    // tanh: every layer in front of an activation is scaled by 2 log2(e) (screen_kernel.hip: act_pk); the last layer is not
+    const float hs = pk.act == OMDS_ACT_TANH ? OMDS_SCREEN_TANH_SCALE : 1.f;
+    std::vector<uint16_t>& wh = pk.wh;
+    const int nsl = nhh * 8 + 2;
+    wh.assign((size_t)nsl * 16 * 64 * 8, 0);
+    pk.sbias.assign((size_t)(nhh + 2) * Wd, 0.f);
+    // slice 0: layer 1, fragment 2 fb + cc = positions 32 fb .. +31 x inputs 16 cc .. +15 (slot j of lane-half h = input 16cc + 8h + j)
+    for (int fb = 0; fb < 8; ++fb)
+        for (int cc = 0; cc < 2; ++cc)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int r = unit(0, 32 * fb + (lane & 31)), kk = 16 * cc + 8 * (lane >> 5) + j;
+                    const float v = (kk < F) ? W[0][(size_t)r * F + kk] : 0.f;
+                    wh[(((size_t)(2 * fb + cc)) * 64 + lane) * 8 + j] = f32_to_f16_bits(hs * v);
+                }
+    for (int sl = 1; sl < nsl; ++sl) {
+        const bool lastl = sl == nsl - 1;
+        const int lin = lastl ? n_linear - 1 : (sl - 1) / 8 + 1;   // the Linear layer this slice belongs to
+        const float* Wsrc = W[lin];
+        const int fb = lastl ? 0 : (sl - 1) % 8, rows = lastl ? C : Wd;
+        for (int cc = 0; cc < 16; ++cc)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int rp = 32 * fb + (lane & 31), r = (lastl || rp >= Wd) ? rp : unit(lin, rp);
+                    const int kk = real_col(lin, 16 * cc + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3));
+                    const float v = (rp < rows && kk >= 0) ? Wsrc[(size_t)r * Wd + kk] : 0.f;
+                    wh[(((size_t)sl * 16 + cc) * 64 + lane) * 8 + j] = f32_to_f16_bits(lastl ? v : hs * v);
+                }
+    }
+    for (int L = 0; L <= nhh; ++L)
+        for (int p = 0; p < Wd; ++p) pk.sbias[(size_t)L * Wd + p] = hs * b[L][unit(L, p)];
+    std::memcpy(&pk.sbias[(size_t)(nhh + 1) * Wd], b[n_linear - 1], C * sizeof(float));
+}
 #define PREQ(cond, code, msg) do { if (!(cond)) { err = (msg); return (code); } } while (0)
 static int build_mlp_packs(int n, int n_linear, const int32_t* in_dims, const int32_t* out_dims, const float* const* W,
                            const float* const* b, int act, float out_div, int n_skips, const int32_t* skip_after, MlpPacks& pk,
@@ -451,52 +513,12 @@ static int build_mlp_packs(int n, int n_linear, const int32_t* in_dims, const in
             }
     pk.whraw.assign((size_t)std::max(nhh, 1) * Wd * Wd, 0.f);
     for (int l = 0; l < nhh; ++l) std::memcpy(&pk.whraw[(size_t)l * Wd * Wd], W[l + 1], (size_t)Wd * Wd * sizeof(float));
-    // fp16 screening network: slices of 32 output rows x 256 k in A-fragment order of v_mfma_f32_32x32x16_f16, with the k
-    // order permuted to the C layout of the previous layer (chunk cc, lane-half h, slot j <-> feature 16cc + 8(j>>2) + 4h + (j&3))
-    // Behind a skip concatenation (level L = output of Linear L) the consuming layer's input columns are packed in a VIRTUAL
-    // order: its own c0 = out_dims[L] columns first, the 3d concatenated input columns LAST (virtual 256 - 3d .. 255 = k-chunks
-    // 14 and 15 whatever c0 is -- the K order of a dot product is free), zeros in between: omds_screen_sidx puts the inputs there
-    auto real_col = [&](int consumer, int v) -> int {   // virtual input column v of Linear `consumer` -> column of Wpad, -1 = zero
-        const int L = consumer - 1;
-        if (L < 0 || !((skip_mask >> L) & 1u)) return v;
-        const int c0 = out_dims[L];
-        if (v < c0) return v;
-        if (v >= Wd - F) return c0 + (v - (Wd - F));
-        return -1;
-    };
     if ((act == OMDS_ACT_RELU || act == OMDS_ACT_TANH) && nhh >= 1 && nhh <= 4) {
-        // tanh: every layer in front of an activation is scaled by 2 log2(e) (screen_kernel.hip: act_pk); the last layer is not
-        const float hs = act == OMDS_ACT_TANH ? OMDS_SCREEN_TANH_SCALE : 1.f;
-        std::vector<uint16_t>& wh = pk.wh;
-        const int nsl = nhh * 8 + 2;
-        wh.assign((size_t)nsl * 16 * 64 * 8, 0);
-        pk.sbias.assign((size_t)(nhh + 2) * Wd, 0.f);
-        // slice 0: layer 1, fragment 2 fb + cc = rows 32 fb .. +31 x inputs 16 cc .. +15 (slot j of lane-half h = input 16cc + 8h + j)
-        for (int fb = 0; fb < 8; ++fb)
-            for (int cc = 0; cc < 2; ++cc)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j) {
-                        const int r = 32 * fb + (lane & 31), kk = 16 * cc + 8 * (lane >> 5) + j;
-                        const float v = (kk < F) ? W[0][(size_t)r * F + kk] : 0.f;
-                        wh[(((size_t)(2 * fb + cc)) * 64 + lane) * 8 + j] = f32_to_f16_bits(hs * v);
-                    }
-        for (int sl = 1; sl < nsl; ++sl) {
-            const bool lastl = sl == nsl - 1;
-            const int lin = lastl ? n_linear - 1 : (sl - 1) / 8 + 1;   // the Linear layer this slice belongs to
-            const float* Wsrc = W[lin];
-            const int fb = lastl ? 0 : (sl - 1) % 8, rows = lastl ? C : Wd;
-            for (int cc = 0; cc < 16; ++cc)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j) {
-                        const int r = 32 * fb + (lane & 31), kk = real_col(lin, 16 * cc + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3));
-                        const float v = (r < rows && kk >= 0) ? Wsrc[(size_t)r * Wd + kk] : 0.f;
-                        wh[(((size_t)sl * 16 + cc) * 64 + lane) * 8 + j] = f32_to_f16_bits(lastl ? v : hs * v);
-                    }
-        }
-        for (int c = 0; c < Wd; ++c) pk.sbias[c] = hs * b[0][c];
-        for (int l = 0; l < nhh; ++l)
-            for (int c = 0; c < Wd; ++c) pk.sbias[(size_t)(l + 1) * Wd + c] = hs * b[l + 1][c];
-        std::memcpy(&pk.sbias[(size_t)(nhh + 1) * Wd], b[n_linear - 1], C * sizeof(float));
+        // the padded fp32 weights stay on the host: the screening pack is built again when the unit order changes (screen_reorder)
+        pk.host_W.assign(Wpad.begin(), Wpad.end());
+        pk.host_b.assign(bpad.begin(), bpad.end());
+        pk.out_dims.assign(out_dims, out_dims + n_linear);
+        build_screen_pack(pk, nullptr);
     }
     pk.f_fwd = 0.0;
     for (int i = 0; i < n_linear; ++i) pk.f_fwd += 2.0 * in_dims[i] * out_dims[i];   // algorithmic: un-padded
@@ -641,12 +663,17 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
     if (!ctx->screen_eps_fixed) ctx->screen_eps = 0.f;
     ctx->screen_suspended = false;
     ctx->screen_consec = 0;
+    ctx->scr_W.clear(); ctx->scr_b.clear(); ctx->scr_out_dims.clear();
+    ctx->scr_reorder_pending = false;
     if (!pk.wh.empty()) {
         const uint16_t* dwh = nullptr;
         if ((rc = upload(ctx, pk.wh, &dwh))) return rc;
         if ((rc = upload(ctx, pk.sbias, &ctx->screen.bias))) return rc;
         ctx->screen.Wh = dwh;
         ctx->screen_ok = true;
+        ctx->scr_W = std::move(pk.host_W);
+        ctx->scr_b = std::move(pk.host_b);
+        ctx->scr_out_dims = std::move(pk.out_dims);
         if (skip_mask) {   // the concatenation operands of the screening kernel (omds_screen_sidx), beside FqH / FpH
             const size_t bq = (size_t)ctx->cfg.n_traj * 32 * 2, bp = (size_t)ctx->cfg.max_obs * 32 * 2;
             if (!ctx->d_FqS) CK(hipMalloc(&ctx->d_FqS, bq));
@@ -1079,6 +1106,7 @@ static bool screen_wanted(omds_ctx* ctx) {
 static int calibrate_screen(omds_ctx* ctx, const float* q_center) {
     ctx->screen_cal = true;
     ctx->obs_cal = ctx->obs_now;
+    ctx->scr_reorder_pending = true;   // the unit order follows the scene too (screen_reorder, behind the next accepted propagate)
     if (ctx->screen_eps_fixed && ctx->screen_eps > 0.f) return OMDS_OK;   // set by the caller (omds_set_screening)
     const int n = ctx->cfg.n_dof, O = ctx->n_obs;
     const int B = std::min(ctx->cfg.n_traj, 1024);
@@ -1393,6 +1421,75 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
 //   serr  = (every sweep_every-th propagate) max |Da - D| over ALL pairs of the swept horizon step(s).
 // Accepted only while the errors keep a 2x margin to eps and no slack check failed; otherwise the propagate is redone with
 // the fp32 pass 1 -- its results are then the fp32 ones by construction -- before omds_propagate returns.
+// The screening pack's unit order from what the network does on live data.  k_exact (the fp32 tile code, mode 1) is run once on a
+// uniform pseudo-random sample of the (rollout, obstacle) pairs of the propagate's last states and leaves their ReLU masks
+// (ExactOut::mask, [entries][hidden levels][8 words]); per hidden level the units are sorted by how many of the sampled rows they
+// fired in (ties by index), the pack is built again in that order and copied over the old one.  (The candidates' own masks would be
+// there for free, but they are the NEAREST obstacles only: ordered by them, 17 % of the k-chunks of the shipped network are dead for a
+// wave; ordered by a uniform sample, 25 %.)  Any order computes the same screening function up to the rounding of the fp32
+// accumulation; what the order buys is that k_screen's zero test finds whole 16-unit chunks dead.  The fp32 kernels do not use this
+// pack: no returned number changes.
+static int screen_reorder(omds_ctx* ctx) {
+    ctx->scr_reorder_pending = false;
+    static const int enabled = OMDS_EXP_ENV("OMDS_SCREEN_REORDER", 1);   // experiment builds: 0 keeps the natural order (A/B runs)
+    const MlpDev& m = ctx->mlp;
+    if (!enabled || m.act != OMDS_ACT_RELU || m.skip_mask || ctx->scr_W.empty() || !ctx->d_exMask) return OMDS_OK;
+    const int nhid = m.nhh + 1, Wd = OMDS_WIDTH, N = ctx->cfg.n_traj, H = ctx->cfg.horizon, n = ctx->cfg.n_dof, O = ctx->n_obs;
+    const long long pairs = (long long)N * O;
+    const int S = (int)std::min<long long>({8192, (long long)ctx->ex_cap, pairs});
+    if (S < 64) return OMDS_OK;
+    if (!ctx->d_scr_tmp) CK(hipMalloc(&ctx->d_scr_tmp, 8 * sizeof(int)));
+    std::vector<int32_t> list(S + 1);
+    uint64_t x = 0x9E3779B97F4A7C15ull * (uint64_t)(ctx->screen_recals + 1);
+    for (int j = 0; j < S; ++j) {   // splitmix64: a fixed sequence per calibration
+        x += 0x9E3779B97F4A7C15ull;
+        uint64_t z = x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        list[j] = (int32_t)(z % (uint64_t)pairs);
+    }
+    list[S] = S;
+    // pageable sources: the copies have read them when the calls return
+    CK(hipMemcpyAsync(ctx->d_rowlist, list.data(), (size_t)S * 4, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipMemsetAsync(ctx->d_scr_tmp, 0, 8 * sizeof(int), ctx->stream));
+    CK(hipMemcpyAsync(ctx->d_scr_tmp + 4, &list[S], 4, hipMemcpyHostToDevice, ctx->stream));
+    // layer-1 halves of the last states the propagate reached (d_Apre is rebuilt at the start of every propagate)
+    omds_launch_rollout_layer1(ctx->stream, m, ctx->d_trajT + (size_t)(H - 1) * n * N, N, N, ctx->d_Apre);
+    ExactOut ex{ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->ex_cap};
+    omds_launch_exact(ctx->stream, m, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, O, N, ctx->prm.ignored_links, ctx->d_Dmin, ctx->d_rowlist,
+                      ctx->d_scr_tmp + 4, reinterpret_cast<unsigned*>(ctx->d_scr_tmp), ex);
+    CK(hipGetLastError());
+    std::vector<uint32_t> masks((size_t)S * nhid * 8);
+    CK(hipMemcpyAsync(masks.data(), ctx->d_exMask, masks.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    std::vector<int32_t> order((size_t)nhid * Wd);
+    std::vector<int> count(Wd);
+    for (int L = 0; L < nhid; ++L) {
+        std::fill(count.begin(), count.end(), 0);
+        for (int e = 0; e < S; ++e) {
+            const uint32_t* mr = &masks[((size_t)e * nhid + L) * 8];
+            for (int u = 0; u < Wd; ++u) {
+                // level 0: ballot of component u & 3 over the lanes u >> 2; later levels: one ballot half per 32 columns (mlp_device.h)
+                const uint32_t bit = L == 0 ? (mr[(u & 3) * 2 + (u >> 7)] >> ((u >> 2) & 31)) & 1u : (mr[u >> 5] >> (u & 31)) & 1u;
+                count[u] += (int)bit;
+            }
+        }
+        int32_t* ord = &order[(size_t)L * Wd];
+        for (int u = 0; u < Wd; ++u) ord[u] = u;
+        std::stable_sort(ord, ord + Wd, [&](int a1, int a2) { return count[a1] > count[a2]; });
+        ctx->scr_never_fired[L] = (int)std::count(count.begin(), count.end(), 0);
+    }
+    MlpPacks pk;
+    pk.nhh = m.nhh; pk.C = m.C; pk.d = m.d; pk.act = m.act; pk.skip_mask = m.skip_mask;
+    pk.host_W = std::move(ctx->scr_W); pk.host_b = std::move(ctx->scr_b); pk.out_dims = ctx->scr_out_dims;
+    build_screen_pack(pk, order.data());
+    ctx->scr_W = std::move(pk.host_W); ctx->scr_b = std::move(pk.host_b);
+    // the stream is idle: the pack is replaced in place
+    CK(hipMemcpy(const_cast<void*>(ctx->screen.Wh), pk.wh.data(), pk.wh.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(const_cast<float*>(ctx->screen.bias), pk.sbias.data(), pk.sbias.size() * 4, hipMemcpyHostToDevice));
+    ctx->scr_reorders++;
+    return OMDS_OK;
+}
+
 static int screened_verdict(omds_ctx* ctx, StepArgs& a, bool tail) {
     const int N = ctx->cfg.n_traj, H = ctx->cfg.horizon;
     const float* hv = ctx->h_verdict;
@@ -1413,6 +1510,7 @@ static int screened_verdict(omds_ctx* ctx, StepArgs& a, bool tail) {
         // network is less accurate widen it gradually instead of tripping the fallback
         if (!noguard && 4.f * worst > ctx->screen_eps) ctx->screen_eps = 4.f * worst;
         ctx->screen_consec = 0;
+        if (ctx->scr_reorder_pending) return screen_reorder(ctx);
         return OMDS_OK;
     }
     // the bound lost its margin on live data (or the list outgrew its buffers): this propagate is redone in fp32 and the bound
@@ -1873,6 +1971,14 @@ int omds_screen_sweep_stats(omds_ctx* ctx, int32_t* every, int64_t* sweeps, floa
     if (every) *every = ctx->sweep_every;
     if (sweeps) *sweeps = ctx->screen_sweeps;
     if (sweep_max_err) *sweep_max_err = ctx->screen_sweep_err_seen;
+    return OMDS_OK;
+}
+int omds_screen_order_stats(omds_ctx* ctx, int64_t* reorders, int32_t* never_fired, int n_levels) {
+    if (!ctx) return OMDS_ERR_INVALID_ARG;
+    REQUIRE(n_levels >= 0 && n_levels <= OMDS_MAX_HIDDEN + 1, OMDS_ERR_INVALID_ARG, "omds_screen_order_stats: 0 <= n_levels <= 9");
+    if (reorders) *reorders = ctx->scr_reorders;
+    if (never_fired)
+        for (int L = 0; L < n_levels; ++L) never_fired[L] = ctx->scr_never_fired[L];
     return OMDS_OK;
 }
 int omds_screen_fallback_stats(omds_ctx* ctx, int64_t* by_error, int64_t* by_slack, int64_t* by_overflow, int64_t* suspensions) {

@@ -33,6 +33,10 @@
 //     rollout and per obstacle (four 16-byte loads per lane and tile; reading the separable fp32 halves Apre[t] + Bpre[o]
 //     like k_pass1 does cost 36 % of the kernel, their fp16 copies still 25 %), W1 is one more slice of the ring.
 //   * persistent workgroups (one per CU) loop over their tiles: the ring never drains, no refill gap between tiles.
+//   * ReLU networks: a k-chunk (16 hidden units) whose activations are zero for all 32 pairs of the wave adds nothing to any
+//     output, so its MFMAs are not issued (a ballot per tested chunk and layer, a scalar branch per MFMA of chunks 8-15).  The
+//     host orders the units of this pack by how often they fire (capi.hip: screen_reorder), which puts the units a trained
+//     network never uses -- 300 of the shipped one's 1024 -- into whole chunks: a quarter of the MFMAs go.
 #include <algorithm>
 #include <cstdio>
 #include <vector>
@@ -67,6 +71,10 @@ constexpr int SC_RING = OMDS_SC_RING;         // ring slots of 16 KB (a power of
 constexpr int SC_DIST = OMDS_SC_DIST;         // slices in flight ahead of the one being multiplied (<= RING - 1)
 constexpr int SC_PW = 16 / SC_WAVES;          // LDS-DMA pieces (1 KiB fragments) per wave and slice
 constexpr int SC_MAX_TILES = 20;              // tiles per workgroup whose results fit the LDS next to the ring
+#ifndef OMDS_SC_TEST0
+#define OMDS_SC_TEST0 8
+#endif
+constexpr int SC_TEST0 = OMDS_SC_TEST0;       // first k-chunk whose activations are tested for "all zero" before its MFMAs (ReLU networks)
 
 struct ScreenArgs {
     const _Float16* Wh;      // [nhh*8 + 2 slices][16 fragments][64 lane][8 halfs], fragment order (packed by omds_set_mlp)
@@ -488,6 +496,27 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
             if constexpr (SKIP) { sk[rb][0] = __builtin_bit_cast(h8, skn[rb][0]); sk[rb][1] = __builtin_bit_cast(h8, skn[rb][1]); }
         }
         h8 act[SC_RB][16];
+        // ReLU networks: bit cc = some pair of this wave has a non-zero activation in k-chunk cc of the layer about to be consumed.
+        // A chunk whose 16 units are zero for all 32 pairs contributes exactly nothing to any output: its MFMAs are not issued.
+        // (The host orders the hidden units of the screening pack by how often they fire, so that the units a trained network
+        //  never uses -- a third of the shipped one's -- fill whole chunks: omds_internal.h, screen reorder.)
+        unsigned alive = 0xffffu;
+        auto find_alive = [&]() {
+            if constexpr (ACT == OMDS_ACT_RELU && !SKIP) {
+                unsigned mk = (1u << SC_TEST0) - 1u;   // the first chunks hold the units that fire most: multiplied without a test
+#pragma unroll
+                for (int cc = SC_TEST0; cc < 16; ++cc) {
+                    unsigned nz = 0;
+#pragma unroll
+                    for (int rb = 0; rb < SC_RB; ++rb) {
+                        const u4 v = __builtin_bit_cast(u4, act[rb][cc]);
+                        nz |= v.x | v.y | v.z | v.w;
+                    }
+                    mk |= (__builtin_amdgcn_ballot_w64(nz != 0u) != 0ull ? 1u : 0u) << cc;
+                }
+                alive = mk;
+            }
+        };
         auto concat = [&](int level) {   // wave-uniform test; the OR touches 8 registers
             if constexpr (SKIP) {
                 if ((a.skip_mask >> level) & 1u) {
@@ -540,6 +569,7 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
                 to_act(pb[rb], act[rb][14], act[rb][15]);
             }
             concat(0);
+            find_alive();
         }
         SC_TL(1);
         // ---- steps 1 .. S-1: hidden->hidden layers and the last layer
@@ -564,7 +594,7 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (g == 1) sync_and_issue(s);
-                const AGroup pre = (g < 3) ? read_group(sl, g + 1) : read_group(sl_next, 0);
+                const AGroup pre = (g < 3) ? read_group(sl, g + 1) : read_group(sl_next, 0);   // (reading only the fragments that will be multiplied: 96 -> 103 us)
                 if (g == 2 && !last) acc_next = (s + 1 == S - 1) ? read_bias(NHH + 1, 0) : read_bias(((s) >> 3) + 1, s & 7);
                 if (s == S - 2 && g == 2) {   // the next tile's inputs, fetched under the last two steps of this one
 #pragma unroll
@@ -576,10 +606,13 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
+                    if (4 * g + i < SC_TEST0 || ((alive >> (4 * g + i)) & 1u)) {
 #pragma unroll
-                    for (int rb = 0; rb < SC_RB; ++rb)
-                        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[i], act[rb][4 * g + i], acc[rb], 0, 0, 0);
+                        for (int rb = 0; rb < SC_RB; ++rb)
+                            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.f[i], act[rb][4 * g + i], acc[rb], 0, 0, 0);
+                    }
+                }
                 // issue order inside the group: one fragment read of the NEXT group ahead of each fragment's MFMAs (the
                 // group's MFMAs = 128+ cycles of lead for the LDS latency; group 2 also carries the four bias reads of the
                 // next step); everything else (the previous step's epilogue VALU) fills in behind
@@ -607,7 +640,7 @@ __global__ __launch_bounds__(SC_NT, SC_WAVES == 4 ? 1 : 2) void k_screen(ScreenA
                         for (int cc = 0; cc < 16; ++cc) act[rb][cc] = nxt[rb][cc];
                     }
                 }
-                if (fb == 7) concat(((s - 1) >> 3) + 1);
+                if (fb == 7) { concat(((s - 1) >> 3) + 1); find_alive(); }
             } else {
                 // last layer: the links sit on the A rows (rows >= C are zero); min over the valid, un-ignored links
 #pragma unroll

@@ -52,6 +52,7 @@ class Engine:
         Wp = (L.F32P * nl)(*[L.fptr(w) for w in Ws])
         bp = (L.F32P * nl)(*[L.fptr(b) for b in bs])
         self.C = int(outs[-1])
+        self.n_hidden_levels = nl - 1
         self.d = int(ins[0]) // 3                       # raw network inputs: n + 3, or n + 2 for the toy networks
         if out_div is None:
             out_div = 100.0 if self.C == 9 else 1.0     # MPPI.py:236-237
@@ -369,7 +370,11 @@ class Engine:
         self._ck(self.lib.omds_screen_sweep_stats(self.h, C.byref(sw_every), C.byref(sw_n), C.byref(sw_err)))
         fe, fs, fo, ns = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         self._ck(self.lib.omds_screen_fallback_stats(self.h, C.byref(fe), C.byref(fs), C.byref(fo), C.byref(ns)))
-        return dict(fallbacks_by_error=fe.value, fallbacks_by_slack=fs.value, fallbacks_by_overflow=fo.value, suspensions=ns.value,
+        nre = C.c_int64()
+        never = np.zeros(9, np.int32)
+        self._ck(self.lib.omds_screen_order_stats(self.h, C.byref(nre), L.iptr(never), 9))
+        return dict(unit_reorders=nre.value, units_never_fired=[int(v) for v in never[:max(1, getattr(self, "n_hidden_levels", 9))]],
+                    fallbacks_by_error=fe.value, fallbacks_by_slack=fs.value, fallbacks_by_overflow=fo.value, suspensions=ns.value,
                     active=bool(act.value), eps=eps.value, max_err_seen=err.value, candidates_per_rollout_step=cand.value,
                     fallbacks=fb.value, audit_one_in=one_in.value, audit_rows_per_rollout_step=arows.value,
                     audit_max_err=aerr.value, suspended=bool(susp.value), calibrations=ncal.value,

@@ -393,3 +393,66 @@ def test_every_tile_shape_computes_the_same_bits(kind, n, k, N):
         for it in range(2):
             for key in KEYS:
                 assert np.array_equal(ref[it][key], got[it][key], equal_nan=True), (kind, k, name, it, key, float(np.nanmax(np.abs(ref[it][key] - got[it][key]))))
+
+
+@pytest.mark.parametrize("kind", ["franka", "planar7_128"])
+def test_unit_reorder_changes_no_result(kind):
+    """Behind a calibration the hidden units of the fp16 pack are sorted by how often they fire (omds_screen_order_stats) so that
+    k_screen's zero test finds whole k-chunks dead.  The order is a property of the SCREENING pack only: the screening values stay
+    inside the bound, and every number a propagate returns is the all-fp32 step's -- before the reorder (first propagate), after it,
+    and after a second calibration has reordered again.  The 128-wide network is zero-padded to 256: half of its chunks are dead in
+    any order, and none of its padded units may ever count as having fired."""
+    from optimalmodulationds_amd import scenes
+    from optimalmodulationds_amd.engine import Engine
+    m = orc.Mlp.from_npz(weights_path(kind))
+    N, H = 256, 6
+    if kind == "franka":
+        obs, q0, qf, dst_thr, dt, ign = scenes.shelf_scene(), scenes.FRANKA_Q0, scenes.FRANKA_QF, 0.01, 0.5, 0b111
+    else:
+        obs = np.tile(scenes.planar7_scene(), (40, 1)).astype(np.float32)      # enough pairs for the screened step (N * O >= 65536)
+        obs[:, :2] += np.random.RandomState(4).uniform(-3, 3, (obs.shape[0], 2)).astype(np.float32)
+        q0 = np.zeros(7, np.float32); q0[0] = np.pi / 2
+        qf = np.zeros(7, np.float32); qf[0] = -np.pi / 2
+        dst_thr, dt, ign = 0.25, 0.3, 0
+
+    def ctx(mode):
+        e = Engine(7, N, H, 5, max_obs=max(64, obs.shape[0]))
+        e.set_mlp(m.W, m.b)
+        e.set_obstacles(obs)
+        e.params.dt, e.params.dst_thr, e.params.ignored_links = dt, dst_thr, ign
+        e.push_params()
+        e.set_ds(qf)
+        e.set_screening(mode)
+        return e
+    a, b = ctx(1), ctx(0)
+    rng = np.random.RandomState(7)
+    q = np.asarray(q0, np.float32).copy()
+    nre = []
+    for it in range(5):
+        if it == 3:
+            a.set_screening(1, -1.0)                     # discard the calibration: the next propagate calibrates and reorders again
+        for e in (a, b):
+            e.sample_policy(None, None, None, 0, 0, 0, 0, seed=100 + it)
+            e.propagate(q)
+        ra, rb = a.get_rollouts(), b.get_rollouts()
+        for key in KEYS:
+            assert np.array_equal(ra[key], rb[key]), (it, key)
+        st = a.screen_stats()
+        assert st["active"] and (st["fallbacks"] == 0 or kind != "franka"), st
+        nre.append(st["unit_reorders"])
+        q = (q + 0.05 * (np.asarray(qf) - q) + 0.02 * rng.standard_normal(7)).astype(np.float32)
+    assert nre == [1, 1, 1, 2, 2], nre                   # one reorder behind each calibration's first accepted propagate
+    st = a.screen_stats()
+    never = st["units_never_fired"]
+    assert len(never) == len(m.W) - 1
+    if kind == "planar7_128":
+        assert all(v >= 128 for v in never), never       # the zero padding of a 128-wide layer never fires
+    else:
+        assert sum(never) >= 150, never                  # the shipped network: a third of its hidden units are silent on this scene
+    # the reordered pack still computes the screening function: values within the bound of the fp32 matrix
+    qq = (np.asarray(q0) + (np.asarray(qf) - np.asarray(q0)) * rng.rand(128, 1) + 0.3 * rng.standard_normal((128, 7))).astype(np.float32)
+    _, _, ref, _ = b.dist_grad(qq, want_mindist=True)
+    apx = a.screen_mindist(qq)
+    assert np.abs(apx - ref).max() <= st["eps"], (np.abs(apx - ref).max(), st["eps"])
+    assert b.screen_stats()["unit_reorders"] == 0
+    a.close(); b.close()
