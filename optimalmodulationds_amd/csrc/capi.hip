@@ -1095,6 +1095,89 @@ static bool screen_wanted(omds_ctx* ctx) {
     return (long long)ctx->cfg.n_traj * ctx->n_obs >= 64LL * 1024 && ctx->n_obs >= 4 * ctx->cfg.n_closest;
 }
 
+// The screening pack's unit order from what the network does on the calibration batch.  k_exact (the fp32 tile code, mode 1) is run
+// once on a uniform pseudo-random sample of the (state, obstacle) pairs of the B calibration states (their layer-1 halves are in
+// d_Apre) and leaves their ReLU masks
+// (ExactOut::mask, [entries][hidden levels][8 words]); per hidden level the units are sorted by how many of the sampled 32-pair blocks
+// they fired in (ties by index), the pack is built again in that order and copied over the old one.  (The candidates' own masks would be
+// there for free, but they are the NEAREST obstacles only: ordered by them, 17 % of the k-chunks of the shipped network are dead for a
+// wave; ordered by a uniform sample, 25 %.)  Any order computes the same screening function up to the rounding of the fp32
+// accumulation; what the order buys is that k_screen's zero test finds whole 16-unit chunks dead.  The fp32 kernels do not use this
+// pack: no returned number changes.
+// Called twice per calibration: by the calibration itself on its batch of states (B of them, layer-1 halves in d_Apre) -- so that the
+// bound is measured on a sorted pack and the first propagate already runs on one -- and behind the first propagate that is accepted
+// afterwards on the states its rollouts ended in (from_rollouts: B = n_traj), which is where the next rollouts will be: the
+// calibration batch is deliberately broader than the rollouts, and fewer units are silent on it (3 / 41 / 92 / 120 of the shipped
+// network's 256 per layer against 27 / 42 / 93 / 120).
+static int screen_reorder(omds_ctx* ctx, int B, bool from_rollouts) {
+    static const int enabled = OMDS_EXP_ENV("OMDS_SCREEN_REORDER", 1);   // experiment builds: 0 keeps the natural order, 2 = the calibration's order only (A/B runs)
+    const MlpDev& m = ctx->mlp;
+    if (from_rollouts) ctx->scr_reorder_pending = false;
+    if (!enabled || (enabled == 2 && from_rollouts) || m.act != OMDS_ACT_RELU || m.skip_mask || ctx->scr_W.empty() || !ctx->d_exMask) return OMDS_OK;
+    if (from_rollouts)   // layer-1 halves of the last states the propagate reached (d_Apre is rebuilt at the start of every propagate)
+        omds_launch_rollout_layer1(ctx->stream, m, ctx->d_trajT + (size_t)(ctx->cfg.horizon - 1) * ctx->cfg.n_dof * ctx->cfg.n_traj, ctx->cfg.n_traj, B, ctx->d_Apre);
+    const int nhid = m.nhh + 1, Wd = OMDS_WIDTH, O = ctx->n_obs;
+    const long long pairs = (long long)B * O;
+    const int S = (int)std::min<long long>({8192, (long long)ctx->ex_cap, pairs});
+    if (S < 64) return OMDS_OK;
+    if (!ctx->d_scr_tmp) CK(hipMalloc(&ctx->d_scr_tmp, 8 * sizeof(int)));
+    std::vector<int32_t> list(S + 1);
+    uint64_t x = 0x9E3779B97F4A7C15ull * (uint64_t)(ctx->screen_recals + 1);
+    // the sample is made of BLOCKS of 32 consecutive pairs (one state, 32 consecutive obstacles): what a wave of k_screen multiplies
+    // together, and so what a chunk has to be silent for
+    for (int j = 0; j < S; j += 32) {   // splitmix64: a fixed sequence per calibration
+        x += 0x9E3779B97F4A7C15ull;
+        uint64_t z = x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        const long long p0 = (long long)(z % (uint64_t)std::max<long long>(pairs - 31, 1));
+        for (int i = 0; i < 32 && j + i < S; ++i) list[j + i] = (int32_t)std::min<long long>(p0 + i, pairs - 1);
+    }
+    list[S] = S;
+    // pageable sources: the copies have read them when the calls return
+    CK(hipMemcpyAsync(ctx->d_rowlist, list.data(), (size_t)S * 4, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipMemsetAsync(ctx->d_scr_tmp, 0, 8 * sizeof(int), ctx->stream));
+    CK(hipMemcpyAsync(ctx->d_scr_tmp + 4, &list[S], 4, hipMemcpyHostToDevice, ctx->stream));
+    ExactOut ex{ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->ex_cap};
+    omds_launch_exact(ctx->stream, m, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin, ctx->d_rowlist,
+                      ctx->d_scr_tmp + 4, reinterpret_cast<unsigned*>(ctx->d_scr_tmp), ex);
+    CK(hipGetLastError());
+    std::vector<uint32_t> masks((size_t)S * nhid * 8);
+    CK(hipMemcpyAsync(masks.data(), ctx->d_exMask, masks.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    std::vector<int32_t> order((size_t)nhid * Wd);
+    std::vector<int> count(Wd);
+    for (int L = 0; L < nhid; ++L) {
+        std::fill(count.begin(), count.end(), 0);
+        for (int e0 = 0; e0 < S; e0 += 32) {   // a unit counts once per block it fires in
+            uint32_t any[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int e = e0; e < std::min(e0 + 32, S); ++e)
+                for (int wi = 0; wi < 8; ++wi) any[wi] |= masks[((size_t)e * nhid + L) * 8 + wi];
+            const uint32_t* mr = any;
+            for (int wi = 0; wi < 8; ++wi)
+                for (uint32_t w = mr[wi]; w; w &= w - 1) {
+                    const int bit = __builtin_ctz(w);
+                    // level 0: word 2c + h holds the ballot of component c over lanes 32h .. 32h + 31, lane l <-> unit 4l + c;
+                    // later levels: word wi holds units 32 wi .. 32 wi + 31 (mlp_device.h)
+                    count[L == 0 ? 4 * (32 * (wi & 1) + bit) + (wi >> 1) : 32 * wi + bit]++;
+                }
+        }
+        int32_t* ord = &order[(size_t)L * Wd];
+        for (int u = 0; u < Wd; ++u) ord[u] = u;
+        std::stable_sort(ord, ord + Wd, [&](int a1, int a2) { return count[a1] > count[a2]; });
+        ctx->scr_never_fired[L] = (int)std::count(count.begin(), count.end(), 0);
+    }
+    MlpPacks pk;
+    pk.nhh = m.nhh; pk.C = m.C; pk.d = m.d; pk.act = m.act; pk.skip_mask = m.skip_mask;
+    pk.host_W = std::move(ctx->scr_W); pk.host_b = std::move(ctx->scr_b); pk.out_dims = ctx->scr_out_dims;
+    build_screen_pack(pk, order.data());
+    ctx->scr_W = std::move(pk.host_W); ctx->scr_b = std::move(pk.host_b);
+    // the stream is idle (synchronised above, nothing enqueued since): the pack is replaced in place
+    CK(hipMemcpy(const_cast<void*>(ctx->screen.Wh), pk.wh.data(), pk.wh.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(const_cast<float*>(ctx->screen.bias), pk.sbias.data(), pk.sbias.size() * 4, hipMemcpyHostToDevice));
+    ctx->scr_reorders++;
+    return OMDS_OK;
+}
+
 // eps = 6 x the largest |screening value - fp32 value| over a calibration batch of up to 1024 states x all obstacles
 // (~3e5 pairs: about what one propagate evaluates per step), against the CURRENT obstacle set: half of the states uniform
 // inside the joint limits (omds_set_cost) or [-pi, pi], half drawn from the rollouts of the last propagate -- where the next
@@ -1106,8 +1189,6 @@ static bool screen_wanted(omds_ctx* ctx) {
 static int calibrate_screen(omds_ctx* ctx, const float* q_center) {
     ctx->screen_cal = true;
     ctx->obs_cal = ctx->obs_now;
-    ctx->scr_reorder_pending = true;   // the unit order follows the scene too (screen_reorder, behind the next accepted propagate)
-    if (ctx->screen_eps_fixed && ctx->screen_eps > 0.f) return OMDS_OK;   // set by the caller (omds_set_screening)
     const int n = ctx->cfg.n_dof, O = ctx->n_obs;
     const int B = std::min(ctx->cfg.n_traj, 1024);
     float lo[OMDS_MAX_DOF], hi[OMDS_MAX_DOF];
@@ -1118,6 +1199,11 @@ static int calibrate_screen(omds_ctx* ctx, const float* q_center) {
     omds_launch_calib_states(ctx->stream, ctx->d_qstage, B, n, lo, hi, q_center, ctx->have_rollouts ? ctx->d_trajT : nullptr,
                              ctx->cfg.n_traj, ctx->cfg.horizon, 0x9E3779B9u * (unsigned)(ctx->screen_recals + 1));
     omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Apre, ctx->d_FqH, ctx->cfg.n_traj);
+    // first the unit order of the screening pack (it follows the scene and the states too), then the bound of THAT pack
+    int rc;
+    if ((rc = screen_reorder(ctx, B, false))) return rc;
+    ctx->scr_reorder_pending = true;
+    if (ctx->screen_eps_fixed && ctx->screen_eps > 0.f) return OMDS_OK;   // the bound was set by the caller (omds_set_screening)
     float* apx = ctx->d_stage;   // [B][O] screening values (stage_bytes >= n_traj * max_obs * 4)
     omds_launch_pass1(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
     omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_FqH, ctx->cfg.n_traj, ctx->d_FpH, ctx->cfg.max_obs, ctx->d_radius, O, B, ctx->prm.ignored_links, apx);
@@ -1421,75 +1507,6 @@ int omds_propagate(omds_ctx* ctx, const float* q_cur, int per_rollout) {
 //   serr  = (every sweep_every-th propagate) max |Da - D| over ALL pairs of the swept horizon step(s).
 // Accepted only while the errors keep a 2x margin to eps and no slack check failed; otherwise the propagate is redone with
 // the fp32 pass 1 -- its results are then the fp32 ones by construction -- before omds_propagate returns.
-// The screening pack's unit order from what the network does on live data.  k_exact (the fp32 tile code, mode 1) is run once on a
-// uniform pseudo-random sample of the (rollout, obstacle) pairs of the propagate's last states and leaves their ReLU masks
-// (ExactOut::mask, [entries][hidden levels][8 words]); per hidden level the units are sorted by how many of the sampled rows they
-// fired in (ties by index), the pack is built again in that order and copied over the old one.  (The candidates' own masks would be
-// there for free, but they are the NEAREST obstacles only: ordered by them, 17 % of the k-chunks of the shipped network are dead for a
-// wave; ordered by a uniform sample, 25 %.)  Any order computes the same screening function up to the rounding of the fp32
-// accumulation; what the order buys is that k_screen's zero test finds whole 16-unit chunks dead.  The fp32 kernels do not use this
-// pack: no returned number changes.
-static int screen_reorder(omds_ctx* ctx) {
-    ctx->scr_reorder_pending = false;
-    static const int enabled = OMDS_EXP_ENV("OMDS_SCREEN_REORDER", 1);   // experiment builds: 0 keeps the natural order (A/B runs)
-    const MlpDev& m = ctx->mlp;
-    if (!enabled || m.act != OMDS_ACT_RELU || m.skip_mask || ctx->scr_W.empty() || !ctx->d_exMask) return OMDS_OK;
-    const int nhid = m.nhh + 1, Wd = OMDS_WIDTH, N = ctx->cfg.n_traj, H = ctx->cfg.horizon, n = ctx->cfg.n_dof, O = ctx->n_obs;
-    const long long pairs = (long long)N * O;
-    const int S = (int)std::min<long long>({8192, (long long)ctx->ex_cap, pairs});
-    if (S < 64) return OMDS_OK;
-    if (!ctx->d_scr_tmp) CK(hipMalloc(&ctx->d_scr_tmp, 8 * sizeof(int)));
-    std::vector<int32_t> list(S + 1);
-    uint64_t x = 0x9E3779B97F4A7C15ull * (uint64_t)(ctx->screen_recals + 1);
-    for (int j = 0; j < S; ++j) {   // splitmix64: a fixed sequence per calibration
-        x += 0x9E3779B97F4A7C15ull;
-        uint64_t z = x;
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
-        list[j] = (int32_t)(z % (uint64_t)pairs);
-    }
-    list[S] = S;
-    // pageable sources: the copies have read them when the calls return
-    CK(hipMemcpyAsync(ctx->d_rowlist, list.data(), (size_t)S * 4, hipMemcpyHostToDevice, ctx->stream));
-    CK(hipMemsetAsync(ctx->d_scr_tmp, 0, 8 * sizeof(int), ctx->stream));
-    CK(hipMemcpyAsync(ctx->d_scr_tmp + 4, &list[S], 4, hipMemcpyHostToDevice, ctx->stream));
-    // layer-1 halves of the last states the propagate reached (d_Apre is rebuilt at the start of every propagate)
-    omds_launch_rollout_layer1(ctx->stream, m, ctx->d_trajT + (size_t)(H - 1) * n * N, N, N, ctx->d_Apre);
-    ExactOut ex{ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->ex_cap};
-    omds_launch_exact(ctx->stream, m, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, O, N, ctx->prm.ignored_links, ctx->d_Dmin, ctx->d_rowlist,
-                      ctx->d_scr_tmp + 4, reinterpret_cast<unsigned*>(ctx->d_scr_tmp), ex);
-    CK(hipGetLastError());
-    std::vector<uint32_t> masks((size_t)S * nhid * 8);
-    CK(hipMemcpyAsync(masks.data(), ctx->d_exMask, masks.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
-    std::vector<int32_t> order((size_t)nhid * Wd);
-    std::vector<int> count(Wd);
-    for (int L = 0; L < nhid; ++L) {
-        std::fill(count.begin(), count.end(), 0);
-        for (int e = 0; e < S; ++e) {
-            const uint32_t* mr = &masks[((size_t)e * nhid + L) * 8];
-            for (int u = 0; u < Wd; ++u) {
-                // level 0: ballot of component u & 3 over the lanes u >> 2; later levels: one ballot half per 32 columns (mlp_device.h)
-                const uint32_t bit = L == 0 ? (mr[(u & 3) * 2 + (u >> 7)] >> ((u >> 2) & 31)) & 1u : (mr[u >> 5] >> (u & 31)) & 1u;
-                count[u] += (int)bit;
-            }
-        }
-        int32_t* ord = &order[(size_t)L * Wd];
-        for (int u = 0; u < Wd; ++u) ord[u] = u;
-        std::stable_sort(ord, ord + Wd, [&](int a1, int a2) { return count[a1] > count[a2]; });
-        ctx->scr_never_fired[L] = (int)std::count(count.begin(), count.end(), 0);
-    }
-    MlpPacks pk;
-    pk.nhh = m.nhh; pk.C = m.C; pk.d = m.d; pk.act = m.act; pk.skip_mask = m.skip_mask;
-    pk.host_W = std::move(ctx->scr_W); pk.host_b = std::move(ctx->scr_b); pk.out_dims = ctx->scr_out_dims;
-    build_screen_pack(pk, order.data());
-    ctx->scr_W = std::move(pk.host_W); ctx->scr_b = std::move(pk.host_b);
-    // the stream is idle: the pack is replaced in place
-    CK(hipMemcpy(const_cast<void*>(ctx->screen.Wh), pk.wh.data(), pk.wh.size() * 2, hipMemcpyHostToDevice));
-    CK(hipMemcpy(const_cast<float*>(ctx->screen.bias), pk.sbias.data(), pk.sbias.size() * 4, hipMemcpyHostToDevice));
-    ctx->scr_reorders++;
-    return OMDS_OK;
-}
-
 static int screened_verdict(omds_ctx* ctx, StepArgs& a, bool tail) {
     const int N = ctx->cfg.n_traj, H = ctx->cfg.horizon;
     const float* hv = ctx->h_verdict;
@@ -1510,7 +1527,7 @@ static int screened_verdict(omds_ctx* ctx, StepArgs& a, bool tail) {
         // network is less accurate widen it gradually instead of tripping the fallback
         if (!noguard && 4.f * worst > ctx->screen_eps) ctx->screen_eps = 4.f * worst;
         ctx->screen_consec = 0;
-        if (ctx->scr_reorder_pending) return screen_reorder(ctx);
+        if (ctx->scr_reorder_pending) return screen_reorder(ctx, N, true);   // the unit order once more, on the states the rollouts reached
         return OMDS_OK;
     }
     // the bound lost its margin on live data (or the list outgrew its buffers): this propagate is redone in fp32 and the bound

@@ -184,10 +184,10 @@ struct omds_ctx {
     long long screen_recals = 0;         // calibrations run since creation
     // Unit order of the screening pack (capi.hip: build_screen_pack / screen_reorder).  k_screen skips the k-chunks whose 16 units are
     // zero for all 32 pairs of a wave; which units fire depends on the trained weights (a third of the shipped network's never do),
-    // so after a calibration the hidden units are sorted by how often they fired among the candidate rows of one propagate.
+    // so every calibration first sorts the hidden units by how often they fire on a uniform sample of its batch's pairs.
     std::vector<std::vector<float>> scr_W, scr_b;   // the network, zero-padded to width 256 (host copy for building the pack again)
     std::vector<int32_t> scr_out_dims;
-    bool scr_reorder_pending = false;    // set by a calibration, cleared by the reorder behind the next accepted propagate
+    bool scr_reorder_pending = false;    // set by a calibration: the order is refined behind the next accepted propagate, on its rollouts' states
     long long scr_reorders = 0;
     int* d_scr_tmp = nullptr;            // [8] device words of screen_reorder: error words of its k_exact launch (unused), the list length
     int scr_never_fired[OMDS_MAX_HIDDEN + 1] = {0};   // per hidden level: units that fired in no row of the last reorder's sample
