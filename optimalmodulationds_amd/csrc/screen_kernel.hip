@@ -72,9 +72,13 @@ constexpr int SC_DIST = OMDS_SC_DIST;         // slices in flight ahead of the o
 constexpr int SC_PW = 16 / SC_WAVES;          // LDS-DMA pieces (1 KiB fragments) per wave and slice
 constexpr int SC_MAX_TILES = 20;              // tiles per workgroup whose results fit the LDS next to the ring
 #ifndef OMDS_SC_TEST0
-#define OMDS_SC_TEST0 8
+#define OMDS_SC_TEST0 10
 #endif
-constexpr int SC_TEST0 = OMDS_SC_TEST0;       // first k-chunk whose activations are tested for "all zero" before its MFMAs (ReLU networks)
+// first k-chunk whose activations are tested for "all zero" before its MFMAs (ReLU networks).  Measured on the shipped network
+// (tools/studies/screen_test0_sweep.sh, 1024 x 32 / 4096 x 32): 4: 100.0 / 365.5 us, 8: 98.0 / 357.7, 9: 96.7 / 351.2, 10: 96.1 / 349.5,
+// 11: 97.0 / 351.7, 12: 97.2 / 355.3 -- its silent units begin at chunk 9-13 depending on the layer; every test and branch in front of
+// them costs issue slots
+constexpr int SC_TEST0 = OMDS_SC_TEST0;
 
 struct ScreenArgs {
     const _Float16* Wh;      // [nhh*8 + 2 slices][16 fragments][64 lane][8 halfs], fragment order (packed by omds_set_mlp)
