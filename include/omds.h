@@ -345,7 +345,7 @@ OMDS_API int omds_screen_fallback_stats(omds_ctx* ctx, int64_t* by_error, int64_
  * for all 32 pairs of a wave -- exact: such a chunk adds nothing to any output.  Which units fire is a property of the trained
  * weights (of the shipped Franka network's 1024 hidden units, 300 fire for no pair of the shelf scene), so every calibration
  * sorts the hidden units of the fp16 pack by how often they fire on a uniform sample of 256 wave-sized blocks of (state, obstacle)
- * pairs (one k_exact launch, about 10 ms; once on its own batch, once more on the states the first accepted propagate reaches),
+ * pairs (one k_exact launch, 6-7 ms; once on its own batch, once more on the states the first accepted propagate reaches),
  * which puts the silent ones into whole chunks.  ReLU networks without skip
  * concatenations; the fp32 kernels do not use this pack, so no returned number depends on the order.
  * reorders: packs rebuilt since creation; never_fired [n_levels <= 9] (NULL = skip): per hidden level, units that fired in no
