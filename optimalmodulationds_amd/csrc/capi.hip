@@ -742,6 +742,15 @@ int omds_test_pack_mlp(int n_dof, int n_linear, const int32_t* in_dims, const in
     mix(pk.bh.data(), pk.bh.size() * 4); mix(pk.wl.data(), pk.wl.size() * 16); mix(pk.bl.data(), pk.bl.size() * 4);
     mix(pk.wlraw.data(), pk.wlraw.size() * 4); mix(pk.whraw.data(), pk.whraw.size() * 4); mix(pk.w1t.data(), pk.w1t.size() * 4);
     mix(pk.b1.data(), pk.b1.size() * 4); mix(pk.w1b.data(), pk.w1b.size() * 16);
+    // the screening pack once more in another unit order (what screen_reorder does behind a calibration): every hidden level reversed.
+    // A permuted pack holds the same multiset of weights per slice row set; its bytes go into the same checksum
+    if (!pk.host_W.empty() && pk.skip_mask == 0) {
+        std::vector<int32_t> order((size_t)(pk.nhh + 1) * OMDS_WIDTH);
+        for (int L = 0; L <= pk.nhh; ++L)
+            for (int q = 0; q < OMDS_WIDTH; ++q) order[(size_t)L * OMDS_WIDTH + q] = OMDS_WIDTH - 1 - q;
+        build_screen_pack(pk, order.data());
+        mix(pk.wh.data(), pk.wh.size() * 2); mix(pk.sbias.data(), pk.sbias.size() * 4);
+    }
     if (checksum) *checksum = h;
     if (bytes) *bytes = total;
     return OMDS_OK;
