@@ -554,6 +554,7 @@ static int set_mlp_wide(omds_ctx* ctx, int n_linear, const int32_t* in_dims, con
     for (void* p : ctx->mlp_allocs) (void)hipFree(p);
     ctx->mlp_allocs.clear();
     ctx->have_mlp = false;
+    ctx->wide = WideNet{};   // a previous wide network's buffers were in mlp_allocs
     ctx->screen = ScreenDev{};
     ctx->screen_ok = false;
     ctx->screen_cal = false;
@@ -616,7 +617,8 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
         for (int i = 0; i + 1 < n_linear; ++i) is_wide = is_wide || out_dims[i] > OMDS_WIDTH;
         if (is_wide) return set_mlp_wide(ctx, n_linear, in_dims, out_dims, W, b, act, out_div, n_skips);
     }
-    ctx->wide = WideNet{};
+    // everything that can reject the call happens before the context is touched: a rejected network (bad act, bad dims, null W)
+    // leaves the previous one -- fused or wide -- installed and usable
     MlpPacks pk;
     int rc;
     if ((rc = build_mlp_packs(n, n_linear, in_dims, out_dims, W, b, act, out_div, n_skips, skip_after, pk, ctx->err))) return rc;
@@ -627,6 +629,7 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
     for (void* p : ctx->mlp_allocs) (void)hipFree(p);
     ctx->mlp_allocs.clear();
     ctx->have_mlp = false;
+    ctx->wide = WideNet{};   // its buffers were in mlp_allocs
     MlpDev m{};
     m.nhh = pk.nhh;
     m.C = pk.C;
@@ -1383,9 +1386,13 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
         // mode, of every step (omds_set_screening_sweep).  The audit sample sees every step thinly, a sweep sees a step whole.
         ctx->sweep_now = false;
         ctx->sweep_steps_now = 0;
-        if (screen && ctx->sweep_every > 0 && (ctx->screen_propagates++ % ctx->sweep_every) == 0) {
+        // ... and so does the first propagate on a screening pack whose unit order changed after the bound was measured
+        // (screened_verdict: the re-sort on the rollouts' own states): the bound is checked on every pair of a step of the new pack
+        // before anything else relies on it
+        if (screen && ctx->sweep_every > 0 && ((ctx->screen_propagates++ % ctx->sweep_every) == 0 || ctx->sweep_force_next)) {
             if ((rc = prepare_sweep(ctx))) return rc;
             ctx->sweep_now = true;
+            ctx->sweep_force_next = false;
         }
         omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, apre0, screen ? ctx->d_FqH : nullptr, N);
         for (int i = 1; i <= H; ++i) {
@@ -1536,7 +1543,14 @@ static int screened_verdict(omds_ctx* ctx, StepArgs& a, bool tail) {
         // network is less accurate widen it gradually instead of tripping the fallback
         if (!noguard && 4.f * worst > ctx->screen_eps) ctx->screen_eps = 4.f * worst;
         ctx->screen_consec = 0;
-        if (ctx->scr_reorder_pending) return screen_reorder(ctx, N, true);   // the unit order once more, on the states the rollouts reached
+        if (ctx->scr_reorder_pending) {   // the unit order once more, on the states the rollouts reached.  eps was measured on the
+            // calibration's order: the next propagate carries a sweep (all N x O pairs of a step of the NEW pack in fp32).  The results
+            // of this propagate are published already; d_Apre / d_Dmin / d_ex* are scratch between propagates (omds_internal.h)
+            const long long before = ctx->scr_reorders;
+            const int rrc = screen_reorder(ctx, N, true);
+            if (ctx->scr_reorders != before) ctx->sweep_force_next = true;
+            return rrc;
+        }
         return OMDS_OK;
     }
     // the bound lost its margin on live data (or the list outgrew its buffers): this propagate is redone in fp32 and the bound

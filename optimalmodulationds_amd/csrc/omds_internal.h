@@ -205,6 +205,7 @@ struct omds_ctx {
     size_t sweep_cap = 0;                // pairs the two buffers hold
     unsigned long long* d_sweep_hist = nullptr;   // [OMDS_SWEEP_HIST_WORDS] accumulated statistics of every sweep since creation / the last reset
     long long screen_propagates = 0;     // screened propagates since creation
+    bool sweep_force_next = false;       // the screening pack was re-sorted after its bound was measured: the next screened propagate carries a sweep
     long long screen_sweeps = 0;         // sweeps run since creation
     float screen_sweep_err_seen = 0.f;   // largest |Da - D| a sweep saw since the last calibration
     bool sweep_now = false;              // the propagate being finished carried a sweep (d_scerr[3] is valid)
@@ -255,8 +256,8 @@ struct omds_ctx {
     float* d_alphaT = nullptr;   // [Kmax][n][N]
     float* d_means = nullptr;    // [Kmax*(2n+1)] mu_c, sigma_c, alpha_c staging
     // network scratch
-    float* d_Apre = nullptr;     // [Nrows][256]
-    float* d_Dmin = nullptr;     // [N][max_obs]
+    float* d_Apre = nullptr;     // [Nrows][256]   (d_Apre, d_Dmin and d_ex* are SCRATCH between propagates: calibration and the
+    float* d_Dmin = nullptr;     // [N][max_obs]    screening pack's re-sort overwrite them after the results have been published)
     int32_t* d_idx = nullptr;    // [N][k]
     float* d_gradx = nullptr;    // [N*k][d]
     float* d_drow = nullptr;     // [N*k]

@@ -25,6 +25,7 @@ class Engine:
         self.K = 0
         self.n_obs = 0
         self.C = 0
+        self.config_version = 0      # bumped by every call that changes params / nominal DS / cost on the context (MPPI._push re-syncs on it)
 
     def close(self):
         if getattr(self, "h", None):
@@ -51,11 +52,9 @@ class Engine:
         nl = len(Ws)
         Wp = (L.F32P * nl)(*[L.fptr(w) for w in Ws])
         bp = (L.F32P * nl)(*[L.fptr(b) for b in bs])
-        self.C = int(outs[-1])
-        self.n_hidden_levels = nl - 1
-        self.d = int(ins[0]) // 3                       # raw network inputs: n + 3, or n + 2 for the toy networks
+        C_out = int(outs[-1])
         if out_div is None:
-            out_div = 100.0 if self.C == 9 else 1.0     # MPPI.py:236-237
+            out_div = 100.0 if C_out == 9 else 1.0      # MPPI.py:236-237
         a = 0 if act == "relu" else 1
         sk = np.asarray(list(skip_after), dtype=np.int32)
         if sk.size or (ins[1:] != outs[:-1]).any():   # the explicit form also validates every layer's input width
@@ -63,6 +62,10 @@ class Engine:
         else:
             dims = np.concatenate((ins[:1], outs)).astype(np.int32)
             self._ck(self.lib.omds_set_mlp(self.h, nl, L.iptr(dims), Wp, bp, a, float(out_div)))
+        # a rejected network leaves the previous one installed (capi.hip), so the wrapper's view changes only on success
+        self.C = C_out
+        self.n_hidden_levels = nl - 1
+        self.d = int(ins[0]) // 3                       # raw network inputs: n + 3, or n + 2 for the toy networks
 
     def set_obstacles(self, obs):
         """Any obstacle count: beyond ``max_obs`` the context grows its obstacle buffers (omds.h)."""
@@ -74,12 +77,14 @@ class Engine:
     def set_ds(self, q_goal):
         q = L.f32(q_goal).reshape(self.n)
         self._ck(self.lib.omds_set_ds(self.h, L.fptr(q)))
+        self.config_version += 1
 
     def set_ds_matrix(self, q_goal, A):
         """MPPI_toy's nominal DS: velocity = (q - q_goal) @ A (MPPI_toy.py:89)."""
         q = L.f32(q_goal).reshape(self.n)
         a = L.f32(A).reshape(self.n, self.n)
         self._ck(self.lib.omds_set_ds_matrix(self.h, L.fptr(q), L.fptr(a)))
+        self.config_version += 1
 
     def set_ds_seds(self, q_goal, mu_in, b, sigma_inv, A, prior, den, lin_thr=1e-2, seds_thr=1e-2):
         """SEDS nominal DS (SEDS.py): G components; mu_in/b [G,n], sigma_inv/A [G,n,n], prior/den [G] as SEDS.__init__ / GMR
@@ -91,14 +96,17 @@ class Engine:
         pr, dn = L.f32(prior).reshape(G), L.f32(den).reshape(G)
         self._ck(self.lib.omds_set_ds_seds(self.h, L.fptr(q), G, L.fptr(mu_in), L.fptr(b), L.fptr(si), L.fptr(a), L.fptr(pr), L.fptr(dn),
                                            float(lin_thr), float(seds_thr)))
+        self.config_version += 1
 
     def push_params(self):
         self._ck(self.lib.omds_set_params(self.h, C.byref(self.params)))
+        self.config_version += 1
 
     def set_cost(self, dh_params, q_min, q_max):
         dh = L.f32(dh_params).reshape(self.n + 1, 4)
         lo, hi = L.f32(q_min).reshape(self.n), L.f32(q_max).reshape(self.n)
         self._ck(self.lib.omds_set_cost(self.h, L.fptr(dh), L.fptr(lo), L.fptr(hi)))
+        self.config_version += 1
 
     # ---- policy samples -----------------------------------------------------------------------
     def set_policy_samples(self, mu, sigma, alpha):

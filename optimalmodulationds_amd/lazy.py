@@ -10,8 +10,13 @@ search and the cost run on the device-resident copies.  So:
 * anything else -- ``torch`` functions, arithmetic, comparisons, ``.numpy()``, ``.view()``, ``np.asarray`` ... -- materialises the
   whole tensor once (omds_get_rollouts) and behaves like the torch CPU tensor the reference would have returned.
 
+Writing into one (``x[i] = v``, ``x += 1``) and pickling it (``pickle``, ``torch.save``, ZMQ ``send_pyobj``) materialise it first; a
+written-to tensor no longer stands for the device copy (the candidate search then takes its host path).
+
 A ``LazyRollout`` belongs to the propagate that made it: reading one after the next ``propagate()`` raises (the reference rebinds
-fresh tensors every call, MPPI.py:86-91, so its callers never do that; ``.tensor()`` before the next call keeps a copy)."""
+fresh tensors every call, MPPI.py:86-91, so its callers never do that; ``.tensor()`` before the next call keeps a copy).  It is not a
+``torch.Tensor`` subclass: ``MPPI.propagate()`` only hands these out when asked to (``lazy_rollouts=True``); the default is the
+reference's plain tensors."""
 from __future__ import annotations
 
 import numpy as np
@@ -24,6 +29,7 @@ class LazyRollout:
     def __init__(self, owner, key, shape, generation):
         self._owner, self._key, self._shape, self._gen = owner, key, tuple(shape), generation
         self._full = None
+        self._dirty = False       # written into by the caller: no longer the device copy
 
     # ---- materialisation ---------------------------------------------------------------------------
     def _check(self):
@@ -80,6 +86,13 @@ class LazyRollout:
         out = out[0] if squeeze else out
         return out[rest if squeeze else (slice(None),) + tuple(rest)] if rest else out
 
+    def __setitem__(self, idx, value):
+        self._dirty = True
+        self.tensor()[idx] = value.tensor() if isinstance(value, LazyRollout) else value
+
+    def __reduce__(self):                 # pickle / torch.save / send_pyobj: the plain tensor travels
+        return (_identity, (self.tensor(),))
+
     def __array__(self, dtype=None, copy=None):
         a = self.tensor().numpy()
         return a.astype(dtype) if dtype is not None else a
@@ -106,6 +119,19 @@ class LazyRollout:
         return bool(self.tensor())
 
 
+def _identity(t):
+    return t
+
+
+def _inplace(name):
+    def f(self, other):
+        self._dirty = True
+        getattr(self.tensor(), name)(other.tensor() if isinstance(other, LazyRollout) else other)
+        return self
+    f.__name__ = name
+    return f
+
+
 def _delegate(name):
     def f(self, *a):
         return getattr(self.tensor(), name)(*[x.tensor() if isinstance(x, LazyRollout) else x for x in a])
@@ -116,6 +142,8 @@ def _delegate(name):
 for _n in ("add", "sub", "mul", "truediv", "floordiv", "pow", "matmul", "mod", "and", "or", "xor"):
     setattr(LazyRollout, f"__{_n}__", _delegate(f"__{_n}__"))
     setattr(LazyRollout, f"__r{_n}__", _delegate(f"__r{_n}__"))
+for _n in ("iadd", "isub", "imul", "itruediv"):
+    setattr(LazyRollout, f"__{_n}__", _inplace(f"__{_n}__"))
 for _n in ("lt", "le", "gt", "ge", "eq", "ne", "neg", "abs", "invert"):
     setattr(LazyRollout, f"__{_n}__", _delegate(f"__{_n}__"))
 LazyRollout.__hash__ = object.__hash__      # __eq__ is elementwise like a tensor's; identity hashing like a tensor's

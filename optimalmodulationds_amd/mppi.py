@@ -63,7 +63,7 @@ class _LazyBasis:
 
 class MPPI:
     def __init__(self, q0, qf, dh_params, obs, dt, dt_H, N_traj, DS_ARRAY, dh_a, nn_model, n_closest_obs,
-                 device=0, warmup=False, seed=1234, rollout_offset=0, max_obs=None):
+                 device=0, warmup=False, seed=1234, rollout_offset=0, max_obs=None, lazy_rollouts=False):
         self.tensor_args = {'device': 'cpu', 'dtype': torch.float32}
         self.q0 = torch.as_tensor(_np(q0))
         self.n_dof = self.q0.shape[0]
@@ -97,7 +97,12 @@ class MPPI:
         self.cur_cost = None
         self._cache = {}
         self._generation = 0          # propagate() calls so far (LazyRollout tensors belong to one of them)
+        # False (default): propagate() returns and binds torch CPU tensors like the reference (one fetch of all rollout tensors per
+        # call, 0.4 ms at 1024 x 32).  True: LazyRollout objects that stay on the GPU until read (lazy.py) -- for loops that, like
+        # the reference's planner, read a handful of rows per iteration and never keep a tensor across propagate() calls
+        self.lazy_rollouts = bool(lazy_rollouts)
         self._pushed = None           # what the device context last received (_push skips an unchanged set)
+        self._pushed_version = -1     # Engine.config_version after that push
         self._qdot_cache = {}         # get_qdot values of the current cost (filled by shift_policy_means)
         self.all_traj = torch.zeros(N_traj, dt_H, self.n_dof)
         self.closest_dist_all = 100 + torch.zeros(N_traj, dt_H)
@@ -138,26 +143,34 @@ class MPPI:
         for l in self.ignored_links:
             mask |= 1 << int(l)
         qf, dh, qmin, qmax = _np(self.qf), _np(self.dh_params), _np(self.Cost.q_min), _np(self.Cost.q_max)
-        sig = (float(self.dt), float(self.dst_thr), float(self.DS.lin_thr), float(self.Policy.p), mask, id(self.DS), qf.tobytes(),
+        # the nominal DS by VALUE (an id() can be reused by a new object, and a SEDS DS can be edited in place)
+        seds = self.DS.device_params() if hasattr(self.DS, "device_params") else None
+        ds_sig = (type(self.DS).__name__, float(getattr(self.DS, "seds_thr", 0.0)), b"".join(a.tobytes() for a in seds) if seds else b"")
+        sig = (float(self.dt), float(self.dst_thr), float(self.DS.lin_thr), float(self.Policy.p), mask, ds_sig, qf.tobytes(),
                dh.tobytes(), qmin.tobytes(), qmax.tobytes(), e.params.variant, e.params.cost_terms)
-        if sig == self._pushed:
+        # config_version: somebody configured the context through the Engine directly since our last push -> ours again
+        if sig == self._pushed and e.config_version == self._pushed_version:
             return
         p = e.params
         p.dt, p.dst_thr, p.lin_thr, p.rbf_p, p.ignored_links = sig[0], sig[1], sig[2], sig[3], mask
         e.push_params()
-        if hasattr(self.DS, "device_params"):       # SEDS nominal DS (seds.py)
-            e.set_ds_seds(qf, *self.DS.device_params(), lin_thr=float(self.DS.lin_thr), seds_thr=float(self.DS.seds_thr))
+        if seds is not None:                        # SEDS nominal DS (seds.py)
+            e.set_ds_seds(qf, *seds, lin_thr=float(self.DS.lin_thr), seds_thr=float(self.DS.seds_thr))
         else:
             e.set_ds(qf)
         e.set_cost(dh, qmin, qmax)
         self._pushed = sig
+        self._pushed_version = e.config_version
 
     # ---- rollouts (MPPI.py:97-224) -------------------------------------------------------------------
-    def propagate(self, fetch=False):
+    def propagate(self, fetch=None):
         """MPPI.py:97-224.  Returns the reference's 5-tuple (all_traj, closest_dist_all, kernel_val_all[:, :, :K], dot_products,
-        kernel_activations) and sets the same attributes -- as LazyRollout tensors (lazy.py): they stay on the GPU until read,
-        single rollouts are fetched as rows, and the candidate search / cost / update work on the device-resident copies.
-        ``fetch=True`` materialises everything at once (torch CPU tensors, what rounds 1-3 returned)."""
+        kernel_activations) and sets the same attributes.  By default they are torch CPU tensors, as in the reference (fresh ones
+        every call, MPPI.py:86-91).  With ``lazy_rollouts = True`` (or ``fetch=False``) they are LazyRollout tensors (lazy.py): they
+        stay on the GPU until read, single rollouts are fetched as rows, and the candidate search / cost / update work on the
+        device-resident copies either way."""
+        if fetch is None:
+            fetch = not self.lazy_rollouts
         self._push()
         if self._engine.K != self.Policy.n_kernels:
             # like the reference, propagate() consumes whatever sample tensors exist; with a changed
@@ -169,19 +182,29 @@ class MPPI:
         self._qdot_cache = {}
         self._generation += 1
         N, H, n, K = self.N_traj, self.dt_H, self.n_dof, self.Policy.n_kernels
-        lz = lambda key, shape: LazyRollout(self, key, shape, self._generation)
-        self.all_traj = lz("all_traj", (N, H, n))
-        self.closest_dist_all = lz("closest_dist_all", (N, H))
-        self.kernel_val_all = lz("kernel_val_all", (N, H, K))
-        self.dot_products = lz("dot_products", (N, H))
-        self.kernel_activations = lz("kernel_activations", (N, H))
-        self.qdot = lz("qdot", (N, n))
-        self.normal_dirs = lz("normal", (N, H, n))      # norm_basis[..., 0]
         if fetch:
-            self._fetch()
-            return (self.all_traj.tensor(), self.closest_dist_all.tensor(), self.kernel_val_all.tensor(), self.dot_products.tensor(),
-                    self.kernel_activations.tensor())
+            c = self._fetch()
+            self.all_traj, self.closest_dist_all, self.kernel_val_all = c["all_traj"], c["closest_dist_all"], c["kernel_val_all"]
+            self.dot_products, self.kernel_activations, self.qdot, self.normal_dirs = c["dot_products"], c["kernel_activations"], c["qdot"], c["normal"]
+            # torch counts in-place writes: a caller who edits a returned tensor gets the host path of check_traj_for_kernels
+            self._versions = {id(t): t._version for t in c.values()}
+        else:
+            lz = lambda key, shape: LazyRollout(self, key, shape, self._generation)
+            self.all_traj = lz("all_traj", (N, H, n))
+            self.closest_dist_all = lz("closest_dist_all", (N, H))
+            self.kernel_val_all = lz("kernel_val_all", (N, H, K))
+            self.dot_products = lz("dot_products", (N, H))
+            self.kernel_activations = lz("kernel_activations", (N, H))
+            self.qdot = lz("qdot", (N, n))
+            self.normal_dirs = lz("normal", (N, H, n))      # norm_basis[..., 0]
         return (self.all_traj, self.closest_dist_all, self.kernel_val_all, self.dot_products, self.kernel_activations)
+
+    def _is_device_copy(self, t):
+        """True while ``t`` is a rollout tensor of the last propagate() that still equals the device-resident copy: a LazyRollout of
+        this generation, or a fetched torch tensor nobody has written into since."""
+        if isinstance(t, LazyRollout):
+            return t._owner is self and t._gen == self._generation and not t._dirty
+        return isinstance(t, torch.Tensor) and getattr(self, "_versions", {}).get(id(t), -1) == t._version
 
     def _fetch(self):
         """All rollout tensors of the last propagate as torch CPU tensors (one omds_get_rollouts), cached until the next one."""

@@ -59,10 +59,15 @@ class MPPI(_MPPI):
         return super().update_obstacles(obs4)
 
     def _push(self):
+        before = self._pushed_version
         super()._push()
-        self._engine.set_ds_matrix(_np(self.qf), _np(self.A))
+        a = _np(self.A).tobytes()
+        if self._pushed_version != before or a != getattr(self, "_pushed_A", None):   # the base class re-installed the linear DS, or A changed
+            self._engine.set_ds_matrix(_np(self.qf), _np(self.A))
+            self._pushed_A = a
+            self._pushed_version = self._engine.config_version
 
-    def propagate(self, fetch=False):
+    def propagate(self, fetch=None):
         r = super().propagate(fetch)
         return None if r is None else r[:4]
 

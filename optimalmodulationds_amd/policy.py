@@ -128,7 +128,8 @@ class TensorPolicyMPPI:
         cross PCIe; for foreign tensors the same logic runs on the host."""
         own = getattr(self, "_owner", None)
         if own is not None and all_traj is own.all_traj and closests_dist_all is own.closest_dist_all \
-                and dotproducts_all is own.dot_products and self._engine is not None:
+                and dotproducts_all is own.dot_products and self._engine is not None \
+                and all(own._is_device_copy(t) for t in (all_traj, closests_dist_all, dotproducts_all)):
             own._push()     # Policy.p (the RBF norm order) and the other mutable attributes, when they changed
             q, th, total = self._engine.kernel_candidates(thr_dist, thr_kernel, thr_dot, self.mu_c.numpy(),
                                                           self.sigma_c.numpy(), self.n_kernels)

@@ -493,11 +493,26 @@ def test_integrator_with_a_seds_nominal_ds():
 
 
 def test_lazy_rollout_tensors_fetch_rows_and_behave_like_tensors():
-    """``propagate()`` returns LazyRollout tensors (lazy.py): indexing by rollout fetches only those rows (omds_get_rollout_rows) and
-    equals the same index into the fully fetched tensor; every other use behaves like the torch tensor of ``propagate(fetch=True)``;
-    a tensor of an earlier propagate that was never read refuses to hand out the next propagate's numbers."""
+    """With ``lazy_rollouts = True`` ``propagate()`` returns LazyRollout tensors (lazy.py): indexing by rollout fetches only those rows
+    (omds_get_rollout_rows) and equals the same index into the fully fetched tensor; every other use behaves like the torch tensor of
+    the default (eager) form; a tensor of an earlier propagate that was never read refuses to hand out the next propagate's numbers;
+    writing into one and pickling one materialise it.  The default hands out and binds plain torch tensors like the reference."""
+    import pickle
     from optimalmodulationds_amd.lazy import LazyRollout
     mppi, _ = _franka_mppi()
+    mppi.Policy.sample_policy()
+    eager = mppi.propagate()                                               # the class default: the reference's plain tensors
+    assert all(isinstance(x, torch.Tensor) for x in eager) and eager[0] is mppi.all_traj and isinstance(mppi.qdot, torch.Tensor)
+    cand_dev = mppi.Policy.check_traj_for_kernels(eager[0], eager[1], eager[3], 0.3, 0.5, 0.5)      # device search on the unmodified tensors
+    eager[1][0, 0] = eager[1][0, 0]                                        # an in-place write: the host path from here on, same answer
+    assert not mppi._is_device_copy(eager[1])
+    cand_host = mppi.Policy.check_traj_for_kernels(eager[0], eager[1], eager[3], 0.3, 0.5, 0.5)
+    assert torch.equal(cand_dev, cand_host)
+    kept_eager = eager[0].clone()
+    mppi.Policy.sample_policy()
+    mppi.propagate()
+    assert torch.equal(eager[0], kept_eager)                               # a tensor kept across propagate() calls keeps its numbers
+    mppi.lazy_rollouts = True
     N, H, n = 64, 6, 7
     mppi.Policy.add_kernel(mppi.q_cur + 0.1, 0.0, torch.eye(7))
     mppi.Policy.add_kernel(mppi.q_cur - 0.2, 0.0, torch.eye(7))
@@ -525,7 +540,16 @@ def test_lazy_rollout_tensors_fetch_rows_and_behave_like_tensors():
     assert np.array_equal(np.asarray(dist), full["closest_dist_all"].numpy()) and np.array_equal(kval.numpy(), full["kernel_val_all"].numpy())
     assert torch.equal(all_traj.view(-1, n), full["all_traj"].view(-1, n)) and float(dist.min()) == float(full["closest_dist_all"].min())
     assert torch.equal(torch.cat((all_traj[:2], all_traj[2:4])), full["all_traj"][:4])
-    # the eager form
+    # writes and pickles materialise
+    mppi.Policy.sample_policy()
+    w = mppi.propagate()
+    full_w = mppi._fetch()["all_traj"].clone()
+    w[0][3] = 0.0
+    w[1].__iadd__(1.0)
+    assert torch.equal(w[0][3], torch.zeros(H, n)) and torch.equal(w[0][4], full_w[4]) and not mppi._is_device_copy(w[0])
+    back = pickle.loads(pickle.dumps(w[3]))
+    assert isinstance(back, torch.Tensor) and torch.equal(back, w[3].tensor())
+    # the eager form on request
     mppi.Policy.sample_policy()
     eager = mppi.propagate(fetch=True)
     assert all(isinstance(x, torch.Tensor) for x in eager)

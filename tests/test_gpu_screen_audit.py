@@ -247,7 +247,7 @@ def test_sweep_checks_every_pair_of_a_step_and_catches_what_a_disabled_audit_mis
         r = _step_both(engines, q, pol, 700 + it, f"clean #{it}")
         q = (q + 0.02 * r["qdot"][0]).astype(np.float32)
     st = engines[1].screen_stats()
-    assert st["sweep_every"] == 32 and st["sweeps"] == 2, st            # propagates 0 and 32
+    assert st["sweep_every"] == 32 and st["sweeps"] == 3, st            # propagates 0 and 32, and 1: the first on the re-sorted pack
     assert 0.0 < st["sweep_max_err"] <= 0.5 * st["eps"] and st["fallbacks"] == 0, st
     for e in engines:
         e.close()

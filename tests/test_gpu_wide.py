@@ -114,7 +114,7 @@ def test_wide_network_through_the_facade_and_its_limits():
     mppi.Policy.sample_policy()
     all_traj, dist, _, _, _ = mppi.propagate()
     cost = mppi.get_cost()
-    assert torch.isfinite(all_traj.tensor()).all() and cost.shape == (64,)
+    assert torch.isfinite(all_traj).all() and cost.shape == (64,)
     d, g = mppi.distance_repulsion_nn(q_0[None])
     od, og, _, _ = orc.distance_repulsion_nn(m, q_0.numpy()[None], scenes.shelf_scene(), 5, [0, 1, 2])
     assert abs(float(d[0]) - float(od[0])) <= 1e-5 * max(1.0, abs(float(od[0])))
@@ -127,4 +127,29 @@ def test_wide_network_through_the_facade_and_its_limits():
         W = [rng.standard_normal((300, 30)).astype(np.float32), rng.standard_normal((64, 330)).astype(np.float32), rng.standard_normal((9, 64)).astype(np.float32)]
         b = [np.zeros(300, np.float32), np.zeros(64, np.float32), np.zeros(9, np.float32)]
         e.set_mlp(W, b, skip_after=(0,))
+    e.close()
+
+
+def test_rejected_network_leaves_the_wide_one_installed():
+    """A narrow network the library rejects (first layer of the wrong width) on a context that holds a wide one: the call fails
+    with a status, and the wide network keeps answering with the numbers it gave before (the rejected call used to clear the
+    wide state first, leaving a context whose fused kernels had null weight pointers)."""
+    from optimalmodulationds_amd import scenes, _lib
+    from optimalmodulationds_amd.engine import Engine
+    m = _net((384, 384), "relu", seed=5)
+    e = Engine(7, 32, 2, 5, max_obs=512)
+    e.set_mlp(m.W, m.b)
+    e.set_obstacles(scenes.shelf_scene())
+    q = (scenes.FRANKA_Q0 + 0.2 * np.random.RandomState(1).standard_normal((32, 7))).astype(np.float32)
+    d0, g0 = e.dist_grad(q)[:2]
+    rng = np.random.RandomState(0)
+    W = [rng.standard_normal((64, 29)).astype(np.float32), rng.standard_normal((9, 64)).astype(np.float32)]   # 29 != 3 (n + 3)
+    with pytest.raises(_lib.OmdsError):
+        e.set_mlp(W, [np.zeros(64, np.float32), np.zeros(9, np.float32)])
+    d1, g1 = e.dist_grad(q)[:2]
+    assert np.array_equal(d0, d1) and np.array_equal(g0, g1)
+    e.set_ds(scenes.FRANKA_QF)
+    e.set_policy_samples(np.zeros((32, 0, 7), np.float32), None, None)
+    e.propagate(q)
+    assert np.isfinite(e.get_rollouts()["all_traj"]).all()
     e.close()
