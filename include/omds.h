@@ -245,8 +245,13 @@ OMDS_API int omds_kernel_candidates(omds_ctx* ctx, float thr_dist, float thr_ker
  *                           mask_out [K]; qdot_weighted [n] = get_qdot('weighted') or NULL; qdot_best [n] =
  *                           get_qdot('best') over all shards or NULL (NULL skips the MINLOC gather);
  *                           n_total_out = number of rollouts over all shards or NULL.  Without a communicator it
- *                           is the single-shard update.  Failures of RCCL return OMDS_ERR_RCCL.                  */
+ *                           is the single-shard update.  Failures of RCCL return OMDS_ERR_RCCL.
+ *   omds_comm_probe       : OMDS_OK when RCCL can be loaded in this process (no device touched, no communicator made),
+ *                           OMDS_ERR_RCCL otherwise (message: omds_comm_last_error).  A launcher calls it on EVERY rank and
+ *                           lets the ranks agree before any of them enters omds_comm_init_rank: a rank that cannot load
+ *                           RCCL would otherwise leave the others waiting inside ncclCommInitRank.                    */
 #define OMDS_COMM_ID_BYTES 128
+OMDS_API int omds_comm_probe(void);
 OMDS_API int omds_comm_unique_id(uint8_t* out128);
 OMDS_API const char* omds_comm_last_error(void);
 OMDS_API int omds_comm_init_rank(omds_ctx* ctx, const uint8_t* id128, int rank, int world);
@@ -399,6 +404,9 @@ OMDS_API int omds_prof_read_ex(omds_ctx* ctx, double* ms, int64_t* launches, dou
 /* Asynchronous form used by bench loops: propagate + cost + weighted update enqueued without
  * host round trips of rollout data; omds_sync waits for the stream.                       */
 OMDS_API int omds_sync(omds_ctx* ctx);
+/* Number of HIP devices this process can see (0 on a box without a GPU: not an error).  Launchers size their rank count by it
+ * (bench.py --gpus N refuses when N exceeds it); no context needed.                                                        */
+OMDS_API int omds_device_count(int32_t* count);
 OMDS_API int omds_version(void);
 
 #ifdef __cplusplus

@@ -86,6 +86,7 @@ SIGNATURES = {
     "omds_local_sums": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_int, F32P]),
     "omds_apply_update": (C.c_int, [C.c_int, C.c_int, C.c_int, F32P, C.c_float, C.c_float, C.c_float, C.c_uint32,
                                     F32P, F32P, F32P, I32P]),
+    "omds_comm_probe": (C.c_int, []),
     "omds_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "omds_comm_last_error": (C.c_char_p, []),
     "omds_comm_init_rank": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
@@ -122,6 +123,7 @@ SIGNATURES = {
     "omds_prof_read_ex": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                     C.POINTER(C.c_char_p)]),
     "omds_sync": (C.c_int, [C.c_void_p]),
+    "omds_device_count": (C.c_int, [C.POINTER(C.c_int32)]),
 }
 
 # include/omds_test.h: exported by libomds_hip_test.so only (the product library does not have them)
@@ -133,7 +135,7 @@ TEST_HOOK_SIGNATURES = {
 }
 TEST_LIB_PATH = os.path.join(_HERE, "csrc", "libomds_hip_test.so")
 
-ABI_VERSION = 401      # omds_version() of the library this binding was written against
+ABI_VERSION = 500      # omds_version() of the library this binding was written against
 _libs = {}             # path -> bound CDLL
 
 
@@ -220,6 +222,21 @@ def check(ctx, rc, lib=None):
     if rc != 0:
         msg = (lib or load()).omds_last_error(ctx)
         raise OmdsError(f"omds error {rc}: {msg.decode() if msg else '?'}")
+
+
+def device_count() -> int:
+    """HIP devices visible to this process (omds_device_count; 0 on a box without a GPU)."""
+    n = C.c_int32(0)
+    rc = load().omds_device_count(C.byref(n))
+    if rc != 0:
+        raise OmdsError(f"omds_device_count failed ({rc})")
+    return int(n.value)
+
+
+def comm_probe() -> str:
+    """'' when RCCL can be loaded in this process, else the loader's message (omds_comm_probe)."""
+    lib = load()
+    return "" if lib.omds_comm_probe() == 0 else (lib.omds_comm_last_error() or b"RCCL not available").decode()
 
 
 def default_params() -> OmdsParams:

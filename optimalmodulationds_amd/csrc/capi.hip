@@ -87,7 +87,15 @@ static uint16_t f32_to_f16_bits(float f) {
 
 extern "C" {
 
-int omds_version(void) { return 401; }
+int omds_version(void) { return 500; }
+
+int omds_device_count(int32_t* count) {
+    if (!count) return OMDS_ERR_INVALID_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }   // no device / no driver: zero devices, not a failure
+    *count = n;
+    return OMDS_OK;
+}
 
 void omds_default_params(omds_params* p) {
     if (!p) return;

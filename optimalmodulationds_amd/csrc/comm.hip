@@ -115,6 +115,11 @@ extern "C" {
 
 const char* omds_comm_last_error(void) { return g_comm_err.c_str(); }
 
+int omds_comm_probe(void) {
+    if (!rccl().ok()) { g_comm_err = rccl().err; return OMDS_ERR_RCCL; }
+    return OMDS_OK;
+}
+
 int omds_comm_unique_id(uint8_t* out128) {
     if (!out128) { g_comm_err = "omds_comm_unique_id: null output"; return OMDS_ERR_INVALID_ARG; }
     if (!rccl().ok()) { g_comm_err = rccl().err; return OMDS_ERR_RCCL; }

@@ -28,15 +28,23 @@ from .engine import apply_update, red_layout
 
 def init_native_comm(engine, group=None):
     """Creates the RCCL communicator of ``engine`` over the ranks of ``group`` (any torch.distributed
-    backend -- it only carries the id).  Raises OmdsError (OMDS_ERR_RCCL) if RCCL cannot be used: there is
-    no fallback.  Without an initialised process group: a single-rank communicator."""
+    backend -- it only carries the id).  Raises OmdsError (OMDS_ERR_RCCL) ON EVERY RANK if RCCL cannot be used on any of
+    them: there is no fallback, and no rank is left waiting inside ncclCommInitRank for one that could not load the
+    library (every rank probes the loader first -- omds_comm_probe -- and the ranks agree before the collective init).
+    Without an initialised process group: a single-rank communicator."""
+    from . import _lib as L
     if dist.is_initialized():
         rank, world = dist.get_rank(group), dist.get_world_size(group)
+        probes = [None] * world
+        dist.all_gather_object(probes, L.comm_probe(), group=group)
+        bad = [f"rank {r}: {m}" for r, m in enumerate(probes) if m]
+        if bad:
+            raise L.OmdsError("omds error 3: RCCL is not usable on every rank -- " + "; ".join(bad))
         box = [None]
         if rank == 0:
             try:
                 box = [engine.comm_unique_id()]
-            except Exception as e:          # RCCL not loadable: the other ranks are waiting in the broadcast -- tell them
+            except Exception as e:          # ncclGetUniqueId failed: the other ranks are waiting in the broadcast -- tell them
                 box = [e]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         if isinstance(box[0], Exception):

@@ -389,6 +389,10 @@ class Engine:
                     sweep_every=sw_every.value, sweeps=sw_n.value, sweep_max_err=sw_err.value)
 
     # ---- measurement --------------------------------------------------------------------------
+    def sync(self):
+        """Waits for everything enqueued on the context's stream (omds_sync)."""
+        self._ck(self.lib.omds_sync(self.h))
+
     def prof_enable(self, on=True):
         """on: False/0 off, True/1 every launch of the dominant kernel, n > 1 every n-th launch."""
         self._ck(self.lib.omds_prof_enable(self.h, int(on)))

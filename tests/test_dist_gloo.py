@@ -69,9 +69,10 @@ def test_two_rank_update_matches_single_process(tmp_path, name):
     assert_close(o["qb"], fx["it0_qdot_best"], 1e-6, "best qdot")
 
 
-def _worker_no_rccl(rank, world, port, outdir):
+def _worker_no_rccl(rank, world, port, outdir, which):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
-    os.environ["OMDS_RCCL_LIB"] = "/nonexistent/librccl-not-here.so"
+    if which == "all" or rank == 1:
+        os.environ["OMDS_RCCL_LIB"] = "/nonexistent/librccl-not-here.so"
     import torch.distributed as dist
     from optimalmodulationds_amd import _lib
     from optimalmodulationds_amd.dist import init_native_comm
@@ -84,7 +85,7 @@ def _worker_no_rccl(rank, world, port, outdir):
         comm_unique_id = staticmethod(Engine.comm_unique_id)
 
         def comm_init(self, uid, rank, world):
-            raise AssertionError("no id can exist without RCCL")
+            raise AssertionError("no rank may enter the collective init while one of them has no RCCL")
 
     msg = ""
     try:
@@ -98,13 +99,16 @@ def _worker_no_rccl(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_a_missing_rccl_fails_on_every_rank_instead_of_hanging_the_others(tmp_path):
-    """Rank 0 cannot make the communicator id (librccl not loadable): the other ranks, waiting for it in the broadcast, must get
-    the same error -- not block until the launcher's timeout."""
+@pytest.mark.parametrize("which", ["all", "rank1"])
+def test_a_missing_rccl_fails_on_every_rank_instead_of_hanging_the_others(tmp_path, which):
+    """librccl is not loadable on every rank / on rank 1 only: every rank probes the loader (omds_comm_probe) and the ranks agree
+    BEFORE any of them enters the collective init, so all of them get the same error naming the rank(s) without RCCL -- nobody
+    blocks inside ncclCommInitRank (or in the id broadcast) until the launcher's timeout."""
     import __graft_entry__ as g
     g.build()
     world = 2
-    mp.spawn(_worker_no_rccl, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_no_rccl, args=(world, _free_port(), str(tmp_path), which), nprocs=world, join=True)
     for r in range(world):
         flags, msg = open(tmp_path / f"r{r}.txt").read().split("|", 1)
-        assert flags == "[True, True]" and "RCCL not available" in msg and "librccl-not-here" in msg, (r, flags, msg)
+        assert flags == "[True, True]" and "RCCL not available" in msg and "librccl-not-here" in msg and "rank 1:" in msg, (r, flags, msg)
+        assert ("rank 0:" in msg) == (which == "all"), msg

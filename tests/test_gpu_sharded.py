@@ -319,33 +319,39 @@ def test_bench_under_torchrun_single_rank_uses_rccl(workload):
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["config"]["collectives"] == "rccl" and d["value"] > 1e5, d
     assert d["scaling"] == "weak" and d["steps"] == 3 and d["reps"] == 2
+    assert d["config"]["pytorch_on_device"] is False      # gloo plumbing only: PyTorch never initialised the GPU in the measured process
 
 
-@pytest.mark.parametrize("mode", ["share", "rccl_missing"])
+@pytest.mark.parametrize("mode", ["share", "rccl_missing", "rccl_missing_strict"])
 def test_bench_two_ranks_on_one_gpu(mode):
-    """World size 2 under the driver's launcher on a 1-GPU box: both ranks on GPU 0, sums through the launcher's gloo group (two
-    ranks on one GPU cannot form a RCCL communicator) -- the barrier, the max over ranks, the rank-0 kernel decision + broadcast of
-    the dynamic workload and the whole-job value all run.  'rccl_missing': the ranks attempt the RCCL communicator, cannot load the
-    library (OMDS_RCCL_LIB points nowhere), agree on the host-mediated path and say so in the line instead of crashing."""
+    """World size 2 on a 1-GPU box THROUGH THE SELF-LAUNCHER: `python bench.py --gpus 2 --share-gpu` starts its own two ranks (a child
+    torch.distributed.run, before the parent touches the GPU) and relays rank 0's line.  Both ranks on GPU 0, sums through the
+    launcher's gloo group (two ranks on one GPU cannot form a RCCL communicator) -- the barrier, the max over ranks, the rank-0 kernel
+    decision + broadcast of the dynamic workload and the whole-job value all run.  'rccl_missing': the ranks attempt the RCCL
+    communicator, cannot load the library (OMDS_RCCL_LIB points nowhere), and -- because --allow-host-collectives asks for it -- agree
+    on the host-mediated path and say so in the line.  'rccl_missing_strict': the same without that flag: no number, exit non-zero."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     extra = []
-    if mode == "rccl_missing":
+    if mode != "share":
         env["OMDS_RCCL_LIB"] = "/nonexistent/librccl.so"
-        extra = ["--try-rccl"]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541" if mode == "share" else "29542", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--reps", "2", "--no-cpu-baseline", "--no-secondary", "--share-gpu", "--workload", "franka_dynamic_1024x32"] + extra
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=root, env=env)
+        extra = ["--try-rccl"] + (["--allow-host-collectives"] if mode == "rccl_missing" else [])
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--reps", "2", "--no-cpu-baseline",
+           "--no-secondary", "--share-gpu", "--path", "screened", "--workload", "franka_dynamic_1024x32"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    if mode == "rccl_missing_strict":
+        assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")], r.stdout[-2000:]
+        assert "could not be formed" in r.stderr and "refusing" in r.stderr and "no number is reported" in r.stderr, r.stderr[-3000:]
+        return
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, "rank 0 alone prints the line"
+    assert len(lines) == 1, "rank 0 alone prints the line, the launcher relays it once"
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 1e5, d
-    assert d["config"]["parallelism"] == "rollout-sharded x2"
+    assert d["config"]["parallelism"] == "rollout-sharded x2" and d["config"]["rollouts_total"] == 2048
     coll = d["config"]["collectives"]
     if mode == "share":
         assert coll.startswith("gloo-host (--share-gpu"), coll
@@ -355,3 +361,21 @@ def test_bench_two_ranks_on_one_gpu(mode):
     # whole-job value = both ranks' rollouts over the slowest rank's time (medians of two blocks: of the rates / of the times)
     assert abs(d["value"] - 2 * 1024 * 32 / (d["ms_per_step"] * 1e-3)) < 5e-3 * d["value"]
     assert d["value_min"] <= 2 * 1024 * 32 / (max(d["rep_ms_per_step"]) * 1e-3) * (1 + 1e-4)
+
+
+def test_bench_strong_scaling_splits_the_rollouts_over_the_ranks():
+    """--scaling strong at two ranks (sharing the one GPU of the box): the workload's 1024 rollouts are split 512 + 512, the line counts
+    1024 rollouts per iteration, and rank 1's samples start at rollout offset 512."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--reps", "2", "--no-cpu-baseline",
+           "--no-secondary", "--share-gpu", "--scaling", "strong"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2 and d["dtype"] == "f32", d
+    assert d["config"]["rollouts_per_gpu"] == 512 and d["config"]["rollouts_total"] == 1024
+    assert abs(d["value"] - 1024 * 32 / (d["ms_per_step"] * 1e-3)) < 5e-3 * d["value"]

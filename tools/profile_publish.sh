@@ -2,7 +2,7 @@
 # Copies the summaries tools/profile_refresh.sh left under gpurun_out/prof_<round>/ (scratch, merged back by gpurun) into profiles/
 # under their committed names.  Run here, after the gpurun call:  bash tools/profile_publish.sh r04
 set -eu
-R=${1:-r04}
+R=${1:-r05}
 S=gpurun_out/prof_$R
 D=profiles
 cp "$S/bench.json" "$D/${R}_bench_franka_shelf_1024x32.json"
@@ -15,6 +15,7 @@ cat "$S/pmc_FETCH_SIZE.txt" "$S/pmc_WRITE_SIZE.txt" > "$D/${R}_pmc_hbm.txt"
 cat "$S/pmc_fp32_FETCH_SIZE.txt" "$S/pmc_fp32_WRITE_SIZE.txt" > "$D/${R}_pmc_hbm_fp32.txt"
 cat "$S/pmc_p7_FETCH_SIZE.txt" "$S/pmc_p7_WRITE_SIZE.txt" > "$D/${R}_pmc_hbm_planar7_1024x32.txt"
 cp "$S/pmc_sq.txt" "$D/${R}_pmc_sq.txt"
+[ -s "$S/pmc_sq_fp32.txt" ] && cp "$S/pmc_sq_fp32.txt" "$D/${R}_pmc_sq_fp32.txt"
 cp "$S/parity_fullsize.txt" "$D/${R}_parity_fullsize.txt"
 cp "$S/pmc_traffic.json" "$D/pmc_traffic.json"
 [ -s gpurun_out/${R}_soak.txt ] && cp gpurun_out/${R}_soak.txt "$D/${R}_screen_error_hist.txt"
