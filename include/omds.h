@@ -292,7 +292,13 @@ OMDS_API int omds_apply_update(int n_kernels, int n_dof, int horizon, const floa
  *   - calibration: eps = 6 x the largest |Da - D| over ~3e5 pairs (states uniform in the joint box + states of the last
  *     propagate's rollouts, against the current obstacles), at the first screened propagate after omds_set_mlp, after
  *     omds_set_obstacles when the scene differs from the calibrated one (another count or radius, a sphere moved by more
- *     than 0.1), after a change of params.ignored_links, and on request (eps < 0 below);
+ *     than 0.1), after a change of params.ignored_links, and on request (eps < 0 below).
+ *     LATENCY: a calibration runs inside the omds_propagate that needs it -- one fp32 and one f16 pass over the batch plus two
+ *     host re-sorts of the f16 weight pack by how often the hidden units fire (one in the calibration, one behind the first
+ *     accepted propagate) -- about 21 ms on the first screened propagate against 5.8 ms for an ordinary 1024 x 32 iteration
+ *     (tools/studies/reorder_cost.py), and the propagate after the second re-sort carries a sweep (+1 ms).  A translating
+ *     scene does not recalibrate; a caller who SWAPS scenes at rate and cannot take the spike fixes the bound (eps > 0) or
+ *     switches screening off for those iterations;
  *   - every step of every propagate: |Da - D| of every candidate; Da - D of the AUDIT rows, a pseudo-random 1-in-`one_in`
  *     sample (another one every step) of the pairs that are not candidates, re-evaluated in fp32 by one launch at the end
  *     of the horizon loop (k_audit); the slack of every rollout (tau - exact k-th smallest >= eps).

@@ -190,8 +190,10 @@ def test_only_the_audit_rows_can_see_a_misplaced_far_looking_obstacle():
     assert st["max_err_seen"] <= 0.5 * eps0, st              # ... the candidates could not
     for e in engines:
         e.close()
-    # the same damage with the audit switched off goes unnoticed: this is what the audit rows are for
+    # the same damage with the audit switched off goes unnoticed: this is what the audit rows are for (sweeps off too: the first
+    # propagate after the pack's re-sort would carry one, and a sweep sees every pair of its step)
     engines = _pair(N, H, obs, audit=0)
+    engines[1].set_screening_sweep(0)
     mu_c, sg_c, al_c = pol
     outs = []
     for e in engines:

