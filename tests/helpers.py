@@ -64,7 +64,7 @@ def velocity_envelope(q, qf, d_raw, grads, mu, sg, al, prm, delta):
     return us.min(axis=0), us.max(axis=0)
 
 
-def assert_velocity_in_envelope(u_dev, q, qf, d_raw, grads, mu, sg, al, prm, d_scale, what, pad=0.0):
+def assert_velocity_in_envelope(u_dev, q, qf, d_raw, grads, mu, sg, al, prm, d_scale, what, pad=0.0, family=None):
     """The device's modulated velocity must lie, per component, in the interval the oracle's modulation spans when the network
     distance moves by +-DIST_ULP * max(1, d_scale) -- MPPI.py:149-155 multiplies a distance difference by sigmoid slopes of up
     to 100, so two valid fp32 evaluations of the network differ by more than 1e-5 in the velocity near an obstacle -- for each
@@ -76,6 +76,11 @@ def assert_velocity_in_envelope(u_dev, q, qf, d_raw, grads, mu, sg, al, prm, d_s
     tol = RTOL * uscale + pad
     u_dev = np.asarray(u_dev)
     excess = float(np.maximum(np.maximum(lo - u_dev, u_dev - hi), 0).max()) if u_dev.size else 0.0
+    if family is not None and u_dev.size:      # the plain bar beside it: the same rows against the oracle's own step, no envelope
+        from oracle import omds_oracle as orc
+        u_orc = orc.modulation_step(q, qf, np.asarray(d_raw, np.float32), grads[0], mu, sg, al, prm)["u"]
+        in_env = ((u_dev >= lo - tol) & (u_dev <= hi + tol)).all(axis=-1)
+        log_plain_bar(family, what, "oracle", plain_bar(u_dev, u_orc, in_env)[0])
     assert excess <= tol, f"{what}: modulated velocity {excess:.3e} outside the +-{delta:.1e} distance envelope (allowed {tol:.1e})"
     return excess
 
@@ -86,3 +91,40 @@ def seds_of(fx):
         return None
     return dict(mu_in=fx["seds_mu_in"], b=fx["seds_b"], sigma_inv=fx["seds_sigma_inv"], A=fx["seds_A"], prior=fx["seds_prior"],
                 den=fx["seds_den"], lin_thr=float(fx["seds_lin_thr"]), seds_thr=float(fx["seds_thr"]))
+
+
+# ---- the plain north-star bar -------------------------------------------------------------------------------------------------
+# BASELINE.json: "matching reference modulated velocities within 1e-5 rel-fp32".  The parity tests hold every row to that bar through
+# two admissions (the +-DIST_ULP distance envelope; for rows with a hidden pre-activation within 5e-6 of zero, any admissible ReLU-mask
+# assignment).  plain_bar() counts how many rows need NEITHER: |u_device - u_reference| <= 1e-5 x the velocity scale of the batch,
+# no envelope, no alternatives.  Every GPU test that compares velocities files its counts here; test_plain_bar_summary (the last test
+# of tests/test_gpu_parity.py) prints the table per fixture family and asserts floors on the plain fraction.
+PLAIN_LOG = os.path.join(ROOT, "gpurun_out", "parity_plain_bar.jsonl")
+
+
+def plain_bar(u_dev, u_ref, in_envelope=None):
+    """Per-row classification of a velocity comparison: 'plain' = max_j |u_dev - u_ref| <= RTOL x max(|u_ref| over the batch) (the
+    tensor's own scale, never clamped up to 1); of the others 'envelope' = inside the single-assignment +-DIST_ULP envelope
+    (``in_envelope`` [rows] bool, from velocity_envelope), 'mask' = the rest (they pass only under another admissible ReLU-mask
+    assignment -- the calling test asserts that they do).  Returns (counts dict, per-row error / scale)."""
+    u_dev, u_ref = np.asarray(u_dev, np.float64), np.asarray(u_ref, np.float64)
+    if u_dev.size == 0:
+        return dict(rows=0, plain=0, envelope=0, mask=0, worst_plain=0.0, worst=0.0), np.zeros(0)
+    scale = max(float(np.abs(np.nan_to_num(u_ref)).max()), 1e-30)
+    e = np.abs(np.nan_to_num(u_dev) - np.nan_to_num(u_ref)).max(axis=-1) / scale
+    plain = e <= RTOL
+    env = ~plain & (np.ones_like(plain) if in_envelope is None else np.asarray(in_envelope, bool))
+    return dict(rows=int(e.size), plain=int(plain.sum()), envelope=int(env.sum()), mask=int((~plain & ~env).sum()),
+                worst_plain=float(e[plain].max()) if plain.any() else 0.0, worst=float(e.max())), e
+
+
+def log_plain_bar(family, what, against, counts):
+    """Appends one record to PLAIN_LOG (scratch; copied to profiles/ by hand) -- family = fixture family, what = the test,
+    against = 'reference' (the fixture's own velocity) or 'oracle'."""
+    import json
+    try:
+        os.makedirs(os.path.dirname(PLAIN_LOG), exist_ok=True)
+        with open(PLAIN_LOG, "a") as f:
+            f.write(json.dumps(dict(counts, family=family, what=what, against=against)) + "\n")
+    except OSError:
+        pass

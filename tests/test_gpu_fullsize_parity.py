@@ -9,7 +9,7 @@ import time
 import numpy as np
 import pytest
 
-from helpers import weights_path
+from helpers import DIST_ULP, RTOL, log_plain_bar, plain_bar, velocity_envelope, weights_path
 from oracle import omds_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -83,6 +83,15 @@ def test_fullsize_rollout_rederived_by_the_oracle(N, S):
     vel = (r["all_traj"][tt[nxt], hh[nxt] + 1] - q[nxt]) / np.float32(0.5)
     e_vel = _err(vel, st["u"][nxt], ok[nxt])
     rows.append(("integrated velocity (unflagged)", e_vel))
+    # the PLAIN north-star bar on EVERY sampled row with a next state (flagged rows included, no envelope, no mask alternatives): the
+    # integrated velocity (q_next - q) / dt against the oracle's own step; then what the others need (helpers.plain_bar)
+    prm = orc.Params(dst_thr=0.01)
+    sel = np.nonzero(nxt)[0]
+    lo, hi = velocity_envelope(q[sel], qf, d[sel], (g[sel], gn[sel]), mu[tt][sel], sg[tt][sel], al[tt][sel], prm, DIST_ULP * max(1.0, float(np.abs(d).max())))
+    pad = RTOL * max(1.0, float(np.abs(hi).max())) + 4e-6 * max(1.0, float(np.abs(q).max())) / 0.5      # (q_next - q) / dt loses bits
+    in_env = ((vel >= lo - pad) & (vel <= hi + pad)).all(axis=1) & ok[sel]
+    pb, e_rows = plain_bar(vel, st["u"][sel], in_env)
+    log_plain_bar("franka", f"full size {N} x {H}, screened step", "oracle", pb)
     ocost, _ = orc.evaluate_costs(r["all_traj"], r["closest_dist_all"], qf, dh, qmin, qmax)
     e_cost = _err(cost, ocost, scale=float(np.abs(ocost).max()))
     rows.append(("cost (all rollouts, rel. to max)", e_cost))
@@ -99,7 +108,11 @@ def test_fullsize_rollout_rederived_by_the_oracle(N, S):
     for name, (mx, mean) in rows:
         print(f"{name:36s} {mx:.3e}    {mean:.3e}")
     print(f"obstacle normal, flagged rows under the best admissible mask assignment: max err {worst_alt:.3e}, rows above 2e-5: {n_unmatched} of {int((~ok).sum())}")
+    print(f"plain 1e-5 bar (integrated velocity vs the oracle, all {pb['rows']} sampled rows with a next state, no envelope, no mask alternatives): "
+          f"{pb['plain']} rows = {100.0 * pb['plain'] / pb['rows']:.2f} % (worst of them {pb['worst_plain']:.2e}); {pb['envelope']} more inside the "
+          f"+-{DIST_ULP:.0e} distance envelope; {pb['mask']} need another admissible ReLU-mask assignment (worst row {pb['worst']:.2e})")
     print("update mask identical:", bool(np.array_equal(mask, omask)), " finite outputs:", bool(np.isfinite(r["all_traj"]).all()))
+    assert pb["plain"] >= 0.95 * pb["rows"], pb
     assert np.isfinite(r["all_traj"]).all() and np.array_equal(mask, omask)
     assert e_dist[0] <= 1e-6, e_dist
     assert e_norm[0] <= 2e-5 and n_unmatched == 0, (e_norm, worst_alt, n_unmatched)

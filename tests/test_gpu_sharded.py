@@ -218,7 +218,8 @@ def test_shard_4096x64_config4():
     nxt = (hh + 1 < H) & ok
     vel = (r["all_traj"][tt[nxt], hh[nxt] + 1] - q[nxt]) / np.float32(0.5)
     assert_velocity_in_envelope(vel, q[nxt], qf, d[nxt], (g[nxt], r["normal"][tt[nxt], hh[nxt]]), mu[tt][nxt], sg[tt][nxt], al[tt][nxt],
-                                orc.Params(dst_thr=0.01), float(np.abs(d).max()), "sampled velocities", pad=4e-6 * max(1.0, float(np.abs(q).max())) / 0.5)
+                                orc.Params(dst_thr=0.01), float(np.abs(d).max()), "shard 4096 x 64, clear-margin rows", pad=4e-6 * max(1.0, float(np.abs(q).max())) / 0.5,
+                                family="franka")
     cost = e.cost()
     ocost, _ = orc.evaluate_costs(r["all_traj"], r["closest_dist_all"], qf, dh, qmin, qmax)
     assert np.abs(cost - ocost).max() <= 1e-5 * max(1.0, np.abs(ocost).max())

@@ -110,7 +110,7 @@ def test_fused_small_step_against_the_oracle():
     from helpers import assert_velocity_in_envelope
     prm = orc.Params(dst_thr=0.25)
     assert_velocity_in_envelope(vel, q[nxt], qf, d[nxt], (g[nxt], r["normal"][tt, hh][nxt]), mu[tt][nxt], sg[tt][nxt], al[tt][nxt], prm,
-                                float(np.abs(d).max()), "integrated velocity", pad=4e-6 * max(1.0, float(np.abs(q).max())) / 0.3)
+                                float(np.abs(d).max()), "fused small step 1024 x 32, clear rows", pad=4e-6 * max(1.0, float(np.abs(q).max())) / 0.3, family="planar7")
     e.close()
 
 
