@@ -1403,6 +1403,13 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
             ctx->sweep_force_next = false;
         }
         omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, apre0, screen ? ctx->d_FqH : nullptr, N);
+#ifdef OMDS_EXPERIMENT
+        static const int corun = OMDS_EXP_ENV("OMDS_EXACT_CORUN", 0);
+        static hipStream_t s2 = nullptr;
+        static hipEvent_t ev = nullptr, ev_done = nullptr;
+        static ExactOut ex2{};
+        static unsigned* err2 = nullptr;
+#endif
         for (int i = 1; i <= H; ++i) {
             float* apre_i = apre0 + (size_t)(i - 1) * apre_slab;
             float* apre_next = apre0 + (size_t)std::min(i, H - 1) * apre_slab;
@@ -1411,6 +1418,31 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
                 if ((rc = prof_begin(ctx))) return rc;
                 if (screen) {
                     sink = static_cast<const SelectSink*>(ctx->h_sinks)[i - 1];
+#ifdef OMDS_EXPERIMENT
+                    // Upper-bound experiment for "k_exact under k_screen" (EXPERIMENTS.md, round 5): a REDUNDANT k_exact over the previous
+                    // step's candidate list (scratch outputs: the step's own results are untouched) on a second stream, released when
+                    // the previous step is done, so that it runs beside this step's k_screen.  What it adds to the iteration is what
+                    // k_screen pays for a co-resident k_exact -- the most a flag-driven overlap could get back is k_exact's own 36 us
+                    // minus that.
+                    if (corun && i >= 2) {
+                        if (!s2) {
+                            CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+                            CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                            CK(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+                            ex2.cap = ctx->ex_cap;
+                            CK(hipMalloc(&ex2.D, (size_t)ex2.cap * 4)); CK(hipMalloc(&ex2.dr, (size_t)ex2.cap * 4)); CK(hipMalloc(&ex2.amin, (size_t)ex2.cap * 4));
+                            CK(hipMalloc(&ex2.mask, (size_t)ex2.cap * (OMDS_MAX_HIDDEN + 1) * 8 * 4));
+                            CK(hipMalloc(&err2, 16));
+                        }
+                        CK(hipEventRecord(ev, ctx->stream));
+                        CK(hipStreamWaitEvent(s2, ev, 0));
+                        omds_launch_exact(s2, ctx->mlp, apre0 + (size_t)(i - 2) * apre_slab, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N, ctx->prm.ignored_links,
+                                          ctx->d_Dmin, ctx->d_rowlist, ctx->d_sctotal + (i - 2), err2, ex2);
+                        CK(hipEventRecord(ev_done, s2));
+                        if (corun == 2 || i == H)   // 2 = control: the same redundant launch IN the main stream's order (the serial cost of one more k_exact)
+                            CK(hipStreamWaitEvent(ctx->stream, ev_done, 0));
+                    }
+#endif
                     omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_FqH, ctx->cfg.n_traj, ctx->d_FpH, ctx->cfg.max_obs, ctx->d_radius, ctx->n_obs, N,
                                        ctx->prm.ignored_links, ctx->d_Dmin, fuse_select ? d_sinks + (i - 1) : nullptr);
                     if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs, -1.0, "k_screen"))) return rc;
