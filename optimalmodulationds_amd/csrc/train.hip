@@ -17,9 +17,7 @@
 #include <new>
 #include <vector>
 
-#include "omds_internal.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "mlp_device.h"   // gemm256: the fp32 MFMA GEMM core of the rollout kernels (k_pass1 runs it at 0.93 of the peak)
 
 namespace {
 
@@ -149,6 +147,212 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
                     Cz[(size_t)gm * ldc + gn] = v;
                 }
             }
+}
+
+// ---- the tall GEMMs of a 256-wide layer: C [M x N] = A [M x K] . B with M = the batch and 128 < N, K <= 256 ----------------------------
+// (forward H . W^T and input gradient G . W of the hidden layers: 2/3 of an epoch's FLOPs).  The general kernel above stages both
+// operands through LDS 16 k at a time, two barriers per step: 0.62 of the fp32 MFMA peak.  Here a workgroup owns 64 rows and ALL
+// columns: its A tile [64 x 256] sits in LDS for the whole product (row stride 260: conflict-free 16-byte fragment reads), the
+// weights arrive as MFMA B fragments straight from L2 into registers (k_pack256 below re-packs the layer's matrix once per call:
+// 256 KB, every workgroup streams the same bytes), and the product is gemm256 of mlp_device.h -- fully unrolled, no VALU in the
+// loop, loads pinned between the MFMAs.  Two workgroups per CU: one's tile load / epilogue runs beside the other's GEMM.
+// Arithmetic of an output element: ONE fmaf chain over ascending k, like the general kernel's; deterministic, independent of M.
+__global__ __launch_bounds__(256) void k_pack256(const float* __restrict__ W, int ld, int N, int K, int trans, float4* __restrict__ P) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;       // [8 column blocks][32 k chunks][64 lanes]
+    const int lane = idx & 63, c = (idx >> 6) & 31, cb = idx >> 11;
+    const int n = 32 * cb + (lane & 31), k0 = 8 * c + (lane >> 5);     // lane half h holds k = 8c + h, + 2, + 4, + 6: MFMA step m contracts k = 8c + 2m, + 1
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + 2 * j;
+        v[j] = (n < N && k < K) ? (trans ? W[(size_t)k * ld + n] : W[(size_t)n * ld + k]) : 0.f;   // B(k, n): W[n][k] (forward) or W[k][n] (input gradient)
+    }
+    P[idx] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+constexpr int TALL_ROWS = 64;
+constexpr int TALL_BUF = TALL_ROWS * LDH * 4;        // bytes of one LDS tile [64][LDH]
+// LDS-DMA (screen_kernel.hip's idiom): 4 bytes per lane from (wave-uniform base + per-lane byte offset) to LDS [lds_dst + 4 * lane]
+// (256 B per instruction); the immediate advances the global AND the LDS address.  The lane picks WHICH element of the row lands in
+// its LDS slot, i.e. a row can arrive k-permuted.  Invisible to hipcc's s_waitcnt bookkeeping by design: completion is waited for
+// explicitly (tall_wait_all).  nt: streamed once -- the weights and the next rows keep the L2.
+template <int IMM>
+__device__ __forceinline__ void tall_dma4(const void* gbase_uniform, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 offset:%4 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(gbase_uniform), "s"(lds_dst), "n"(IMM)
+                 : "memory");
+}
+__device__ __forceinline__ void tall_wait_all() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// PERSISTENT workgroups (one per CU, 8 waves), two LDS tiles, and the WEIGHTS IN REGISTERS.  A wave owns 32 output columns for the
+// whole launch, so its 32 k-chunks of B fragments (one float4 each: 128 VGPRs) are tile-invariant: they are fetched once, and the
+// product loop of a tile contains no vector-memory instruction at all -- A fragments come from LDS, MFMAs, nothing else.  That is
+// what lets the HBM traffic overlap the product: vmcnt is an in-order counter per wave, so a wave that prefetches the next tile
+// and then waits for its next weight fragment (an L2 hit) waits for the prefetch too.  Every form of this kernel that streamed
+// its weights ran the traffic in series with the MFMAs and stayed at 0.60-0.65 of the peak (two workgroups per CU; persistent +
+// double-buffered; separate mover waves, which an MFMA stream starves of issue slots: EXPERIMENTS.md; tools/studies/tall_ablation.sh:
+// the product alone 1.00 ms, with its traffic 1.33-1.53).  Per tile: the rows of tile t + 1 arrive in the other buffer by LDS-DMA
+// (8 instructions per wave, issued before the product), the parked output of tile t - 1 leaves for C (8 x (ds_read_b128 + 16-byte
+// store) per thread, masked with the stored activation for the input gradient, which is requested a tile ahead), and ONE wait for
+// all of it stands at the top of the next tile, a whole product later.
+// Requires K == lda == 256 (a row is exactly one 1 KB DMA piece) and a 16-byte aligned A; N <= 256 arbitrary.
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void k_gemm_tall(const float* __restrict__ A, const float4* __restrict__ P, float* __restrict__ C,
+                                                      int ldc, int M, int N, const float* __restrict__ aux, int act, int ntiles, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) float Hs[];     // [2][64][LDH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(Hs);
+    const int kq = 4 * lane;
+    const bool c_vec = (ldc & 3) == 0 && (reinterpret_cast<size_t>(C) & 15) == 0 && (EPI != 2 || (reinterpret_cast<size_t>(aux) & 15) == 0);
+    // One row per call: a wave moves row p * 8 + wave of a tile -- the SAME rows in and out of a buffer, so a buffer's turn from parked
+    // output to next input needs no workgroup barrier, only this wave's own program order (read the row out, then DMA over it).
+    // The A rows arrive k-PERMUTED inside every group of 8: LDS slot 8c + 4h + j holds k = 8c + 2j + h, so that the one 16-byte
+    // fragment read of lane half h is k = 8c + h + {0, 2, 4, 6} -- MFMA step m then contracts k = 8c + 2m and 8c + 2m + 1: ASCENDING k,
+    // the fmaf chain of the general kernel above and of a plain sgemm micro-kernel (see k ORDER below).  The permutation costs nothing
+    // on the way in: LDS-DMA at 4 bytes per lane lets each lane name the element it fetches (4 instructions per row instead of 1).
+    const unsigned perm_voff = 4u * (unsigned)(8 * (lane >> 3) + 2 * (lane & 3) + ((lane >> 2) & 1));   // slot `lane` of a 64-slot piece <- this k (bytes)
+    auto fetch_half = [&](int tile, int buf, int p, int half) {   // half a row (2 pieces of 256 B) of tile -> LDS buffer buf; rows past M are zero-filled
+        if (OMDS_DBG(dbg) & 1) return;                    // experiment builds: no A traffic (the product runs on whatever the buffer holds)
+        const int row = p * 8 + wave;
+        const size_t g = (size_t)tile * TALL_ROWS + row;
+        const unsigned dst = lds0 + (unsigned)(buf * TALL_BUF + row * (LDH * 4));
+        if (g < (size_t)M) {
+            if (half == 0) { tall_dma4<0>(A + g * 256, perm_voff, dst); tall_dma4<256>(A + g * 256, perm_voff, dst); }
+            else { tall_dma4<512>(A + g * 256, perm_voff, dst); tall_dma4<768>(A + g * 256, perm_voff, dst); }
+        } else if (lane < 32) {
+            *reinterpret_cast<float4*>(Hs + buf * (TALL_ROWS * LDH) + row * LDH + 128 * half + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto aux_row = [&](int tile, int p) {                 // the stored activation the input gradient of `tile` is masked with
+        const size_t g = (size_t)tile * TALL_ROWS + p * 8 + wave;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g < (size_t)M && !(OMDS_DBG(dbg) & 4)) {
+            const float* src = aux + g * ldc + kq;
+            if (c_vec && kq + 3 < N) {
+                typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                const nt_f4 o = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(src));
+                v = make_float4(o.x, o.y, o.z, o.w);
+            } else {
+                if (kq < N) v.x = src[0];
+                if (kq + 1 < N) v.y = src[1];
+                if (kq + 2 < N) v.z = src[2];
+                if (kq + 3 < N) v.w = src[3];
+            }
+        }
+        return v;
+    };
+    auto park_read = [&](int buf, int p) {                // parked output row p * 8 + wave of buffer buf
+        return *reinterpret_cast<const float4*>(Hs + buf * (TALL_ROWS * LDH) + (p * 8 + wave) * LDH + kq);
+    };
+    auto drain_row = [&](int tile, int p, float4 v, const float4& a) {   // parked output row of `tile` (already read: v) -> C
+        if (OMDS_DBG(dbg) & 2) return;                    // experiment builds: no C traffic
+        const size_t g = (size_t)tile * TALL_ROWS + p * 8 + wave;
+        if (g >= (size_t)M) return;                       // wave-uniform
+        if constexpr (EPI == 2) {
+            if (act == 0) {
+                v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+            } else {
+                v.x *= 1.f - a.x * a.x; v.y *= 1.f - a.y * a.y; v.z *= 1.f - a.z * a.z; v.w *= 1.f - a.w * a.w;
+            }
+        }
+        float* dst = C + g * ldc + kq;
+        if (c_vec && kq + 3 < N) {                        // streamed once: non-temporal, so that the weights and the next rows keep the L2
+            typedef float nt_f4 __attribute__((ext_vector_type(4)));
+            nt_f4 o = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(o, reinterpret_cast<nt_f4*>(dst));
+        } else {
+            if (kq < N) dst[0] = v.x;
+            if (kq + 1 < N) dst[1] = v.y;
+            if (kq + 2 < N) dst[2] = v.z;
+            if (kq + 3 < N) dst[3] = v.w;
+        }
+    };
+    // this wave's B fragments, all 32 k-chunks: lane l's float4 = B(k = 8c + (l >> 5) + {0, 2, 4, 6}, n = 32 wave + (l & 31))  (k_pack256)
+    float4 wreg[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) wreg[c] = P[(size_t)wave * (32 * 64) + c * 64 + lane];
+    const int col = 32 * wave + (lane & 31);
+    float bias = 0.f;
+    if constexpr (EPI == 1) bias = col < N ? aux[col] : 0.f;
+    float4 hprev[TALL_ROWS / 8], hcur[TALL_ROWS / 8];
+#pragma unroll
+    for (int p = 0; p < TALL_ROWS / 8; ++p) hprev[p] = hcur[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int tile = blockIdx.x, prev = -1, it = 0;
+    if (tile < ntiles) {
+#pragma unroll
+        for (int p = 0; p < TALL_ROWS / 8; ++p) { fetch_half(tile, 0, p, 0); fetch_half(tile, 0, p, 1); }
+    }
+    for (; tile < ntiles; tile += gridDim.x, ++it) {
+        const int buf = it & 1;
+        tall_wait_all();                             // this tile's rows have landed, the previous tile's output is parked (and everything older has retired)
+        const int next = tile + gridDim.x;
+        f32x16 acc0, acc1;
+        float4 rd[TALL_ROWS / 8];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+        // The product, with the tile's memory traffic dealt into it one instruction per k-chunk (a CU has ONE vector-memory path:
+        // issued as a block in front of the product, the 24 instructions per wave kept the matrix pipe waiting 1.3-2.4 us per tile):
+        // chunks 0-8 send the parked rows of tile t - 1 to C (the LDS read of a row one chunk ahead of its store), chunks 9-24 request
+        // the rows of tile t + 1 over them (half a row each), chunks 25-31 request this tile's mask rows.  Nothing in here waits on vmcnt.  k order of gemm256: chunk c adds k = 8c + {0, 4, 1, 5, 2, 6, 3, 7}
+        // k ORDER: ascending -- MFMA step m of chunk c contracts k = 8c + 2m (lanes 0-31) and 8c + 2m + 1 (lanes 32-63): torch-CPU's sgemm
+        // order too, so a run of this trainer from trained ReLU weights tracks the torch run to 1e-6 in the loss over 30 epochs --
+        // near-dead units get the SAME rounding-level gradients, and Adam's first steps are lr * sign(g) whatever |g| is; in gemm256's
+        // order 8c + {0, 4, 1, 5, ...} 5 % of the weights had taken a step the other way after 5 epochs (tests/test_gpu_train.py).
+        const float* arow = Hs + buf * (TALL_ROWS * LDH) + (lane & 31) * LDH + 4 * (lane >> 5);
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const float4 a0 = *reinterpret_cast<const float4*>(arow + 8 * c);
+            const float4 a1 = *reinterpret_cast<const float4*>(arow + 32 * LDH + 8 * c);
+            const float4 w = wreg[c];
+            if (c < 8) { if (prev >= 0) rd[c] = park_read(buf ^ 1, c); }
+            if (c >= 1 && c <= 8) { if (prev >= 0) drain_row(prev, c - 1, rd[c - 1], hprev[c - 1]); }
+            else if (c >= 9 && c <= 24) { if (next < ntiles) fetch_half(next, buf ^ 1, (c - 9) >> 1, (c - 9) & 1); }
+            else if (c >= 25) {
+                if constexpr (EPI == 2) {
+                    hcur[c - 25] = aux_row(tile, c - 25);
+                    if (c == 31) hcur[7] = aux_row(tile, 7);
+                }
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, w.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, w.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, w.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, w.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, w.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, w.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, w.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, w.w, acc1, 0, 0, 0);
+        }
+        __syncthreads();                             // every wave has read the A tile: it becomes the parked output
+        if constexpr (EPI == 1) {                    // the activation switch outside the element loop (it was a branch per element)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] += bias; acc1[r] += bias; }
+            if (act == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] = fmaxf(acc0[r], 0.f); acc1[r] = fmaxf(acc1[r], 0.f); }
+            } else if (act == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] = tanhf(acc0[r]); acc1[r] = tanhf(acc1[r]); }
+            }
+        }
+        float* park = Hs + buf * (TALL_ROWS * LDH) + (4 * (lane >> 5)) * LDH + col;   // crow(r, lane) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            park[((r & 3) + 8 * (r >> 2)) * LDH] = acc0[r];
+            park[(32 + (r & 3) + 8 * (r >> 2)) * LDH] = acc1[r];
+        }
+        prev = tile;
+        if constexpr (EPI == 2) {
+#pragma unroll
+            for (int p = 0; p < TALL_ROWS / 8; ++p) hprev[p] = hcur[p];
+        }
+    }
+    __syncthreads();
+    if (prev >= 0) {
+#pragma unroll
+        for (int p = 0; p < TALL_ROWS / 8; ++p) drain_row(prev, p, park_read((it - 1) & 1, p), hprev[p]);
+    }
 }
 
 __global__ void k_sum_partials(const float* __restrict__ P, int S, size_t n, float* __restrict__ out) {
@@ -289,13 +493,42 @@ static void launch_gemm(hipStream_t s, const float* A, int lda, const float* Bm,
     hipLaunchKernelGGL((k_gemm<TA, TB, EPI>), grid, dim3(256), 0, s, A, lda, Bm, ldb, C, ldc, M, N, K, kchunk, cstride, aux, act);
 }
 
+// The tall fast path: A row-major [M x K], one output tile row per 64 rows, 128 < N, K <= 256.  W is the layer's [out x in] matrix;
+// trans = 0: B(k, n) = W[n][k] (forward, N = out, K = in); trans = 1: B(k, n) = W[k][n] (input gradient, N = in, K = out).
+// The tall fast path: A row-major [M x 256], 128 < N <= 256.  W is the layer's [out x in] matrix;
+// trans = 0: B(k, n) = W[n][k] (forward, N = out, K = in); trans = 1: B(k, n) = W[k][n] (input gradient, N = in, K = out).
+static bool tall_shape(int N, int K) { return N > 128 && N <= 256 && K == 256; }
+static float4* g_pack256[8] = {};     // one 256 KB fragment pack per device (a launch re-packs it: the weights change every step)
+template <int EPI>
+static int launch_gemm_tall(hipStream_t s, int dev, const float* A, int lda, const float* W, int ldw, int trans, float* C, int ldc, int M, int N, int K,
+                            const float* aux, int act) {
+    static bool attr_set = false;
+    static const int dbg = OMDS_EXP_ENV("OMDS_TALL_DBG", 0);   // experiment builds: 1 no A traffic, 2 no C traffic, 4 no mask traffic, 8 the general kernel instead
+    const int lds = 2 * TALL_BUF;
+    if (dbg & 8) return 1;
+    if (lda != 256 || K != 256 || (reinterpret_cast<size_t>(A) & 15) || dev < 0 || dev >= 8) return 1;   // the general kernel takes it
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tall<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tall<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tall<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    if (!g_pack256[dev] && hipMalloc(&g_pack256[dev], 8 * 32 * 64 * sizeof(float4)) != hipSuccess) return 1;
+    hipLaunchKernelGGL(k_pack256, dim3(8 * 32 * 64 / 256), dim3(256), 0, s, W, ldw, N, K, trans, g_pack256[dev]);
+    const int ntiles = (M + TALL_ROWS - 1) / TALL_ROWS;
+    hipLaunchKernelGGL((k_gemm_tall<EPI>), dim3((unsigned)std::min(ntiles, omds_cu_count())), dim3(512), lds, s, A, g_pack256[dev], C, ldc, M, N, aux, act, ntiles, dbg);
+    return 0;
+}
+
 static int forward(omds_trainer* tr, int B, const float* x) {
     hipStream_t s = tr->stream;
     const int d = tr->d;
     hipLaunchKernelGGL(k_encode, dim3((unsigned)(((size_t)B * d + 255) / 256)), dim3(256), 0, s, x, B, d, tr->H[0]);
     for (int i = 0; i < tr->L; ++i) {
         const int in = tr->dims[i], out = tr->dims[i + 1];
-        launch_gemm<false, true, 1>(s, tr->H[i], in, tr->W[i], in, tr->H[i + 1], out, B, out, in, 1, in, 0, tr->b[i], i + 1 < tr->L ? tr->act : -1);
+        const int a = i + 1 < tr->L ? tr->act : -1;
+        if (!tall_shape(out, in) || launch_gemm_tall<1>(s, tr->dev, tr->H[i], in, tr->W[i], in, 0, tr->H[i + 1], out, B, out, in, tr->b[i], a))
+            launch_gemm<false, true, 1>(s, tr->H[i], in, tr->W[i], in, tr->H[i + 1], out, B, out, in, 1, in, 0, tr->b[i], a);
     }
     TCK(hipGetLastError());   // an invalid launch configuration must not go on as a loss computed from stale buffers
     return OMDS_OK;
@@ -533,7 +766,8 @@ int omds_trainer_step(omds_trainer* tr, float lr, float beta1, float beta2, floa
         hipLaunchKernelGGL(k_colsum_partial, dim3((out + 255) / 256, rsplit), dim3(256), 0, s, G, (size_t)B, out, rows_per, tr->partial);
         hipLaunchKernelGGL(k_sum_partials, dim3((out + 255) / 256), dim3(256), 0, s, tr->partial, rsplit, (size_t)out, tr->gb[i]);
         if (i > 0) {   // gradient at this layer's input, through the activation of the layer in front
-            launch_gemm<false, false, 2>(s, G, out, tr->W[i], in, Gn, in, B, in, out, 1, out, 0, tr->H[i], tr->act);
+            if (!tall_shape(in, out) || launch_gemm_tall<2>(s, tr->dev, G, out, tr->W[i], in, 1, Gn, in, B, in, out, tr->H[i], tr->act))
+                launch_gemm<false, false, 2>(s, G, out, tr->W[i], in, Gn, in, B, in, out, 1, out, 0, tr->H[i], tr->act);
             std::swap(G, Gn);
         }
     }

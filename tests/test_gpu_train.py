@@ -69,6 +69,7 @@ def test_training_at_the_shipped_network_size_against_torch_cpu(act):
     bt = [torch.tensor(v.copy(), requires_grad=True) for v in m.b]
     opt = torch.optim.Adam(Wt + bt, lr=2e-4)
     xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+    worst = 0.0
     for e in range(30):
         h = torch.cat((xt, torch.sin(xt), torch.cos(xt)), dim=1)
         for i in range(5):
@@ -80,7 +81,11 @@ def test_training_at_the_shipped_network_size_against_torch_cpu(act):
         opt.step()
         opt.zero_grad()
         got = tr.step(lr=2e-4)
-        assert abs(got - loss.item()) <= 1e-5 * loss.item(), (e, got, loss.item())
+        # the loss BEFORE any update is the forward pass alone: 1e-5.  From the second update on, the trained ReLU weights' rounding-level
+        # gradients (below) have moved some weights by +-lr in opposite directions in the two runs, and the loss follows: 1e-4
+        # (seen 2.4e-5 at the third epoch with the 256-wide layers on gemm256's summation order, 0.9e-5 with the general kernel's)
+        worst = max(worst, abs(got - loss.item()) / loss.item())
+        assert abs(got - loss.item()) <= (1e-5 if (e < 2 or act == "tanh") else 1e-4) * loss.item(), (e, got, loss.item())
         if e + 1 in (5, 30):
             # Trained weights carry units whose gradient is at rounding level (near-dead ReLUs); Adam's first steps are
             # lr * g / |g| whatever |g| is, so two fp32 evaluations move such a weight by +-lr in different directions.
@@ -92,6 +97,7 @@ def test_training_at_the_shipped_network_size_against_torch_cpu(act):
                 err = np.concatenate([np.abs(g - r).ravel() for g, r in zip(got_l, ref_l)])
                 assert (err > bar * dmax).mean() <= 5e-3, (e + 1, float((err > bar * dmax).mean()), dmax)
                 assert err.max() <= 2.0 * 2e-4 * (e + 1), (e + 1, float(err.max()))
+    print(f"{act}: largest relative loss difference over 30 epochs {worst:.2e}")
     tr.close()
 
 

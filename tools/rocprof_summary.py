@@ -49,6 +49,18 @@ def markers(db):
     return "\n".join(out)
 
 
+def shapes(db):
+    """Per (kernel, grid) launch shape: calls and mean / min duration -- one GEMM template serves several layer shapes, which the
+    per-kernel table averages together."""
+    cur = sqlite3.connect(db).cursor()
+    out = [f"{'kernel':48s} {'grid':>22s} {'wg':>5s} {'n':>5s} {'avg_us':>10s} {'min_us':>10s}"]
+    q = ("select name, grid_x, grid_y, grid_z, workgroup_x, count(*), avg(duration)/1000.0, min(duration)/1000.0 from kernels "
+         "group by name, grid_x, grid_y, grid_z order by sum(duration) desc")
+    for r in cur.execute(q):
+        out.append(f"{r[0][:48]:48s} {str(r[1]) + 'x' + str(r[2]) + 'x' + str(r[3]):>22s} {r[4]:5d} {r[5]:5d} {r[6]:10.2f} {r[7]:10.2f}")
+    return "\n".join(out)
+
+
 if __name__ == "__main__":
     mode, db = sys.argv[1], sys.argv[2]
-    print({"stats": kernel_stats, "pmc": pmc, "markers": markers}[mode](db))
+    print({"stats": kernel_stats, "pmc": pmc, "markers": markers, "shapes": shapes}[mode](db))
