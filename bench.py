@@ -552,9 +552,11 @@ def main():
                 e2["kernels_at_block_end"] = rs["k_trace"]   # K grows from 0 inside every timed block (one add_kernel per iteration at most)
             return e2
 
+        # the other workloads and the sweeps are single-GPU context for the headline; a multi-rank run measures the headline on both paths
+        # and nothing else (every extra context would form another RCCL communicator across all ranks)
         for wl2, st2, rp2 in (("planar7_1024x32", 10, 5), ("franka_shelf_4096x32", 5, 3), ("franka_dynamic_1024x32", 20, 3),
                               ("franka_tanh_4096x32", 5, 3), ("franka_shelf_4096x64", 3, 3), ("franka_shelf_8192x32", 3, 3)):
-            if wl2 != args.workload:
+            if wl2 != args.workload and world == 1:
                 also.append(both(wl2, st2, rp2))
         if world == 1:
             # SURVEY 8d "policy state for timing": K in {0, 10, 50} (policy.py:17 N_KERNEL_MAX = 50); the primary line is K = --kernels

@@ -318,7 +318,7 @@ OMDS_API int omds_apply_update(int n_kernels, int n_dof, int horizon, const floa
  * mode: -1 auto (on for ReLU / tanh networks, with or without skip concatenations, when n_traj * n_obs >= 65536; env
  * OMDS_SCREEN=0|1 overrides), 0 off, 1 on.  eps > 0 sets the bound in place of a calibration (never recalibrated; the run-time checks
  * still widen it when they must); eps == 0 changes the mode only; eps < 0 discards the calibration (measured again at the next screened propagate).
- * omds_set_screening_audit: one_in = 0 (no audit sample) or a power of two; default 128 (DESIGN.md 4.1b has the measured cost per rate).
+ * omds_set_screening_audit: one_in = 0 (no audit sample) or a power of two; default 128 (EXPERIMENTS.md C 4.1b has the measured cost per rate).
  * omds_screen_stats: active, eps in use, largest candidate error seen since the last calibration, mean candidates per
  * (rollout, step) since the last omds_prof_reset, fp32 fallbacks since creation (NULL = skip).
  * omds_screen_audit_stats: one_in, mean audit rows per (rollout, step) since the last omds_prof_reset, largest audit error

@@ -386,7 +386,7 @@ struct SelectSink {
     int* total = nullptr;     // number of listed rows (zeroed before the launch)
     int k = 0;
     float delta = 0.f;        // tau = (k-th smallest screening value) + delta
-    // AUDIT sample (DESIGN.md 4.1b): a non-candidate pair is recorded when (hash(pair ^ audit_seed) & audit_mask) == 0 (mask
+    // AUDIT sample (DESIGN.md 4.3): a non-candidate pair is recorded when (hash(pair ^ audit_seed) & audit_mask) == 0 (mask
     // 0xffffffff: never) as (row = (step_row0 + t) * O + o, screening value) in a list of the whole propagate;
     // omds_launch_audit evaluates the list in fp32 against the layer-1 slabs of all horizon steps: max (Da - D) -> maxerr_bits[2]
     unsigned audit_mask = 0xffffffffu;

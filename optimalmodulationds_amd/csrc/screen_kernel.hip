@@ -10,7 +10,7 @@
 //   k_select  : per rollout, tau = (k-th smallest Da) + 1.25 eps; every obstacle with Da <= tau is a CANDIDATE.  If the rows
 //               that are NOT candidates have a screening error Da - D <= eps and the exact k-th smallest candidate stays eps
 //               below tau (the slack guard k_tail_sel checks from exact numbers), the exact top-k over the candidates is the
-//               exact top-k over all obstacles, ties included (proof in DESIGN.md 4.1b).  The candidates of a rollout take a
+//               exact top-k over all obstacles, ties included (proof in DESIGN.md 4.3).  The candidates of a rollout take a
 //               contiguous range of a compact list (range start, length and tau per rollout).
 //   k_exact   : the fp32 pass-1 tile code (pass1_tile, bit-identical arithmetic per row: an MFMA output element is one
 //               k-ordered fmaf chain of its own row) on the listed rows only.  Per entry it leaves the exact D and what
@@ -36,7 +36,7 @@
 //   * ReLU networks: a k-chunk (16 hidden units) whose activations are zero for all 32 pairs of the wave adds nothing to any
 //     output, so its MFMAs are not issued (a ballot per tested chunk and layer, a scalar branch per MFMA of chunks 8-15).  The
 //     host orders the units of this pack by how often they fire (capi.hip: screen_reorder), which puts the units a trained
-//     network never uses -- 300 of the shipped one's 1024 -- into whole chunks: a quarter of the MFMAs go.
+//     network never uses -- 300 of the shipped one's 1024 -- into whole chunks: a quarter of the MFMAs go (EXPERIMENTS.md C 4.1d).
 #include <algorithm>
 #include <cstdio>
 #include <vector>
@@ -149,7 +149,7 @@ __device__ __forceinline__ void wait_vm_barrier(int n) {
 
 // two fp32 pre-activations -> two fp16 activations (the next layer's B operand).  ReLU: convert, then one packed max.
 // tanh: 1 - 2 / (1 + exp(2x)) in fp32 (v_exp_f32 / v_rcp_f32: +inf and 0 give the saturated values, tanh(0) = 0 exactly), then
-// convert -- 7 VALU instructions per pair against 2 (DESIGN.md 4.1b has what that costs beside the MFMAs)
+// convert -- 7 VALU instructions per pair against 2 (EXPERIMENTS.md C 4.1b has what that costs beside the MFMAs)
 template <int ACT>
 __device__ __forceinline__ h2 act_pk(float a, float b) {
     if constexpr (ACT == OMDS_ACT_RELU) {

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
             sm.rowO[rl * k + j] = bi;
             // screened step of a tanh network: the matrix holds exact values on the candidates and screening values (all above
             // tau) elsewhere; the k smallest are exact ones, and no unevaluated row can belong among them, as long as the k-th
-            // stays e_bound below tau (the slack guard, DESIGN.md 4.1b)
+            // stays e_bound below tau (the slack guard, DESIGN.md 4.3)
             if (a.range && j == k - 1 && !(__builtin_bit_cast(float, a.range[4 * t + 2]) - a.Dmin[(size_t)t * O + bi] >= a.e_bound)) atomicAdd(a.viol, 1u);
         });
     }

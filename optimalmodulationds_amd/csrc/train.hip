@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     // The two operand tiles of a k step (128 x 16 elements each, 8 per thread; zeros outside the matrices) travel global -> registers
     // -> LDS.  The NEXT step's global loads are issued before this step's MFMAs and parked in registers, so their latency hides
     // under 32 MFMAs per wave instead of standing between two barriers (round 4: the trainer's three GEMM shapes 64-71 -> see
-    // DESIGN.md 4.8; the arithmetic of an output element is unchanged: the same products in the same k order).
+    // EXPERIMENTS.md C 4.8; the arithmetic of an output element is unchanged: the same products in the same k order).
     // Staging in 16-byte pieces (two per thread and operand): an operand stored with k contiguous (A of the forward and the input
     // gradient, B = W of the forward) is read as float4 along k -- thread (row = idx >> 2, k quad = idx & 3) -- and transposed into the
     // [k][row] tile by four scalar stores; an operand stored with its row index contiguous (G^T, H of the weight gradient, W of the

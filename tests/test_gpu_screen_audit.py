@@ -1,4 +1,4 @@
-"""GPU tests of what the screened step MEASURES about itself (csrc/capi.hip omds_propagate, DESIGN.md 4.1b): the audit sample
+"""GPU tests of what the screened step MEASURES about itself (csrc/capi.hip omds_propagate, DESIGN.md 4.3): the audit sample
 (a pseudo-random subset of the pairs that are NOT re-evaluated, drawn anew every step and evaluated in fp32 by k_audit at the
 end of the horizon loop), the
 recalibration of the bound when the scene changes, and the fp32 fallback.  Every case runs the same planner iterations on

@@ -1,7 +1,7 @@
 """Would a spatial order of the OBSTACLES let k_screen skip more? (EXPERIMENTS.md)
 
 A wave of k_screen multiplies 32 consecutive pairs t * O + o: one rollout (or the end of one and the start of the next) x 32
-consecutive obstacles.  A k-chunk of 16 hidden units is skipped when all 16 are zero for all 32 pairs (DESIGN.md 4.1; exact).  The
+consecutive obstacles.  A k-chunk of 16 hidden units is skipped when all 16 are zero for all 32 pairs (DESIGN.md 4.3; exact).  The
 hidden units are already sorted by firing frequency (screen_reorder); this study asks what the order of the obstacle axis adds:
 natural (the scene's own construction order: runs of 12 spheres along one shelf board), Morton (z-order of the sphere centres),
 k-means clusters of 32, a 1-D sort along the principal axis, and a random permutation as the floor.  States: real rollouts of the

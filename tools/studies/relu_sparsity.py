@@ -1,4 +1,4 @@
-"""How sparse the shipped distance network is under ReLU, and what a unit order buys the screening kernel: per
+"""How sparse the shipped distance network is under ReLU, and what a unit order buys the screening kernel (EXPERIMENTS.md C 4.1d): per
 hidden layer the density of the activations over states x obstacles of the shelf task, the units that never fire, and the fraction
 of 16-unit k-chunks that are zero for a whole block of 32 consecutive pairs -- natural order, sorted by firing frequency over all
 pairs, sorted by the 8 nearest obstacles only.  numpy on the oracle (test infrastructure):  python tools/studies/relu_sparsity.py"""

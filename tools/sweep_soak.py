@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Exhaustive check of the screening assumption (omds.h, "Screening of pass 1"; DESIGN.md 4.1b) over >= 1e10 (rollout, obstacle)
+"""Exhaustive check of the screening assumption (omds.h, "Screening of pass 1"; DESIGN.md 4.3) over >= 1e10 (rollout, obstacle)
 pairs: every horizon step of every propagate SWEPT -- all N x O pairs in fp32 (k_pass1) beside their fp16 screening values --
 and the difference Da - D of the pairs that were NOT candidates (never re-evaluated: the population the bound eps is about)
 counted into histograms on the device (omds_set_screening_sweep(1, all_steps=1), omds_screen_sweep_hist).

@@ -1,6 +1,6 @@
 // Microbenchmark: issue rate of v_mfma_f32_32x32x16_f16 (registers only) vs waves per SIMD and independent accumulators
 // per wave, with and without an LDS fragment read (1 KiB per wave) per MFMA or per two MFMAs -- the practical ceiling of
-// the screening kernel's inner loop (DESIGN.md 4.1b).
+// the screening kernel's inner loop (DESIGN.md 4.3).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
