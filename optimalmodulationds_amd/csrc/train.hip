@@ -450,6 +450,7 @@ struct omds_trainer {
     float* xv = nullptr; float* yv = nullptr;
     std::vector<float*> H;                 // [L + 1] activations: H[0] = encoded input ... H[L] = prediction
     float* G[2] = {nullptr, nullptr};      // gradient ping-pong [cap x max width]
+    float4* pack256 = nullptr;             // MFMA fragment pack of the layer a tall GEMM is about to multiply (k_pack256), 256 KB
     float* partial = nullptr;              // split-K partials of the weight gradient / column-sum partials
     size_t partial_floats = 0;
     double* lossp = nullptr; double* h_lossp = nullptr;
@@ -498,25 +499,25 @@ static void launch_gemm(hipStream_t s, const float* A, int lda, const float* Bm,
 // The tall fast path: A row-major [M x 256], 128 < N <= 256.  W is the layer's [out x in] matrix;
 // trans = 0: B(k, n) = W[n][k] (forward, N = out, K = in); trans = 1: B(k, n) = W[k][n] (input gradient, N = in, K = out).
 static bool tall_shape(int N, int K) { return N > 128 && N <= 256 && K == 256; }
-static float4* g_pack256[8] = {};     // one 256 KB fragment pack per device (a launch re-packs it: the weights change every step)
+// pack = the caller's 256 KB fragment buffer (one per trainer: a launch re-packs it on the trainer's own stream -- the weights change
+// every step -- so two trainers on one device never share it)
 template <int EPI>
-static int launch_gemm_tall(hipStream_t s, int dev, const float* A, int lda, const float* W, int ldw, int trans, float* C, int ldc, int M, int N, int K,
+static int launch_gemm_tall(hipStream_t s, float4* pack, const float* A, int lda, const float* W, int ldw, int trans, float* C, int ldc, int M, int N, int K,
                             const float* aux, int act) {
     static bool attr_set = false;
     static const int dbg = OMDS_EXP_ENV("OMDS_TALL_DBG", 0);   // experiment builds: 1 no A traffic, 2 no C traffic, 4 no mask traffic, 8 the general kernel instead
     const int lds = 2 * TALL_BUF;
     if (dbg & 8) return 1;
-    if (lda != 256 || K != 256 || (reinterpret_cast<size_t>(A) & 15) || dev < 0 || dev >= 8) return 1;   // the general kernel takes it
+    if (!pack || lda != 256 || K != 256 || (reinterpret_cast<size_t>(A) & 15)) return 1;   // the general kernel takes it
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tall<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tall<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tall<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    if (!g_pack256[dev] && hipMalloc(&g_pack256[dev], 8 * 32 * 64 * sizeof(float4)) != hipSuccess) return 1;
-    hipLaunchKernelGGL(k_pack256, dim3(8 * 32 * 64 / 256), dim3(256), 0, s, W, ldw, N, K, trans, g_pack256[dev]);
+    hipLaunchKernelGGL(k_pack256, dim3(8 * 32 * 64 / 256), dim3(256), 0, s, W, ldw, N, K, trans, pack);
     const int ntiles = (M + TALL_ROWS - 1) / TALL_ROWS;
-    hipLaunchKernelGGL((k_gemm_tall<EPI>), dim3((unsigned)std::min(ntiles, omds_cu_count())), dim3(512), lds, s, A, g_pack256[dev], C, ldc, M, N, aux, act, ntiles, dbg);
+    hipLaunchKernelGGL((k_gemm_tall<EPI>), dim3((unsigned)std::min(ntiles, omds_cu_count())), dim3(512), lds, s, A, pack, C, ldc, M, N, aux, act, ntiles, dbg);
     return 0;
 }
 
@@ -527,7 +528,7 @@ static int forward(omds_trainer* tr, int B, const float* x) {
     for (int i = 0; i < tr->L; ++i) {
         const int in = tr->dims[i], out = tr->dims[i + 1];
         const int a = i + 1 < tr->L ? tr->act : -1;
-        if (!tall_shape(out, in) || launch_gemm_tall<1>(s, tr->dev, tr->H[i], in, tr->W[i], in, 0, tr->H[i + 1], out, B, out, in, tr->b[i], a))
+        if (!tall_shape(out, in) || launch_gemm_tall<1>(s, tr->pack256, tr->H[i], in, tr->W[i], in, 0, tr->H[i + 1], out, B, out, in, tr->b[i], a))
             launch_gemm<false, true, 1>(s, tr->H[i], in, tr->W[i], in, tr->H[i + 1], out, B, out, in, 1, in, 0, tr->b[i], a);
     }
     TCK(hipGetLastError());   // an invalid launch configuration must not go on as a loss computed from stale buffers
@@ -593,6 +594,7 @@ int omds_trainer_create(int device, int n_linear, const int32_t* dims, int act, 
     tr->H.assign(n_linear + 1, nullptr);
     tr->partial_floats = 256 * wmax;     // up to 256 split-K partials of the largest weight gradient
     if ((e = hipMalloc(&tr->partial, tr->partial_floats * 4)) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMalloc(&tr->pack256, 8 * 32 * 64 * sizeof(float4))) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipMalloc(&tr->lossp, 1024 * 8)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipHostMalloc(&tr->h_lossp, 1024 * 8)) != hipSuccess) return fail("hipHostMalloc", e);
     (void)hipStreamSynchronize(tr->stream);
@@ -608,6 +610,7 @@ void omds_trainer_destroy(omds_trainer* tr) {
     for (auto* vec : {&tr->W, &tr->b, &tr->gW, &tr->gb, &tr->mW, &tr->mb, &tr->vW, &tr->vb})
         for (float* p : *vec) if (p) (void)hipFree(p);
     if (tr->partial) (void)hipFree(tr->partial);
+    if (tr->pack256) (void)hipFree(tr->pack256);
     if (tr->lossp) (void)hipFree(tr->lossp);
     if (tr->h_lossp) (void)hipHostFree(tr->h_lossp);
     if (tr->stream) (void)hipStreamDestroy(tr->stream);
@@ -766,7 +769,7 @@ int omds_trainer_step(omds_trainer* tr, float lr, float beta1, float beta2, floa
         hipLaunchKernelGGL(k_colsum_partial, dim3((out + 255) / 256, rsplit), dim3(256), 0, s, G, (size_t)B, out, rows_per, tr->partial);
         hipLaunchKernelGGL(k_sum_partials, dim3((out + 255) / 256), dim3(256), 0, s, tr->partial, rsplit, (size_t)out, tr->gb[i]);
         if (i > 0) {   // gradient at this layer's input, through the activation of the layer in front
-            if (!tall_shape(in, out) || launch_gemm_tall<2>(s, tr->dev, G, out, tr->W[i], in, 1, Gn, in, B, in, out, tr->H[i], tr->act))
+            if (!tall_shape(in, out) || launch_gemm_tall<2>(s, tr->pack256, G, out, tr->W[i], in, 1, Gn, in, B, in, out, tr->H[i], tr->act))
                 launch_gemm<false, false, 2>(s, G, out, tr->W[i], in, Gn, in, B, in, out, 1, out, 0, tr->H[i], tr->act);
             std::swap(G, Gn);
         }
