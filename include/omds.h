@@ -61,6 +61,9 @@ typedef struct {
 /* Keep scenes with few obstacles (O <= 32) on the two-launch k_pass1 + k_tail step instead of the one-launch fused
  * small-scene step (k_step_small) that omds_propagate picks for them by itself.                                      */
 #define OMDS_FLAG_TWO_KERNEL_STEP 2
+/* the all-fp32 step keeps its tail with a forward of its own (k_tail) instead of taking pass 2's forward from pass 1 (k_pass1 in
+ * its emitting mode + k_tail_sel: same bits, one forward less); for A/B runs and the tests that compare the two            */
+#define OMDS_FLAG_TAIL_FORWARD 4
 
 /* The constants the reference hard-codes inside propagate() (MPPI.py:117-217,277) and
  * LinDS (LinDS.py:9), as parameters; omds_default_params() fills the reference values.   */

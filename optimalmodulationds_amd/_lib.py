@@ -37,6 +37,7 @@ class OmdsParams(C.Structure):
 
 
 FLAG_UNFUSED_STEP = 1
+FLAG_TAIL_FORWARD = 4      # the fp32 step's tail keeps its own forward (omds.h: OMDS_FLAG_TAIL_FORWARD)
 FLAG_TWO_KERNEL_STEP = 2   # keep few-obstacle scenes on k_pass1 + k_tail (omds.h: OMDS_FLAG_TWO_KERNEL_STEP)   # omds_config.flags
 # omds_params.variant / cost_terms bits (include/omds.h)
 VARIANT_KVAL_TIMES_ACT = 1

@@ -128,7 +128,7 @@ static void free_all(omds_ctx* ctx) {
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
                     ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
                     ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
-                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP, ctx->d_seds, ctx->d_audit_rows, ctx->d_audit_da, ctx->d_ApreAll, ctx->d_featQAll, ctx->d_FqS, ctx->d_FpS, ctx->d_listDa, ctx->d_sinks, ctx->d_qcur, ctx->d_sweepD, ctx->d_sweepDa, ctx->d_sweep_hist, ctx->d_uev, ctx->d_exDeriv, ctx->d_scr_tmp};
+                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP, ctx->d_seds, ctx->d_audit_rows, ctx->d_audit_da, ctx->d_ApreAll, ctx->d_featQAll, ctx->d_FqS, ctx->d_FpS, ctx->d_listDa, ctx->d_sinks, ctx->d_qcur, ctx->d_sweepD, ctx->d_sweepDa, ctx->d_sweep_hist, ctx->d_uev, ctx->d_exDeriv, ctx->d_scr_tmp, ctx->d_allDr, ctx->d_allMin, ctx->d_allMask};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : ctx->mlp_allocs)
@@ -1402,6 +1402,36 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
             ctx->sweep_now = true;
             ctx->sweep_force_next = false;
         }
+        // SMALL BATCHES of the all-fp32 step of a ReLU network run without a second forward: k_pass1 in its emitting mode leaves, for
+        // EVERY pair, what pass 2's forward would compute for it (pass-2 distance, arg-min link, ReLU masks: the two forwards are
+        // bit-identical), and k_tail_sel selects from the row of Dmin and runs the backward alone.  The chain of a step loses three
+        // dependent GEMMs: integrator tick (N = 1) 0.66 -> 0.56 ms per 10-step propagate, planner defaults (N = 40) 1.02 -> 0.95.
+        // Up to 24 576 pairs only: the masks cost the pass-1 epilogue 32 ballots + 64 single-lane LDS stores per wave and layer, which
+        // a throughput-bound launch cannot hide (k_pass1 +18 % at 1024 x 294, the step 29.5 -> 33.3 ms: EXPERIMENTS.md B.5).
+        bool emit = false;
+        ExactOut ex_all{};
+        static const int emit_env = OMDS_EXP_ENV("OMDS_PASS1_EMIT", 1);   // experiment builds: 0 keeps k_tail (A/B runs)
+        if (!screen && relu && emit_env && !(ctx->cfg.flags & OMDS_FLAG_TAIL_FORWARD) && ctx->mlp.skip_mask == 0 && ctx->mlp.nhh >= 1 &&
+            omds_tail_sel_supported(n, a.k) && (long long)N * ctx->n_obs <= 24576) {
+            const long long pairs = (long long)N * ctx->cfg.max_obs;
+            const int nhid = ctx->mlp.nhh + 1;
+            if (pairs > ctx->all_cap || nhid > ctx->all_nhid) {
+                for (void** o : {(void**)&ctx->d_allDr, (void**)&ctx->d_allMin, (void**)&ctx->d_allMask}) { if (*o) (void)hipFree(*o); *o = nullptr; }
+                ctx->all_cap = 0; ctx->all_nhid = 0;
+                const size_t mask_bytes = (size_t)pairs * nhid * 32;
+                if (mask_bytes <= ((size_t)8 << 30) && hipMalloc(&ctx->d_allDr, (size_t)pairs * 4) == hipSuccess &&
+                    hipMalloc(&ctx->d_allMin, (size_t)pairs * 4) == hipSuccess && hipMalloc(&ctx->d_allMask, mask_bytes) == hipSuccess) {
+                    ctx->all_cap = pairs; ctx->all_nhid = nhid;
+                } else {
+                    (void)hipGetLastError();
+                    for (void** o : {(void**)&ctx->d_allDr, (void**)&ctx->d_allMin, (void**)&ctx->d_allMask}) { if (*o) (void)hipFree(*o); *o = nullptr; }
+                }
+            }
+            if (ctx->all_cap >= pairs && ctx->all_nhid >= nhid) {
+                emit = true;
+                ex_all = ExactOut{ctx->d_Dmin, ctx->d_allDr, ctx->d_allMin, ctx->d_allMask, (int)std::min<long long>((long long)N * ctx->n_obs, 0x7fffffffLL)};
+            }
+        }
         omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, apre0, screen ? ctx->d_FqH : nullptr, N);
 #ifdef OMDS_EXPERIMENT
         static const int corun = OMDS_EXP_ENV("OMDS_EXACT_CORUN", 0);
@@ -1449,6 +1479,10 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
                     if (!fuse_select) omds_launch_select(ctx->stream, ctx->d_Dmin, N, ctx->n_obs, sink);
                     omds_launch_exact(ctx->stream, ctx->mlp, apre_i, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
                                       ctx->prm.ignored_links, ctx->d_Dmin, ctx->d_rowlist, sink.total, ctx->d_scerr, ex);
+                } else if (emit) {   // pass 1 leaves pass 2's forward of every pair (pass1_tile mode 6): the tail runs the backward only
+                    omds_launch_pass1_emit(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
+                                           ctx->prm.ignored_links, ctx->d_Dmin, ex_all);
+                    if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs))) return rc;
                 } else {
                     omds_launch_pass1(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
                                       ctx->prm.ignored_links, ctx->d_Dmin);
@@ -1467,6 +1501,9 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
             else if (screen)
                 omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, apre_i,
                                  ctx->d_dscr, ctx->n_obs, a, 0, N, ctx->d_FqH, N, apre_next, ctx->d_range, ctx->screen_eps, ctx->d_scerr + 1);
+            else if (emit)   // top-k over the rollout's row of Dmin, masks of the k selected pairs, backward, blend, modulation, Euler step
+                omds_launch_tail_sel(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Apre, ctx->n_obs, a,
+                                     nullptr, nullptr, ex_all, nullptr, 0, 0.f, ctx->d_scerr + 1);
             else
                 omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, ctx->d_Apre,
                                  ctx->d_dscr, ctx->n_obs, a, 0, N);

@@ -342,6 +342,9 @@ struct OmdsDivisor {
 // networks with the derivative hand-over): mode 1 with the rows' activation derivatives 1 - h^2 of every hidden layer
 // (ex->deriv[(level * cap + entry) * 256 + column]: 1 KB per entry and layer, written row-wise from the tile) in place of the
 // ReLU masks -- what pass 2's forward would have left in its scratch, so that the tail runs the backward only (k_tail_sel).
+// MODE 6 (the all-fp32 step without a second forward): rows and Dmin as in mode 0, and what mode 1 leaves per list entry --
+// pass-2 distance, arg-min link, ReLU masks -- for EVERY pair, indexed by the pair (ex->dr / amin / mask [row]): the forward of
+// the k rows a rollout ends up selecting has been computed here anyway, so the tail selects from Dmin and runs the backward only.
 // The arithmetic of a row is the same in all forms and independent of the other rows of the tile: bit-identical results.
 template <int MT, int MR, int NR, int ACT, int MODE = 0>
 __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const float* __restrict__ Apre,
@@ -350,7 +353,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                                            const long long row0, const OmdsDivisor odiv,
                                            const int* __restrict__ rowlist = nullptr, unsigned* maxerr_bits = nullptr,
                                            const ExactOut* ex = nullptr) {
-    constexpr bool LIST = MODE == 1 || MODE == 3 || MODE == 4 || MODE == 5, EMIT = MODE == 1 || MODE == 2, DERIV = MODE == 5;
+    constexpr bool LIST = MODE == 1 || MODE == 3 || MODE == 4 || MODE == 5, EMIT = MODE == 1 || MODE == 2 || MODE == 6, DERIV = MODE == 5;
     constexpr bool EMITY = EMIT || DERIV;   // pass 2's distance and arg-min link per row (ex->dr, ex->amin)
     static_assert(!DERIV || MT == 16, "the derivative hand-over is written for the 16-row tiles of k_exact");
     using G = Geo<MT, MR, NR>;
@@ -686,14 +689,21 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
             const long long g = row0 + r4;
             if (g + 3 < total_rows) {
                 *reinterpret_cast<float4*>(Dmin + g) = make_float4(y[0], y[1], y[2], y[3]);   // row0 and r4 are multiples of 4
+                if constexpr (MODE == 6) {
+                    *reinterpret_cast<float4*>(ex->dr + g) = make_float4(ydr[0], ydr[1], ydr[2], ydr[3]);
+                    *reinterpret_cast<int4*>(ex->amin + g) = make_int4(yam[0], yam[1], yam[2], yam[3]);
+                }
             } else {
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg)
-                    if (g + reg < total_rows) Dmin[g + reg] = y[reg];
+                    if (g + reg < total_rows) {
+                        Dmin[g + reg] = y[reg];
+                        if constexpr (MODE == 6) { ex->dr[g + reg] = ydr[reg]; ex->amin[g + reg] = yam[reg]; }
+                    }
             }
         }
     }
-    if constexpr (MODE == 1) {   // the tile's rows are consecutive list entries: one contiguous block of masks
+    if constexpr (MODE == 1 || MODE == 6) {   // the tile's rows are consecutive entries (list entries / pairs): one contiguous block of masks
         __syncthreads();
         const long long words = (long long)((total_rows - row0 < MT) ? (total_rows - row0) : MT) * nhid * 8;
         for (int i = tid; i < words; i += G::NT) {

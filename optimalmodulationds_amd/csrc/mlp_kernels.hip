@@ -128,6 +128,32 @@ __global__ __launch_bounds__(512) void k_pass1_mixed(const float* __restrict__ A
     }
 }
 
+// The same two kernels in pass1_tile's MODE 6 (kernels of their own: the tuned mode-0 kernels keep their argument lists and code):
+// beside Dmin every pair's pass-2 distance, arg-min link and ReLU masks go to `ex`, indexed by the pair.
+template <int MT, int MR, int NR, int ACT>
+__global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1e(MlpDev m, const float* __restrict__ Apre,
+                                                                const float* __restrict__ Bpre,
+                                                                const float* __restrict__ radius, int O,
+                                                                long long total_rows, uint32_t ignored,
+                                                                float* __restrict__ Dmin, OmdsDivisor odiv, ExactOut ex) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    pass1_tile<MT, MR, NR, ACT, 6>(m, smem, Apre, Bpre, radius, O, total_rows, ignored, Dmin, (long long)blockIdx.x * MT, odiv, nullptr, nullptr, &ex);
+}
+template <int ACT>
+__global__ __launch_bounds__(512) void k_pass1e_mixed(const float* __restrict__ Apre, const float* __restrict__ Bpre,
+                                                      const float* __restrict__ radius, float* __restrict__ Dmin,
+                                                      long long total_rows, int O, uint32_t ignored, int n_big,
+                                                      OmdsDivisor odiv, MlpDev m, ExactOut ex) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    if (b < n_big) {
+        pass1_tile<64, 2, 1, ACT, 6>(m, smem, Apre, Bpre, radius, O, total_rows, ignored, Dmin, (long long)b * 64, odiv, nullptr, nullptr, &ex);
+    } else {
+        pass1_tile<32, 1, 1, ACT, 6>(m, smem, Apre, Bpre, radius, O, total_rows, ignored, Dmin,
+                                     (long long)n_big * 64 + (long long)(b - n_big) * 32, odiv, nullptr, nullptr, &ex);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // top-k (ascending, ties by lower obstacle index): one wave per rollout
 // ------------------------------------------------------------------------------------------------
@@ -275,6 +301,43 @@ void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Apre, const 
         case 6: launch_pass1_t<16, 1, 1>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
         default: launch_pass1_t<32, 1, 1>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin); break;
     }
+}
+
+// pass 1 that also leaves every pair's pass-2 distance, arg-min link and ReLU masks (pass1_tile MODE 6) -- the same tile choice as
+// omds_launch_pass1, so Dmin is the same launch shape's bits (they are the same bits in every shape anyway).  ReLU networks only.
+template <int MT, int MR, int NR>
+static void launch_pass1e_t(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
+                            int O, long long total, uint32_t ignored, float* Dmin, const ExactOut& ex) {
+    using G = Geo<MT, MR, NR>;
+    const size_t lds = (size_t)MT * LDH * 4 + (size_t)MT * 8 + (size_t)MT * (m.nhh + 1) * 32;
+    static std::atomic<uint64_t> configured{0};
+    if (omds_first_use_on_device(configured)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1e<MT, MR, NR, OMDS_ACT_RELU>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)MT * LDH * 4 + (size_t)MT * 8 + (size_t)MT * (OMDS_MAX_HIDDEN + 1) * 32));
+    }
+    const long long tiles = (total + MT - 1) / MT;
+    hipLaunchKernelGGL((k_pass1e<MT, MR, NR, OMDS_ACT_RELU>), dim3((unsigned)tiles), dim3(G::NT), lds, s, m, Apre, Bpre, radius, O,
+                       total, ignored, Dmin, OmdsDivisor::make((unsigned)O), ex);
+}
+void omds_launch_pass1_emit(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
+                            int O, int B, uint32_t ignored, float* Dmin, const ExactOut& ex) {
+    const long long total = (long long)B * O;
+    if (total <= 0) return;
+    if (total >= 64LL * 1024) {
+        const size_t lds = (size_t)64 * LDH * 4 + 64 * 8 + (size_t)64 * (m.nhh + 1) * 32;
+        static std::atomic<uint64_t> configured{0};
+        if (omds_first_use_on_device(configured)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1e_mixed<OMDS_ACT_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)((size_t)64 * LDH * 4 + 64 * 8 + (size_t)64 * (OMDS_MAX_HIDDEN + 1) * 32));
+        }
+        const long long tiles64 = total / 64, keep = 512 / 2;   // one round of 32-row tiles at the end, like omds_launch_pass1
+        const long long n_big = tiles64 > keep ? tiles64 - keep : 0;
+        const long long n_small = (total - n_big * 64 + 31) / 32;
+        hipLaunchKernelGGL((k_pass1e_mixed<OMDS_ACT_RELU>), dim3((unsigned)(n_big + n_small)), dim3(512), lds, s, Apre, Bpre, radius, Dmin,
+                           total, O, ignored, (int)n_big, OmdsDivisor::make((unsigned)O), m, ex);
+    } else if (total >= 64LL * 512) launch_pass1e_t<64, 2, 1>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin, ex);
+    else if (total <= 32LL * 128) launch_pass1e_t<16, 1, 1>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin, ex);
+    else launch_pass1e_t<32, 1, 1>(s, m, Apre, Bpre, radius, O, total, ignored, Dmin, ex);
 }
 
 void omds_launch_topk(hipStream_t s, const float* Dmin, int B, int O, int k, int32_t* idx) {

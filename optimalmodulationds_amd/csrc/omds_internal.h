@@ -166,6 +166,9 @@ struct omds_ctx {
     float* d_exDr = nullptr;
     int* d_exMin = nullptr;
     uint32_t* d_exMask = nullptr;
+    // the all-fp32 step without a second forward (pass1_tile mode 6): per PAIR what k_exact leaves per candidate
+    float* d_allDr = nullptr; int* d_allMin = nullptr; uint32_t* d_allMask = nullptr;   // [all_cap], [all_cap], [all_cap][all_nhid][8]
+    long long all_cap = 0; int all_nhid = 0;
     float* d_exDeriv = nullptr;  // tanh networks: [hidden layers][ex_cap][256] activation derivatives of the list entries (allocated by omds_set_mlp)
     int* d_sctotal = nullptr;    // [H+2]: candidate rows listed per horizon step; [H+1]: audit entries recorded in this propagate
     int* d_audit_rows = nullptr; // [audit_cap] audit sample of a propagate: pair rows into d_ApreAll's row space, their screening values
@@ -377,6 +380,9 @@ struct ExactOut {
     const float* Da = nullptr;   // audit list only (pass1_tile mode 4): [entries] screening value of each listed pair
     float* deriv = nullptr;      // tanh networks (pass1_tile mode 5): [hidden layers][cap][256] 1 - h^2 of every entry's hidden units
 };
+
+void omds_launch_pass1_emit(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
+                            int O, int B, uint32_t ignored, float* Dmin, const ExactOut& ex);
 
 // What the selection (k_select, or the flush phase of k_screen) produces per horizon step
 struct SelectSink {

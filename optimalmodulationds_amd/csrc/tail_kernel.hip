@@ -190,8 +190,11 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
     for (int rl = wave; rl < RW; rl += 8) {
         const int t = t_base + rl;
         if (t >= t_end) break;
-        const int base = a.range[4 * t], cnt = a.range[4 * t + 1];
-        const float tau = __builtin_bit_cast(float, a.range[4 * t + 2]);
+        // rowlist == nullptr: EVERY pair of the rollout is an entry and the entry index is the pair index (pass1_tile mode 6: the
+        // all-fp32 step); no window, no slack to check
+        const bool dense = a.rowlist == nullptr;
+        const int base = dense ? t * O : a.range[4 * t], cnt = dense ? O : a.range[4 * t + 1];
+        const float tau = dense ? __builtin_inff() : __builtin_bit_cast(float, a.range[4 * t + 2]);
         if (lane == 0 && cnt < k) atomicAdd(a.viol, 1u);
         if (cnt <= 64) {
             // the usual case, a few candidates: one per lane, and its rank under (D, obstacle) by comparing with every other
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
             const int e = base + lane;
             const bool have = lane < cnt && e < a.ex.cap;   // list longer than k_exact's outputs: the host redoes the propagate in fp32
             const float x = have ? a.ex.D[e] : __builtin_inff();
-            const int o = have ? a.rowlist[e] - t * O : 0x7fffffff;
+            const int o = have ? (dense ? e : a.rowlist[e]) - t * O : 0x7fffffff;
             int rank = 0;
             for (int j = 0; j < cnt; ++j) {
                 const float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), j));
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
                 const int e = base + i;
                 if (e >= a.ex.cap) break;   // list longer than k_exact's outputs: the host sees the count and redoes the propagate in fp32
                 const float x = a.ex.D[e];
-                const int o = a.rowlist[e] - t * O;
+                const int o = (dense ? e : a.rowlist[e]) - t * O;
                 const bool after = (x > pv) || (x == pv && o > po);
                 if (after && ((x < bv) || (x == bv && o < bo))) { bv = x; bo = o; be = e; }
             }

@@ -132,3 +132,43 @@ def test_small_step_declines_what_it_cannot_do():
         assert e.prof_read_ex()[3] == "k_pass1", (O, k, act)
         assert np.isfinite(e.get_rollouts()["all_traj"]).all()
         e.close()
+
+
+@pytest.mark.parametrize("N,H,k", [(1, 2, 5), (40, 10, 5), (64, 4, 3), (83, 3, 5)])
+def test_small_batches_take_pass_2s_forward_from_pass_1_and_keep_their_bits(N, H, k):
+    """Up to 24 576 pairs the all-fp32 step of a ReLU network runs k_pass1 in its emitting mode (pass1_tile mode 6: every pair's
+    pass-2 distance, arg-min link and ReLU masks beside Dmin) + k_tail_sel (backward only) instead of k_pass1 + k_tail (its own
+    forward): the same numbers bit for bit as the context that keeps k_tail (OMDS_FLAG_TAIL_FORWARD)."""
+    from optimalmodulationds_amd import scenes, _lib
+    from optimalmodulationds_amd.cost import FRANKA_Q_MAX, FRANKA_Q_MIN
+    from optimalmodulationds_amd.engine import Engine
+    m = orc.Mlp.from_npz(weights_path("franka"))
+    obs = scenes.shelf_scene()
+    K = 6
+    rng = np.random.RandomState(N)
+    mu_c = (scenes.FRANKA_Q0 + 0.2 * rng.standard_normal((K, 7))).astype(np.float32)
+    sg_c, al_c = np.ones(K, np.float32), rng.standard_normal((K, 7)).astype(np.float32)
+    q = (scenes.FRANKA_Q0 + 0.3 * rng.standard_normal((N, 7))).astype(np.float32)
+    outs = []
+    for flags in (0, _lib.FLAG_TAIL_FORWARD):
+        e = Engine(7, N, H, k, max_obs=296, flags=flags)
+        e.set_mlp(m.W, m.b)
+        e.set_obstacles(obs)
+        e.set_screening(0)
+        e.params.dt, e.params.dst_thr, e.params.ignored_links = 0.5, 0.01, 0b111
+        e.push_params()
+        e.set_ds(scenes.FRANKA_QF)
+        e.set_cost(scenes.franka_dh_params(), np.array(FRANKA_Q_MIN, np.float32), np.array(FRANKA_Q_MAX, np.float32))
+        e.sample_policy(mu_c, sg_c, al_c, 0.0, 0.0, 3.0, K, seed=3)
+        e.propagate(q)
+        r = e.get_rollouts()
+        e.set_obstacles(obs[::3])               # another obstacle count on the same context: the per-pair buffers follow
+        e.propagate(q)
+        r2 = e.get_rollouts()
+        outs.append((r, r2, e.cost()))
+        e.close()
+    for a, b in zip(outs[0][:2], outs[1][:2]):
+        for key in a:
+            assert np.array_equal(a[key], b[key]), key
+    assert np.array_equal(outs[0][2], outs[1][2])
+    assert np.isfinite(outs[0][0]["all_traj"]).all()
