@@ -355,6 +355,199 @@ __global__ __launch_bounds__(512, 1) void k_gemm_tall(const float* __restrict__ 
     }
 }
 
+// ---- the thin products at the two ends of the network: C [M x N] = A [M x K] . B with K <= 32 (the encoded input, 3 d = 12 / 30 wide, into the
+// first hidden layer; the output gradient, C = 2 / 9 wide, back into the last hidden layer) ----------------------------------------------------
+// Pure streaming: 1 GB of output (and, for the input gradient, 1 GB of mask) per million rows against 6 GFLOP.  The general kernel moves its
+// 128 x 128 tiles through the MFMA machinery for one or two k steps and reaches 1.7-2.3 TB/s; here a thread owns one output COLUMN, keeps that
+// column's K weights in registers, and walks down the rows of its workgroup's chunk: the A rows of a chunk sit in LDS (every lane reads the same
+// address: a broadcast), one fmaf per k in ASCENDING k from a zero accumulator -- the chain of the MFMA kernels, bit for bit -- then the same
+// epilogue (EPI 1: + bias, activation; EPI 2: x act'(stored activation)), one coalesced 1 KB store per row and wave quartet.
+constexpr int THIN_KMAX = 32, THIN_ROWS = 64;
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_thin(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, int trans,
+                                                   float* __restrict__ C, int ldc, int M, int N, int K, const float* __restrict__ aux, int act) {
+    __shared__ __attribute__((aligned(16))) float As[THIN_ROWS][THIN_KMAX];
+    const int n = threadIdx.x;                       // this thread's output column
+    const bool live = n < N;
+    float w[THIN_KMAX];
+#pragma unroll
+    for (int k = 0; k < THIN_KMAX; ++k) w[k] = (live && k < K) ? (trans ? W[(size_t)k * ldw + n] : W[(size_t)n * ldw + k]) : 0.f;   // B(k, n)
+    float bias = 0.f;
+    if constexpr (EPI == 1) bias = live ? aux[n] : 0.f;
+    const int K4 = (K + 3) & ~3;
+    for (size_t m0 = (size_t)blockIdx.x * THIN_ROWS; m0 < (size_t)M; m0 += (size_t)gridDim.x * THIN_ROWS) {
+        __syncthreads();                             // the previous chunk has been consumed
+        for (int i = threadIdx.x; i < THIN_ROWS * K4; i += 256) {
+            const int r = i / K4, k = i - r * K4;
+            As[r][k] = (m0 + r < (size_t)M && k < K) ? A[(m0 + r) * lda + k] : 0.f;
+        }
+        __syncthreads();
+        const int rows = (int)((size_t)M - m0 < THIN_ROWS ? (size_t)M - m0 : THIN_ROWS);
+        for (int r = 0; r < rows; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < THIN_KMAX / 4; ++k4) {
+                if (4 * k4 < K4) {                   // uniform
+                    const float4 a = *reinterpret_cast<const float4*>(&As[r][4 * k4]);
+                    acc = fmaf(a.x, w[4 * k4], acc);
+                    acc = fmaf(a.y, w[4 * k4 + 1], acc);
+                    acc = fmaf(a.z, w[4 * k4 + 2], acc);
+                    acc = fmaf(a.w, w[4 * k4 + 3], acc);
+                }
+            }
+            if (live) {
+                float v = acc;
+                const size_t o = (m0 + r) * ldc + n;
+                if constexpr (EPI == 1) {
+                    v += bias;
+                    v = act == 0 ? fmaxf(v, 0.f) : (act == 1 ? tanhf(v) : v);
+                } else if constexpr (EPI == 2) {
+                    const float h = __builtin_nontemporal_load(aux + o);
+                    v = act == 0 ? (h > 0.f ? v : 0.f) : v * (1.f - h * h);
+                }
+                __builtin_nontemporal_store(v, C + o);
+            }
+        }
+    }
+}
+
+// The thin-OUTPUT forward (the last layer, 256 -> C = 2 / 9): out [M x N] = A [M x K] . W^T + bias with N <= 16, K <= 256.  Streams A once (1 GB
+// per million rows; the general kernel reads it at 1.7 TB/s through 128-column tiles of which 2 columns are real).  A chunk of 32 rows sits in LDS
+// (row stride 260: conflict-free 16-byte reads down the rows), the whole W beside it; thread (row, group g) computes outputs g, g + 4, ... of its
+// row as fmaf chains in ASCENDING k from zero, then + bias (and the activation, if the layer has one): the general kernel's bits.
+constexpr int THINN_ROWS = 32, THINN_NMAX = 16;
+__global__ __launch_bounds__(128) void k_gemm_thin_out(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* __restrict__ C,
+                                                       int ldc, int M, int N, int K, const float* __restrict__ bias, int act) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* As = sm;                                   // [32][LDH]
+    float* Ws = sm + THINN_ROWS * LDH;                // [N][LDH]
+    const int tid = threadIdx.x, row = tid & 31, g = tid >> 5;
+    const int K4 = (K + 3) & ~3;
+    for (int i = tid; i < N * LDH; i += 128) { const int n = i / LDH, k = i - n * LDH; Ws[i] = k < K ? W[(size_t)n * ldw + k] : 0.f; }
+    const bool vec = (lda & 3) == 0 && (reinterpret_cast<size_t>(A) & 15) == 0 && (K & 3) == 0;
+    for (size_t m0 = (size_t)blockIdx.x * THINN_ROWS; m0 < (size_t)M; m0 += (size_t)gridDim.x * THINN_ROWS) {
+        __syncthreads();
+        for (int i = tid; i < THINN_ROWS * (K4 / 4); i += 128) {
+            const int r = i / (K4 / 4), k = 4 * (i - r * (K4 / 4));
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + r < (size_t)M) {
+                const float* src = A + (m0 + r) * lda + k;
+                if (vec) {
+                    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                    const nt_f4 o = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(src));
+                    v = make_float4(o.x, o.y, o.z, o.w);
+                } else {
+                    if (k < K) v.x = src[0];
+                    if (k + 1 < K) v.y = src[1];
+                    if (k + 2 < K) v.z = src[2];
+                    if (k + 3 < K) v.w = src[3];
+                }
+            }
+            *reinterpret_cast<float4*>(As + r * LDH + k) = v;
+        }
+        __syncthreads();
+        if (m0 + row >= (size_t)M) continue;
+        float acc[THINN_NMAX / 4];
+#pragma unroll
+        for (int u = 0; u < THINN_NMAX / 4; ++u) acc[u] = 0.f;
+        for (int k = 0; k < K4; k += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(As + row * LDH + k);
+#pragma unroll
+            for (int u = 0; u < THINN_NMAX / 4; ++u) {
+                const int n = g + 4 * u;
+                if (n < N) {
+                    const float4 w = *reinterpret_cast<const float4*>(Ws + n * LDH + k);
+                    acc[u] = fmaf(a.x, w.x, acc[u]);
+                    acc[u] = fmaf(a.y, w.y, acc[u]);
+                    acc[u] = fmaf(a.z, w.z, acc[u]);
+                    acc[u] = fmaf(a.w, w.w, acc[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < THINN_NMAX / 4; ++u) {
+            const int n = g + 4 * u;
+            if (n < N) {
+                float v = acc[u] + bias[n];
+                v = act == 0 ? fmaxf(v, 0.f) : (act == 1 ? tanhf(v) : v);
+                C[(m0 + row) * ldc + n] = v;
+            }
+        }
+    }
+}
+
+// The thin weight gradients (the first layer's dW [256 x 3 d], the last layer's dW [C x 256]): one of the two matrices of dW = G^T . H is at most 32
+// wide.  The contraction runs over the batch in the SAME chunks as the general kernel's split (blockIdx.y = chunk z), every (z, wide column, thin
+// column) sum is one fmaf chain over the chunk's rows in ascending order from zero -- the general kernel's partials bit for bit, summed by the same
+// k_sum_partials -- but the wide matrix streams through once, coalesced, 16 rows in flight per lane, instead of through MFMA tiles that are 90 %
+// padding.  thin_is_n: the thin matrix indexes dW's columns (first layer: Y = H, X = G), else its rows (last layer: Y = G, X = H).
+constexpr int WG_TMAX = 32, WG_YROWS = 256, WG_BATCH = 32;
+// (256 chunks x 256 columns are 1024 waves, one per SIMD: nothing hides a wave's own load latency but the wave itself -- the next batch of 32 rows
+// is requested before the current one is multiplied, and a batch's thin rows are read from LDS one row ahead.)
+template <int TT>
+__global__ __launch_bounds__(256) void k_wgrad_thin(const float* __restrict__ X, int ldx, int Wd, const float* __restrict__ Y, int ldy, int T,
+                                                    int thin_is_n, float* __restrict__ P, int B, int kchunk, size_t cstride, int ldp) {
+    __shared__ __attribute__((aligned(16))) float Ys[WG_YROWS][TT];
+    const int c = blockIdx.x * 256 + threadIdx.x;    // wide column
+    const bool live = c < Wd;
+    const int z = blockIdx.y;
+    const int r_begin = z * kchunk, r_end = min(B, r_begin + kchunk);
+    float acc[TT];
+#pragma unroll
+    for (int j = 0; j < TT; ++j) acc[j] = 0.f;
+    const float* Xc = X + (live ? c : 0);
+    auto fetch = [&](float (&x)[WG_BATCH], int row0, int rows_left) {   // rows row0 .. of column c; past the end: zeros (they multiply zeros of Ys)
+#pragma unroll
+        for (int u = 0; u < WG_BATCH; ++u) x[u] = (live && u < rows_left) ? __builtin_nontemporal_load(Xc + (size_t)(row0 + u) * ldx) : 0.f;
+    };
+    auto multiply = [&](const float (&x)[WG_BATCH], int yrow0, int rows_left) {
+#pragma unroll
+        for (int u = 0; u < WG_BATCH; ++u) {
+            if (u < rows_left) {                     // uniform
+#pragma unroll
+                for (int j4 = 0; j4 < TT / 4; ++j4) {
+                    const float4 y = *reinterpret_cast<const float4*>(&Ys[yrow0 + u][4 * j4]);
+                    acc[4 * j4] = fmaf(x[u], y.x, acc[4 * j4]);
+                    acc[4 * j4 + 1] = fmaf(x[u], y.y, acc[4 * j4 + 1]);
+                    acc[4 * j4 + 2] = fmaf(x[u], y.z, acc[4 * j4 + 2]);
+                    acc[4 * j4 + 3] = fmaf(x[u], y.w, acc[4 * j4 + 3]);
+                }
+            }
+        }
+    };
+    float xa[WG_BATCH], xb[WG_BATCH];
+    fetch(xa, r_begin, r_end - r_begin);
+    for (int r0 = r_begin; r0 < r_end; r0 += WG_YROWS) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < WG_YROWS * TT; i += 256) {
+            const int r = i / TT, j = i - r * TT;
+            Ys[r][j] = (r0 + r < r_end && j < T) ? Y[(size_t)(r0 + r) * ldy + j] : 0.f;
+        }
+        __syncthreads();
+        const int rows = min(WG_YROWS, r_end - r0);
+        for (int rb = 0; rb < rows; rb += 2 * WG_BATCH) {        // two batches per trip: xa and xb swap roles without copies
+            fetch(xb, r0 + rb + WG_BATCH, r_end - (r0 + rb + WG_BATCH));
+            multiply(xa, rb, rows - rb);
+            fetch(xa, r0 + rb + 2 * WG_BATCH, r_end - (r0 + rb + 2 * WG_BATCH));
+            multiply(xb, rb + WG_BATCH, rows - rb - WG_BATCH);
+        }
+    }
+    if (live) {
+        float* Pz = P + (size_t)z * cstride;
+#pragma unroll
+        for (int j = 0; j < TT; ++j)
+            if (j < T) Pz[thin_is_n ? (size_t)c * ldp + j : (size_t)j * ldp + c] = acc[j];
+    }
+}
+static void launch_wgrad_thin(hipStream_t s, int wide_blocks, int splits, const float* X, int ldx, int Wd, const float* Y, int ldy, int T, int thin_is_n,
+                              float* P, int B, int kchunk, size_t cstride, int ldp) {
+    const dim3 grid(wide_blocks, splits);
+    if (T <= 4) hipLaunchKernelGGL(k_wgrad_thin<4>, grid, dim3(256), 0, s, X, ldx, Wd, Y, ldy, T, thin_is_n, P, B, kchunk, cstride, ldp);
+    else if (T <= 12) hipLaunchKernelGGL(k_wgrad_thin<12>, grid, dim3(256), 0, s, X, ldx, Wd, Y, ldy, T, thin_is_n, P, B, kchunk, cstride, ldp);
+    else if (T <= 16) hipLaunchKernelGGL(k_wgrad_thin<16>, grid, dim3(256), 0, s, X, ldx, Wd, Y, ldy, T, thin_is_n, P, B, kchunk, cstride, ldp);
+    else hipLaunchKernelGGL(k_wgrad_thin<32>, grid, dim3(256), 0, s, X, ldx, Wd, Y, ldy, T, thin_is_n, P, B, kchunk, cstride, ldp);
+}
+
 __global__ void k_sum_partials(const float* __restrict__ P, int S, size_t n, float* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -521,6 +714,16 @@ static int launch_gemm_tall(hipStream_t s, float4* pack, const float* A, int lda
     return 0;
 }
 
+static bool thin_off() { static const int dbg = OMDS_EXP_ENV("OMDS_TALL_DBG", 0); return (dbg & 16) != 0; }   // experiment builds: bit 16 = the general kernel everywhere
+template <int EPI>
+static bool launch_gemm_thin(hipStream_t s, const float* A, int lda, const float* W, int ldw, int trans, float* C, int ldc, int M, int N, int K,
+                             const float* aux, int act) {
+    if (K > THIN_KMAX || N > 256 || N < 64 || M < 1 || thin_off()) return false;   // (N < 64: the thin-output products have a kernel of their own)
+    const int chunks = (M + THIN_ROWS - 1) / THIN_ROWS;
+    hipLaunchKernelGGL((k_gemm_thin<EPI>), dim3((unsigned)std::min(chunks, 8 * omds_cu_count())), dim3(256), 0, s, A, lda, W, ldw, trans, C, ldc, M, N, K, aux, act);
+    return true;
+}
+
 static int forward(omds_trainer* tr, int B, const float* x) {
     hipStream_t s = tr->stream;
     const int d = tr->d;
@@ -528,6 +731,16 @@ static int forward(omds_trainer* tr, int B, const float* x) {
     for (int i = 0; i < tr->L; ++i) {
         const int in = tr->dims[i], out = tr->dims[i + 1];
         const int a = i + 1 < tr->L ? tr->act : -1;
+        if (launch_gemm_thin<1>(s, tr->H[i], in, tr->W[i], in, 0, tr->H[i + 1], out, B, out, in, tr->b[i], a)) continue;
+        if (out <= THINN_NMAX && in <= 256 && in > THIN_KMAX && !thin_off()) {   // the thin-output layer
+            static bool attr = false;
+            const int lds = (THINN_ROWS + THINN_NMAX) * LDH * 4;
+            if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_thin_out), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+            const int chunks = (B + THINN_ROWS - 1) / THINN_ROWS;
+            hipLaunchKernelGGL(k_gemm_thin_out, dim3((unsigned)std::min(chunks, 12 * omds_cu_count())), dim3(128), (THINN_ROWS + out) * LDH * 4, s, tr->H[i], in, tr->W[i], in,
+                               tr->H[i + 1], out, B, out, in, tr->b[i], a);
+            continue;
+        }
         if (!tall_shape(out, in) || launch_gemm_tall<1>(s, tr->pack256, tr->H[i], in, tr->W[i], in, 0, tr->H[i + 1], out, B, out, in, tr->b[i], a))
             launch_gemm<false, true, 1>(s, tr->H[i], in, tr->W[i], in, tr->H[i + 1], out, B, out, in, 1, in, 0, tr->b[i], a);
     }
@@ -761,7 +974,13 @@ int omds_trainer_step(omds_trainer* tr, float lr, float beta1, float beta2, floa
         while ((size_t)splits * out * in > tr->partial_floats) --splits;
         int kchunk = ((B + splits - 1) / splits + TK - 1) / TK * TK;
         splits = (B + kchunk - 1) / kchunk;
-        launch_gemm<true, false, 0>(s, G, out, tr->H[i], in, tr->partial, in, out, in, B, splits, kchunk, (size_t)out * in);
+        // (the thin kernels keep the general kernel's chunk boundaries: the same partial sums, summed in the same order)
+        if (in <= WG_TMAX && out <= 4096 && out > WG_TMAX && !thin_off())        // first layer: thin = H_i [B x in] (dW's columns), wide = G [B x out]
+            launch_wgrad_thin(s, (out + 255) / 256, splits, G, out, out, tr->H[i], in, in, 1, tr->partial, B, kchunk, (size_t)out * in, in);
+        else if (out <= WG_TMAX && in <= 4096 && in > WG_TMAX && !thin_off())    // last layer: thin = G [B x out] (dW's rows), wide = H_i [B x in]
+            launch_wgrad_thin(s, (in + 255) / 256, splits, tr->H[i], in, in, G, out, out, 0, tr->partial, B, kchunk, (size_t)out * in, in);
+        else
+            launch_gemm<true, false, 0>(s, G, out, tr->H[i], in, tr->partial, in, out, in, B, splits, kchunk, (size_t)out * in);
         hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)(((size_t)out * in + 255) / 256)), dim3(256), 0, s, tr->partial, splits, (size_t)out * in, tr->gW[i]);
         // db = column sums of G
         const int rsplit = std::max(1, std::min({2048, B / 256, (int)(tr->partial_floats / (size_t)out)}));
@@ -769,6 +988,7 @@ int omds_trainer_step(omds_trainer* tr, float lr, float beta1, float beta2, floa
         hipLaunchKernelGGL(k_colsum_partial, dim3((out + 255) / 256, rsplit), dim3(256), 0, s, G, (size_t)B, out, rows_per, tr->partial);
         hipLaunchKernelGGL(k_sum_partials, dim3((out + 255) / 256), dim3(256), 0, s, tr->partial, rsplit, (size_t)out, tr->gb[i]);
         if (i > 0) {   // gradient at this layer's input, through the activation of the layer in front
+            if (launch_gemm_thin<2>(s, G, out, tr->W[i], in, 1, Gn, in, B, in, out, tr->H[i], tr->act)) { std::swap(G, Gn); continue; }
             if (!tall_shape(in, out) || launch_gemm_tall<2>(s, tr->pack256, G, out, tr->W[i], in, 1, Gn, in, B, in, out, tr->H[i], tr->act))
                 launch_gemm<false, false, 2>(s, G, out, tr->W[i], in, Gn, in, B, in, out, 1, out, 0, tr->H[i], tr->act);
             std::swap(G, Gn);
