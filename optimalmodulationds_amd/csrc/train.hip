@@ -12,6 +12,7 @@
 // 64 x 64 output tiles, 4 waves, v_mfma_f32_32x32x2_f32 (an fmaf chain in k order, tools/ubench/mfma_order.hip), operands staged
 // through LDS 16 k at a time with either operand read transposed.  Everything else of a step is elementwise or a column sum.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -697,16 +698,15 @@ static bool tall_shape(int N, int K) { return N > 128 && N <= 256 && K == 256; }
 template <int EPI>
 static int launch_gemm_tall(hipStream_t s, float4* pack, const float* A, int lda, const float* W, int ldw, int trans, float* C, int ldc, int M, int N, int K,
                             const float* aux, int act) {
-    static bool attr_set = false;
+    static std::atomic<uint64_t> configured{0};    // per device: function attributes belong to the device the kernel is loaded on
     static const int dbg = OMDS_EXP_ENV("OMDS_TALL_DBG", 0);   // experiment builds: 1 no A traffic, 2 no C traffic, 4 no mask traffic, 8 the general kernel instead
     const int lds = 2 * TALL_BUF;
     if (dbg & 8) return 1;
     if (!pack || lda != 256 || K != 256 || (reinterpret_cast<size_t>(A) & 15)) return 1;   // the general kernel takes it
-    if (!attr_set) {
+    if (omds_first_use_on_device(configured)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tall<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tall<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tall<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL(k_pack256, dim3(8 * 32 * 64 / 256), dim3(256), 0, s, W, ldw, N, K, trans, pack);
     const int ntiles = (M + TALL_ROWS - 1) / TALL_ROWS;
@@ -733,9 +733,9 @@ static int forward(omds_trainer* tr, int B, const float* x) {
         const int a = i + 1 < tr->L ? tr->act : -1;
         if (launch_gemm_thin<1>(s, tr->H[i], in, tr->W[i], in, 0, tr->H[i + 1], out, B, out, in, tr->b[i], a)) continue;
         if (out <= THINN_NMAX && in <= 256 && in > THIN_KMAX && !thin_off()) {   // the thin-output layer
-            static bool attr = false;
+            static std::atomic<uint64_t> configured{0};
             const int lds = (THINN_ROWS + THINN_NMAX) * LDH * 4;
-            if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_thin_out), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+            if (omds_first_use_on_device(configured)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_thin_out), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             const int chunks = (B + THINN_ROWS - 1) / THINN_ROWS;
             hipLaunchKernelGGL(k_gemm_thin_out, dim3((unsigned)std::min(chunks, 12 * omds_cu_count())), dim3(128), (THINN_ROWS + out) * LDH * 4, s, tr->H[i], in, tr->W[i], in,
                                tr->H[i + 1], out, B, out, in, tr->b[i], a);
