@@ -315,7 +315,8 @@ OMDS_API int omds_apply_update(int n_kernels, int n_dof, int horizon, const floa
  * screening until the next calibration.  A row outside the audit sample whose error exceeds eps can still go unseen in
  * one propagate: at run time the identity is measured on a sample, not proven.  What the sample stands on: the exhaustive count of
  * tools/sweep_soak.py -- every horizon step of 5 183 propagates swept, 1.93e11 pairs over ten scene / network legs, none of the
- * 1.87e11 unevaluated pairs above eps / 2, the worst at 0.197 eps (profiles/r04_screen_error_hist.txt; the survival function of
+ * 1.87e11 unevaluated pairs above eps / 2, the worst at 0.197 eps (profiles/r04_screen_error_hist.txt; the round-5 build: 2.4e11 more pairs, none above eps / 2, worst 0.182 eps,
+ * profiles/r05_screen_error_hist.txt; the survival function of
  * (Da - D) / eps falls by half a decade or more per 1/128).  A caller who wants the reference's arithmetic on every row regardless calls
  * omds_set_screening(ctx, 0, 0).
  * mode: -1 auto (on for ReLU / tanh networks, with or without skip concatenations, when n_traj * n_obs >= 65536; env
