@@ -23,6 +23,8 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
+from . import chain
+
 F32 = np.float32
 FLT_MAX = np.finfo(np.float32).max
 
@@ -62,8 +64,14 @@ def _dact(z, h, act):
 
 
 def positional_encoding(x):
-    """x -> [x, sin x, cos x]  (ML/network_macros_mod.py:139-140)."""
-    return np.concatenate((x, np.sin(x), np.cos(x)), axis=-1).astype(F32)
+    """x -> [x, sin x, cos x]  (ML/network_macros_mod.py:139-140), sin / cos as oracle/chain_arith.c restates them."""
+    x = np.asarray(x, dtype=F32)
+    return np.concatenate((x, chain.sin(x), chain.cos(x)), axis=-1).astype(F32)
+
+
+def linear(h, W, b):
+    """nn.Linear as torch-CPU computes it: ascending-k fmaf chains from zero, bias last (oracle/chain_arith.c)."""
+    return chain.linear(h, W, b)
 
 
 def mlp_forward(m: Mlp, x):
@@ -72,10 +80,10 @@ def mlp_forward(m: Mlp, x):
     feats = positional_encoding(np.asarray(x, dtype=F32))
     h = feats
     for i in range(len(m.W) - 1):
-        h = _act(h @ m.W[i].T + m.b[i], m.act)
+        h = _act(linear(h, m.W[i], m.b[i]), m.act)
         if i in m.skip_after:
             h = np.concatenate((h, feats), axis=1)
-    return (h @ m.W[-1].T + m.b[-1]).astype(F32)
+    return linear(h, m.W[-1], m.b[-1])
 
 
 def mlp_vjp_argmin(m: Mlp, x, seed=None):
@@ -87,11 +95,11 @@ def mlp_vjp_argmin(m: Mlp, x, seed=None):
     feats = positional_encoding(x)
     hs, zs, cur = [feats], [], feats
     for i in range(len(m.W) - 1):
-        z = cur @ m.W[i].T + m.b[i]
+        z = linear(cur, m.W[i], m.b[i])
         zs.append(z)
         hs.append(_act(z, m.act))
         cur = np.concatenate((hs[-1], feats), axis=1) if i in m.skip_after else hs[-1]
-    y = (cur @ m.W[-1].T + m.b[-1]).astype(F32)
+    y = linear(cur, m.W[-1], m.b[-1])
     min_idx = np.argmin(y, axis=1) if seed is None else np.asarray(seed, dtype=np.int64)
     g = m.W[-1][min_idx]                                     # dy/d(input of the last layer)  [B, width]
     g_feat = np.zeros_like(feats)                            # direct paths into the encoded input (skip concatenations)
@@ -100,9 +108,9 @@ def mlp_vjp_argmin(m: Mlp, x, seed=None):
             w = hs[i + 1].shape[1]
             g_feat = g_feat + g[:, w:]
             g = g[:, :w]
-        g = (g * _dact(zs[i], hs[i + 1], m.act)) @ m.W[i]    # -> grad wrt layer i input
+        g = chain.matmul((g * _dact(zs[i], hs[i + 1], m.act)).astype(F32), m.W[i])    # -> grad wrt layer i input
     g = g + g_feat
-    grad = g[:, :d] + g[:, d:2 * d] * np.cos(x) - g[:, 2 * d:] * np.sin(x)
+    grad = g[:, :d] + g[:, d:2 * d] * chain.cos(x) - g[:, 2 * d:] * chain.sin(x)
     return y, grad.astype(F32), min_idx
 
 
@@ -383,7 +391,7 @@ def relu_margin(m: Mlp, x):
         return marg                      # smooth activation: no masks to flip
     feats = h
     for i in range(len(m.W) - 1):
-        z = h @ m.W[i].T + m.b[i]
+        z = linear(h, m.W[i], m.b[i])
         az = np.abs(z)
         marg = np.minimum(marg, az.min(axis=1) / np.maximum(az.max(axis=1), F32(1e-30)))
         h = _act(z, m.act)
@@ -417,11 +425,11 @@ def blended_gradient_alternatives(m: Mlp, q_row, obs, idx_row, margin, softmax_k
     feats = positional_encoding(x)
     hs, zs, cur = [feats], [], feats
     for i in range(len(m.W) - 1):
-        z = cur @ m.W[i].T + m.b[i]
+        z = linear(cur, m.W[i], m.b[i])
         zs.append(z)
         hs.append(_act(z, m.act))
         cur = np.concatenate((hs[-1], feats), axis=1) if i in m.skip_after else hs[-1]
-    y = (cur @ m.W[-1].T + m.b[-1]).astype(F32)
+    y = linear(cur, m.W[-1], m.b[-1])
     min_idx = np.argmin(y, axis=1)
     yd = y / F32(100) if m.out_channels == 9 else y
     dist = (yd - np.asarray(obs, dtype=F32)[np.asarray(idx_row), 3:4])[np.arange(k), min_idx]
@@ -442,9 +450,9 @@ def blended_gradient_alternatives(m: Mlp, q_row, obs, idx_row, margin, softmax_k
             if i in m.skip_after:
                 g_feat = g_feat + g[:, hs[i + 1].shape[1]:]
                 g = g[:, :hs[i + 1].shape[1]]
-            g = (g * masks[i]) @ m.W[i]
+            g = chain.matmul((g * masks[i]).astype(F32), m.W[i])
         g = g + g_feat
-        gx = g[:, :d] + g[:, d:2 * d] * np.cos(x) - g[:, 2 * d:] * np.sin(x)
+        gx = g[:, :d] + g[:, d:2 * d] * chain.cos(x) - g[:, 2 * d:] * chain.sin(x)
         return (gx[:, :n_dof].astype(F32) * w[:, None]).sum(axis=0).astype(F32)
 
     out = [grad_with(masks0)]
