@@ -124,11 +124,11 @@ const char* omds_last_error(const omds_ctx* ctx) { return ctx ? ctx->err.c_str()
 
 static void free_all(omds_ctx* ctx) {
     omds_comm_release(ctx);
-    void* ptrs[] = {ctx->d_obs, ctx->d_Bpre, ctx->d_radius, ctx->d_trajT, ctx->d_distT, ctx->d_dotT, ctx->d_actT,
+    void* ptrs[] = {ctx->d_obs, ctx->d_Fp, ctx->d_radius, ctx->d_trajT, ctx->d_distT, ctx->d_dotT, ctx->d_actT,
                     ctx->d_normalT, ctx->d_kvalT, ctx->d_qdotT, ctx->d_maxact, ctx->d_phisum0, ctx->d_qstage,
-                    ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Apre, ctx->d_Dmin, ctx->d_idx,
+                    ctx->d_muT, ctx->d_sigmaT, ctx->d_alphaT, ctx->d_means, ctx->d_Fq, ctx->d_Dmin, ctx->d_idx,
                     ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dist, ctx->d_nngrad, ctx->d_cost,
-                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_featQ, ctx->d_featP, ctx->d_seds, ctx->d_audit_rows, ctx->d_audit_da, ctx->d_ApreAll, ctx->d_featQAll, ctx->d_FqS, ctx->d_FpS, ctx->d_listDa, ctx->d_sinks, ctx->d_qcur, ctx->d_sweepD, ctx->d_sweepDa, ctx->d_sweep_hist, ctx->d_uev, ctx->d_exDeriv, ctx->d_scr_tmp, ctx->d_allDr, ctx->d_allMin, ctx->d_allMask};
+                    ctx->d_w, ctx->d_red, ctx->d_stage, ctx->d_cflags, ctx->d_ccounts, ctx->d_coffsets, ctx->d_dscr, ctx->d_A, ctx->d_rowlist, ctx->d_sctotal, ctx->d_scerr, ctx->d_FpH, ctx->d_FqH, ctx->d_evalT, ctx->d_vjp_xyzr, ctx->d_vjp_B, ctx->d_vjp_rad, ctx->d_range, ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->d_seds, ctx->d_audit_rows, ctx->d_audit_da, ctx->d_FqAll, ctx->d_FqS, ctx->d_FpS, ctx->d_listDa, ctx->d_sinks, ctx->d_qcur, ctx->d_sweepD, ctx->d_sweepDa, ctx->d_sweep_hist, ctx->d_uev, ctx->d_exDeriv, ctx->d_scr_tmp, ctx->d_allDr, ctx->d_allMin, ctx->d_allMask};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : ctx->mlp_allocs)
@@ -193,7 +193,7 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
     const size_t rows2 = N * k;
     CKC(hipMalloc(&ctx->d_obs, Om * 4 * 4));
     CKC(hipMalloc(&ctx->d_A, OMDS_MAX_DOF * OMDS_MAX_DOF * 4));
-    CKC(hipMalloc(&ctx->d_Bpre, std::max(Om, rows2) * OMDS_WIDTH * 4));
+    CKC(hipMalloc(&ctx->d_Fp, std::max(Om, rows2) * OMDS_FROW * 4));   // zeroed by omds_set_mlp (the slot assignment follows the network's d)
     CKC(hipMalloc(&ctx->d_radius, std::max(Om, rows2) * 4));
     CKC(hipMalloc(&ctx->d_FpH, Om * 32 * 2));
     CKC(hipMalloc(&ctx->d_FqH, N * 32 * 2));
@@ -214,7 +214,7 @@ int omds_create(const omds_config* cfg, omds_ctx** out) {
     CKC(hipMalloc(&ctx->d_alphaT, Km * n * N * 4));
     CKC(hipMalloc(&ctx->d_means, Km * (2 * n + 1) * 4));
     CKC(hipMalloc(&ctx->d_qcur, OMDS_MAX_DOF * 4));
-    CKC(hipMalloc(&ctx->d_Apre, rows2 * OMDS_WIDTH * 4));
+    CKC(hipMalloc(&ctx->d_Fq, rows2 * OMDS_FROW * 4));
     CKC(hipMalloc(&ctx->d_Dmin, N * Om * 4));
     CKC(hipMalloc(&ctx->d_rowlist, N * Om * 4));
     CKC(hipMalloc(&ctx->d_listDa, N * Om * 4));
@@ -300,7 +300,7 @@ struct MlpPacks {
     float out_div = 1.f;
     uint32_t skip_mask = 0;
     uint8_t skip_col[OMDS_MAX_HIDDEN + 1] = {0};
-    std::vector<float4> wf, wb, wf16, wb16, wb4, wl, w1b, w1b16;
+    std::vector<float4> wf, wb, wf16, wb16, wb4, wl, w1b, w1b16, w1f, w1f16;
     std::vector<float> bh, bl, wlraw, whraw, w1t, b1, sbias;
     std::vector<uint16_t> wh;
     double f_fwd = 0.0, f_bwd = 0.0;
@@ -435,17 +435,20 @@ static int build_mlp_packs(int n, int n_linear, const int32_t* in_dims, const in
         for (int cb = 0; cb < OMDS_NCB; ++cb)
             for (int c = 0; c < 32; ++c)
                 for (int lane = 0; lane < 64; ++lane) {
-                    const int j = 32 * cb + (lane & 31), k0 = 8 * c + 4 * (lane >> 5);
+                    // the lane's fragment covers POSITIONS 8c + 4(lane>>5) .. +3 of the k-permuted tile: columns omds_kat(position)
+                    const int j = 32 * cb + (lane & 31), s0 = 8 * c + 4 * (lane >> 5);
+                    const int k0 = omds_kat(s0), k1 = omds_kat(s0 + 1), k2 = omds_kat(s0 + 2), k3 = omds_kat(s0 + 3);
                     const size_t o = (((size_t)l * OMDS_NCB + cb) * 32 + c) * 64 + lane;
-                    wf[o] = make_float4(Wl[j * Wd + k0], Wl[j * Wd + k0 + 1], Wl[j * Wd + k0 + 2], Wl[j * Wd + k0 + 3]);
-                    wb[o] = make_float4(Wl[(k0)*Wd + j], Wl[(k0 + 1) * Wd + j], Wl[(k0 + 2) * Wd + j], Wl[(k0 + 3) * Wd + j]);
+                    wf[o] = make_float4(Wl[j * Wd + k0], Wl[j * Wd + k1], Wl[j * Wd + k2], Wl[j * Wd + k3]);
+                    wb[o] = make_float4(Wl[k0 * Wd + j], Wl[k1 * Wd + j], Wl[k2 * Wd + j], Wl[k3 * Wd + j]);
                 }
         std::memcpy(&pk.bh[(size_t)l * Wd], b[l + 1], Wd * sizeof(float));
     }
-    // 16-row packs (v_mfma_f32_16x16x4): the four k of lane group g in steps 0..3 of chunk c are
-    // 16c + pa[g] + {0, 2, 8, 10}, pa = {0, 4, 1, 5} -- the k SEQUENCE of the 32-row kernels (8c'+{0,4,1,5,2,6,3,7}), so a
-    // 16-row tile is bit-identical to a 32-row tile (both MFMAs are fmaf chains in k order, tools/ubench/mfma_order.hip)
-    auto k16 = [](int c, int g, int mm) { return 16 * c + ((g >> 1) + 4 * (g & 1)) + 8 * (mm >> 1) + 2 * (mm & 1); };
+    // 16-row packs (v_mfma_f32_16x16x4): the four tile positions of lane group g in steps 0..3 of chunk c are
+    // 16c + pa[g] + {0, 2, 8, 10}, pa = {0, 4, 1, 5} -- the position SEQUENCE of the 32-row kernels (8c'+{0,4,1,5,2,6,3,7}), i.e.
+    // columns 16c + 0 .. 15 in ascending order (omds_kat), so a 16-row tile is bit-identical to a 32-row tile (both MFMAs are
+    // fmaf chains in k order, tools/ubench/mfma_order.hip)
+    auto k16 = [](int c, int g, int mm) { return omds_kat(16 * c + ((g >> 1) + 4 * (g & 1)) + 8 * (mm >> 1) + 2 * (mm & 1)); };
     std::vector<float4>&wf16 = pk.wf16, &wb16 = pk.wb16;
     wf16.assign(wf.size(), make_float4(0, 0, 0, 0));
     wb16.assign(wf.size(), make_float4(0, 0, 0, 0));
@@ -470,9 +473,10 @@ static int build_mlp_packs(int n, int n_linear, const int32_t* in_dims, const in
         for (int cb = 0; cb < 4; ++cb)
             for (int kq = 0; kq < 64; ++kq)
                 for (int lane = 0; lane < 64; ++lane) {
-                    const int j = 64 * cb + lane, k0 = 4 * kq;
+                    const int j = 64 * cb + lane, s0 = 4 * kq;   // positions 4 kq .. +3 of the gradient tile
+                    const int k0 = omds_kat(s0), k1 = omds_kat(s0 + 1), k2 = omds_kat(s0 + 2), k3 = omds_kat(s0 + 3);
                     wb4[(((size_t)l * 4 + cb) * 64 + kq) * 64 + lane] =
-                        make_float4(Wl[(size_t)k0 * Wd + j], Wl[(size_t)(k0 + 1) * Wd + j], Wl[(size_t)(k0 + 2) * Wd + j], Wl[(size_t)(k0 + 3) * Wd + j]);
+                        make_float4(Wl[(size_t)k0 * Wd + j], Wl[(size_t)k1 * Wd + j], Wl[(size_t)k2 * Wd + j], Wl[(size_t)k3 * Wd + j]);
                 }
     }
     // last layer: 16x16x4 B-fragments, channels padded to 16
@@ -481,10 +485,10 @@ static int build_mlp_packs(int n, int n_linear, const int32_t* in_dims, const in
     wl.assign(16 * 64, make_float4(0, 0, 0, 0));
     for (int c = 0; c < 16; ++c)
         for (int lane = 0; lane < 64; ++lane) {
-            const int j = lane & 15, k0 = 16 * c + 4 * (lane >> 4);
+            const int j = lane & 15;   // the last layer reads the tile like gemm16 (load_a16): the same ascending k sequence
             float v[4] = {0, 0, 0, 0};
             if (j < C)
-                for (int mm = 0; mm < 4; ++mm) v[mm] = WL[j * Wd + k0 + mm];
+                for (int mm = 0; mm < 4; ++mm) v[mm] = WL[j * Wd + k16(c, lane >> 4, mm)];
             wl[c * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
         }
     pk.bl.assign(OMDS_CPAD, 0.f);
@@ -502,10 +506,10 @@ static int build_mlp_packs(int n, int n_linear, const int32_t* in_dims, const in
     w1b.assign(32 * 64, make_float4(0, 0, 0, 0));
     for (int c = 0; c < 32; ++c)
         for (int lane = 0; lane < 64; ++lane) {
-            const int f = lane & 31, k0 = 8 * c + 4 * (lane >> 5);
+            const int f = lane & 31, s0 = 8 * c + 4 * (lane >> 5);
             float v[4] = {0, 0, 0, 0};
             if (f < F)
-                for (int mm = 0; mm < 4; ++mm) v[mm] = W[0][(k0 + mm) * F + f];
+                for (int mm = 0; mm < 4; ++mm) v[mm] = W[0][omds_kat(s0 + mm) * F + f];
             w1b[c * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
         }
     std::vector<float4>& w1b16 = pk.w1b16;
@@ -518,6 +522,28 @@ static int build_mlp_packs(int n, int n_linear, const int32_t* in_dims, const in
                 if (f < F)
                     for (int mm = 0; mm < 4; ++mm) v[mm] = W[0][k16(c, g, mm) * F + f];
                 w1b16[(c * 2 + jb) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+    // first layer, forward: K = 32 over the encoded inputs at positions 0..31 of the tile rows (feature omds_kat(position), zero
+    // weights for the padding 3d .. 31), in the fragment orders of gemm_k32 and gemm16_k32
+    std::vector<float4>& w1f = pk.w1f;
+    w1f.assign(OMDS_NCB * 4 * 64, make_float4(0, 0, 0, 0));
+    for (int cb = 0; cb < OMDS_NCB; ++cb)
+        for (int c = 0; c < 4; ++c)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int j = 32 * cb + (lane & 31), s0 = 8 * c + 4 * (lane >> 5);
+                float v[4];
+                for (int mm = 0; mm < 4; ++mm) { const int kk = omds_kat(s0 + mm); v[mm] = kk < F ? W[0][(size_t)j * F + kk] : 0.f; }
+                w1f[((size_t)cb * 4 + c) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+    std::vector<float4>& w1f16 = pk.w1f16;
+    w1f16.assign(16 * 2 * 64, make_float4(0, 0, 0, 0));
+    for (int cb = 0; cb < 16; ++cb)
+        for (int c = 0; c < 2; ++c)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int j = 16 * cb + (lane & 15), g = lane >> 4;
+                float v[4];
+                for (int mm = 0; mm < 4; ++mm) { const int kk = k16(c, g, mm); v[mm] = kk < F ? W[0][(size_t)j * F + kk] : 0.f; }
+                w1f16[((size_t)cb * 2 + c) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
             }
     pk.whraw.assign((size_t)std::max(nhh, 1) * Wd * Wd, 0.f);
     for (int l = 0; l < nhh; ++l) std::memcpy(&pk.whraw[(size_t)l * Wd * Wd], W[l + 1], (size_t)Wd * Wd * sizeof(float));
@@ -647,14 +673,12 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
     m.act = act;
     m.skip_mask = skip_mask;
     std::memcpy(m.skip_col, pk.skip_col, sizeof(m.skip_col));
-    if (skip_mask) {   // encoded-input tables beside Apre / Bpre, written by the layer-1 kernels (zero in the other operand's slots)
-        const size_t rowsA = (size_t)ctx->cfg.n_traj * ctx->cfg.n_closest, rowsB = (size_t)ctx->cfg.max_obs;
-        if (!ctx->d_featQ) CK(hipMalloc(&ctx->d_featQ, rowsA * 32 * 4));
-        if (!ctx->d_featP) CK(hipMalloc(&ctx->d_featP, rowsB * 32 * 4));
-        CK(hipMemsetAsync(ctx->d_featQ, 0, rowsA * 32 * 4, ctx->stream));
-        CK(hipMemsetAsync(ctx->d_featP, 0, rowsB * 32 * 4, ctx->stream));
-        m.featQ = ctx->d_featQ;
-        m.featP = ctx->d_featP;
+    {   // the encoded-input tables keep zeros in the slots the other operand owns and in the padding; the slot assignment follows d
+        const size_t rows2 = (size_t)ctx->cfg.n_traj * ctx->cfg.n_closest, rowsB = std::max((size_t)ctx->cfg.max_obs, rows2);
+        CK(hipMemsetAsync(ctx->d_Fq, 0, rows2 * OMDS_FROW * 4, ctx->stream));
+        CK(hipMemsetAsync(ctx->d_Fp, 0, rowsB * OMDS_FROW * 4, ctx->stream));
+        if (ctx->d_FqAll) CK(hipMemsetAsync(ctx->d_FqAll, 0, (size_t)ctx->cfg.n_traj * ctx->cfg.horizon * OMDS_FROW * 4, ctx->stream));
+        if (ctx->d_vjp_B) CK(hipMemsetAsync(ctx->d_vjp_B, 0, (size_t)ctx->vjp_cap * OMDS_FROW * 4, ctx->stream));
     }
     if (ctx->d_dscr) { (void)hipFree(ctx->d_dscr); ctx->d_dscr = nullptr; }
     if (ctx->d_exDeriv) { (void)hipFree(ctx->d_exDeriv); ctx->d_exDeriv = nullptr; }
@@ -709,6 +733,8 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
     if ((rc = upload(ctx, pk.w1t, &m.W1t))) return rc;
     if ((rc = upload(ctx, pk.b1, &m.b1))) return rc;
     if ((rc = upload(ctx, pk.w1b, &m.W1b))) return rc;
+    if ((rc = upload(ctx, pk.w1f, &m.W1f))) return rc;
+    if ((rc = upload(ctx, pk.w1f16, &m.W1f16))) return rc;
 #ifdef OMDS_TIMELINE
     {
         static unsigned long long* tl = nullptr;
@@ -723,7 +749,7 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
     ctx->f_bwd = pk.f_bwd;
     ctx->have_mlp = true;
     if (ctx->n_obs > 0) {  // re-derive the obstacle half of layer 1 for the new weights
-        omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, ctx->n_obs, ctx->d_Bpre, ctx->d_radius, ctx->d_FpH, ctx->cfg.max_obs, ctx->mlp.featP);
+        omds_launch_obstacle_features(ctx->stream, ctx->mlp, ctx->d_obs, ctx->n_obs, ctx->d_Fp, ctx->d_radius, ctx->d_FpH, ctx->cfg.max_obs);
         CK(hipGetLastError());
         CK(hipStreamSynchronize(ctx->stream));
     }
@@ -782,12 +808,13 @@ static int grow_obstacle_capacity(omds_ctx* ctx, int n_obs) {
     // (n_obs == 0) and the next omds_set_obstacles starts the growth again (max_obs == 0) instead of touching freed buffers
     ctx->n_obs = 0;
     ctx->cfg.max_obs = 0;
-    void** olds[] = {(void**)&ctx->d_obs, (void**)&ctx->d_Bpre, (void**)&ctx->d_radius, (void**)&ctx->d_FpH, (void**)&ctx->d_Dmin,
-                     (void**)&ctx->d_rowlist, (void**)&ctx->d_listDa, (void**)&ctx->d_featP, (void**)&ctx->d_FpS};
-    const bool had_featP = ctx->d_featP != nullptr, had_FpS = ctx->d_FpS != nullptr;
+    void** olds[] = {(void**)&ctx->d_obs, (void**)&ctx->d_Fp, (void**)&ctx->d_radius, (void**)&ctx->d_FpH, (void**)&ctx->d_Dmin,
+                     (void**)&ctx->d_rowlist, (void**)&ctx->d_listDa, (void**)&ctx->d_FpS};
+    const bool had_FpS = ctx->d_FpS != nullptr;
     for (void** o : olds) { if (*o) (void)hipFree(*o); *o = nullptr; }
     CK(hipMalloc(&ctx->d_obs, Om * 4 * 4));
-    CK(hipMalloc(&ctx->d_Bpre, std::max(Om, rows2) * OMDS_WIDTH * 4));
+    CK(hipMalloc(&ctx->d_Fp, std::max(Om, rows2) * OMDS_FROW * 4));
+    CK(hipMemsetAsync(ctx->d_Fp, 0, std::max(Om, rows2) * OMDS_FROW * 4, ctx->stream));   // the joints' slots and the padding stay zero
     CK(hipMalloc(&ctx->d_radius, std::max(Om, rows2) * 4));
     CK(hipMalloc(&ctx->d_FpH, Om * 32 * 2));
     CK(hipMemsetAsync(ctx->d_FpH, 0, Om * 32 * 2, ctx->stream));
@@ -798,11 +825,6 @@ static int grow_obstacle_capacity(omds_ctx* ctx, int n_obs) {
         CK(hipMalloc(&ctx->d_FpS, Om * 32 * 2));
         CK(hipMemsetAsync(ctx->d_FpS, 0, Om * 32 * 2, ctx->stream));
         ctx->mlp.scrP = ctx->d_FpS;
-    }
-    if (had_featP) {
-        CK(hipMalloc(&ctx->d_featP, Om * 32 * 4));
-        CK(hipMemsetAsync(ctx->d_featP, 0, Om * 32 * 4, ctx->stream));
-        ctx->mlp.featP = ctx->d_featP;
     }
     const size_t stage = std::max({N * H * std::max(Km, n) * 4, N * Om * 4, Km * n * N * 4, rows2 * OMDS_CPAD * 4});
     if (stage > ctx->stage_bytes) {
@@ -859,7 +881,7 @@ int omds_set_obstacles(omds_ctx* ctx, const float* xyzr, int n_obs) {
     }
     ctx->obs_now.assign(xyzr, xyzr + (size_t)n_obs * 4);
     if (ctx->have_mlp && !ctx->wide.on) {
-        omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, ctx->d_obs, n_obs, ctx->d_Bpre, ctx->d_radius, ctx->d_FpH, ctx->cfg.max_obs, ctx->mlp.featP);
+        omds_launch_obstacle_features(ctx->stream, ctx->mlp, ctx->d_obs, n_obs, ctx->d_Fp, ctx->d_radius, ctx->d_FpH, ctx->cfg.max_obs);
         CK(hipGetLastError());
     }
     CK(hipStreamSynchronize(ctx->stream));
@@ -1015,7 +1037,7 @@ int omds_get_policy_samples(omds_ctx* ctx, float* mu, float* sigma, float* alpha
     return OMDS_OK;
 }
 
-// ---- distance network on a batch: Apre -> pass 1 -> top-k -> pass 2 ---------------------------------
+// ---- distance network on a batch: Fq -> pass 1 -> top-k -> pass 2 ---------------------------------
 static int prof_collect(omds_ctx* ctx);
 static int prof_begin(omds_ctx* ctx) {
     if (!ctx->prof_on) return OMDS_OK;
@@ -1072,21 +1094,21 @@ static int enqueue_network(omds_ctx* ctx, const float* qT, int ldq, int B) {
         CK(hipGetLastError());
         return OMDS_OK;
     }
-    omds_launch_rollout_layer1(ctx->stream, m, qT, ldq, B, ctx->d_Apre);
+    omds_launch_rollout_features(ctx->stream, m, qT, ldq, B, ctx->d_Fq);
     int rc;
     if (small_step_wanted(ctx)) {   // the arithmetic the step of this context uses: the batch entry point reproduces it bit for bit
         if ((rc = prof_begin(ctx))) return rc;
-        omds_launch_net_small(ctx->stream, m, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Apre, O, ctx->prm.ignored_links,
+        omds_launch_net_small(ctx->stream, m, ctx->d_Fp, ctx->d_radius, ctx->d_obs, ctx->d_Fq, O, ctx->prm.ignored_links,
                               ctx->cfg.n_dof, k, qT, ldq, B, ctx->d_gradx, ctx->d_drow, ctx->d_idx, ctx->d_Dmin);
         if ((rc = prof_end(ctx, (int64_t)B * O, (double)B * O * ctx->f_fwd + (double)B * k * ctx->f_bwd, "k_step_small"))) return rc;
         CK(hipGetLastError());
         return OMDS_OK;
     }
     if ((rc = prof_begin(ctx))) return rc;
-    omds_launch_pass1(ctx->stream, m, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
+    omds_launch_pass1(ctx->stream, m, ctx->d_Fq, ctx->d_Fp, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
     if ((rc = prof_end(ctx, (int64_t)B * O))) return rc;
     omds_launch_topk(ctx->stream, ctx->d_Dmin, B, O, k, ctx->d_idx);
-    omds_launch_pass2(ctx->stream, m, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_idx, B, k, qT, ldq,
+    omds_launch_pass2(ctx->stream, m, ctx->d_Fq, ctx->d_Fp, ctx->d_radius, ctx->d_obs, ctx->d_idx, B, k, qT, ldq,
                       ctx->d_gradx, ctx->d_drow, nullptr, nullptr, ctx->d_dscr);
     CK(hipGetLastError());
     return OMDS_OK;
@@ -1117,14 +1139,14 @@ static bool screen_wanted(omds_ctx* ctx) {
 
 // The screening pack's unit order from what the network does on the calibration batch.  k_exact (the fp32 tile code, mode 1) is run
 // once on a uniform pseudo-random sample of the (state, obstacle) pairs of the B calibration states (their layer-1 halves are in
-// d_Apre) and leaves their ReLU masks
+// d_Fq) and leaves their ReLU masks
 // (ExactOut::mask, [entries][hidden levels][8 words]); per hidden level the units are sorted by how many of the sampled 32-pair blocks
 // they fired in (ties by index), the pack is built again in that order and copied over the old one.  (The candidates' own masks would be
 // there for free, but they are the NEAREST obstacles only: ordered by them, 17 % of the k-chunks of the shipped network are dead for a
 // wave; ordered by a uniform sample, 25 %.)  Any order computes the same screening function up to the rounding of the fp32
 // accumulation; what the order buys is that k_screen's zero test finds whole 16-unit chunks dead.  The fp32 kernels do not use this
 // pack: no returned number changes.
-// Called twice per calibration: by the calibration itself on its batch of states (B of them, layer-1 halves in d_Apre) -- so that the
+// Called twice per calibration: by the calibration itself on its batch of states (B of them, layer-1 halves in d_Fq) -- so that the
 // bound is measured on a sorted pack and the first propagate already runs on one -- and behind the first propagate that is accepted
 // afterwards on the states its rollouts ended in (from_rollouts: B = n_traj), which is where the next rollouts will be: the
 // calibration batch is deliberately broader than the rollouts, and fewer units are silent on it (3 / 41 / 92 / 120 of the shipped
@@ -1134,8 +1156,8 @@ static int screen_reorder(omds_ctx* ctx, int B, bool from_rollouts) {
     const MlpDev& m = ctx->mlp;
     if (from_rollouts) ctx->scr_reorder_pending = false;
     if (!enabled || (enabled == 2 && from_rollouts) || m.act != OMDS_ACT_RELU || m.skip_mask || ctx->scr_W.empty() || !ctx->d_exMask) return OMDS_OK;
-    if (from_rollouts)   // layer-1 halves of the last states the propagate reached (d_Apre is rebuilt at the start of every propagate)
-        omds_launch_rollout_layer1(ctx->stream, m, ctx->d_trajT + (size_t)(ctx->cfg.horizon - 1) * ctx->cfg.n_dof * ctx->cfg.n_traj, ctx->cfg.n_traj, B, ctx->d_Apre);
+    if (from_rollouts)   // layer-1 halves of the last states the propagate reached (d_Fq is rebuilt at the start of every propagate)
+        omds_launch_rollout_features(ctx->stream, m, ctx->d_trajT + (size_t)(ctx->cfg.horizon - 1) * ctx->cfg.n_dof * ctx->cfg.n_traj, ctx->cfg.n_traj, B, ctx->d_Fq);
     const int nhid = m.nhh + 1, Wd = OMDS_WIDTH, O = ctx->n_obs;
     const long long pairs = (long long)B * O;
     const int S = (int)std::min<long long>({8192, (long long)ctx->ex_cap, pairs});
@@ -1158,7 +1180,7 @@ static int screen_reorder(omds_ctx* ctx, int B, bool from_rollouts) {
     CK(hipMemsetAsync(ctx->d_scr_tmp, 0, 8 * sizeof(int), ctx->stream));
     CK(hipMemcpyAsync(ctx->d_scr_tmp + 4, &list[S], 4, hipMemcpyHostToDevice, ctx->stream));
     ExactOut ex{ctx->d_exD, ctx->d_exDr, ctx->d_exMin, ctx->d_exMask, ctx->ex_cap};
-    omds_launch_exact(ctx->stream, m, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin, ctx->d_rowlist,
+    omds_launch_exact(ctx->stream, m, ctx->d_Fq, ctx->d_Fp, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin, ctx->d_rowlist,
                       ctx->d_scr_tmp + 4, reinterpret_cast<unsigned*>(ctx->d_scr_tmp), ex);
     CK(hipGetLastError());
     std::vector<uint32_t> masks((size_t)S * nhid * 8);
@@ -1218,14 +1240,14 @@ static int calibrate_screen(omds_ctx* ctx, const float* q_center) {
     }
     omds_launch_calib_states(ctx->stream, ctx->d_qstage, B, n, lo, hi, q_center, ctx->have_rollouts ? ctx->d_trajT : nullptr,
                              ctx->cfg.n_traj, ctx->cfg.horizon, 0x9E3779B9u * (unsigned)(ctx->screen_recals + 1));
-    omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Apre, ctx->d_FqH, ctx->cfg.n_traj);
+    omds_launch_rollout_features(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Fq, ctx->d_FqH, ctx->cfg.n_traj);
     // first the unit order of the screening pack (it follows the scene and the states too), then the bound of THAT pack
     int rc;
     if ((rc = screen_reorder(ctx, B, false))) return rc;
     ctx->scr_reorder_pending = true;
     if (ctx->screen_eps_fixed && ctx->screen_eps > 0.f) return OMDS_OK;   // the bound was set by the caller (omds_set_screening)
     float* apx = ctx->d_stage;   // [B][O] screening values (stage_bytes >= n_traj * max_obs * 4)
-    omds_launch_pass1(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
+    omds_launch_pass1(ctx->stream, ctx->mlp, ctx->d_Fq, ctx->d_Fp, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
     omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_FqH, ctx->cfg.n_traj, ctx->d_FpH, ctx->cfg.max_obs, ctx->d_radius, O, B, ctx->prm.ignored_links, apx);
     CK(hipMemsetAsync(ctx->d_scerr + 3, 0, 4, ctx->stream));
     omds_launch_max_abs_diff(ctx->stream, ctx->d_Dmin, apx, (long long)B * O, ctx->d_scerr + 3);
@@ -1279,10 +1301,9 @@ static int prepare_audit(omds_ctx* ctx, SelectSink& sk) {
         CK(hipMalloc(&ctx->d_audit_da, (size_t)want * 4));
         ctx->audit_cap = (int)std::min<long long>(want, 0x7fffffff);
     }
-    if (!ctx->d_ApreAll) CK(hipMalloc(&ctx->d_ApreAll, (size_t)N * H * OMDS_WIDTH * 4));
-    if (ctx->mlp.featQ && !ctx->d_featQAll) {
-        CK(hipMalloc(&ctx->d_featQAll, (size_t)N * H * 32 * 4));
-        CK(hipMemsetAsync(ctx->d_featQAll, 0, (size_t)N * H * 32 * 4, ctx->stream));
+    if (!ctx->d_FqAll) {
+        CK(hipMalloc(&ctx->d_FqAll, (size_t)N * H * OMDS_FROW * 4));
+        CK(hipMemsetAsync(ctx->d_FqAll, 0, (size_t)N * H * OMDS_FROW * 4, ctx->stream));   // the obstacles' slots and the padding stay zero
     }
     sk.audit_rows = ctx->d_audit_rows;
     sk.audit_da = ctx->d_audit_da;
@@ -1315,8 +1336,8 @@ static int prepare_sweep(omds_ctx* ctx) {
 // matrix mode on the step's fp16 inputs), compared against the tau the step's selection used (d_range): max |Da - D| ->
 // d_scerr[3], the distribution of Da - D over the non-candidates -> d_sweep_hist.  Must be enqueued between the step's selection
 // and its tail (the tail overwrites the fp16 inputs with the next step's states).
-static void enqueue_sweep_of_step(omds_ctx* ctx, const float* apre_step, int N) {
-    omds_launch_pass1(ctx->stream, ctx->mlp, apre_step, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N, ctx->prm.ignored_links, ctx->d_sweepD);
+static void enqueue_sweep_of_step(omds_ctx* ctx, const float* fq_step, int N) {
+    omds_launch_pass1(ctx->stream, ctx->mlp, fq_step, ctx->d_Fp, ctx->d_radius, ctx->n_obs, N, ctx->prm.ignored_links, ctx->d_sweepD);
     omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_FqH, ctx->cfg.n_traj, ctx->d_FpH, ctx->cfg.max_obs, ctx->d_radius, ctx->n_obs, N,
                        ctx->prm.ignored_links, ctx->d_sweepDa);
     omds_launch_sweep_hist(ctx->stream, ctx->d_sweepD, ctx->d_sweepDa, ctx->d_range, N, ctx->n_obs, ctx->screen_eps, ctx->d_sweep_hist, ctx->d_scerr + 3);
@@ -1327,12 +1348,12 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
     const int N = a.N, H = a.H, n = a.n;
     int rc;
     if (tail && !screen && small_step_wanted(ctx)) {
-        omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, ctx->d_Apre, nullptr, N);
+        omds_launch_rollout_features(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, ctx->d_Fq, nullptr, N);
         for (int i = 1; i <= H; ++i) {
             RoctxRange r1("TAG: evaluate NN_2-5 + Modulation-propagation (fused small-scene step)");
             a.step = i;
             if ((rc = prof_begin(ctx))) return rc;
-            omds_launch_step_small(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Apre, ctx->n_obs,
+            omds_launch_step_small(ctx->stream, ctx->mlp, ctx->d_Fp, ctx->d_radius, ctx->d_obs, ctx->d_Fq, ctx->n_obs,
                                    ctx->prm.ignored_links, a);
             if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs, (double)N * ctx->n_obs * ctx->f_fwd + (double)N * a.k * ctx->f_bwd, "k_step_small"))) return rc;
         }
@@ -1349,8 +1370,8 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
         // With an audit sample the rollout halves of layer 1 of ALL horizon steps are kept ([H][N][256]: step i reads slab
         // i - 1, its tail writes slab i) so that k_audit can re-evaluate pairs of any step at the end; otherwise one slab
         // is updated in place
-        float* apre0 = ctx->d_Apre;
-        size_t apre_slab = 0;
+        float* fq0 = ctx->d_Fq;
+        size_t fq_slab = 0;
         SelectSink sink{};
         // ReLU networks: k_exact leaves masks and k_tail_sel runs the backward only; when a rollout's obstacles fit a
         // workgroup's LDS, k_screen selects in its flush phase (no matrix, no k_select)
@@ -1376,7 +1397,7 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
             sink.k = a.k;
             sink.delta = OMDS_SCREEN_WINDOW * ctx->screen_eps;
             if ((rc = prepare_audit(ctx, sink))) return rc;
-            if (sink.audit_rows) { apre0 = ctx->d_ApreAll; apre_slab = (size_t)N * OMDS_WIDTH; }
+            if (sink.audit_rows) { fq0 = ctx->d_FqAll; fq_slab = (size_t)N * OMDS_FROW; }
         }
         ex.Da = sink.listDa;
         SelectSink* d_sinks = static_cast<SelectSink*>(ctx->d_sinks);
@@ -1432,7 +1453,7 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
                 ex_all = ExactOut{ctx->d_Dmin, ctx->d_allDr, ctx->d_allMin, ctx->d_allMask, (int)std::min<long long>((long long)N * ctx->n_obs, 0x7fffffffLL)};
             }
         }
-        omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, apre0, screen ? ctx->d_FqH : nullptr, N);
+        omds_launch_rollout_features(ctx->stream, ctx->mlp, ctx->d_trajT, N, N, fq0, screen ? ctx->d_FqH : nullptr, N);
 #ifdef OMDS_EXPERIMENT
         static const int corun = OMDS_EXP_ENV("OMDS_EXACT_CORUN", 0);
         static hipStream_t s2 = nullptr;
@@ -1441,8 +1462,8 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
         static unsigned* err2 = nullptr;
 #endif
         for (int i = 1; i <= H; ++i) {
-            float* apre_i = apre0 + (size_t)(i - 1) * apre_slab;
-            float* apre_next = apre0 + (size_t)std::min(i, H - 1) * apre_slab;
+            float* fq_i = fq0 + (size_t)(i - 1) * fq_slab;
+            float* fq_next = fq0 + (size_t)std::min(i, H - 1) * fq_slab;
             {
                 RoctxRange r1("TAG: evaluate NN_2 (forward pass)");
                 if ((rc = prof_begin(ctx))) return rc;
@@ -1466,7 +1487,7 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
                         }
                         CK(hipEventRecord(ev, ctx->stream));
                         CK(hipStreamWaitEvent(s2, ev, 0));
-                        omds_launch_exact(s2, ctx->mlp, apre0 + (size_t)(i - 2) * apre_slab, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N, ctx->prm.ignored_links,
+                        omds_launch_exact(s2, ctx->mlp, fq0 + (size_t)(i - 2) * fq_slab, ctx->d_Fp, ctx->d_radius, ctx->n_obs, N, ctx->prm.ignored_links,
                                           ctx->d_Dmin, ctx->d_rowlist, ctx->d_sctotal + (i - 2), err2, ex2);
                         CK(hipEventRecord(ev_done, s2));
                         if (corun == 2 || i == H)   // 2 = control: the same redundant launch IN the main stream's order (the serial cost of one more k_exact)
@@ -1477,35 +1498,35 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
                                        ctx->prm.ignored_links, ctx->d_Dmin, fuse_select ? d_sinks + (i - 1) : nullptr);
                     if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs, -1.0, "k_screen"))) return rc;
                     if (!fuse_select) omds_launch_select(ctx->stream, ctx->d_Dmin, N, ctx->n_obs, sink);
-                    omds_launch_exact(ctx->stream, ctx->mlp, apre_i, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
+                    omds_launch_exact(ctx->stream, ctx->mlp, fq_i, ctx->d_Fp, ctx->d_radius, ctx->n_obs, N,
                                       ctx->prm.ignored_links, ctx->d_Dmin, ctx->d_rowlist, sink.total, ctx->d_scerr, ex);
                 } else if (emit) {   // pass 1 leaves pass 2's forward of every pair (pass1_tile mode 6): the tail runs the backward only
-                    omds_launch_pass1_emit(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
+                    omds_launch_pass1_emit(ctx->stream, ctx->mlp, ctx->d_Fq, ctx->d_Fp, ctx->d_radius, ctx->n_obs, N,
                                            ctx->prm.ignored_links, ctx->d_Dmin, ex_all);
                     if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs))) return rc;
                 } else {
-                    omds_launch_pass1(ctx->stream, ctx->mlp, ctx->d_Apre, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, N,
+                    omds_launch_pass1(ctx->stream, ctx->mlp, ctx->d_Fq, ctx->d_Fp, ctx->d_radius, ctx->n_obs, N,
                                       ctx->prm.ignored_links, ctx->d_Dmin);
                     if ((rc = prof_end(ctx, (int64_t)N * ctx->n_obs))) return rc;
                 }
             }
             if (ctx->sweep_now && (ctx->sweep_all_steps || i == H)) {
                 RoctxRange r4("screening sweep (all pairs of this step in fp32)");
-                enqueue_sweep_of_step(ctx, apre_i, N);
+                enqueue_sweep_of_step(ctx, fq_i, N);
             }
             RoctxRange r2("TAG: evaluate NN_3-5 + Modulation-propagation");
             a.step = i;
             if (screen && list_tail)
-                omds_launch_tail_sel(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, apre_next, ctx->n_obs, a,
+                omds_launch_tail_sel(ctx->stream, ctx->mlp, ctx->d_Fp, ctx->d_radius, ctx->d_obs, fq_next, ctx->n_obs, a,
                                      ctx->d_rowlist, ctx->d_range, ex, ctx->d_FqH, N, ctx->screen_eps, ctx->d_scerr + 1);
             else if (screen)
-                omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, apre_i,
-                                 ctx->d_dscr, ctx->n_obs, a, 0, N, ctx->d_FqH, N, apre_next, ctx->d_range, ctx->screen_eps, ctx->d_scerr + 1);
+                omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Fp, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, fq_i,
+                                 ctx->d_dscr, ctx->n_obs, a, 0, N, ctx->d_FqH, N, fq_next, ctx->d_range, ctx->screen_eps, ctx->d_scerr + 1);
             else if (emit)   // top-k over the rollout's row of Dmin, masks of the k selected pairs, backward, blend, modulation, Euler step
-                omds_launch_tail_sel(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Apre, ctx->n_obs, a,
+                omds_launch_tail_sel(ctx->stream, ctx->mlp, ctx->d_Fp, ctx->d_radius, ctx->d_obs, ctx->d_Fq, ctx->n_obs, a,
                                      nullptr, nullptr, ex_all, nullptr, 0, 0.f, ctx->d_scerr + 1);
             else
-                omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Bpre, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, ctx->d_Apre,
+                omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Fp, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, ctx->d_Fq,
                                  ctx->d_dscr, ctx->n_obs, a, 0, N);
         }
         if (screen) {
@@ -1517,13 +1538,7 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
             // profiles/r04_audit_stream_ab.txt: the cross-stream dependency costs more than the 0.07 ms of kernels it overlaps.)
             if (sink.audit_rows) {
                 RoctxRange r3("screening audit sample (fp32 re-evaluation of unevaluated pairs)");
-                MlpDev ma = ctx->mlp;
-                if (ma.featQ) {   // skip-connection networks: the encoded joint inputs of every step's states, rebuilt from the stored
-                                  // rollouts (trajT [H][n][N] as H slabs; the same kernel, so ApreAll is rewritten with the same bits)
-                    ma.featQ = ctx->d_featQAll;
-                    omds_launch_rollout_layer1(ctx->stream, ma, ctx->d_trajT, N, H * N, ctx->d_ApreAll, nullptr, 0, N);
-                }
-                omds_launch_audit(ctx->stream, ma, ctx->d_ApreAll, ctx->d_Bpre, ctx->d_radius, ctx->n_obs, ctx->prm.ignored_links,
+                omds_launch_audit(ctx->stream, ctx->mlp, ctx->d_FqAll, ctx->d_Fp, ctx->d_radius, ctx->n_obs, ctx->prm.ignored_links,
                                   sink.audit_rows, sink.audit_da, sink.audit_total, sink.audit_cap, ctx->d_scerr);
             }
             CK(hipGetLastError());
@@ -1622,7 +1637,7 @@ static int screened_verdict(omds_ctx* ctx, StepArgs& a, bool tail) {
         ctx->screen_consec = 0;
         if (ctx->scr_reorder_pending) {   // the unit order once more, on the states the rollouts reached.  eps was measured on the
             // calibration's order: the next propagate carries a sweep (all N x O pairs of a step of the NEW pack in fp32).  The results
-            // of this propagate are published already; d_Apre / d_Dmin / d_ex* are scratch between propagates (omds_internal.h)
+            // of this propagate are published already; d_Fq / d_Dmin / d_ex* are scratch between propagates (omds_internal.h)
             const long long before = ctx->scr_reorders;
             const int rrc = screen_reorder(ctx, N, true);
             if (ctx->scr_reorders != before) ctx->sweep_force_next = true;
@@ -1744,7 +1759,7 @@ static int mlp_rows_vjp(omds_ctx* ctx, const char* who, const float* x, int B, i
         CK(hipMemcpyAsync(ctx->d_stage, x, (size_t)B * d * 4, hipMemcpyHostToDevice, ctx->stream));
         if ((rcw = omds_wide_vjp(ctx, ctx->d_stage, B, seed_col))) return rcw;
     } else {
-        // every row is its own (rollout, obstacle) pair: Apre from x[:, :n], Bpre from x[:, n:], radius 0
+        // every row is its own (rollout, obstacle) pair: Fq from x[:, :n], Fp from x[:, n:], radius 0
         std::vector<float> xyzr((size_t)B * 4, 0.f), qrow((size_t)B * n);
         std::vector<int32_t> ident(B);
         for (int r = 0; r < B; ++r) {
@@ -1755,7 +1770,9 @@ static int mlp_rows_vjp(omds_ctx* ctx, const char* who, const float* x, int B, i
         // per-row "obstacle" buffers of this entry point, allocated on first use for the context's capacity and kept
         if (!ctx->d_vjp_xyzr) {
             CK(hipMalloc(&ctx->d_vjp_xyzr, (size_t)cap * 16));
-            CK(hipMalloc(&ctx->d_vjp_B, (size_t)cap * OMDS_WIDTH * 4));
+            CK(hipMalloc(&ctx->d_vjp_B, (size_t)cap * OMDS_FROW * 4));
+            CK(hipMemsetAsync(ctx->d_vjp_B, 0, (size_t)cap * OMDS_FROW * 4, ctx->stream));
+            ctx->vjp_cap = cap;
             CK(hipMalloc(&ctx->d_vjp_rad, (size_t)cap * 4));
         }
         float *d_xyzr = ctx->d_vjp_xyzr, *d_B = ctx->d_vjp_B, *d_rad = ctx->d_vjp_rad;
@@ -1764,9 +1781,9 @@ static int mlp_rows_vjp(omds_ctx* ctx, const char* who, const float* x, int B, i
         CK(hipMemcpyAsync(ctx->d_stage, qrow.data(), (size_t)B * n * 4, hipMemcpyHostToDevice, ctx->stream));
         CK(hipMemcpyAsync(ctx->d_idx, ident.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
         omds_launch_transpose(ctx->stream, ctx->d_stage, ctx->d_qstage, B, n);
-        omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Apre);
-        omds_launch_obstacle_layer1(ctx->stream, ctx->mlp, d_xyzr, B, d_B, d_rad);
-        omds_launch_pass2(ctx->stream, ctx->mlp, ctx->d_Apre, d_B, d_rad, d_xyzr, ctx->d_idx, B, 1, ctx->d_qstage, B,
+        omds_launch_rollout_features(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Fq);
+        omds_launch_obstacle_features(ctx->stream, ctx->mlp, d_xyzr, B, d_B, d_rad);
+        omds_launch_pass2(ctx->stream, ctx->mlp, ctx->d_Fq, d_B, d_rad, d_xyzr, ctx->d_idx, B, 1, ctx->d_qstage, B,
                           ctx->d_gradx, ctx->d_drow, ctx->d_yraw, ctx->d_minidx, ctx->d_dscr, seed_col);
     }
     CK(hipGetLastError());
@@ -2162,7 +2179,7 @@ int omds_screen_mindist(omds_ctx* ctx, const float* q, int B, float* mindist) {
     const int n = ctx->cfg.n_dof, O = ctx->n_obs;
     CK(hipMemcpyAsync(ctx->d_stage, q, (size_t)B * n * 4, hipMemcpyHostToDevice, ctx->stream));
     omds_launch_transpose(ctx->stream, ctx->d_stage, ctx->d_qstage, B, n);
-    omds_launch_rollout_layer1(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Apre, ctx->d_FqH, ctx->cfg.n_traj);
+    omds_launch_rollout_features(ctx->stream, ctx->mlp, ctx->d_qstage, B, B, ctx->d_Fq, ctx->d_FqH, ctx->cfg.n_traj);
     omds_launch_screen(ctx->stream, ctx->screen, ctx->mlp, ctx->d_FqH, ctx->cfg.n_traj, ctx->d_FpH, ctx->cfg.max_obs, ctx->d_radius, O, B, ctx->prm.ignored_links, ctx->d_Dmin);
     CK(hipGetLastError());
     CK(hipMemcpyAsync(mindist, ctx->d_Dmin, (size_t)B * O * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -2,6 +2,7 @@
 // per-step tail kernel (tail_kernel.hip): fp32 MFMA GEMM core, MFMA C-layout helper, pass-2 body.
 #pragma once
 #include "omds_internal.h"
+#include "trig_device.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -171,6 +172,52 @@ __device__ __forceinline__ void gemm16(const float* __restrict__ Hs, const float
 #undef OMDS_INTERLEAVE16
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Layer 1: [rows x 32] . [32 x 256] over the tile's ENCODED INPUTS [x, sin x, cos x] (3d <= 30 features, zero-padded), which sit
+// at positions 0..31 of the tile rows.  The reference computes the layer as one chain over the 3d features in their order
+// [q, p, sin q, sin p, cos q, cos p] (network_macros_mod.py:139-141): joint and obstacle terms alternate along the chain, so the
+// layer does NOT split into a rollout half plus an obstacle half without changing its bits -- it is a K = 32 product like
+// every other layer (four k-chunks of the 32x32x2 shape, two of the 16x16x4 shape), 4 % of a launch's MFMA work.
+// ------------------------------------------------------------------------------------------------
+template <int MR, int NR>
+__device__ __forceinline__ void gemm_k32(const float* __restrict__ Hw, const float4* __restrict__ W1f, int cb0, int lane, f32x16 (&acc)[MR][NR]) {
+    const float* arow = Hw + (lane & 31) * LDH + 4 * (lane >> 5);
+    const float4* wbase = W1f + (size_t)__builtin_amdgcn_readfirstlane(cb0) * (4 * 64);
+    const __amdgpu_buffer_rsrc_t wp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wbase), 0, NR * 4 * 64 * 16, 0x00020000);
+    const int wv = lane * 16;
+    float4 a[4][MR], w[4][NR];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const omds_f4 v = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(wp, wv, (j * (4 * 64) + c * 64) * 16, 0));
+            w[c][j] = make_float4(v.x, v.y, v.z, v.w);
+        }
+#pragma unroll
+        for (int i = 0; i < MR; ++i) a[c][i] = *reinterpret_cast<const float4*>(arow + i * 32 * LDH + 8 * c);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) mfma_chunk<MR, NR>(a[c], w[c], acc);
+}
+// W1f16 = [16 colblk16][2 kchunk][64 lane]; wave w produces columns 32w .. 32w+31 (blocks 2w, 2w+1)
+__device__ __forceinline__ void gemm16_k32(const float* __restrict__ Hs, const float4* __restrict__ W1f16, int wave, int lane, f32x4 (&acc)[2]) {
+    const float* arow = Hs + (lane & 15) * LDH + pa16(lane);
+    const float4* wbase = W1f16 + (size_t)__builtin_amdgcn_readfirstlane(wave) * (2 * 2 * 64);
+    const __amdgpu_buffer_rsrc_t wp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wbase), 0, 2 * 2 * 64 * 16, 0x00020000);
+    float4 a[2], w[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const omds_f4 v = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(wp, lane * 16, (j * 2 + c) * 64 * 16, 0));
+            w[c][j] = make_float4(v.x, v.y, v.z, v.w);
+        }
+        a[c] = load_a16(arow, c);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) mfma_chunk16(a[c], w[c], acc);
+}
 
 // ------------------------------------------------------------------------------------------------
 // [4 NG x 256] . [256 x 64] on v_mfma_f32_4x4x1_16B_f32 with the A operand of ONE block broadcast to all 16 blocks
@@ -347,8 +394,8 @@ struct OmdsDivisor {
 // the k rows a rollout ends up selecting has been computed here anyway, so the tail selects from Dmin and runs the backward only.
 // The arithmetic of a row is the same in all forms and independent of the other rows of the tile: bit-identical results.
 template <int MT, int MR, int NR, int ACT, int MODE = 0>
-__device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const float* __restrict__ Apre,
-                                           const float* __restrict__ Bpre, const float* __restrict__ radius, int O,
+__device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const float* __restrict__ Fq,
+                                           const float* __restrict__ Fp, const float* __restrict__ radius, int O,
                                            long long total_rows, uint32_t ignored, float* __restrict__ Dmin,
                                            const long long row0, const OmdsDivisor odiv,
                                            const int* __restrict__ rowlist = nullptr, unsigned* maxerr_bits = nullptr,
@@ -390,95 +437,70 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
     const int cb0 = wn * NR;
     constexpr int NBIAS = MT == 16 ? 2 : NR;   // distinct output columns per thread
     auto bias_col = [&](int j) { return MT == 16 ? wave * 32 + 16 * j + (lane & 15) : (cb0 + j) * 32 + (lane & 31); };
-    float bcur[NBIAS];   // bias of the first hidden->hidden layer: in flight across the whole layer-1 build
+    float bcur[NBIAS];   // bias of the layer about to be multiplied, fetched one layer ahead (layer 1's: in flight across the gather)
 #pragma unroll
-    for (int j = 0; j < NBIAS; ++j) bcur[j] = m.nhh > 0 ? m.bh[bias_col(j)] : 0.f;
+    for (int j = 0; j < NBIAS; ++j) bcur[j] = m.b1[bias_col(j)];
 
-    // ---- layer 1: H1 = act(Apre[t] + Bpre[o]).  A wave builds one whole row (64 lanes x float4) per step, so the
-    //      row bookkeeping (rollout t, obstacle o, bounds) is wave-uniform and stays on the scalar unit, and the two
-    //      row fetches are buffer loads with scalar row offsets: the build is ~20 instructions per row instead of
-    //      ~100.  That matters more than it looks: next to a co-resident workgroup that streams MFMAs these
-    //      instructions issue at roughly one per MFMA slot (tools/ubench/corun.hip), and the matrix pipe idles
-    //      whenever both residents of a CU are outside their GEMM loops (tools/pass1_timeline.py). ----------------
+    // ---- the tile's encoded inputs: row r = pair (t, o) gets Fq[t] | Fp[o] (each table is zero in the other's slots) at positions
+    //      0..31.  A wave fills two rows per step, one per lane half; the row bookkeeping (rollout t, obstacle o, bounds) is
+    //      wave-uniform and stays on the scalar unit, the fetches are buffer loads.  Kept short on purpose: next to a co-resident
+    //      workgroup that streams MFMAs these instructions issue at roughly one per MFMA slot (tools/ubench/corun.hip), and the
+    //      matrix pipe idles whenever both residents of a CU are outside their GEMM loops (tools/pass1_timeline.py). ----------
     {
         constexpr int IT = MT / G::NW;                          // rows per wave
+        static_assert(IT % 2 == 0, "two rows per step");
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         const unsigned row0u = (unsigned)row0;                  // the launcher keeps total_rows below 2^31
-        const unsigned t0 = odiv.div(row0u);                    // row0 / O by multiplication (three scalar instructions)
+        const unsigned t0 = LIST ? 0u : odiv.div(row0u);        // row0 / O by multiplication (three scalar instructions)
         const int rows_here = (int)((total_rows - row0 < MT) ? (total_rows - row0) : MT);
-        const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Apre) + (size_t)t0 * OMDS_WIDTH, 0,
-                                                                            0x7fffffff, 0x00020000);
-        const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bpre), 0, 0x7fffffff, 0x00020000);
-        const int lv = lane * 16;
-        omds_f4 av[IT], bv[IT];
-        float rad[IT];
-        int pidx[IT];
-        if constexpr (LIST) {
-            const __amdgpu_buffer_rsrc_t ar0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Apre), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t qr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Fq) + (size_t)t0 * OMDS_FROW, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Fp), 0, 0x7fffffff, 0x00020000);
+        const bool hi = lane >= 32;
+        const int f4 = (lane & 31) * 4;
+        int o = LIST ? 0 : (int)(row0u - t0 * (unsigned)O) + wv, dt = 0;   // un-listed rows: row r = wv + it * NW is pair (t0 + dt, o)
+        if constexpr (!LIST) { while (o >= O) { o -= O; ++dt; } }
+        float myrad = 0.f;                                      // lane it of the wave collects the radius of its row it
+        int myidx = 0;
+        uint32_t fv[IT / 2];
 #pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                if (wv + it * G::NW < rows_here) {
-                    const int idx = __builtin_amdgcn_readfirstlane(rowlist[row0 + wv + it * G::NW]);
-                    const unsigned tt = odiv.div((unsigned)idx);
-                    const int oo = (int)((unsigned)idx - tt * (unsigned)O);
-                    av[it] = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(ar0, lv, (int)(tt * (OMDS_WIDTH * 4)), 0));
-                    bv[it] = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(br, lv, oo * (OMDS_WIDTH * 4), 0));
-                    rad[it] = radius[oo];
-                    pidx[it] = idx;
+        for (int it = 0; it < IT; it += 2) {
+            int offq[2], offp[2];
+            bool ok[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                ok[h] = wv + (it + h) * G::NW < rows_here;
+                float rad = 0.f;
+                int idx = 0;
+                offq[h] = 0; offp[h] = 0;
+                if constexpr (LIST) {
+                    if (ok[h]) {
+                        idx = __builtin_amdgcn_readfirstlane(rowlist[row0 + wv + (it + h) * G::NW]);
+                        const unsigned tt = odiv.div((unsigned)idx);
+                        const int oo = (int)((unsigned)idx - tt * (unsigned)O);
+                        offq[h] = (int)(tt * (OMDS_FROW * 4)); offp[h] = oo * (OMDS_FROW * 4);
+                        rad = radius[oo];
+                    }
                 } else {
-                    av[it] = omds_f4{0.f, 0.f, 0.f, 0.f};
-                    bv[it] = av[it];
-                    rad[it] = 0.f;
-                    pidx[it] = 0;
+                    if (ok[h]) { offq[h] = dt * (OMDS_FROW * 4); offp[h] = o * (OMDS_FROW * 4); rad = radius[o]; }
+                    o += G::NW;
+                    while (o >= O) { o -= O; ++dt; }
+                }
+                const int rbits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rad));   // wave-uniform: keep it in an SGPR for the asm
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(myrad) : "s"(rbits), "n"(it + h));
+                if constexpr (LIST) {
+                    const int ib = __builtin_amdgcn_readfirstlane(idx);
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(myidx) : "s"(ib), "n"(it + h));
                 }
             }
-        } else {
-        int o = (int)(row0u - t0 * (unsigned)O) + wv, dt = 0;   // row r = wv + it * NW is pair (t0 + dt, o)
-        while (o >= O) { o -= O; ++dt; }
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            if (wv + it * G::NW < rows_here) {
-                av[it] = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(ar, lv, dt * (OMDS_WIDTH * 4), 0));
-                bv[it] = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(br, lv, o * (OMDS_WIDTH * 4), 0));
-                rad[it] = radius[o];
-            } else {
-                av[it] = omds_f4{0.f, 0.f, 0.f, 0.f};
-                bv[it] = av[it];
-                rad[it] = 0.f;
-            }
-            o += G::NW;
-            while (o >= O) { o -= O; ++dt; }
-        }
+            const uint32_t fq = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(qr, (hi ? offq[1] : offq[0]) + f4, 0, 0);
+            const uint32_t fp = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(pr, (hi ? offp[1] : offp[0]) + f4, 0, 0);
+            fv[it / 2] = (hi ? ok[1] : ok[0]) ? (fq | fp) : 0u;   // rows past the end: zero inputs (their results are never stored)
         }
         OMDS_TL_WAIT("vmcnt(0)");
         OMDS_TL(8);
-        float* hrow = Hs + wv * LDH + 4 * lane;
-        float myrad = 0.f;                                      // lane it of the wave collects the radius of its row it
-        int myidx = 0;
+        uint32_t* frow = reinterpret_cast<uint32_t*>(Hs) + (wv + (hi ? G::NW : 0)) * LDH + omds_kpos(lane & 31);
 #pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const omds_f4 z = av[it] + bv[it];                  // vector add -> two v_pk_add_f32
-            if constexpr (EMIT) {                               // layer-1 masks of this row: four ballots, written by lane 0
-                const unsigned long long b0 = __ballot(z.x > 0.f), b1 = __ballot(z.y > 0.f), b2 = __ballot(z.z > 0.f), b3 = __ballot(z.w > 0.f);
-                if (lane == 0) {
-                    uint32_t* ms = maskS + (size_t)(wv + it * G::NW) * nhid * 8;
-                    ms[0] = (uint32_t)b0; ms[1] = (uint32_t)(b0 >> 32); ms[2] = (uint32_t)b1; ms[3] = (uint32_t)(b1 >> 32);
-                    ms[4] = (uint32_t)b2; ms[5] = (uint32_t)(b2 >> 32); ms[6] = (uint32_t)b3; ms[7] = (uint32_t)(b3 >> 32);
-                }
-            }
-            float4 v;                                           // rows past the end were loaded as zeros: act(0) = 0
-            v.x = actf(z.x, ACT);
-            v.y = actf(z.y, ACT);
-            v.z = actf(z.z, ACT);
-            v.w = actf(z.w, ACT);
-            *reinterpret_cast<float4*>(hrow + it * G::NW * LDH) = v;
-            const int rbits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rad[it]));   // wave-uniform: keep it in an SGPR for the asm
-            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(myrad) : "s"(rbits), "n"(it));
-            if constexpr (LIST) {
-                const int ib = __builtin_amdgcn_readfirstlane(pidx[it]);
-                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(myidx) : "s"(ib), "n"(it));
-            }
-        }
+        for (int it = 0; it < IT; it += 2) frow[it * G::NW * LDH] = fv[it / 2];
         if (lane < IT) rowRad[wv + lane * G::NW] = myrad;
         if constexpr (LIST) { if (lane < IT) rowIdx[wv + lane * G::NW] = myidx; }
     }
@@ -486,45 +508,48 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
     OMDS_TL(9);
     __syncthreads();
     OMDS_TL(1);
-    emit_deriv(0);
     // skip-connection networks: the encoded input of each row goes behind the activations of `level` (MlpDev::skip_mask)
     auto inject = [&](int level) {
         const int c0 = m.skip_col[level], F = 3 * m.d;
         for (int e = tid; e < MT * 32; e += G::NT) {
             const int r = e >> 5, f = e & 31;
             if (f < F) {
-                float v = 0.f;
+                uint32_t v = 0u;
                 if (row0 + r < total_rows) {
                     unsigned pair;
                     if constexpr (LIST) pair = (unsigned)rowIdx[r];
                     else pair = (unsigned)row0 + (unsigned)r;
                     const unsigned t = odiv.div(pair), o = pair - t * (unsigned)O;
-                    v = m.featQ[(size_t)t * 32 + f] + m.featP[(size_t)o * 32 + f];
+                    v = __builtin_bit_cast(uint32_t, Fq[(size_t)t * OMDS_FROW + f]) | __builtin_bit_cast(uint32_t, Fp[(size_t)o * OMDS_FROW + f]);
                 }
-                Hs[r * LDH + c0 + f] = v;
+                reinterpret_cast<uint32_t*>(Hs)[r * LDH + omds_kpos(c0 + f)] = v;
             }
         }
         __syncthreads();
     };
-    if (m.skip_mask & 1u) inject(0);
 
-    // ---- hidden -> hidden layers.  The accumulators start at the bias (fetched one layer ahead), so the epilogue
-    //      is activation + LDS write only -----------------------------------------------------------------
+    // ---- layer 1 (l = -1, K = 32 over the encoded inputs) and the hidden -> hidden layers, each the reference's product: the
+    //      accumulators start at ZERO, the k order is ascending (omds_kpos), the bias is added in the epilogue ----------------
     const float* Hw = Hs + (wm * MR * 32) * LDH;
     if constexpr (MT == 16) {
-        for (int l = 0; l < m.nhh; ++l) {
-            f32x4 acc[2];
+        const int scol0 = wave * 32 + omds_kpos(lane & 15);   // position of column wave*32 + 16 j + (lane & 15): + 16 j
+        for (int l = -1; l < m.nhh; ++l) {
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            float bnow[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[j][r] = bcur[j];
+            for (int j = 0; j < 2; ++j) bnow[j] = bcur[j];
             if (l + 1 < m.nhh) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) bcur[j] = m.bh[(l + 1) * OMDS_WIDTH + bias_col(j)];
             }
-            gemm16(Hs, m.Wf16 + (size_t)l * (16 * 16 * 64), wave, lane, acc);
+            if (l < 0) gemm16_k32(Hs, m.W1f16, wave, lane, acc);
+            else gemm16(Hs, m.Wf16 + (size_t)l * (16 * 16 * 64), wave, lane, acc);
             __syncthreads();  // every wave has finished reading the tile
             if (l == 0) OMDS_TL(6);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[j][r] += bnow[j];
             if constexpr (EMIT) {   // ReLU masks of this level: row 4g + reg = ballot bits of lanes 16g .. 16g+15, columns 32 wave + 16 j + (lane & 15)
                 uint32_t mw = 0;
                 const int sh = 16 * ((lane & 15) >> 2);
@@ -537,40 +562,45 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
             }
 #pragma unroll
             for (int r = 0; r < 8; ++r)
-                Hs[(4 * (lane >> 4) + (r & 3)) * LDH + wave * 32 + 16 * (r >> 2) + (lane & 15)] = actf(acc[r >> 2][r & 3], ACT);
+                Hs[(4 * (lane >> 4) + (r & 3)) * LDH + scol0 + 16 * (r >> 2)] = actf(acc[r >> 2][r & 3], ACT);
             __syncthreads();
             emit_deriv(l + 1);
             if ((m.skip_mask >> (l + 1)) & 1u) inject(l + 1);
-            OMDS_TL(2 + l);
+            OMDS_TL(2 + (l < 0 ? 0 : l));
         }
     } else
-    for (int l = 0; l < m.nhh; ++l) {
+    for (int l = -1; l < m.nhh; ++l) {
         f32x16 acc[MR][NR];
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
             for (int j = 0; j < NR; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = bcur[j];
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        float bnow[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) bnow[j] = bcur[j];
         if (l + 1 < m.nhh) {
 #pragma unroll
             for (int j = 0; j < NR; ++j) bcur[j] = m.bh[(l + 1) * OMDS_WIDTH + (cb0 + j) * 32 + (lane & 31)];
         }
-        gemm256<MR, NR>(Hw, m.Wf + (size_t)l * (OMDS_NCB * 32 * 64), cb0, lane, acc);
+        if (l < 0) gemm_k32<MR, NR>(Hw, m.W1f, cb0, lane, acc);
+        else gemm256<MR, NR>(Hw, m.Wf + (size_t)l * (OMDS_NCB * 32 * 64), cb0, lane, acc);
         __syncthreads();  // every wave has finished reading the tile
         if (l == 0) OMDS_TL(6);
         // one lane-dependent base address per column block; everything else of (row, col) is a compile-time offset, so the
         // 16 * MR stores of a block use immediate offsets (hipcc otherwise builds a VGPR address per row: VALU = matrix-pipe time)
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-            float* hb = Hs + (wm * MR * 32 + 4 * (lane >> 5)) * LDH + (cb0 + j) * 32 + (lane & 31);
+            float* hb = Hs + (wm * MR * 32 + 4 * (lane >> 5)) * LDH + (cb0 + j) * 32 + omds_kpos(lane & 31);
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    hb[(i * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = actf(acc[i][j][r], ACT);
+                    const float z = acc[i][j][r] + bnow[j];
+                    hb[(i * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = actf(z, ACT);
                     if constexpr (EMIT) {   // lanes 0-31 hold row (r&3) + 8(r>>2) of this 32-column block, lanes 32-63 that row + 4
-                        const unsigned long long bal = __ballot(acc[i][j][r] > 0.f);
+                        const unsigned long long bal = __ballot(z > 0.f);
                         if (lane == 0) {
                             const int rr = wm * MR * 32 + i * 32 + (r & 3) + 8 * (r >> 2);
                             maskS[((size_t)rr * nhid + (l + 1)) * 8 + cb0 + j] = (uint32_t)bal;
@@ -581,7 +611,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
         }
         __syncthreads();
         if ((m.skip_mask >> (l + 1)) & 1u) inject(l + 1);
-        OMDS_TL(2 + l);
+        OMDS_TL(2 + (l < 0 ? 0 : l));
     }
 
     // ---- last layer (256 -> C, padded to 16) on v_mfma_f32_16x16x4_f32, 16 rows per wave.  Kept short on purpose
@@ -590,7 +620,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
     const __amdgpu_buffer_rsrc_t wlr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(m.Wl), 0, 16 * 64 * 16, 0x00020000);
     for (int rb = __builtin_amdgcn_readfirstlane(wave); rb < MT / 16; rb += G::NW) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* arow = Hs + (rb * 16 + (lane & 15)) * LDH + 4 * (lane >> 4);
+        const float* arow = Hs + (rb * 16 + (lane & 15)) * LDH + pa16(lane);   // the k sequence of gemm16 (ascending k through omds_kpos)
         const int r4 = rb * 16 + 4 * (lane >> 4);
         [[maybe_unused]] float scr[4];   // LIST: the screening values of this lane's four rows (guard), in flight across the MFMA loop
         if constexpr (LIST) {
@@ -612,7 +642,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
         }
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            const float4 a = *reinterpret_cast<const float4*>(arow + 16 * c);
+            const float4 a = load_a16(arow, c);
             const omds_f4 w = wq[c % LPD];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
@@ -790,24 +820,31 @@ struct P2Geo {
         return ROWS == 32 ? wave * 32 + (lane & 31) : wave * 32 + 16 * (r >> 2) + (lane & 15);
     }
     static __device__ __forceinline__ int blk(int r) { return ROWS == 32 ? 0 : (r >> 2); }
+    // position of that column in the k-permuted tile (omds_kpos keeps groups of eight columns together)
+    static __device__ __forceinline__ int pos(int r, int wave, int lane) {
+        return ROWS == 32 ? wave * 32 + omds_kpos(lane & 31) : wave * 32 + 16 * (r >> 2) + omds_kpos(lane & 15);
+    }
 };
 
-// One [ROWS x 256] . [256 x 256] GEMM of pass 2 (forward pack or transposed pack of layer l); out[r] in P2Geo order.
-// init[jb] = start value of the accumulators of column block jb: the bias in the forward pass -- the same start as in
-// pass1_tile, so that the forward of a row is bit-identical in pass 1 and pass 2 (32-row tiles) -- and 0 in the backward.
+// One [ROWS x 256] . [256 x 256] GEMM of pass 2 (forward pack or transposed pack of layer l; l = -1: layer 1 over the encoded
+// inputs at positions 0..31, K = 32); out[r] in P2Geo order.  The accumulators start at zero in every product, forward and
+// backward (the reference's chains; the forward's bias is added by the caller) -- the same arithmetic as pass1_tile, so the
+// forward of a row is bit-identical in pass 1 and pass 2.
 template <int ROWS>
 __device__ __forceinline__ void p2_gemm(const float* Hs, const MlpDev& m, int l, bool backward, int wave, int lane,
-                                        float (&out)[P2Geo<ROWS>::NV], const float (&init)[P2Geo<ROWS>::NB]) {
+                                        float (&out)[P2Geo<ROWS>::NV]) {
     if constexpr (ROWS == 32) {
         f32x16 acc[1][1];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][0][r] = init[0];
-        gemm256<1, 1>(Hs, (backward ? m.Wb : m.Wf) + (size_t)l * (OMDS_NCB * 32 * 64), wave, lane, acc);
+        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+        if (l < 0) gemm_k32<1, 1>(Hs, m.W1f, wave, lane, acc);
+        else gemm256<1, 1>(Hs, (backward ? m.Wb : m.Wf) + (size_t)l * (OMDS_NCB * 32 * 64), wave, lane, acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[r] = acc[0][0][r];
     } else {
-        f32x4 acc[2] = {{init[0], init[0], init[0], init[0]}, {init[1], init[1], init[1], init[1]}};
-        gemm16(Hs, (backward ? m.Wb16 : m.Wf16) + (size_t)l * (16 * 16 * 64), wave, lane, acc);
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (l < 0) gemm16_k32(Hs, m.W1f16, wave, lane, acc);
+        else gemm16(Hs, (backward ? m.Wb16 : m.Wf16) + (size_t)l * (16 * 16 * 64), wave, lane, acc);
 #pragma unroll
         for (int r = 0; r < 8; ++r) out[r] = acc[r >> 2][r & 3];
     }
@@ -825,8 +862,8 @@ __device__ __forceinline__ void p2_backward_first(const MlpDev& m, const P2Smem&
 // caller).  R0 = global index of row 0 (tanh scratch, yraw, minidx); outputs go to
 // gradx[(dbase + row) * d + j] and drow[dbase + row] (global memory or LDS).
 template <int ACT, int ROWS = 32>
-__device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, const float* __restrict__ Apre,
-                                           const float* __restrict__ Bpre, const float* __restrict__ radius,
+__device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, const float* __restrict__ Fq,
+                                           const float* __restrict__ Fp, const float* __restrict__ radius,
                                            const float* __restrict__ xyzr, int R0, int total_rows,
                                            const float* __restrict__ qT, int ldq, float* gradx, float* drow, int dbase,
                                            float* __restrict__ yraw, int32_t* __restrict__ minidx,
@@ -847,57 +884,36 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr bool relu = ACT == OMDS_ACT_RELU;
 
-    float bnext[G::NB];   // bias of the first hidden -> hidden layer: in flight across the layer-1 build
+    float bnext[G::NB];   // bias of the layer about to be multiplied, fetched one layer ahead (no L2 round trip in front of its epilogue)
 #pragma unroll
-    for (int jb = 0; jb < G::NB; ++jb) bnext[jb] = m.nhh > 0 ? m.bh[G::col(4 * jb, wave, lane)] : 0.f;
-    // ---- layer 1 in C-layout ------------------------------------------------------------------
-    {
-        uint32_t bits = 0;
-        float za[NV], zb[NV];   // all loads in flight before the first use (padding rows read row 0)
-#pragma unroll
-        for (int r = 0; r < NV; ++r) {
-            const int row = G::row(r, lane), col = G::col(r, wave, lane);
-            const int t = rowT[row];
-            za[r] = Apre[(size_t)(t < 0 ? 0 : t) * OMDS_WIDTH + col];
-            zb[r] = Bpre[(size_t)rowO[row] * OMDS_WIDTH + col];
-        }
-#pragma unroll
-        for (int r = 0; r < NV; ++r) {
-            const int row = G::row(r, lane), col = G::col(r, wave, lane);
-            const float z = (rowT[row] >= 0) ? za[r] + zb[r] : 0.f;
-            bits |= (z > 0.f ? 1u : 0u) << r;
-            const float h = actf(z, ACT);
-            Hs[row * LDH + col] = h;
-            if (!relu) dscr[(size_t)(S0 + row) * OMDS_WIDTH + col] = 1.f - h * h;
-        }
-        maskL[tid] = (uint16_t)bits;
+    for (int jb = 0; jb < G::NB; ++jb) bnext[jb] = m.b1[G::col(4 * jb, wave, lane)];
+    // ---- the rows' encoded inputs [x, sin x, cos x] at positions 0..31: Fq[t] | Fp[o] (padding rows: zero) ----------------
+    for (int e = tid; e < ROWS * 32; e += P2_NT) {
+        const int r = e >> 5, f = e & 31, t = rowT[r];
+        uint32_t v = 0u;
+        if (t >= 0) v = __builtin_bit_cast(uint32_t, Fq[(size_t)t * OMDS_FROW + f]) | __builtin_bit_cast(uint32_t, Fp[(size_t)rowO[r] * OMDS_FROW + f]);
+        reinterpret_cast<uint32_t*>(Hs)[r * LDH + omds_kpos(f)] = v;
     }
     __syncthreads();
-    if (dbg == 10) return;
-    // skip-connection networks: [x, sin x, cos x] of each row behind the activations of `level` (MlpDev::skip_mask); the same
-    // sinf / cosf as the layer-1 kernels, so pass 1 (tables) and pass 2 see the same values
+    // skip-connection networks: the encoded input of each row behind the activations of `level` (MlpDev::skip_mask)
     auto inject = [&](int level) {
-        const int c0 = m.skip_col[level], d = m.d, n = m.n_dof, F = 3 * d;
+        const int c0 = m.skip_col[level], F = 3 * m.d;
         for (int e = tid; e < ROWS * 32; e += P2_NT) {
             const int r = e >> 5, f = e & 31;
             if (f < F) {
-                float v = 0.f;
                 const int t = rowT[r];
-                if (t >= 0) {
-                    const int part = f / d, jj = f - part * d;
-                    const float x = (jj < n) ? qT[(size_t)jj * ldq + t] : xyzr[rowO[r] * 4 + (jj - n)];
-                    v = part == 0 ? x : (part == 1 ? sinf(x) : cosf(x));
-                }
-                Hs[r * LDH + c0 + f] = v;
+                uint32_t v = 0u;
+                if (t >= 0) v = __builtin_bit_cast(uint32_t, Fq[(size_t)t * OMDS_FROW + f]) | __builtin_bit_cast(uint32_t, Fp[(size_t)rowO[r] * OMDS_FROW + f]);
+                reinterpret_cast<uint32_t*>(Hs)[r * LDH + omds_kpos(c0 + f)] = v;
             }
         }
         __syncthreads();
     };
-    if (m.skip_mask & 1u) inject(0);
 
-    // ---- forward through the hidden -> hidden layers -------------------------------------------
-    for (int l = 0; l < m.nhh; ++l) {
-        float bv[G::NB];   // the accumulators start at the bias, fetched one layer ahead (no L2 round trip in front of the GEMM)
+    // ---- forward: layer 1 (l = -1) and the hidden -> hidden layers, each the reference's product (from zero, ascending k, bias
+    //      last); level l + 1 of the masks / derivatives ---------------------------------------------------------------------
+    for (int l = -1; l < m.nhh; ++l) {
+        float bv[G::NB];
 #pragma unroll
         for (int jb = 0; jb < G::NB; ++jb) bv[jb] = bnext[jb];
         if (l + 1 < m.nhh) {
@@ -905,20 +921,21 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
             for (int jb = 0; jb < G::NB; ++jb) bnext[jb] = m.bh[(l + 1) * OMDS_WIDTH + G::col(4 * jb, wave, lane)];
         }
         float acc[NV];
-        p2_gemm<ROWS>(Hs, m, l, false, wave, lane, acc, bv);
+        p2_gemm<ROWS>(Hs, m, l, false, wave, lane, acc);
         __syncthreads();
         uint32_t bits = 0;
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
             const int row = G::row(r, lane), col = G::col(r, wave, lane);
-            const float z = acc[r];
+            const float z = acc[r] + bv[G::blk(r)];
             bits |= (z > 0.f ? 1u : 0u) << r;
             const float h = actf(z, ACT);
-            Hs[row * LDH + col] = h;
+            Hs[row * LDH + G::pos(r, wave, lane)] = h;
             if (!relu) dscr[(l + 1) * dlayer + (size_t)(S0 + row) * OMDS_WIDTH + col] = 1.f - h * h;
         }
         maskL[(l + 1) * P2_NT + tid] = (uint16_t)bits;
         __syncthreads();
+        if (dbg == 10 && l < 0) return;
         if ((m.skip_mask >> (l + 1)) & 1u) inject(l + 1);
     }
 
@@ -926,7 +943,7 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
     // ---- last layer, arg-min over ALL raw outputs (robot_sdf.py:155), distance of that link -------
     if (wave < ROWS / 16) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* arow = Hs + (wave * 16 + (lane & 15)) * LDH + 4 * (lane >> 4);
+        const float* arow = Hs + (wave * 16 + (lane & 15)) * LDH + pa16(lane);
         const int j = lane & 15;
         const float bj = m.bl[j];
         // all 16 weight fragments in flight at once: the MFMA chain below is latency-bound otherwise
@@ -936,7 +953,7 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
             for (int c = 0; c < 16; ++c) wl[c] = m.Wl[c * 64 + lane];
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                const float4 a = *reinterpret_cast<const float4*>(arow + 16 * c);
+                const float4 a = load_a16(arow, c);
                 const float4 w = wl[c];
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
@@ -983,8 +1000,8 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
 // sm.rowE, from the derivative rows k_exact left for the list entry of each backward row (a padding row multiplies by zero)
 __device__ __forceinline__ float p2_tanh_deriv(const P2Smem& sm, const float* __restrict__ dscr, size_t level_off, int S0, int row, int col) {
     if (sm.rowE == nullptr) return dscr[level_off + (size_t)(S0 + row) * OMDS_WIDTH + col];
-    const int e = sm.rowE[row];
-    return e >= 0 ? dscr[level_off + (size_t)e * OMDS_WIDTH + col] : 0.f;
+    const int e = sm.rowE[row];   // k_exact wrote its rows as they sit in the tile: column col at position omds_kpos(col)
+    return e >= 0 ? dscr[level_off + (size_t)e * OMDS_WIDTH + omds_kpos(col)] : 0.f;
 }
 
 // The backward half of pass 2: from sm.rowMin (arg-min link of each row), the activation derivatives -- sm.maskL (ReLU:
@@ -1022,7 +1039,7 @@ __device__ __forceinline__ void pass2_backward(const MlpDev& m, const P2Smem& sm
             const float g = m.Wlraw[(size_t)rowMin[row] * OMDS_WIDTH + col];
             if (cap && col >= c0 && col < c0 + F3) gf[row * 33 + col - c0] += g;
             const float dv = relu ? (((bits >> r) & 1u) ? 1.f : 0.f) : p2_tanh_deriv(sm, dscr, m.nhh * dlayer, S0, row, col);
-            Hs[row * LDH + col] = g * dv;
+            Hs[row * LDH + G::pos(r, wave, lane)] = g * dv;
         }
     }
     __syncthreads();
@@ -1032,8 +1049,7 @@ __device__ __forceinline__ void pass2_backward(const MlpDev& m, const P2Smem& sm
     // ---- backward through the hidden -> hidden layers ------------------------------------------
     for (int l = m.nhh - 1; l >= 0; --l) {
         float acc[NV];
-        const float zinit[G::NB] = {};
-        p2_gemm<ROWS>(Hs, m, l, true, wave, lane, acc, zinit);
+        p2_gemm<ROWS>(Hs, m, l, true, wave, lane, acc);
         if (l == m.nhh - 1) OMDS_TL_STAMP(5);
         __syncthreads();
         if (l == m.nhh - 1) OMDS_TL_STAMP(6);
@@ -1045,7 +1061,7 @@ __device__ __forceinline__ void pass2_backward(const MlpDev& m, const P2Smem& sm
             const int row = G::row(r, lane), col = G::col(r, wave, lane);
             const float dv = relu ? (((bits >> r) & 1u) ? 1.f : 0.f) : p2_tanh_deriv(sm, dscr, l * dlayer, S0, row, col);
             if (cap && col >= c0 && col < c0 + F3) gf[row * 33 + col - c0] += acc[r];
-            Hs[row * LDH + col] = acc[r] * dv;
+            Hs[row * LDH + G::pos(r, wave, lane)] = acc[r] * dv;
         }
         __syncthreads();
         if (l == m.nhh - 1) OMDS_TL_STAMP(7);
@@ -1120,7 +1136,7 @@ __device__ __forceinline__ void p2_backward_first(const MlpDev& m, const P2Smem&
         const int R = R0 + row;
         if (R < total_rows && rowT[row] >= 0) {
             const float x = (jj < n) ? qT[(size_t)jj * ldq + rowT[row]] : xyzr[rowO[row] * 4 + (jj - n)];
-            gradx[(size_t)(dbase + row) * d + jj] = gf[row * 33 + jj] + gf[row * 33 + d + jj] * cosf(x) - gf[row * 33 + 2 * d + jj] * sinf(x);
+            gradx[(size_t)(dbase + row) * d + jj] = gf[row * 33 + jj] + gf[row * 33 + d + jj] * omds_cosf(x) - gf[row * 33 + 2 * d + jj] * omds_sinf(x);
         }
     }
 }
@@ -1140,7 +1156,7 @@ __device__ __forceinline__ void pass2_backward_hidden_g4(const MlpDev& m, const 
     float* Hs = sm.Hs;
     const int* rowMin = sm.rowMin;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cw = wave & 3, col = 64 * cw + lane;
+    const int cw = wave & 3, col = 64 * cw + lane, pcol = omds_kpos(col);   // the column's position in the k-permuted tile
     const bool mine = wave < 4;   // waves 4-7 take no part in the GEMMs: a second wave per SIMD would fetch the same weight fragments
                                   // from L2 a second time (0.5 B per FLOP on this shape), and that, not the matrix pipe, then bounds the layer
     constexpr int PD = 8;
@@ -1157,7 +1173,7 @@ __device__ __forceinline__ void pass2_backward_hidden_g4(const MlpDev& m, const 
 #pragma unroll
         for (int e = 0; e < 4 * NG; ++e) {
             const float gz = m.Wlraw[(size_t)rowMin[e] * OMDS_WIDTH + col];
-            Hs[e * LDH + col] = ((bseed >> e) & 1u) ? gz : 0.f;
+            Hs[e * LDH + pcol] = ((bseed >> e) & 1u) ? gz : 0.f;
         }
     }
     __syncthreads();
@@ -1173,7 +1189,7 @@ __device__ __forceinline__ void pass2_backward_hidden_g4(const MlpDev& m, const 
         if (mine) {
             const uint32_t bl = sm.maskG4[l * 256 + (tid & 255)];
 #pragma unroll
-            for (int e = 0; e < 4 * NG; ++e) Hs[e * LDH + col] = ((bl >> e) & 1u) ? acc[e >> 2][e & 3] : 0.f;
+            for (int e = 0; e < 4 * NG; ++e) Hs[e * LDH + pcol] = ((bl >> e) & 1u) ? acc[e >> 2][e & 3] : 0.f;
         }
         __syncthreads();
         if (l == m.nhh - 1) OMDS_TL_STAMP(7);

@@ -27,6 +27,21 @@ constexpr int OMDS_LDH = 260;          // LDS row stride of the activation tile 
 constexpr int OMDS_CPAD = 16;          // output channels padded to one 16-wide MFMA tile
 constexpr int OMDS_MAX_HIDDEN = 8;     // hidden layers supported (reference nets: 4)
 constexpr int OMDS_NCB = OMDS_WIDTH / 32;  // 32-column blocks per hidden layer
+constexpr int OMDS_FROW = 32;          // floats per row of the encoded-input tables Fq / Fp (3 (n_dof + 3) <= 30 features, zero-padded)
+
+// ---- the reference's summation order on the MFMA --------------------------------------------------------------------------
+// torch-CPU computes every Linear layer (network_macros_mod.py:137-146: addmm = MKL sgemm) and every product of the vjp
+// (robot_sdf.py:153-158) as ONE fmaf chain per output element over k in ASCENDING order, starting from zero, the bias added
+// afterwards (tools/studies/assoc_order_study.py: bit for bit for M >= 11 rows).  An fp32 MFMA is an fmaf chain over its K
+// indices in lane-group order (tools/ubench/mfma_order.hip), so the order a kernel sums in is the order in which its A / B
+// fragments present k.  The GEMM cores read the activation tile from LDS as 16-byte fragments: lane half h of the 32x32x2
+// shape takes four consecutive floats at 8c + 4h and feeds them to four MFMAs, which therefore contract positions
+// 8c + {0, 4, 1, 5, 2, 6, 3, 7} in that order (gemm16 and gemm4 visit the same sequence).  For that sequence to be k = 8c + 0..7
+// the tile is STORED k-permuted inside every group of eight columns -- logical column k sits at position omds_kpos(k) -- and
+// the weight packs put W[.][omds_kat(s)] where a fragment reads position s.  Every writer of an activation / gradient tile
+// goes through omds_kpos; the GEMM cores are untouched.
+__host__ __device__ inline int omds_kpos(int k) { return (k & ~7) | ((k & 1) << 2) | ((k & 7) >> 1); }   // column -> position
+__host__ __device__ inline int omds_kat(int s) { return (s & ~7) | ((s & 3) << 1) | ((s >> 2) & 1); }    // position -> column
 
 // Device-side view of the distance network, weights pre-packed into MFMA fragment order.
 struct MlpDev {
@@ -37,8 +52,10 @@ struct MlpDev {
     const float* bl;     // [16]
     const float* Wlraw;  // [C][256] last layer, row-major (backward seed)
     const float* Whraw;  // [nhh][256][256] hidden->hidden layers, row-major [out][in] (the small-O step's 4-row backward streams them)
-    const float* W1t;    // [3d][256] first layer transposed
+    const float* W1t;    // [3d][256] first layer transposed (the small-O step's first-layer backward)
     const float* b1;     // [256]
+    const float4* W1f;   // [8 colblk][4 kchunk][64 lane] first layer, forward pack over the 3d encoded inputs (padded to K = 32)
+    const float4* W1f16; // [16 colblk16][2 kchunk][64 lane] the same for the 16-row tiles
     const float4* W1b;   // [32 kchunk][64 lane] first layer, backward pack (cols = 3d features, padded to 32)
     // the same three packs in v_mfma_f32_16x16x4 fragment order, for the 16-row pass-2 tiles of small batches:
     // lane l of chunk c holds 4 consecutive k = 16c + 4(l>>4) .. +3 of column 16*cb + (l&15)
@@ -58,8 +75,6 @@ struct MlpDev {
     // columns skip_col[L] .. +3d-1 of the activation tile, whose padded units are zero there.
     uint32_t skip_mask;  // bit L: concatenation behind level L
     uint8_t skip_col[OMDS_MAX_HIDDEN + 1];
-    float* featQ;        // [Apre rows][32] joint part of the encoded input of each Apre row (others 0); null without skips
-    float* featP;        // [max_obs][32] obstacle part of each Bpre row
     // the same encoded input as fp16 at the slots of the CONCATENATED columns of the screening kernel (omds_screen_sidx), written
     // beside FqH / FpH with their row capacities; null without skips or without a screening network
     uint16_t* scrQ;      // [4 pieces][n_traj][8]
@@ -171,11 +186,10 @@ struct omds_ctx {
     long long all_cap = 0; int all_nhid = 0;
     float* d_exDeriv = nullptr;  // tanh networks: [hidden layers][ex_cap][256] activation derivatives of the list entries (allocated by omds_set_mlp)
     int* d_sctotal = nullptr;    // [H+2]: candidate rows listed per horizon step; [H+1]: audit entries recorded in this propagate
-    int* d_audit_rows = nullptr; // [audit_cap] audit sample of a propagate: pair rows into d_ApreAll's row space, their screening values
+    int* d_audit_rows = nullptr; // [audit_cap] audit sample of a propagate: pair rows into d_FqAll's row space, their screening values
     float* d_audit_da = nullptr;
     int audit_cap = 0;
-    float* d_ApreAll = nullptr;  // [H][N][256] rollout half of layer 1 at the states of every horizon step (kept by a screened propagate with an audit sample)
-    float* d_featQAll = nullptr; // [H*N][32] skip-connection networks: the encoded joint inputs likewise
+    float* d_FqAll = nullptr;  // [H][N][OMDS_FROW] encoded joint inputs at the states of every horizon step (kept by a screened propagate with an audit sample)
     unsigned* d_scerr = nullptr; // [4]: max |screening - exact| over the candidates (float bits); rollouts whose slack guard failed;
                                  //      max (screening - exact) over the audit sample (float bits); calibration scratch
     double screen_rows = 0.0;    // statistics since the last omds_prof_reset: candidate rows, (rollout, step)s, audit rows
@@ -219,10 +233,8 @@ struct omds_ctx {
     // scene
     int n_obs = 0;
     float* d_obs = nullptr;      // [max_obs][4]
-    float* d_Bpre = nullptr;     // [max_obs][256] obstacle part of layer 1
+    float* d_Fp = nullptr;     // [max_obs][OMDS_FROW] encoded obstacle points [p, sin p, cos p] at their feature slots (the joints' slots zero)
     uint16_t* d_FpH = nullptr;   // [4][n_obs][8] fp16 network inputs of the obstacle points for the screening kernel
-    float* d_featQ = nullptr;    // [n_traj*n_closest][32] / [max_obs][32] encoded inputs (skip-connection networks, MlpDev::featQ/featP)
-    float* d_featP = nullptr;
     uint16_t* d_FqH = nullptr;   // [4][batch][8] rollout states likewise
     uint16_t* d_FqS = nullptr;   // skip-connection networks with a screening network: MlpDev::scrQ / scrP
     uint16_t* d_FpS = nullptr;
@@ -259,7 +271,7 @@ struct omds_ctx {
     float* d_alphaT = nullptr;   // [Kmax][n][N]
     float* d_means = nullptr;    // [Kmax*(2n+1)] mu_c, sigma_c, alpha_c staging
     // network scratch
-    float* d_Apre = nullptr;     // [Nrows][256]   (d_Apre, d_Dmin and d_ex* are SCRATCH between propagates: calibration and the
+    float* d_Fq = nullptr;     // [Nrows][OMDS_FROW] encoded joint states [q, sin q, cos q] at their feature slots (d_Fq, d_Dmin and d_ex* are SCRATCH between propagates: calibration and the
     float* d_Dmin = nullptr;     // [N][max_obs]    screening pack's re-sort overwrite them after the results have been published)
     int32_t* d_idx = nullptr;    // [N][k]
     float* d_gradx = nullptr;    // [N*k][d]
@@ -273,6 +285,7 @@ struct omds_ctx {
     float* d_evalT = nullptr;    // omds_cost_eval scratch (first use): caller tensors in SoA + their cost
     float* d_vjp_xyzr = nullptr; // omds_mlp_forward_vjp scratch (first use): per-row points, their layer-1 halves, zero radii
     float* d_vjp_B = nullptr;
+    int vjp_cap = 0;             // rows the three hold
     float* d_vjp_rad = nullptr;
     // cost / reduction
     float* d_cost = nullptr;     // [N]
@@ -326,14 +339,16 @@ int omds_update_impl(omds_ctx* ctx, bool use_comm, float rate, float ker_thr, fl
 // alias them with data of an earlier call
 // slab > 0: the B rows are `B / slab` consecutive [n][ldq] state slabs of `slab` rollouts each (the stored rollouts trajT
 // [H][n][N] as ONE batch of H*N states: row h*slab + t reads qT[(h*n + c) * ldq + t])
-void omds_launch_rollout_layer1(hipStream_t s, const MlpDev& m, const float* qT, int ldq, int B, float* Apre, uint16_t* FqH = nullptr, int ldF = 0,
-                                int slab = 0);
-void omds_launch_obstacle_layer1(hipStream_t s, const MlpDev& m, const float* xyzr, int O, float* Bpre, float* radius, uint16_t* FpH = nullptr, int ldF = 0,
-                                 float* featP = nullptr);
-void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
+// Fq [B][OMDS_FROW] / Fp [O][OMDS_FROW]: the fp32 encoded inputs [x, sin x, cos x] of the rollout states / obstacle points at
+// their feature slots (feature part * d + j; the other operand's slots and the padding stay zero: a pair's input row is the
+// bitwise OR of its two rows).  The tables must have been zeroed once for the network's d (omds_set_mlp does)
+void omds_launch_rollout_features(hipStream_t s, const MlpDev& m, const float* qT, int ldq, int B, float* Fq, uint16_t* FqH = nullptr, int ldF = 0,
+                                  int slab = 0);
+void omds_launch_obstacle_features(hipStream_t s, const MlpDev& m, const float* xyzr, int O, float* Fp, float* radius, uint16_t* FpH = nullptr, int ldF = 0);
+void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Fq, const float* Fp, const float* radius,
                        int O, int B, uint32_t ignored_links, float* Dmin);
 void omds_launch_topk(hipStream_t s, const float* Dmin, int B, int O, int k, int32_t* idx);
-void omds_launch_pass2(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
+void omds_launch_pass2(hipStream_t s, const MlpDev& m, const float* Fq, const float* Fp, const float* radius,
                        const float* xyzr, const int32_t* idx, int B, int k, const float* qT, int ldq,
                        float* gradx, float* drow, float* yraw, int32_t* minidx, float* dscr, int seed_col = -1);
 void omds_launch_blend(hipStream_t s, const float* gradx, const float* drow, int B, int k, int d, int n,
@@ -361,8 +376,7 @@ bool omds_screen_can_select(int O);
 // What k_exact leaves behind for the screened step's tail (k_tail_sel), per entry of the candidate list: the pass-1 value,
 // and everything pass 2's forward would produce for that row -- its arithmetic is the same bit for bit -- so that the tail
 // only runs the backward: the pass-2 distance, the arg-min link, and the ReLU masks of every hidden layer.  mask layout per
-// entry: [hidden layer][8 words]; layer 0 (the separable layer 1, built one row per wave) holds the four 64-lane ballots of
-// the lanes' float4 components (column 4 l + c = bit l of ballot c), layers >= 1 hold bit (col & 31) of word col >> 5.
+// entry: [hidden layer][8 words], bit (col & 31) of word col >> 5 = the unit of (logical) column col fired.
 // Window of the candidate list in units of the error bound eps: tau = (k-th smallest screening value) + OMDS_SCREEN_WINDOW * eps.
 // eps bounds the screening error of the rows that are NOT re-evaluated; the extra quarter absorbs the shift of the k-th row
 // itself (a re-evaluated row, whose error is measured: the slack guard of k_tail_sel checks tau - D*_k >= eps per rollout).
@@ -381,7 +395,7 @@ struct ExactOut {
     float* deriv = nullptr;      // tanh networks (pass1_tile mode 5): [hidden layers][cap][256] 1 - h^2 of every entry's hidden units
 };
 
-void omds_launch_pass1_emit(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius,
+void omds_launch_pass1_emit(hipStream_t s, const MlpDev& m, const float* Fq, const float* Fp, const float* radius,
                             int O, int B, uint32_t ignored, float* Dmin, const ExactOut& ex);
 
 // What the selection (k_select, or the flush phase of k_screen) produces per horizon step
@@ -404,7 +418,7 @@ struct SelectSink {
     int step_row0 = 0;        // (step - 1) * N: row of rollout 0 in the all-steps layer-1 table k_audit reads
 };
 void omds_launch_select(hipStream_t s, const float* Dmin, int B, int O, const SelectSink& sel);
-void omds_launch_audit(hipStream_t s, const MlpDev& m, const float* ApreAll, const float* Bpre, const float* radius, int O,
+void omds_launch_audit(hipStream_t s, const MlpDev& m, const float* FqAll, const float* Fp, const float* radius, int O,
                        uint32_t ignored, const int* rows, const float* da, const int* total, int cap, unsigned* maxerr_bits);
 // calibration of the screening bound on the device: the batch of states, and max |x - y| into *out_bits (float bits, atomicMax)
 void omds_launch_calib_states(hipStream_t s, float* qT, int B, int n, const float* lo, const float* hi, const float* center,
@@ -417,7 +431,7 @@ constexpr int OMDS_HIST_PAIRS = 0, OMDS_HIST_NONCAND = 1, OMDS_HIST_ABOVE_HALF =
 static_assert(OMDS_HIST_BINS0 + 2 * OMDS_HIST_LOG_BINS + OMDS_HIST_RATIO_BINS == OMDS_SWEEP_HIST_WORDS, "omds.h: OMDS_SWEEP_HIST_WORDS");
 void omds_launch_sweep_hist(hipStream_t s, const float* D, const float* Da, const int* range, int N, int O, float eps,
                             unsigned long long* hist, unsigned* maxabs_bits);
-void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius, int O,
+void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Fq, const float* Fp, const float* radius, int O,
                        int B, uint32_t ignored, float* Dmin, const int* rowlist, const int* total, unsigned* maxerr_bits,
                        const ExactOut& ex);
 
@@ -427,12 +441,12 @@ void omds_launch_modulate(hipStream_t s, const StepArgs& a);
 bool omds_tail_supported(int n_dof, int k);
 int omds_tail_scratch_rows(int N, int k);
 int omds_tail_rows(int N, int k);            // pass-2 tile height (16 | 32) for a batch of N rollouts with k closest obstacles   // rows of the tanh-derivative scratch the tail may touch (either tile height)
-// ApreOut: where the next step's layer-1 halves go (nullptr: in place).  guard_range / e_bound / viol: screened tanh step --
+// FqOut: where the next step's encoded joint inputs go (nullptr: in place).  guard_range / e_bound / viol: screened tanh step --
 // Dmin holds exact values on the candidates and screening values elsewhere; the tail counts the rollouts whose k-th smallest
 // value is not e_bound below k_select's tau (range[4 t + 2]) into *viol
-void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
-                      const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st, int t_begin, int t_end,
-                      uint16_t* FqH = nullptr, int ldF = 0, float* ApreOut = nullptr, const int* guard_range = nullptr,
+void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Fp, const float* radius, const float* xyzr,
+                      const float* Dmin, float* Fq, float* dscr, int O, const StepArgs& st, int t_begin, int t_end,
+                      uint16_t* FqH = nullptr, int ldF = 0, float* FqOut = nullptr, const int* guard_range = nullptr,
                       float e_bound = 0.f, unsigned* viol = nullptr);
 // screened step's tail: top-k over the candidates k_exact evaluated + pass-2 backward on its masks + the rest of k_tail
 bool omds_tail_sel_supported(int n_dof, int k);
@@ -440,14 +454,14 @@ int omds_cu_count();   // CUs of the current device (asked once per device)
 #ifdef OMDS_TEST_HOOKS
 void omds_force_tile_rows(int tail_sel_rows, int tail_rows);   // test hook (libomds_hip_test.so): 0 = the launcher's own choice
 #endif
-void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
-                          float* Apre, int O, const StepArgs& st, const int* rowlist, const int* range, const ExactOut& ex,
+void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Fp, const float* radius, const float* xyzr,
+                          float* Fq, int O, const StepArgs& st, const int* rowlist, const int* range, const ExactOut& ex,
                           uint16_t* FqH, int ldF, float e_bound, unsigned* viol);
 // fused one-launch step for scenes with few obstacles (step_small.hip): rollouts per workgroup, 0 = scene does not qualify
 int omds_step_small_rollouts(const MlpDev& m, int n_dof, int O, int k);
-void omds_launch_step_small(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr, float* Apre,
+void omds_launch_step_small(hipStream_t s, const MlpDev& m, const float* Fp, const float* radius, const float* xyzr, float* Fq,
                             int O, uint32_t ignored, const StepArgs& st);
-void omds_launch_net_small(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr, float* Apre,
+void omds_launch_net_small(hipStream_t s, const MlpDev& m, const float* Fp, const float* radius, const float* xyzr, float* Fq,
                            int O, uint32_t ignored, int n_dof, int k, const float* qT, int ldq, int B, float* gradx, float* drow,
                            int32_t* idx, float* Dmin);
 struct CostArgs {

@@ -30,7 +30,7 @@
 //     16 KB slices (32 output features x 256 k) through a 4-slot ring shared by the 8 waves of the workgroup (256 pairs):
 //     128 KB per layer per 256 pairs instead of per 32, one s_barrier per slice, counted vmcnt, loads two slices ahead.
 //   * layer 1 runs on the matrix pipe too: its 3(n+3) <= 32 inputs are two k-chunks, fetched as fp16 from a 64-byte row per
-//     rollout and per obstacle (four 16-byte loads per lane and tile; reading the separable fp32 halves Apre[t] + Bpre[o]
+//     rollout and per obstacle (four 16-byte loads per lane and tile; reading the separable fp32 halves Fq[t] + Fp[o]
 //     like k_pass1 does cost 36 % of the kernel, their fp16 copies still 25 %), W1 is one more slice of the ring.
 //   * persistent workgroups (one per CU) loop over their tiles: the ring never drains, no refill gap between tiles.
 //   * ReLU networks: a k-chunk (16 hidden units) whose activations are zero for all 32 pairs of the wave adds nothing to any
@@ -723,14 +723,14 @@ __global__ __launch_bounds__(SEL_WAVES * 64) void k_select(SelectArgs a) {
 // other) and 58.0 (16-row tiles, two resident).
 // ------------------------------------------------------------------------------------------------
 template <int ACT, int MODE>
-__global__ __launch_bounds__(512, 6) void k_exact(MlpDev m, const float* __restrict__ Apre, const float* __restrict__ Bpre,
+__global__ __launch_bounds__(512, 6) void k_exact(MlpDev m, const float* __restrict__ Fq, const float* __restrict__ Fp,
                                                   const float* __restrict__ radius, int O, uint32_t ignored,
                                                   float* __restrict__ Dmin, OmdsDivisor odiv, const int* __restrict__ rowlist,
                                                   const int* __restrict__ total, unsigned* __restrict__ maxerr_bits, ExactOut ex) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = *total;
     for (int blk = blockIdx.x; blk * 16 < n; blk += gridDim.x) {
-        pass1_tile<16, 1, 1, ACT, MODE>(m, smem, Apre, Bpre, radius, O, n, ignored, Dmin, (long long)blk * 16, odiv, rowlist, maxerr_bits, &ex);
+        pass1_tile<16, 1, 1, ACT, MODE>(m, smem, Fq, Fp, radius, O, n, ignored, Dmin, (long long)blk * 16, odiv, rowlist, maxerr_bits, &ex);
         __syncthreads();   // the tile buffer is reused by the next tile
     }
 }
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(512, 6) void k_exact(MlpDev m, const float* __restr
 // Output: max (Da - D) over the sample, the one-sided error the selection rule bounds by eps (maxerr_bits[2]).
 // ------------------------------------------------------------------------------------------------
 template <int ACT>
-__global__ __launch_bounds__(512) void k_audit(MlpDev m, const float* __restrict__ ApreAll, const float* __restrict__ Bpre,
+__global__ __launch_bounds__(512) void k_audit(MlpDev m, const float* __restrict__ FqAll, const float* __restrict__ Fp,
                                                const float* __restrict__ radius, int O, uint32_t ignored, OmdsDivisor odiv,
                                                const int* __restrict__ rows, const int* __restrict__ total, int cap,
                                                unsigned* __restrict__ maxerr_bits, ExactOut ex) {
@@ -755,18 +755,18 @@ __global__ __launch_bounds__(512) void k_audit(MlpDev m, const float* __restrict
     const int full = n / (64 * G);                  // rounds in which every workgroup has a full tile
     const int rest0 = full * 64 * G, rest = n - rest0;
     for (int r = 0; r < full; ++r) {
-        pass1_tile<64, 2, 1, ACT, 4>(m, smem, ApreAll, Bpre, radius, O, n, ignored, nullptr, ((long long)r * G + blockIdx.x) * 64, odiv, rows, maxerr_bits, &ex);
+        pass1_tile<64, 2, 1, ACT, 4>(m, smem, FqAll, Fp, radius, O, n, ignored, nullptr, ((long long)r * G + blockIdx.x) * 64, odiv, rows, maxerr_bits, &ex);
         __syncthreads();
     }
     if (rest > 32 * G) {
         if ((long long)blockIdx.x * 64 < rest)
-            pass1_tile<64, 2, 1, ACT, 4>(m, smem, ApreAll, Bpre, radius, O, n, ignored, nullptr, rest0 + (long long)blockIdx.x * 64, odiv, rows, maxerr_bits, &ex);
+            pass1_tile<64, 2, 1, ACT, 4>(m, smem, FqAll, Fp, radius, O, n, ignored, nullptr, rest0 + (long long)blockIdx.x * 64, odiv, rows, maxerr_bits, &ex);
     } else if ((long long)blockIdx.x * 32 < rest) {
-        pass1_tile<32, 1, 1, ACT, 4>(m, smem, ApreAll, Bpre, radius, O, n, ignored, nullptr, rest0 + (long long)blockIdx.x * 32, odiv, rows, maxerr_bits, &ex);
+        pass1_tile<32, 1, 1, ACT, 4>(m, smem, FqAll, Fp, radius, O, n, ignored, nullptr, rest0 + (long long)blockIdx.x * 32, odiv, rows, maxerr_bits, &ex);
     }
 }
 
-void omds_launch_audit(hipStream_t s, const MlpDev& m, const float* ApreAll, const float* Bpre, const float* radius, int O,
+void omds_launch_audit(hipStream_t s, const MlpDev& m, const float* FqAll, const float* Fp, const float* radius, int O,
                        uint32_t ignored, const int* rows, const float* da, const int* total, int cap, unsigned* maxerr_bits) {
     if (cap <= 0) return;
     const size_t lds = (size_t)64 * LDH * 4 + 64 * 4 + 64 * 4;
@@ -781,9 +781,9 @@ void omds_launch_audit(hipStream_t s, const MlpDev& m, const float* ApreAll, con
     const unsigned grid = (unsigned)std::min<long long>(((long long)cap + 63) / 64, 512);
     const OmdsDivisor od = OmdsDivisor::make((unsigned)O);
     if (m.act == OMDS_ACT_RELU)
-        hipLaunchKernelGGL((k_audit<OMDS_ACT_RELU>), dim3(grid), dim3(512), lds, s, m, ApreAll, Bpre, radius, O, ignored, od, rows, total, cap, maxerr_bits, ex);
+        hipLaunchKernelGGL((k_audit<OMDS_ACT_RELU>), dim3(grid), dim3(512), lds, s, m, FqAll, Fp, radius, O, ignored, od, rows, total, cap, maxerr_bits, ex);
     else
-        hipLaunchKernelGGL((k_audit<OMDS_ACT_TANH>), dim3(grid), dim3(512), lds, s, m, ApreAll, Bpre, radius, O, ignored, od, rows, total, cap, maxerr_bits, ex);
+        hipLaunchKernelGGL((k_audit<OMDS_ACT_TANH>), dim3(grid), dim3(512), lds, s, m, FqAll, Fp, radius, O, ignored, od, rows, total, cap, maxerr_bits, ex);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1048,7 +1048,7 @@ void omds_launch_select(hipStream_t s, const float* Dmin, int B, int O, const Se
 // the tail).  Without ex.deriv (a matrix-mode step: rows too long for the selecting flush AND no derivative buffer), mode 3: the
 // exact value replaces the screening value in the matrix Dmin itself and k_tail takes its top-k from the matrix and runs its own
 // forward.
-void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const float* Bpre, const float* radius, int O,
+void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Fq, const float* Fp, const float* radius, int O,
                        int B, uint32_t ignored, float* Dmin, const int* rowlist, const int* total, unsigned* maxerr_bits,
                        const ExactOut& ex) {
     if (B <= 0) return;
@@ -1060,9 +1060,9 @@ void omds_launch_exact(hipStream_t s, const MlpDev& m, const float* Apre, const 
     const unsigned grid = (unsigned)std::min<long long>(blocks_max, (long long)res * ncu);
     const OmdsDivisor od = OmdsDivisor::make((unsigned)O);
     if (m.act == OMDS_ACT_RELU)
-        hipLaunchKernelGGL((k_exact<OMDS_ACT_RELU, 1>), dim3(grid), dim3(512), lds, s, m, Apre, Bpre, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits, ex);
+        hipLaunchKernelGGL((k_exact<OMDS_ACT_RELU, 1>), dim3(grid), dim3(512), lds, s, m, Fq, Fp, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits, ex);
     else if (ex.deriv)   // the derivative hand-over: k_tail_sel runs the backward on what this launch leaves per entry
-        hipLaunchKernelGGL((k_exact<OMDS_ACT_TANH, 5>), dim3(grid), dim3(512), lds, s, m, Apre, Bpre, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits, ex);
+        hipLaunchKernelGGL((k_exact<OMDS_ACT_TANH, 5>), dim3(grid), dim3(512), lds, s, m, Fq, Fp, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits, ex);
     else
-        hipLaunchKernelGGL((k_exact<OMDS_ACT_TANH, 3>), dim3(grid), dim3(512), lds, s, m, Apre, Bpre, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits, ex);
+        hipLaunchKernelGGL((k_exact<OMDS_ACT_TANH, 3>), dim3(grid), dim3(512), lds, s, m, Fq, Fp, radius, O, ignored, Dmin, od, rowlist, total, maxerr_bits, ex);
 }

@@ -30,10 +30,10 @@ constexpr int SS_NT = 512;
 
 struct SmallArgs {
     MlpDev m;
-    const float* Bpre;
+    const float* Fp;
     const float* radius;
     const float* xyzr;
-    float* Apre;          // [N][256] in: this step, out: next step
+    float* Fq;          // [N][OMDS_FROW] encoded joint inputs, in: this step, out: next step
     int O, R;             // obstacles, rollouts per workgroup (R * O <= 32, R * k <= SS_RK)
     uint32_t ignored;
     OmdsDivisor odiv;
@@ -52,9 +52,8 @@ struct SmallArgs {
 };
 
 __device__ __forceinline__ uint32_t ss_mask_bit(const uint32_t* maskS, int nhid, int row, int level, int col) {
-    const uint32_t* mr = maskS + ((size_t)row * nhid + level) * 8;
-    // level 0 (layer 1): ballot of component col & 3 of lane col >> 2; levels >= 1: one ballot half per 32-column block
-    return level == 0 ? (mr[(col & 3) * 2 + (col >> 7)] >> ((col >> 2) & 31)) & 1u : (mr[col >> 5] >> (col & 31)) & 1u;
+    const uint32_t* mr = maskS + ((size_t)row * nhid + level) * 8;   // one ballot half per 32-column block
+    return (mr[col >> 5] >> (col & 31)) & 1u;
 }
 
 template <int ND, int TR>
@@ -85,7 +84,7 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
     {
         const ExactOut ex{D1, Dr, Amin, nullptr, TR};
         const long long total = (long long)N * O;
-        pass1_tile<TR, 1, 1, ACT, 2>(m, smem, a.Apre, a.Bpre, a.radius, O, total, a.ignored, nullptr, (long long)t_base * O, a.odiv,
+        pass1_tile<TR, 1, 1, ACT, 2>(m, smem, a.Fq, a.Fp, a.radius, O, total, a.ignored, nullptr, (long long)t_base * O, a.odiv,
                                      nullptr, nullptr, &ex);
     }
     if (OMDS_DBG(a.dbg_stop) == 1) return;
@@ -154,7 +153,7 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
     // layer-1 halves in LDS and their navigation kernels in registers over all H steps): 1.82 ms per iteration against 1.74 ms
     // for H launches -- consecutive launches already start with no idle gap, and the loop costs registers (245).
     {
-        const int col = 64 * (wv & 3) + lane;
+        const int col = 64 * (wv & 3) + lane, pcol = omds_kpos(col);   // the column and its position in the k-permuted tile
         // this thread's ReLU masks, all levels: bit 4 l + r = row r at level l (the GEMM waves: their column)
         uint32_t mb = 0;
         int amin[SS_RK];
@@ -170,7 +169,7 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
         if (mine) {        // seed: dy[argmin] / dH_last = Wlast[argmin], masked by the last hidden layer (the tile buffer is idle since the forward)
 #pragma unroll
             for (int r = 0; r < SS_RK; ++r)
-                Hs[r * LDH + col] = ((mb >> (4 * m.nhh + r)) & 1u) ? m.Wlraw[(size_t)amin[r] * OMDS_WIDTH + col] : 0.f;
+                Hs[r * LDH + pcol] = ((mb >> (4 * m.nhh + r)) & 1u) ? m.Wlraw[(size_t)amin[r] * OMDS_WIDTH + col] : 0.f;
         }
         __syncthreads();
 #pragma unroll 1
@@ -185,13 +184,13 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
 #pragma unroll
                 for (int r = 0; r < SS_RK; ++r) {
                     v[r] = ((mb >> (4 * l + r)) & 1u) ? acc[0][r] : 0.f;
-                    Hs[r * LDH + col] = v[r];
+                    Hs[r * LDH + pcol] = v[r];
                 }
                 if (l == 0) gS[col] = make_float4(v[0], v[1], v[2], v[3]);
             }
             __syncthreads();
         }
-        if (m.nhh == 0 && mine) gS[col] = make_float4(Hs[col], Hs[LDH + col], Hs[2 * LDH + col], Hs[3 * LDH + col]);
+        if (m.nhh == 0 && mine) gS[col] = make_float4(Hs[pcol], Hs[LDH + pcol], Hs[2 * LDH + pcol], Hs[3 * LDH + pcol]);
         if (m.nhh == 0) __syncthreads();
     }
     if (OMDS_DBG(a.dbg_stop) == 3) return;
@@ -226,7 +225,7 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
             const int r = tid / d, jj = tid - r * d;
             if (selRow[r] >= 0) {
                 const float x = (jj < n) ? qT[(size_t)jj * ldq + selT[r]] : a.xyzr[selO[r] * 4 + (jj - n)];
-                gx[r * d + jj] = gf[r * 33 + jj] + gf[r * 33 + d + jj] * cosf(x) - gf[r * 33 + 2 * d + jj] * sinf(x);
+                gx[r * d + jj] = gf[r * 33 + jj] + gf[r * 33 + d + jj] * omds_cosf(x) - gf[r * 33 + 2 * d + jj] * omds_sinf(x);
             }
         }
     }
@@ -248,18 +247,6 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
         return;
     }
 
-    // the next step's layer-1 weights of this thread's column: asked for now, used after the modulation (they depend on nothing)
-    float w1n[3 * ND], b1n = 0.f;
-    if (a.st.step < a.st.H) {
-        const int c = tid & 255, d = m.d;
-        b1n = m.b1[c];
-#pragma unroll
-        for (int j = 0; j < ND; ++j) {
-            w1n[j] = m.W1t[(size_t)j * OMDS_WIDTH + c];
-            w1n[ND + j] = m.W1t[(size_t)(d + j) * OMDS_WIDTH + c];
-            w1n[2 * ND + j] = m.W1t[(size_t)(2 * d + j) * OMDS_WIDTH + c];
-        }
-    }
     // ---- 4. modulation / policy / Euler step: 16 lanes per rollout (as k_tail) -----------------------------------------
     {
         const int rl = tid >> 4, sub = tid & 15;
@@ -274,27 +261,18 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
 #pragma unroll
                 for (int j = 1; j < ND; ++j) v = (sub == j) ? qn[j] : v;
                 feat[rl * 3 * ND + sub] = v;
-                feat[rl * 3 * ND + ND + sub] = sinf(v);
-                feat[rl * 3 * ND + 2 * ND + sub] = cosf(v);
+                feat[rl * 3 * ND + ND + sub] = omds_sinf(v);
+                feat[rl * 3 * ND + 2 * ND + sub] = omds_cosf(v);
             }
         }
     }
     if (a.st.step >= a.st.H || OMDS_DBG(a.dbg_stop) == 5) return;   // last step: nothing is integrated, no next network evaluation
     __syncthreads();
-    {   // rollout half of layer 1 for the next step (same arithmetic order as k_rollout_layer1)
-        const int c = tid & 255;
-        for (int rl = tid >> 8; rl < R; rl += 2) {
-            const int t = t_base + rl;
-            if (t >= N) break;
-            const float* f = feat + rl * 3 * ND;
-            float acc = b1n;
-#pragma unroll
-            for (int j = 0; j < ND; ++j) acc = fmaf(w1n[j], f[j], acc);
-#pragma unroll
-            for (int j = 0; j < ND; ++j) acc = fmaf(w1n[ND + j], f[ND + j], acc);
-#pragma unroll
-            for (int j = 0; j < ND; ++j) acc = fmaf(w1n[2 * ND + j], f[2 * ND + j], acc);
-            a.Apre[(size_t)t * OMDS_WIDTH + c] = acc;
+    {   // the encoded joint inputs of the next step (as k_rollout_features writes them)
+        const int d = m.d;
+        for (int e = tid; e < R * 3 * ND; e += SS_NT) {
+            const int rl = e / (3 * ND), cc = e - rl * (3 * ND), part = cc / ND, t = t_base + rl;
+            if (t < N) a.Fq[(size_t)t * OMDS_FROW + part * d + (cc - part * ND)] = feat[e];
         }
     }
 }
@@ -343,10 +321,10 @@ static void launch_small_t(hipStream_t s, SmallArgs& a, int k) {
     else launch_small_r<ND, 32>(s, a);
 }
 
-void omds_launch_step_small(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr, float* Apre,
+void omds_launch_step_small(hipStream_t s, const MlpDev& m, const float* Fp, const float* radius, const float* xyzr, float* Fq,
                             int O, uint32_t ignored, const StepArgs& st) {
     SmallArgs a{};
-    a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Apre = Apre; a.O = O; a.ignored = ignored;
+    a.m = m; a.Fp = Fp; a.radius = radius; a.xyzr = xyzr; a.Fq = Fq; a.O = O; a.ignored = ignored;
     a.R = omds_step_small_rollouts(m, st.n, O, st.k);
     a.odiv = OmdsDivisor::make((unsigned)O);
     a.B = st.N;
@@ -360,12 +338,12 @@ void omds_launch_step_small(hipStream_t s, const MlpDev& m, const float* Bpre, c
     else launch_small_t<2>(s, a, st.k);
 }
 
-// the network part alone on B states (qT [n][ldq]); Apre holds their layer-1 halves
-void omds_launch_net_small(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr, float* Apre,
+// the network part alone on B states (qT [n][ldq]); Fq holds their layer-1 halves
+void omds_launch_net_small(hipStream_t s, const MlpDev& m, const float* Fp, const float* radius, const float* xyzr, float* Fq,
                            int O, uint32_t ignored, int n_dof, int k, const float* qT, int ldq, int B, float* gradx, float* drow,
                            int32_t* idx, float* Dmin) {
     SmallArgs a{};
-    a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Apre = Apre; a.O = O; a.ignored = ignored;
+    a.m = m; a.Fp = Fp; a.radius = radius; a.xyzr = xyzr; a.Fq = Fq; a.O = O; a.ignored = ignored;
     a.R = omds_step_small_rollouts(m, n_dof, O, k);
     a.odiv = OmdsDivisor::make((unsigned)O);
     a.B = B; a.qT = qT; a.ldq = ldq;

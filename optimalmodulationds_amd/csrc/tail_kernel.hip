@@ -1,7 +1,7 @@
 // Fused per-step "tail" kernel for gfx950: everything of one horizon step that is local to a rollout
 // once the pass-1 min-distance matrix exists -- top-k over the obstacles (MPPI.py:245-247), forward +
 // analytic backward on the k closest rows (robot_sdf.py:153-158), softmax blend, modulation / policy /
-// Euler step (MPPI.py:102-223) and the rollout half of layer 1 for the NEXT step.  A workgroup owns
+// Euler step (MPPI.py:102-223) and the encoded joint inputs [q, sin q, cos q] of the NEXT step.  A workgroup owns
 // floor(ROWS/k) rollouts (<= ROWS network rows), so a horizon step is two launches: k_pass1 + k_tail.  ROWS = 32
 // (v_mfma_f32_32x32x2) for large batches; ROWS = 16 (v_mfma_f32_16x16x4) when the batch has too few rows to fill the
 // CUs with 32-row tiles anyway: the workgroup's chain of dependent GEMMs IS the step latency then, and it halves.
@@ -16,12 +16,12 @@
 
 struct TailArgs {
     MlpDev m;
-    const float* Bpre;
+    const float* Fp;
     const float* radius;
     const float* xyzr;
     const float* Dmin;   // [N][O]
-    float* Apre;         // [N][256] in: this step, out: next step (rows of the workgroup's own rollouts)
-    float* ApreOut;      // where the next step's rows go: Apre itself, or the next slab when all steps' halves are kept
+    float* Fq;         // [N][OMDS_FROW] encoded joint inputs, in: this step, out: next step (rows of the workgroup's own rollouts)
+    float* FqOut;      // where the next step's rows go: Fq itself, or the next slab when all steps' halves are kept
     _Float16* FqH;       // next step's states as fp16 network inputs for the screening kernel (nullptr: not screening)
     int ldF;             // row capacity of FqH
     float* dscr;         // tanh derivative scratch
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
 
     // ---- forward + backward on the selected rows; gradients and distances stay in LDS ------------
     const float* qT = a.st.trajT + (size_t)(a.st.step - 1) * ND * N;
-    pass2_body<ACT, ROWS>(m, sm, a.Apre, a.Bpre, a.radius, a.xyzr, t_base * k, N * k, qT, N, gx, dr, 0, nullptr, nullptr,
+    pass2_body<ACT, ROWS>(m, sm, a.Fq, a.Fp, a.radius, a.xyzr, t_base * k, N * k, qT, N, gx, dr, 0, nullptr, nullptr,
                                  a.dscr, (size_t)a.n_slots * ROWS * OMDS_WIDTH, (a.slot0 + (int)blockIdx.x) * ROWS, OMDS_DBG(a.dbg_stop));
     __syncthreads();
     if (OMDS_DBG(a.dbg_stop) == 2) return;
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
 #pragma unroll
                 for (int j = 1; j < ND; ++j) v = (sub == j) ? qn[j] : v;
                 feat[rl * 3 * ND + sub] = v;
-                feat[rl * 3 * ND + ND + sub] = sinf(v);
-                feat[rl * 3 * ND + 2 * ND + sub] = cosf(v);
+                feat[rl * 3 * ND + ND + sub] = omds_sinf(v);
+                feat[rl * 3 * ND + 2 * ND + sub] = omds_cosf(v);
                 if (a.FqH && a.st.step < a.st.H) {
                     const int d = m.d;
                     a.FqH[omds_screen_fidx(sub, t, a.ldF)] = (_Float16)v;
@@ -119,27 +119,13 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
     if (a.st.step >= a.st.H || OMDS_DBG(a.dbg_stop) == 3) return;   // last step: nothing is integrated, no next network evaluation
     __syncthreads();
 
-    // ---- rollout half of layer 1 for the next step (same arithmetic order as k_rollout_layer1) --------
+    // ---- the encoded joint inputs of the next step (as k_rollout_features writes them) --------
     {
-        const int c = tid & 255, d = m.d;
-        for (int rl = tid >> 8; rl < RW; rl += 2) {
-            const int t = t_base + rl;
-            if (t >= t_end) break;
-            const float* f = feat + rl * 3 * ND;
-            float acc = m.b1[c];
-#pragma unroll
-            for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)j * OMDS_WIDTH + c], f[j], acc);
-#pragma unroll
-            for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)(d + j) * OMDS_WIDTH + c], f[ND + j], acc);
-#pragma unroll
-            for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)(2 * d + j) * OMDS_WIDTH + c], f[2 * ND + j], acc);
-            a.ApreOut[(size_t)t * OMDS_WIDTH + c] = acc;
+        const int d = m.d;
+        for (int e = tid; e < RW * 3 * ND; e += P2_NT) {
+            const int rl = e / (3 * ND), cc = e - rl * (3 * ND), part = cc / ND, t = t_base + rl;
+            if (t < t_end) a.FqOut[(size_t)t * OMDS_FROW + part * d + (cc - part * ND)] = feat[e];
         }
-        if (m.featQ)   // skip-connection networks: the encoded joint inputs of the next step (as k_rollout_layer1 writes them)
-            for (int e = tid; e < RW * 3 * ND; e += P2_NT) {
-                const int rl = e / (3 * ND), cc = e - rl * (3 * ND), part = cc / ND, t = t_base + rl;
-                if (t < t_end) m.featQ[(size_t)t * 32 + part * d + (cc - part * ND)] = feat[e];
-            }
     }
 }
 
@@ -277,8 +263,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
 #pragma unroll
             for (int e = 0; e < 4 * G4_NG; ++e) {
                 const uint32_t* mr = maskRow + ((size_t)e * nhid + l) * 8;
-                const uint32_t bit = (l == 0) ? ((mr[(col & 3) * 2 + (col >> 7)] >> ((col >> 2) & 31)) & 1u) : ((mr[col >> 5] >> (col & 31)) & 1u);
-                bits |= bit << e;
+                bits |= ((mr[col >> 5] >> (col & 31)) & 1u) << e;
             }
             sm.maskG4[i] = bits;
         }
@@ -290,9 +275,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
             for (int r = 0; r < G::NV; ++r) {
                 const int col = G::col(r, wave, lane);
                 const uint32_t* mr = maskRow + ((size_t)G::row(r, lane) * nhid + l) * 8;
-                // layer 1: ballot of component col & 3, lane col >> 2; later layers: one ballot half per 32-column block
-                const uint32_t bit = (l == 0) ? ((mr[(col & 3) * 2 + (col >> 7)] >> ((col >> 2) & 31)) & 1u) : ((mr[col >> 5] >> (col & 31)) & 1u);
-                bits |= bit << r;
+                bits |= ((mr[col >> 5] >> (col & 31)) & 1u) << r;   // one ballot half per 32-column block and level
             }
             sm.maskL[l * P2_NT + tid] = (uint16_t)bits;
         }
@@ -328,8 +311,8 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
 #pragma unroll
                 for (int j = 1; j < ND; ++j) v = (sub == j) ? qn[j] : v;
                 feat[rl * 3 * ND + sub] = v;
-                feat[rl * 3 * ND + ND + sub] = sinf(v);
-                feat[rl * 3 * ND + 2 * ND + sub] = cosf(v);
+                feat[rl * 3 * ND + ND + sub] = omds_sinf(v);
+                feat[rl * 3 * ND + 2 * ND + sub] = omds_cosf(v);
                 if (a.FqH && a.st.step < a.st.H) {
                     const int d = m.d;
                     a.FqH[omds_screen_fidx(sub, t, a.ldF)] = (_Float16)v;
@@ -349,27 +332,13 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
     if (a.st.step >= a.st.H) return;   // last step: nothing is integrated, no next network evaluation
     __syncthreads();
 
-    // ---- rollout half of layer 1 for the next step (same arithmetic order as k_rollout_layer1) --------
+    // ---- the encoded joint inputs of the next step (as k_rollout_features writes them) --------
     {
-        const int c = tid & 255, d = m.d;
-        for (int rl = tid >> 8; rl < RW; rl += 2) {
-            const int t = t_base + rl;
-            if (t >= t_end) break;
-            const float* f = feat + rl * 3 * ND;
-            float acc = m.b1[c];
-#pragma unroll
-            for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)j * OMDS_WIDTH + c], f[j], acc);
-#pragma unroll
-            for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)(d + j) * OMDS_WIDTH + c], f[ND + j], acc);
-#pragma unroll
-            for (int j = 0; j < ND; ++j) acc = fmaf(m.W1t[(size_t)(2 * d + j) * OMDS_WIDTH + c], f[2 * ND + j], acc);
-            a.ApreOut[(size_t)t * OMDS_WIDTH + c] = acc;
+        const int d = m.d;
+        for (int e = tid; e < RW * 3 * ND; e += P2_NT) {
+            const int rl = e / (3 * ND), cc = e - rl * (3 * ND), part = cc / ND, t = t_base + rl;
+            if (t < t_end) a.FqOut[(size_t)t * OMDS_FROW + part * d + (cc - part * ND)] = feat[e];
         }
-        if (m.featQ)   // skip-connection networks: the encoded joint inputs of the next step (as k_rollout_layer1 writes them)
-            for (int e = tid; e < RW * 3 * ND; e += P2_NT) {
-                const int rl = e / (3 * ND), cc = e - rl * (3 * ND), part = cc / ND, t = t_base + rl;
-                if (t < t_end) m.featQ[(size_t)t * 32 + part * d + (cc - part * ND)] = feat[e];
-            }
     }
     OMDS_TL_STAMP(11);
     OMDS_TL_STAMP(19);
@@ -442,8 +411,8 @@ static int tail_sel_rows(int N, int k, bool g4_ok) {
 
 bool omds_tail_sel_supported(int n_dof, int k) { return (n_dof == 7 || n_dof == 2) && k >= 1 && k <= 32; }
 
-void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
-                          float* Apre, int O, const StepArgs& st, const int* rowlist, const int* range, const ExactOut& ex,
+void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Fp, const float* radius, const float* xyzr,
+                          float* Fq, int O, const StepArgs& st, const int* rowlist, const int* range, const ExactOut& ex,
                           uint16_t* FqH, int ldF, float e_bound, unsigned* viol) {
     TailArgs a;
     a.e_bound = e_bound;
@@ -454,7 +423,7 @@ void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Bpre, con
     a.slot0 = 0; a.n_slots = 0;
     static const int stop = OMDS_EXP_ENV("OMDS_TAIL_SEL_STOP", 0);
     a.dbg_stop = stop;
-    a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Dmin = nullptr; a.Apre = Apre; a.ApreOut = Apre; a.dscr = nullptr; a.O = O; a.st = st;
+    a.m = m; a.Fp = Fp; a.radius = radius; a.xyzr = xyzr; a.Dmin = nullptr; a.Fq = Fq; a.FqOut = Fq; a.dscr = nullptr; a.O = O; a.st = st;
     a.rowlist = rowlist; a.range = range; a.ex = ex;
     if (m.act == OMDS_ACT_TANH) {   // derivative rows instead of masks: 16- or 32-row tiles (the 4-row-group backward is a ReLU-mask form)
         const int rows = tail_sel_rows(st.N, st.k, false);
@@ -507,9 +476,9 @@ int omds_tail_scratch_rows(int N, int k) {
     return rows;
 }
 
-void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const float* radius, const float* xyzr,
-                      const float* Dmin, float* Apre, float* dscr, int O, const StepArgs& st, int t_begin, int t_end, uint16_t* FqH, int ldF,
-                      float* ApreOut, const int* guard_range, float e_bound, unsigned* viol) {
+void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Fp, const float* radius, const float* xyzr,
+                      const float* Dmin, float* Fq, float* dscr, int O, const StepArgs& st, int t_begin, int t_end, uint16_t* FqH, int ldF,
+                      float* FqOut, const int* guard_range, float e_bound, unsigned* viol) {
     TailArgs a;
     a.FqH = reinterpret_cast<_Float16*>(FqH);
     a.ldF = ldF;
@@ -521,7 +490,7 @@ void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Bpre, const f
     static const int stop = OMDS_EXP_ENV("OMDS_TAIL_STOP", 0);
     a.dbg_stop = stop;
     a.rowlist = nullptr; a.range = guard_range; a.ex = ExactOut{}; a.e_bound = e_bound; a.viol = viol;
-    a.m = m; a.Bpre = Bpre; a.radius = radius; a.xyzr = xyzr; a.Dmin = Dmin; a.Apre = Apre; a.ApreOut = ApreOut ? ApreOut : Apre; a.dscr = dscr; a.O = O; a.st = st;
+    a.m = m; a.Fp = Fp; a.radius = radius; a.xyzr = xyzr; a.Dmin = Dmin; a.Fq = Fq; a.FqOut = FqOut ? FqOut : Fq; a.dscr = dscr; a.O = O; a.st = st;
     if (rows == 16) {
         if (st.n == 7) launch_tail_t<7, 16>(s, a);
         else launch_tail_t<2, 16>(s, a);

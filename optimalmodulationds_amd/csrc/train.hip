@@ -185,7 +185,9 @@ __device__ __forceinline__ void tall_dma4(const void* gbase_uniform, unsigned vo
                  : "v"(voff), "s"(gbase_uniform), "s"(lds_dst), "n"(IMM)
                  : "memory");
 }
-__device__ __forceinline__ void tall_wait_all() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
+// lgkmcnt(0) too: the barrier also orders plain LDS stores (the parked outputs of the previous tile, the zero fill of rows past M)
+// that other waves read behind it, and hipcc inserts no wait in front of an inline-asm barrier
+__device__ __forceinline__ void tall_wait_all() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // PERSISTENT workgroups (one per CU, 8 waves), two LDS tiles, and the WEIGHTS IN REGISTERS.  A wave owns 32 output columns for the
 // whole launch, so its 32 k-chunks of B fragments (one float4 each: 128 VGPRs) are tile-invariant: they are fetched once, and the
@@ -296,11 +298,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm_tall(const float* __restrict__ 
         // The product, with the tile's memory traffic dealt into it one instruction per k-chunk (a CU has ONE vector-memory path:
         // issued as a block in front of the product, the 24 instructions per wave kept the matrix pipe waiting 1.3-2.4 us per tile):
         // chunks 0-8 send the parked rows of tile t - 1 to C (the LDS read of a row one chunk ahead of its store), chunks 9-24 request
-        // the rows of tile t + 1 over them (half a row each), chunks 25-31 request this tile's mask rows.  Nothing in here waits on vmcnt.  k order of gemm256: chunk c adds k = 8c + {0, 4, 1, 5, 2, 6, 3, 7}
+        // the rows of tile t + 1 over them (half a row each), chunks 25-31 request this tile's mask rows.  Nothing in here waits on vmcnt.
         // k ORDER: ascending -- MFMA step m of chunk c contracts k = 8c + 2m (lanes 0-31) and 8c + 2m + 1 (lanes 32-63): torch-CPU's sgemm
         // order too, so a run of this trainer from trained ReLU weights tracks the torch run to 1e-6 in the loss over 30 epochs --
-        // near-dead units get the SAME rounding-level gradients, and Adam's first steps are lr * sign(g) whatever |g| is; in gemm256's
-        // order 8c + {0, 4, 1, 5, ...} 5 % of the weights had taken a step the other way after 5 epochs (tests/test_gpu_train.py).
+        // near-dead units get the SAME rounding-level gradients, and Adam's first steps are lr * sign(g) whatever |g| is; in the
+        // position order 8c + {0, 4, 1, 5, ...} 5 % of the weights had taken a step the other way after 5 epochs (tests/test_gpu_train.py).
         const float* arow = Hs + buf * (TALL_ROWS * LDH) + (lane & 31) * LDH + 4 * (lane >> 5);
 #pragma unroll
         for (int c = 0; c < 32; ++c) {

@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include "omds_internal.h"
+#include "trig_device.h"
 
 namespace {
 
@@ -29,8 +30,8 @@ __global__ __launch_bounds__(256) void k_wide_encode_pairs(const float* __restri
     const float x = j < n ? qT[(size_t)j * ldq + t] : xyzr[(size_t)o * 4 + (j - n)];
     float* xr = X + (size_t)r * 3 * d;
     xr[j] = x;
-    xr[d + j] = sinf(x);
-    xr[2 * d + j] = cosf(x);
+    xr[d + j] = omds_sinf(x);
+    xr[2 * d + j] = omds_cosf(x);
 }
 
 // pass-2 rows: row r = (rollout r / k, its j-th closest obstacle idx[r]); also keeps the obstacle of each row
@@ -43,8 +44,8 @@ __global__ __launch_bounds__(256) void k_wide_encode_sel(const float* __restrict
     const float x = j < n ? qT[(size_t)j * ldq + t] : xyzr[(size_t)o * 4 + (j - n)];
     float* xr = X + (size_t)r * 3 * d;
     xr[j] = x;
-    xr[d + j] = sinf(x);
-    xr[2 * d + j] = cosf(x);
+    xr[d + j] = omds_sinf(x);
+    xr[2 * d + j] = omds_cosf(x);
 }
 
 // raw rows x [B][d] (omds_mlp_forward_vjp): the same encoding
@@ -55,8 +56,8 @@ __global__ __launch_bounds__(256) void k_wide_encode_raw(const float* __restrict
     const float v = x[e];
     float* xr = X + (size_t)r * 3 * d;
     xr[j] = v;
-    xr[d + j] = sinf(v);
-    xr[2 * d + j] = cosf(v);
+    xr[d + j] = omds_sinf(v);
+    xr[2 * d + j] = omds_cosf(v);
 }
 
 // Dmin[row0 + r] = min over the un-ignored links of y / out_div - radius(o)   (MPPI.py:236-242)

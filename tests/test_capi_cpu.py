@@ -53,7 +53,7 @@ def test_test_hooks_live_in_the_test_library_only(lib):
     bound = _lib.load_test_hooks()
     assert bound.omds_version() == lib.omds_version()
     env_names = set(re.findall(rb"OMDS_[A-Z0-9_]+", open(_lib.LIB_PATH, "rb").read()))
-    knobs = {e for e in env_names if not re.match(rb"OMDS_(ERR|ACT|MAX|WIDTH|CPAD|FLAG|COST|VARIANT|OK|HIP|API|H$|TEST|EXP|DBG|SWEEP_HIST)", e)}
+    knobs = {e for e in env_names if not re.match(rb"OMDS_(ERR|ACT|MAX|WIDTH|FROW|CPAD|FLAG|COST|VARIANT|OK|HIP|API|H$|TEST|EXP|DBG|SWEEP_HIST)", e)}
     assert knobs <= {b"OMDS_SCREEN", b"OMDS_ROCTX", b"OMDS_RCCL_LIB"}, knobs
 
 
