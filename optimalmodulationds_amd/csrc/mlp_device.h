@@ -793,12 +793,10 @@ __device__ __forceinline__ void topk_row(const float* __restrict__ row, int O, i
 
 constexpr int P2_MT = 32;
 constexpr int P2_NT = 512;
-constexpr int P2_PSETS = 4;   // split-K partial sets of the first-layer backward kept in sm.P; waves 4-7 park theirs in the (then idle) tile buffer
 
 
 struct P2Smem {
     float* Hs;        // [32][LDH]
-    float* P;         // [P2_PSETS][32][33] split-K partials of the first-layer backward (waves 0-3; waves 4-7 use Hs)
     float* gf;        // [32][33] feature gradients
     uint16_t* maskL;  // [nhh+1][512] ReLU masks, 16 bits per thread and layer
     uint32_t* maskG4; // the same storage seen by the 4-row-group backward: [nhh+1][256 columns], bit e = row e
@@ -1072,71 +1070,64 @@ __device__ __forceinline__ void pass2_backward(const MlpDev& m, const P2Smem& sm
     p2_backward_first<ROWS>(m, sm, xyzr, R0, total_rows, qT, ldq, gradx, dbase, dbg);
 }
 
+// d y / d x of one input from the gradients at its three encoded features, as torch's autograd accumulates them for
+// x_nerf = cat(x, sin x, cos x) (network_macros_mod.py:139-140): (g_x + g_cos * (-sin x)) + g_sin * cos x, every operation rounded
+// on its own (established bit for bit against the reference's gradients, tools/studies/assoc_order_study.py --vjp)
+__device__ __forceinline__ float pe_chain_rule(float gx, float gsin, float gcos, float x) {
+    return __fadd_rn(__fadd_rn(gx, __fmul_rn(gcos, -omds_sinf(x))), __fmul_rn(gsin, omds_cosf(x)));
+}
+
+// The first layer's backward as the reference computes it (robot_sdf.py:153-158: (g * mask) @ W1): for every (row, feature) ONE fmaf
+// chain over the 256 hidden units in ascending order from zero.  [ROWS x 256] . [256 x 32] on v_mfma_f32_16x16x4: wave w owns the
+// 16 x 16 block (rows 16 (w >> 1), features 16 (w & 1)) and runs the whole k range -- 64 dependent MFMAs, 1 us; splitting k over
+// the waves (the round-1 form) was 0.5 us shorter and summed eight partial chains.  Hs = the gradient at the first layer's
+// pre-activations (k-permuted tile, read like gemm16); out[row * 33 + f] = the chain (+ prior[row * 33 + f], the skip
+// concatenations' direct contributions, when prior != nullptr; out may alias prior).
+template <int ROWS>
+__device__ __forceinline__ void first_layer_backward(const MlpDev& m, const float* Hs, float* out, const float* prior) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (wave < ROWS / 8) {
+        const int rb = wave >> 1, jb = wave & 1;
+        const float* arow = Hs + (rb * 16 + (lane & 15)) * LDH + pa16(lane);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float4 wq[16];   // all 16 weight fragments in flight at once: the chain below is latency-bound otherwise
+#pragma unroll
+        for (int c = 0; c < 16; ++c) wq[c] = m.W1b16[(c * 2 + jb) * 64 + lane];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float4 a = load_a16(arow, c);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wq[c].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wq[c].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wq[c].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wq[c].w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {   // C/D layout 16x16: column (feature) lane & 15, row 4 (lane >> 4) + r
+            const int e = (rb * 16 + 4 * (lane >> 4) + r) * 33 + 16 * jb + (lane & 15);
+            out[e] = prior ? acc[r] + prior[e] : acc[r];
+        }
+    }
+}
+
 // The tail of the pass-2 backward: from the gradient at the first layer's pre-activations (sm.Hs) to the input gradients.
 template <int ROWS>
 __device__ __forceinline__ void p2_backward_first(const MlpDev& m, const P2Smem& sm, const float* __restrict__ xyzr, int R0,
                                                   int total_rows, const float* __restrict__ qT, int ldq, float* gradx, int dbase, int dbg) {
-    float* Hs = sm.Hs;
-    float* P = sm.P;
     float* gf = sm.gf;
     int* rowT = sm.rowT;
     int* rowO = sm.rowO;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // ---- first layer backward: g_f[row][f] = sum_c Gz1[row][c] W1[c][f], split-K over the 8 waves -------
-    if constexpr (ROWS == 32) {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* arow = Hs + (lane & 31) * LDH + 4 * (lane >> 5);
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            const int c = wave * 4 + cc;
-            const float4 a = *reinterpret_cast<const float4*>(arow + 8 * c);
-            const float4 w = m.W1b[c * 64 + lane];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc, 0, 0, 0);
-        }
-        __syncthreads();   // every wave has read its A fragments: the tile buffer may take the partials of waves 4-7
-        float* Pw = wave < P2_PSETS ? P + wave * (32 * 32) : Hs + (wave - P2_PSETS) * (32 * 32);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Pw[crow(r, lane) * 32 + (lane & 31)] = acc[r];
-    } else {
-        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        const float* arow = Hs + (lane & 15) * LDH + pa16(lane);
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-            const int c = wave * 2 + cc;
-            const float4 a = load_a16(arow, c);
-            float4 w[2];
-            w[0] = m.W1b16[(c * 2 + 0) * 64 + lane];
-            w[1] = m.W1b16[(c * 2 + 1) * 64 + lane];
-            mfma_chunk16(a, w, acc);
-        }
-        __syncthreads();
-        float* Pw = wave < P2_PSETS ? P + wave * (ROWS * 32) : Hs + (wave - P2_PSETS) * (ROWS * 32);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) Pw[(4 * (lane >> 4) + (r & 3)) * 32 + 16 * (r >> 2) + (lane & 15)] = acc[r >> 2][r & 3];
-    }
+    const int tid = threadIdx.x;
+    first_layer_backward<ROWS>(m, sm.Hs, gf, m.skip_mask ? gf : nullptr);
     __syncthreads();
     if (dbg == 15) return;
-    for (int e = tid; e < ROWS * 32; e += P2_NT) {
-        const int row = e >> 5, f = e & 31;
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) s += (w < P2_PSETS ? P + w * (ROWS * 32) : Hs + (w - P2_PSETS) * (ROWS * 32))[row * 32 + f];
-        gf[row * 33 + f] = m.skip_mask ? s + gf[row * 33 + f] : s;
-    }
-    __syncthreads();
-    // ---- positional-encoding chain rule: d/dx = g[x] + g[sin x] cos x - g[cos x] sin x --------------
+    // ---- positional-encoding chain rule -------------------------------------------------------------------------------
     const int d = m.d, n = m.n_dof;
     if (tid < ROWS * d) {
         const int row = tid / d, jj = tid - row * d;
         const int R = R0 + row;
         if (R < total_rows && rowT[row] >= 0) {
             const float x = (jj < n) ? qT[(size_t)jj * ldq + rowT[row]] : xyzr[rowO[row] * 4 + (jj - n)];
-            gradx[(size_t)(dbase + row) * d + jj] = gf[row * 33 + jj] + gf[row * 33 + d + jj] * omds_cosf(x) - gf[row * 33 + 2 * d + jj] * omds_sinf(x);
+            gradx[(size_t)(dbase + row) * d + jj] = pe_chain_rule(gf[row * 33 + jj], gf[row * 33 + d + jj], gf[row * 33 + 2 * d + jj], x);
         }
     }
 }

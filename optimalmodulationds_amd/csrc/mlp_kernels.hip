@@ -163,8 +163,7 @@ __global__ __launch_bounds__(P2_NT) void k_pass2(MlpDev m, const float* __restri
     extern __shared__ __attribute__((aligned(16))) float smem[];
     P2Smem sm;
     sm.Hs = smem;
-    sm.P = sm.Hs + P2_MT * LDH;
-    sm.gf = sm.P + P2_PSETS * 32 * 33;
+    sm.gf = sm.Hs + P2_MT * LDH;
     sm.maskL = reinterpret_cast<uint16_t*>(sm.gf + 32 * 33);
     sm.rowT = reinterpret_cast<int*>(sm.maskL + ((m.nhh + 2) / 2 * 2) * P2_NT);
     sm.rowO = sm.rowT + P2_MT;
@@ -330,8 +329,8 @@ void omds_launch_pass2(hipStream_t s, const MlpDev& m, const float* Fq, const fl
                        float* drow, float* yraw, int32_t* minidx, float* dscr, int seed_col) {
     const int total = B * k;
     if (total <= 0) return;
-    const size_t lds = ((size_t)P2_MT * LDH + P2_PSETS * 32 * 33 + 32 * 33) * 4 + (size_t)(m.nhh + 1) * P2_NT * 4 + 3 * P2_MT * 4;
-    const int maxlds = (int)(((size_t)P2_MT * LDH + P2_PSETS * 32 * 33 + 32 * 33) * 4 + (size_t)(OMDS_MAX_HIDDEN + 1) * P2_NT * 4 + 3 * P2_MT * 4);
+    const size_t lds = ((size_t)P2_MT * LDH + 32 * 33) * 4 + (size_t)(m.nhh + 1) * P2_NT * 4 + 3 * P2_MT * 4;
+    const int maxlds = (int)(((size_t)P2_MT * LDH + 32 * 33) * 4 + (size_t)(OMDS_MAX_HIDDEN + 1) * P2_NT * 4 + 3 * P2_MT * 4);
     static std::atomic<uint64_t> configured{0};
     if (omds_first_use_on_device(configured)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<OMDS_ACT_RELU, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);

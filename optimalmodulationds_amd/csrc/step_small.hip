@@ -73,9 +73,8 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
     int* selO = selT + SS_RK;                                        // [SS_RK] obstacle
     float* dr = reinterpret_cast<float*>(selO + SS_RK);              // [SS_RK] pass-2 distance of each backward row
     float* gx = dr + SS_RK;                                          // [SS_RK][12] input gradients
-    float* gf = gx + SS_RK * 12;                                     // [SS_RK][33] feature gradients
-    float* feat = gf + SS_RK * 33;                                   // [SS_RK][3 ND] next state, sin, cos
-    float4* gS = reinterpret_cast<float4*>(feat + SS_RK * 3 * OMDS_MAX_DOF + 4);   // [256] gradient of the four rows at each column
+    float* gf = gx + SS_RK * 12;                                     // [16][33] feature gradients (first_layer_backward works on a 16-row block)
+    float* feat = gf + 16 * 33;                                      // [SS_RK][3 ND] next state, sin, cos
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.B, k = a.st.k, O = a.O, R = a.R;
     const int t_base = blockIdx.x * R;
@@ -130,14 +129,6 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
     __syncthreads();
 
     if (OMDS_DBG(a.dbg_stop) == 2) return;
-    // the first-layer backward's weights of this thread (feature tid >> 4, columns (tid & 15) + 16 i): asked for now, used after
-    // the hidden layers
-    float w1b[16];
-    {
-        const int f = tid >> 4, sub = tid & 15;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) w1b[i] = f < 3 * m.d ? m.W1t[(size_t)f * OMDS_WIDTH + sub + 16 * i] : 0.f;
-    }
     // ---- 3. backward on the selected rows: ONE 4-row group on v_mfma_f32_4x4x1 (gemm4, mlp_device.h) -----------------------
     // Four rows are no 16-row MFMA problem (a 16-row tile would run at the 16-row rate to move four useful rows) but they are
     // exactly one row group of the 4x4x1 shape: waves 0-3 multiply 64 columns each, 256 dependent MFMAs per layer (one
@@ -186,36 +177,15 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
                     v[r] = ((mb >> (4 * l + r)) & 1u) ? acc[0][r] : 0.f;
                     Hs[r * LDH + pcol] = v[r];
                 }
-                if (l == 0) gS[col] = make_float4(v[0], v[1], v[2], v[3]);
             }
             __syncthreads();
         }
-        if (m.nhh == 0 && mine) gS[col] = make_float4(Hs[pcol], Hs[LDH + pcol], Hs[2 * LDH + pcol], Hs[3 * LDH + pcol]);
-        if (m.nhh == 0) __syncthreads();
     }
     if (OMDS_DBG(a.dbg_stop) == 3) return;
-    // first layer: g_f[r][f] = sum_c Gz1[r][c] W1[c][f]; 16 lanes per feature, c strided over them
-    {
-        const int f = tid >> 4, sub = tid & 15, F = 3 * m.d;
-        float s[SS_RK] = {};
-        if (f < F) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int c = sub + 16 * i;
-                const float w = w1b[i];
-                const float4 g = gS[c];
-                s[0] = fmaf(g.x, w, s[0]); s[1] = fmaf(g.y, w, s[1]); s[2] = fmaf(g.z, w, s[2]); s[3] = fmaf(g.w, w, s[3]);
-            }
-        }
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1)
-#pragma unroll
-            for (int r = 0; r < SS_RK; ++r) s[r] += __shfl_xor(s[r], off);
-        if (sub == 0 && f < 32) {
-#pragma unroll
-            for (int r = 0; r < SS_RK; ++r) gf[r * 33 + f] = (f < F) ? s[r] : 0.f;
-        }
-    }
+    // first layer: g_f[r][f] = sum_c Gz1[r][c] W1[c][f], one ascending chain per element over the four gradient rows at the top of
+    // the tile (first_layer_backward works on 16-row blocks: rows 4..15 hold the forward's leftovers, whose products stay in their
+    // own rows of the MFMA and are not read)
+    first_layer_backward<16>(m, Hs, gf, nullptr);
     __syncthreads();
     const float* qT = a.qT;
     const int ldq = a.ldq;
@@ -225,7 +195,7 @@ __global__ __launch_bounds__(SS_NT, TR == 16 ? 4 : 2) void k_step_small(SmallArg
             const int r = tid / d, jj = tid - r * d;
             if (selRow[r] >= 0) {
                 const float x = (jj < n) ? qT[(size_t)jj * ldq + selT[r]] : a.xyzr[selO[r] * 4 + (jj - n)];
-                gx[r * d + jj] = gf[r * 33 + jj] + gf[r * 33 + d + jj] * omds_cosf(x) - gf[r * 33 + 2 * d + jj] * omds_sinf(x);
+                gx[r * d + jj] = pe_chain_rule(gf[r * 33 + jj], gf[r * 33 + d + jj], gf[r * 33 + 2 * d + jj], x);
             }
         }
     }
@@ -281,7 +251,7 @@ static size_t small_lds_bytes(int nhid, int TR) {
     // the last term: gemm4's A-operand reads span 32 tile rows (lanes 16-31 are never selected, but they read): a 16-row tile
     // buffer is followed by at least another 16 rows' worth of allocation
     return ((size_t)TR * LDH + 2 * TR + (size_t)TR * nhid * 8) * 4 + (32 * 3 + SS_RK * 3) * 4 +
-           (SS_RK + SS_RK * 12 + SS_RK * 33 + SS_RK * 3 * OMDS_MAX_DOF + 4) * 4 + OMDS_WIDTH * 16 + 16 + (TR == 16 ? (size_t)16 * LDH * 4 : 0);
+           (SS_RK + SS_RK * 12 + 16 * 33 + SS_RK * 3 * OMDS_MAX_DOF + 4) * 4 + 16 + (TR == 16 ? (size_t)16 * LDH * 4 : 0);
 }
 
 // rollouts per workgroup for (O, k) on a tile of `rows` rows, 0 = the scene does not qualify

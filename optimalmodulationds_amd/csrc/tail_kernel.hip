@@ -45,8 +45,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
     const MlpDev& m = a.m;
     P2Smem sm;
     sm.Hs = smem;
-    sm.P = sm.Hs + P2_MT * LDH;
-    sm.gf = sm.P + P2_PSETS * 32 * 33;
+    sm.gf = sm.Hs + P2_MT * LDH;
     sm.maskL = reinterpret_cast<uint16_t*>(sm.gf + 32 * 33);
     sm.rowT = reinterpret_cast<int*>(sm.maskL + ((m.nhh + 2) / 2 * 2) * P2_NT);
     sm.rowO = sm.rowT + P2_MT;
@@ -149,8 +148,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
     const MlpDev& m = a.m;
     P2Smem sm;
     sm.Hs = smem;
-    sm.P = sm.Hs + P2_MT * LDH;
-    sm.gf = sm.P + P2_PSETS * 32 * 33;
+    sm.gf = sm.Hs + P2_MT * LDH;
     sm.maskL = reinterpret_cast<uint16_t*>(sm.gf + 32 * 33);
     sm.rowT = reinterpret_cast<int*>(sm.maskL + ((m.nhh + 2) / 2 * 2) * P2_NT);
     sm.rowO = sm.rowT + P2_MT;
@@ -437,7 +435,7 @@ void omds_launch_tail_sel(hipStream_t s, const MlpDev& m, const float* Fp, const
 }
 
 static size_t tail_lds_bytes(int nhid) {
-    return ((size_t)P2_MT * LDH + P2_PSETS * 32 * 33 + 32 * 33) * 4 + (size_t)nhid * P2_NT * 4 + 3 * P2_MT * 4 +
+    return ((size_t)P2_MT * LDH + 32 * 33) * 4 + (size_t)nhid * P2_NT * 4 + 3 * P2_MT * 4 +
            (32 * 12 + 32 + 32 * 3 * OMDS_MAX_DOF) * 4;
 }
 

@@ -74,6 +74,19 @@ def linear(h, W, b):
     return chain.linear(h, W, b)
 
 
+def pe_chain_rule(g, x):
+    """Backward of x -> cat(x, sin x, cos x) as torch's autograd accumulates it: (g_x + g_cos * (-sin x)) + g_sin * cos x, every
+    operation rounded on its own (bit for bit against the reference's gradients with torch's own sin / cos: tools/studies/
+    assoc_order_study.py)."""
+    x = np.asarray(x, dtype=F32)
+    d = x.shape[1]
+    g = np.asarray(g, dtype=F32)
+    a = g[:, :d]
+    b = (g[:, d:2 * d] * chain.cos(x)).astype(F32)
+    c = (g[:, 2 * d:3 * d] * (-chain.sin(x))).astype(F32)
+    return ((a + c).astype(F32) + b).astype(F32)
+
+
 def mlp_forward(m: Mlp, x):
     """MLPRegression.forward (ML/network_macros_mod.py:137-146); with skips the encoded input is concatenated behind
     the output of each module (``torch.cat((y, x_nerf), dim=1)``)."""
@@ -110,8 +123,8 @@ def mlp_vjp_argmin(m: Mlp, x, seed=None):
             g = g[:, :w]
         g = chain.matmul((g * _dact(zs[i], hs[i + 1], m.act)).astype(F32), m.W[i])    # -> grad wrt layer i input
     g = g + g_feat
-    grad = g[:, :d] + g[:, d:2 * d] * chain.cos(x) - g[:, 2 * d:] * chain.sin(x)
-    return y, grad.astype(F32), min_idx
+    grad = pe_chain_rule(g, x)
+    return y, grad, min_idx
 
 
 def mlp_jacobian(m: Mlp, x, cols, order=None):
@@ -452,7 +465,7 @@ def blended_gradient_alternatives(m: Mlp, q_row, obs, idx_row, margin, softmax_k
                 g = g[:, :hs[i + 1].shape[1]]
             g = chain.matmul((g * masks[i]).astype(F32), m.W[i])
         g = g + g_feat
-        gx = g[:, :d] + g[:, d:2 * d] * chain.cos(x) - g[:, 2 * d:] * chain.sin(x)
+        gx = pe_chain_rule(g, x)
         return (gx[:, :n_dof].astype(F32) * w[:, None]).sum(axis=0).astype(F32)
 
     out = [grad_with(masks0)]
