@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import OWN, RTOL, assert_close, assert_velocity_in_envelope, load, weights_path
+from helpers import OWN, RTOL, assert_close, assert_velocity_plain, load, weights_path
 from oracle import omds_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -218,12 +218,10 @@ def test_fullsize_sampled_rows_against_oracle(big):
         d, g, mind, idx = orc.distance_repulsion_nn(m, q, obs, big["k"], [0, 1, 2])
         assert_close(r["closest_dist_all"][sel, h], d - np.float32(0.01), RTOL, f"distance h={h}", floor=OWN)
         st = orc.modulation_step(q, scenes.FRANKA_QF, d, g, mu[sel], sg[sel], al[sel], orc.Params(dst_thr=0.01))
-        ok = orc.rollout_relu_margin(m, q, obs, idx) >= 5e-6
-        assert ok.mean() > 0.5
-        assert_close(r["normal"][sel, h][ok], st["ghat"][ok], 5e-5, f"normal h={h}")
-        vel = (r["all_traj"][sel, h + 1] - q)[ok] / np.float32(0.5)   # inside the +-DIST_ULP distance envelope (helpers), not a loose bar
-        assert_velocity_in_envelope(vel, q[ok], scenes.FRANKA_QF, d[ok], (g[ok], r["normal"][sel, h][ok]), mu[sel][ok], sg[sel][ok], al[sel][ok],
-                                    orc.Params(dst_thr=0.01), float(np.abs(d).max()), f"velocity h={h}", pad=4e-6 * max(1.0, float(np.abs(q).max())) / 0.5)
+        assert_close(r["normal"][sel, h], st["ghat"], 2e-5, f"normal h={h}")          # every sampled row
+        vel = (r["all_traj"][sel, h + 1] - q) / np.float32(0.5)
+        assert_velocity_plain(vel, q, scenes.FRANKA_QF, d, g, mu[sel], sg[sel], al[sel], orc.Params(dst_thr=0.01), f"velocity h={h}",
+                              pad=4e-6 * max(1.0, float(np.abs(q).max())) / 0.5)
 
 
 def test_fullsize_obstacle_permutation_invariance(big):
@@ -293,12 +291,11 @@ def test_ragged_and_large_shapes(N, H, k, O):
         d, g, _, idx = orc.distance_repulsion_nn(m, q, obs, k, [0, 1, 2])
         assert_close(r["closest_dist_all"][sel, h], d - np.float32(0.01), RTOL, f"distance h={h}", floor=OWN)
         st = orc.modulation_step(q, scenes.FRANKA_QF, d, g, mu[sel], sg[sel], al[sel], orc.Params(dst_thr=0.01))
-        ok = orc.rollout_relu_margin(m, q, obs, idx) >= 5e-6
-        assert_close(r["normal"][sel, h][ok], st["ghat"][ok], 5e-5, f"normal h={h}")
+        assert_close(r["normal"][sel, h], st["ghat"], 2e-5, f"normal h={h}")
         if h + 1 < H:
-            vel = (r["all_traj"][sel, h + 1] - q)[ok] / np.float32(0.5)   # inside the +-DIST_ULP distance envelope (helpers), not a loose bar
-            assert_velocity_in_envelope(vel, q[ok], scenes.FRANKA_QF, d[ok], (g[ok], r["normal"][sel, h][ok]), mu[sel][ok], sg[sel][ok], al[sel][ok],
-                                        orc.Params(dst_thr=0.01), float(np.abs(d).max()), f"velocity h={h}", pad=4e-6 * max(1.0, float(np.abs(q).max())) / 0.5)
+            vel = (r["all_traj"][sel, h + 1] - q) / np.float32(0.5)
+            assert_velocity_plain(vel, q, scenes.FRANKA_QF, d, g, mu[sel], sg[sel], al[sel], orc.Params(dst_thr=0.01), f"velocity h={h}",
+                                  pad=4e-6 * max(1.0, float(np.abs(q).max())) / 0.5)
     eng.close()
 
 

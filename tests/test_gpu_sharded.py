@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import assert_velocity_in_envelope, weights_path
+from helpers import assert_velocity_plain, weights_path
 from oracle import omds_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -212,14 +212,11 @@ def test_shard_4096x64_config4():
     d, g, _, idx = orc.distance_repulsion_nn(m, q, obs, k, [0, 1, 2])
     st = orc.modulation_step(q, qf, d, g, mu[tt], sg[tt], al[tt], orc.Params(dst_thr=0.01))
     assert np.abs(r["closest_dist_all"][tt, hh] - (d - np.float32(0.01))).max() <= 1e-6
-    ok = orc.rollout_relu_margin(m, q, obs, idx) >= 5e-6
-    assert ok.mean() > 0.5
     assert np.abs(r["kernel_val_all"][tt, hh] - st["phi"]).max() <= 1e-5
-    nxt = (hh + 1 < H) & ok
+    nxt = hh + 1 < H             # every sampled row with a next state
     vel = (r["all_traj"][tt[nxt], hh[nxt] + 1] - q[nxt]) / np.float32(0.5)
-    assert_velocity_in_envelope(vel, q[nxt], qf, d[nxt], (g[nxt], r["normal"][tt[nxt], hh[nxt]]), mu[tt][nxt], sg[tt][nxt], al[tt][nxt],
-                                orc.Params(dst_thr=0.01), float(np.abs(d).max()), "shard 4096 x 64, clear-margin rows", pad=4e-6 * max(1.0, float(np.abs(q).max())) / 0.5,
-                                family="franka")
+    assert_velocity_plain(vel, q[nxt], qf, d[nxt], g[nxt], mu[tt][nxt], sg[tt][nxt], al[tt][nxt], orc.Params(dst_thr=0.01),
+                          "shard 4096 x 64, sampled rows", pad=4e-6 * max(1.0, float(np.abs(q).max())) / 0.5, family="franka")
     cost = e.cost()
     ocost, _ = orc.evaluate_costs(r["all_traj"], r["closest_dist_all"], qf, dh, qmin, qmax)
     assert np.abs(cost - ocost).max() <= 1e-5 * max(1.0, np.abs(ocost).max())

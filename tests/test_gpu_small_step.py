@@ -99,18 +99,14 @@ def test_fused_small_step_against_the_oracle():
     st = orc.modulation_step(q, qf, d, g, mu[tt], sg[tt], al[tt], orc.Params(dst_thr=0.25))
     scale = max(1.0, float(np.abs(d).max()))
     assert np.abs(r["closest_dist_all"][tt, hh] - (d - np.float32(0.25))).max() <= 1e-5 * scale
-    ok = orc.rollout_relu_margin(m, q, obs, idx) >= 5e-6
-    assert ok.mean() > 0.9
-    assert_close(r["normal"][tt, hh][ok], st["ghat"][ok], 2e-5, "normal")
+    assert_close(r["normal"][tt, hh], st["ghat"], 2e-5, "normal")          # every sampled row
     assert_close(r["kernel_val_all"][tt, hh], st["phi"], RTOL, "rbf")
-    nxt = (hh + 1 < H) & ok
+    nxt = hh + 1 < H
     vel = (r["all_traj"][tt[nxt], hh[nxt] + 1] - q[nxt]) / np.float32(0.3)
-    # inside the envelope the oracle's modulation spans when the network distance moves by +-DIST_ULP x its scale (helpers), for
-    # the oracle's and the device's own normal -- the bar of every other full-size test, not the 2e-4 this test held until round 3
-    from helpers import assert_velocity_in_envelope
+    from helpers import assert_velocity_plain
     prm = orc.Params(dst_thr=0.25)
-    assert_velocity_in_envelope(vel, q[nxt], qf, d[nxt], (g[nxt], r["normal"][tt, hh][nxt]), mu[tt][nxt], sg[tt][nxt], al[tt][nxt], prm,
-                                float(np.abs(d).max()), "fused small step 1024 x 32, clear rows", pad=4e-6 * max(1.0, float(np.abs(q).max())) / 0.3, family="planar7")
+    assert_velocity_plain(vel, q[nxt], qf, d[nxt], g[nxt], mu[tt][nxt], sg[tt][nxt], al[tt][nxt], prm, "fused small step 1024 x 32, sampled rows",
+                          pad=4e-6 * max(1.0, float(np.abs(q).max())) / 0.3, family="planar7")
     e.close()
 
 

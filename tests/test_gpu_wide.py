@@ -55,10 +55,7 @@ def test_wide_network_against_the_oracle(widths, act):
     assert_close(y, oy, RTOL, "raw forward", floor=OWN)
     assert (mi == omi).mean() >= 0.995                                    # near-ties of two links aside
     same = mi == omi
-    margin = orc.relu_margin(m, x) if act == "relu" else np.full(len(x), 1.0)
-    ok = same & (margin >= 5e-6)
-    assert ok.mean() > 0.9
-    assert_close(g[ok], og[ok], 2e-5, "vjp gradient", floor=float(np.abs(og).max()))
+    assert_close(g[same], og[same], 2e-5, "vjp gradient", floor=float(np.abs(og).max()))   # every row: the trainer's GEMMs sum in the oracle's order
     # distance_repulsion_nn on a batch (MPPI.py:227-282)
     q = (scenes.FRANKA_Q0 + 0.4 * rng.standard_normal((N, 7))).astype(np.float32)
     dist, grad, mind, idx = e.dist_grad(q, want_mindist=True, want_idx=True)
@@ -66,7 +63,7 @@ def test_wide_network_against_the_oracle(widths, act):
     assert_close(mind, omind, RTOL, "pass-1 matrix", floor=OWN)
     agree = (idx == oidx).all(axis=1)
     assert agree.mean() >= 0.97                                           # exact near-ties between two obstacles aside
-    okq = agree & (orc.rollout_relu_margin(m, q, obs, oidx) >= 5e-6 if act == "relu" else True)
+    okq = agree
     assert_close(dist[agree], od[agree], RTOL, "closest distance", floor=OWN)
     assert_close(grad[okq], ogr[okq], 2e-5, "blended gradient", floor=float(np.abs(ogr).max()))
     # a propagate with injected samples, then cost and update on the device's own rollouts
