@@ -39,7 +39,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-ROUND = "r05"      # the profiles/ files of this round (tools/profile_refresh.sh)
+ROUND = "r06"      # the profiles/ files of this round (tools/profile_refresh.sh)
 
 WORKLOADS = {
     # name: (weights, n_dof, C, scene, N, H, dt, k, dst_thr, ker_thr, alpha_s, sigma_nom, ignored)
@@ -79,6 +79,7 @@ class Launch:
     def __init__(self, rank=0, world=1, local_rank=0, dist=None, torch=None):
         self.rank, self.world, self.local_rank, self.dist, self.torch = rank, world, local_rank, dist, torch
         self.collectives = "none"       # "rccl" | "gloo-host (...)" once a multi-rank exchange exists
+        self.rccl = None                # what the library's communicator reported on every rank (measure())
 
     @property
     def use_dist(self):
@@ -214,7 +215,9 @@ def cpu_baseline(w, W, b, obs, q0, qf, dh, qmin, qmax, K, H_full):
     out = {"unit": "rollout-steps/s", "kind": "port", "cpu": cpu, "physical_cores": int(phys), "logical_cpus": int(os.cpu_count() or 1),
            "sample": f"torch {torch.__version__} CPU, unfused op sequence of the reference, {Ns} rollouts x {Hs} steps x "
                      f"{obs.shape[0]} obstacles, K = {K}, full iteration, 3 warm-up + 5 timed, median; H = {H_full} figure = "
-                     f"N*H / (H/{Hs} * t_propagate + t_rest)"}
+                     f"N*H / (H/{Hs} * t_propagate + t_rest).  KINDER to the CPU than the reference is: the port evaluates the FK cost of all "
+                     f"rollouts in one vectorised call, the reference runs a TorchScript loop over the rollouts (fk_num.py:87-88, ~2.4 ms per rollout: "
+                     f"~2.5 s per iteration at 1024 rollouts, more than the whole ported iteration)"}
     for label, T in (("t8", min(8, phys)), ("tall", phys)):
         tp, tr = time_iterations(pl, Ns, Hs, q0, mu_c, sg_c, al_c, w["alpha_s"], w["ker_thr"], T)
         out[label] = {"threads": int(T), "propagate_only": Ns * Hs / tp, "full_iteration": Ns * Hs / (tp + tr),
@@ -272,6 +275,22 @@ def measure(args, L, workload, steps, warmup, time_fetch=False, prof=True, reps=
             err = "--share-gpu test mode"
         if native:
             L.collectives = "rccl"
+            # self-certification: the world size the LIBRARY's RCCL communicator reports on every rank and the devices each
+            # rank's process sees through the C-ABI, gathered over gloo and required to agree
+            from optimalmodulationds_amd import _lib as _olib
+            mine = {"rank": rank, "rccl_rank": int(eng.comm_info()[0]), "rccl_world": int(eng.comm_info()[1]), "devices_seen": int(_olib.device_count()),
+                    "device": int(L.local_rank)}
+            allr = [None] * world
+            dist.all_gather_object(allr, mine)
+            worlds = sorted({a["rccl_world"] for a in allr})
+            if worlds != [world] or sorted(a["rccl_rank"] for a in allr) != list(range(world)):
+                eng.close()
+                if rank == 0:
+                    print(f"bench.py: the RCCL communicator does not span the {world} ranks: {allr}", file=sys.stderr)
+                dist.destroy_process_group()
+                sys.exit(3)
+            L.rccl = {"rccl_ranks": world, "rccl_rank_of_each_process": [a["rccl_rank"] for a in allr],
+                      "devices_seen": [a["devices_seen"] for a in allr], "device_of_each_process": [a["device"] for a in allr]}
         elif args.allow_host_collectives or err == "--share-gpu test mode":
             # asked for: the same two small buffers through the launcher's gloo group, and the line says so
             L.collectives = "gloo-host (--share-gpu test mode)" if err == "--share-gpu test mode" else "gloo-host (RCCL unavailable: " + err + ")"
@@ -414,8 +433,8 @@ def rate(rr, n_total):
 def roofline(args, rr, workload, fp32):
     """The dominant kernel of the measured step against its MFMA peak.  `achieved` / `frac` count ALGORITHMIC FLOPs (SURVEY 8d:
     N x O pairs x the dense network's 2 * sum(in * out)) over the HIP-event launch time; `frac_issued` counts the FLOPs of the
-    MFMA instructions the kernel EXECUTES: k_pass1 adds layer 1 as two separable halves instead of multiplying it (no MFMA) and
-    pads the last layer to 16 columns -- an analytic count; k_screen skips the k-chunks whose 16 hidden units are zero for all
+    MFMA instructions the kernel EXECUTES: k_pass1 pads layer 1's 3(n+3) inputs to K = 32 and the last layer to 16 columns -- an
+    analytic count; k_screen skips the k-chunks whose 16 hidden units are zero for all
     32 pairs of a wave -- data-dependent, so SQ_INSTS_MFMA of the committed PMC pass x 32768 FLOP."""
     ach = rr["p1_flops"] / (rr["p1_ms"] * 1e-3) / 1e12 if rr["p1_ms"] > 0 else 0.0
     kern = rr["p1_kernel"]
@@ -427,11 +446,12 @@ def roofline(args, rr, workload, fp32):
     out = {"bound": "mfma", "kernel": kern, "pipe": pipe, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak}
     W = rr["W"]
     f_alg = 2 * sum(int(x.shape[0]) * int(x.shape[1]) for x in W)
-    if kern == "k_pass1":      # hidden layers as they are + the last layer padded to 16 columns; layer 1 is not a product
-        f_iss = 2 * sum(int(x.shape[0]) * int(x.shape[1]) for x in W[1:-1]) + 2 * int(W[-1].shape[1]) * 16
+    if kern == "k_pass1":      # layer 1 over the encoded inputs padded to K = 32, hidden layers as they are, the last layer padded to 16 columns
+        f_iss = 2 * 32 * int(W[0].shape[0]) + 2 * sum(int(x.shape[0]) * int(x.shape[1]) for x in W[1:-1]) + 2 * int(W[-1].shape[1]) * 16
         out["frac_issued"] = out["frac"] * f_iss / f_alg
-        out["frac_issued_basis"] = (f"analytic: {f_iss} FLOP of MFMA per pair (hidden layers + last layer padded to 16 columns; layer 1 is the sum of two "
-                                    f"precomputed halves) against {f_alg} algorithmic" + (f"; SQ_INSTS_MFMA of the committed pass: {insts:.0f} per launch" if insts else ""))
+        out["frac_issued_basis"] = (f"analytic: {f_iss} FLOP of MFMA per pair (layer 1 as a K = 32 product over the 3(n+3) encoded inputs -- the reference's single "
+                                    f"chain does not split into two precomputed halves --, hidden layers, last layer padded to 16 columns) against {f_alg} algorithmic"
+                                    + (f"; SQ_INSTS_MFMA of the committed pass: {insts:.0f} per launch" if insts else ""))
     elif kern in FLOP_PER_MFMA and insts and avg_ms > 0:
         out["frac_issued"] = insts * FLOP_PER_MFMA[kern] / (avg_ms * 1e-3) / 1e12 / peak
         out["mfma_insts_per_launch"] = insts
@@ -589,6 +609,11 @@ def main():
                        "n_closest": w["k"], "active_kernels": K, "network": "x".join(str(x.shape[1]) for x in W) + f"x{W[-1].shape[0]} {act} "
                        + ("(shipped reference weights)" if act == "relu" else "(seeded synthetic weights)"),
                        "parallelism": f"rollout-sharded x{world}", "collectives": L.collectives,
+                       # the world size the library's own RCCL communicator reports (omds_comm_info on every rank, required to equal --gpus;
+                       # 1 = no communicator: one rank) and the HIP devices visible to each rank's process (omds_device_count)
+                       "rccl_ranks": (L.rccl or {}).get("rccl_ranks", 1 if world == 1 else 0),
+                       "devices_seen": (L.rccl or {}).get("devices_seen", [int(ndev)]),
+                       "device_of_each_process": (L.rccl or {}).get("device_of_each_process", [int(L.local_rank)]),
                        # the device is reached through the C-ABI alone; torch (when imported at all: gloo plumbing, CPU baseline) stays on the CPU
                        "pytorch_on_device": bool("torch" in sys.modules and sys.modules["torch"].cuda.is_initialized())},
             "roofline": roofline(args, r, args.workload, prim_fp32),

@@ -318,6 +318,10 @@ def test_bench_under_torchrun_single_rank_uses_rccl(workload):
     assert d["n_gpus"] == 1 and d["config"]["collectives"] == "rccl" and d["value"] > 1e5, d
     assert d["scaling"] == "weak" and d["steps"] == 3 and d["reps"] == 2
     assert d["config"]["pytorch_on_device"] is False      # gloo plumbing only: PyTorch never initialised the GPU in the measured process
+    # the line certifies its own communicator: the world size the LIBRARY's RCCL communicator reported (omds_comm_info on every rank,
+    # required to equal --gpus) and the devices each rank's process saw through the C-ABI
+    assert d["config"]["rccl_ranks"] == 1 and d["config"]["device_of_each_process"] == [0], d["config"]
+    assert len(d["config"]["devices_seen"]) == 1 and d["config"]["devices_seen"][0] >= 1, d["config"]
 
 
 @pytest.mark.parametrize("mode", ["share", "rccl_missing", "rccl_missing_strict"])
@@ -351,6 +355,7 @@ def test_bench_two_ranks_on_one_gpu(mode):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 1e5, d
     assert d["config"]["parallelism"] == "rollout-sharded x2" and d["config"]["rollouts_total"] == 2048
     coll = d["config"]["collectives"]
+    assert d["config"]["rccl_ranks"] == 0, d["config"]      # two ranks, no RCCL communicator: the line says so in this field too
     if mode == "share":
         assert coll.startswith("gloo-host (--share-gpu"), coll
     else:
