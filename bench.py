@@ -11,8 +11,9 @@ the inverse of the reference's "Time per rollout step" (scripts/standalonePlanar
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 10 --warmup 2      # the driver's form: the same 8 ranks
 
-What `value` is.  The PRIMARY measurement is the all-fp32 step (--path fp32, `dtype: "f32"`): every network evaluation in the
-reference's own arithmetic (k_pass1 + k_tail), priced against the fp32 MFMA peak in `roofline`.  The library's DEFAULT step screens
+What `value` is.  The PRIMARY measurement is the all-fp32 step (--path fp32, `dtype: "f32"`), the library's DEFAULT: every network
+evaluation in the reference's own arithmetic -- ascending-k fmaf chains from zero, bias last, bit for bit the oracle's -- (k_pass1 +
+k_tail), priced against the fp32 MFMA peak in `roofline`.  The OPT-IN screened step (omds_set_screening(ctx, 2, 0)) evaluates
 the N x O first-pass rows -- which only feed the sort that picks the k closest obstacles -- in f16 and re-evaluates the candidates in
 fp32; every number it returns is an fp32 number and bit-identical to the all-fp32 step's as long as a measured error bound holds
 (include/omds.h).  That step is timed in the same run and reported as `value_screened` with its own roofline block
@@ -236,10 +237,11 @@ def cpu_baseline(w, W, b, obs, q0, qf, dh, qmin, qmax, K, H_full):
     return out
 
 
-def measure(args, L, workload, steps, warmup, time_fetch=False, prof=True, reps=1, screening=-1, kernels=None, rollouts=None):
+def measure(args, L, workload, steps, warmup, time_fetch=False, prof=True, reps=1, screening=0, kernels=None, rollouts=None):
     """Times `reps` blocks of exactly `steps` planner iterations of `workload` on this rank's GPU (each block bracketed by a
     barrier + device synchronisation on both sides, elapsed = max over ranks); returns a dict of raw numbers.
-    screening: -1 = the library's default step, 0 = the all-fp32 step (omds_set_screening(0)), 1 = screening forced on.
+    screening: 0 = the all-fp32 step (the library's default; set explicitly), 2 = the opt-in screened step where it pays (omds_set_screening(ctx, 2, 0)),
+    1 = screening forced on.
     rollouts: this rank's rollout count when it is not the workload's (strong scaling, the shard sweep)."""
     from optimalmodulationds_amd.engine import Engine
     rank, world, dist, torch = L.rank, L.world, L.dist, L.torch
@@ -250,8 +252,7 @@ def measure(args, L, workload, steps, warmup, time_fetch=False, prof=True, reps=
     eng = Engine(n, N, H, w["k"], max_obs=max(64, obs.shape[0]), device=L.local_rank)
     eng.set_mlp(W, b, act=w.get("act", "relu"))
     eng.set_obstacles(obs)
-    if screening >= 0:
-        eng.set_screening(screening)
+    eng.set_screening(screening)
     p = eng.params
     p.dt, p.dst_thr = w["dt"], w["dst_thr"]
     p.ignored_links = sum(1 << l for l in w["ignored"])
@@ -486,10 +487,10 @@ def main():
                     help="weak: every rank owns the workload's N rollouts; strong: the N rollouts are split over the ranks")
     ap.add_argument("--path", choices=("fp32", "screened"), default=None,
                     help="the PRIMARY measurement (`value`): fp32 = the all-fp32 step, the reference's arithmetic throughout (default); "
-                         "screened = the library's default step (f16 screening of the first-pass rows + fp32 re-evaluation).  The other one "
+                         "screened = the opt-in step (f16 screening of the first-pass rows + fp32 re-evaluation, omds_set_screening(ctx, 2, 0)).  The other one "
                          "is reported beside it unless --no-secondary")
-    ap.add_argument("--screening", type=int, default=None, choices=(-1, 0, 1),
-                    help="older spelling of --path: 0 = fp32, -1 = screened (the library's own choice), 1 = screening forced on")
+    ap.add_argument("--screening", type=int, default=None, choices=(-1, 0, 1, 2),
+                    help="older spelling of --path: 0 = fp32, 2 (or -1) = screened where it pays, 1 = screening forced on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other path and the workloads / sweeps reported under 'also'")
     ap.add_argument("--allow-host-collectives", action="store_true",
@@ -508,7 +509,7 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if args.path is None:
         args.path = "fp32" if args.screening in (None, 0) else "screened"
-    prim_scr = 0 if args.path == "fp32" else (args.screening if args.screening in (-1, 1) else -1)
+    prim_scr = 0 if args.path == "fp32" else (args.screening if args.screening in (1, 2) else 2)
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between processes on this driver
     under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
@@ -550,24 +551,24 @@ def main():
     other = None
     also = None
     if not args.no_secondary:
-        # the same iterations on the other path (fp32 primary: the library's default, screened step; screened primary: screening off)
-        ro = measure(args, L, args.workload, args.steps, 1, reps=3 if prim_fp32 is False else max(3, args.reps // 2), screening=(-1 if prim_fp32 else 0), rollouts=shard)
+        # the same iterations on the other path (fp32 primary: the opt-in screened step; screened primary: screening off)
+        ro = measure(args, L, args.workload, args.steps, 1, reps=3 if prim_fp32 is False else max(3, args.reps // 2), screening=(2 if prim_fp32 else 0), rollouts=shard)
         other = dict(rate(ro, n_total), roofline=roofline(args, ro, args.workload, not prim_fp32), screening=ro["scr"])
         also = []
 
         def both(wl2, st2, rp2, **kw):
-            """One `also` entry: the workload on the all-fp32 step (`value`) and on the library's default step (`value_screened`;
+            """One `also` entry: the workload on the all-fp32 step (`value`, the library's default) and on the opt-in screened step (`value_screened`;
             absent where the library does not screen: few obstacles, N x O < 65536)."""
             nt = (kw.get("rollouts") or WORKLOADS[wl2]["N"]) * world
             r32 = measure(args, L, wl2, st2, 1, prof=False, reps=rp2, screening=0, **kw)
             e2 = dict({"workload": wl2, "unit": "rollout-steps/s", "steps": st2, "dtype": "f32", "active_kernels": r32["K"], "rollouts_per_gpu": r32["N"]}, **rate(r32, nt))
-            rs = measure(args, L, wl2, st2, 1, prof=False, reps=rp2, screening=-1, **kw)
+            rs = measure(args, L, wl2, st2, 1, prof=False, reps=rp2, screening=2, **kw)
             if rs["scr"]["active"]:
                 rt = rate(rs, nt)
                 e2.update({"value_screened": rt["value"], "ms_per_step_screened": rt["ms_per_step"], "rep_ms_per_step_screened": rt["rep_ms_per_step"],
                            "screening": {k2: rs["scr"][k2] for k2 in SCREEN_KEYS}})
             else:
-                e2["value_screened"] = None      # the default step of this shape IS the fp32 step
+                e2["value_screened"] = None      # omds_set_screening(ctx, 2, 0) keeps the fp32 step at this shape
             if WORKLOADS[wl2].get("dynamic"):
                 e2["kernels_at_block_end"] = rs["k_trace"]   # K grows from 0 inside every timed block (one add_kernel per iteration at most)
             return e2
@@ -602,8 +603,8 @@ def main():
             "dtype": "f32" if (prim_fp32 or not r["scr"]["active"]) else "f32 out / f16 screen", "data": "synthetic",
             "config": {"workload": args.workload,
                        "path": ("all-fp32 step (omds_set_screening(0)): every network evaluation in the reference's arithmetic; value_screened / "
-                                "roofline.screened = the library's default step on the same iterations") if prim_fp32 else
-                               ("the library's default step; value_fp32_only / roofline.fp32_only = the same iterations with every row in fp32"),
+                                "roofline.screened = the opt-in screened step (omds_set_screening(ctx, 2, 0)) on the same iterations") if prim_fp32 else
+                               ("the opt-in screened step; value_fp32_only / roofline.fp32_only = the same iterations with every row in fp32 (the library's default)"),
                        "precision": "fp32 throughout" if (prim_fp32 or not r["scr"]["active"]) else scr_sentence,
                        "rollouts_per_gpu": r["N"], "rollouts_total": n_total, "horizon": H, "obstacles": int(obs.shape[0]),
                        "n_closest": w["k"], "active_kernels": K, "network": "x".join(str(x.shape[1]) for x in W) + f"x{W[-1].shape[0]} {act} "

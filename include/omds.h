@@ -291,6 +291,14 @@ OMDS_API int omds_apply_update(int n_kernels, int n_dof, int horizon, const floa
  * error Da - D <= eps and the exact k-th smallest candidate stays eps below tau.  The distances and gradients a step uses
  * always come from the fp32 pass 2, and omds_dist_grad always uses the fp32 pass 1.
  * The identity with the all-fp32 step is therefore CONDITIONAL on eps, and eps is a measured quantity, not an a-priori one.
+ * THE CONTRACT OF THE DEFAULT.  A context runs the ALL-FP32 step unless the caller opts in (mode 1 | 2 below, or OMDS_SCREEN=1|2 in the
+ * environment): by default every network evaluation of omds_propagate is the reference's arithmetic on every pair, unconditionally.
+ * Screening is an opt-in 5x: its results are the all-fp32 step's bit for bit in every test and soak run of this repository, but on
+ * the strength of a MEASURED bound.  There is no usable a-priori one: propagating the f16 rounding of inputs, weights and activations
+ * (2^-11 relative each) through sum |W| per layer gives |Da - D| <= 455 m for the shipped Franka network on |q| <= 2.9, |p| <= 1.5 m
+ * (first order with sampled activation magnitudes: 58-81 m; planar 7-DoF: 5.8e3) against a measured eps of 0.016 m -- the norm
+ * bound ignores the cancellation a trained network lives on, and is 3e4 times too large to select anything
+ * (tools/studies/screen_apriori_bound.py).
  * What is measured, and when:
  *   - calibration: eps = 6 x the largest |Da - D| over ~3e5 pairs (states uniform in the joint box + states of the last
  *     propagate's rollouts, against the current obstacles), at the first screened propagate after omds_set_mlp, after
@@ -317,10 +325,9 @@ OMDS_API int omds_apply_update(int n_kernels, int n_dof, int horizon, const floa
  * tools/sweep_soak.py -- every horizon step of 5 183 propagates swept, 1.93e11 pairs over ten scene / network legs, none of the
  * 1.87e11 unevaluated pairs above eps / 2, the worst at 0.197 eps (profiles/r04_screen_error_hist.txt; the round-5 build: 2.4e11 more pairs, none above eps / 2, worst 0.182 eps,
  * profiles/r05_screen_error_hist.txt; the survival function of
- * (Da - D) / eps falls by half a decade or more per 1/128).  A caller who wants the reference's arithmetic on every row regardless calls
- * omds_set_screening(ctx, 0, 0).
- * mode: -1 auto (on for ReLU / tanh networks, with or without skip concatenations, when n_traj * n_obs >= 65536; env
- * OMDS_SCREEN=0|1 overrides), 0 off, 1 on.  eps > 0 sets the bound in place of a calibration (never recalibrated; the run-time checks
+ * (Da - D) / eps falls by half a decade or more per 1/128).
+ * mode: -1 the library's default = off (env OMDS_SCREEN=0|1|2 changes the default of contexts left at -1), 0 off, 1 on, 2 on where it pays
+ * (ReLU / tanh networks, with or without skip concatenations, n_traj * n_obs >= 65536 and n_obs >= 4 n_closest; else the fp32 step).  eps > 0 sets the bound in place of a calibration (never recalibrated; the run-time checks
  * still widen it when they must); eps == 0 changes the mode only; eps < 0 discards the calibration (measured again at the next screened propagate).
  * omds_set_screening_audit: one_in = 0 (no audit sample) or a power of two; default 128 (EXPERIMENTS.md C 4.1b has the measured cost per rate).
  * omds_screen_stats: active, eps in use, largest candidate error seen since the last calibration, mean candidates per

@@ -1125,14 +1125,14 @@ static int check_ready(omds_ctx* ctx, bool need_ds) {
 static bool screen_wanted(omds_ctx* ctx) {
     if (!ctx->screen_ok || ctx->screen_suspended) return false;
     int mode = ctx->screen_mode;
-    if (mode < 0) {
+    if (mode < 0) {   // the library's default: the all-fp32 step -- screening is OPT-IN (omds.h); OMDS_SCREEN=0|1|2 sets the default of such contexts
         static int env = -2;
-        if (env == -2) { const char* e = getenv("OMDS_SCREEN"); env = e ? atoi(e) : -1; }
+        if (env == -2) { const char* e = getenv("OMDS_SCREEN"); env = e ? atoi(e) : 0; }
         mode = env;
     }
-    if (mode == 0) return false;
-    if (mode > 0) return true;
-    // auto: worth it once pass 1 is throughput-bound (below that a step is a chain of latency-bound launches and the
+    if (mode <= 0) return false;
+    if (mode == 1) return true;
+    // 2 = where it pays: once pass 1 is throughput-bound (below that a step is a chain of latency-bound launches and the
     // three extra launches cost more than the fp32 pass)
     return (long long)ctx->cfg.n_traj * ctx->n_obs >= 64LL * 1024 && ctx->n_obs >= 4 * ctx->cfg.n_closest;
 }
@@ -2062,7 +2062,7 @@ int omds_kernel_candidates(omds_ctx* ctx, float thr_dist, float thr_kernel, floa
 // ---- screening controls ------------------------------------------------------------------------------
 int omds_set_screening(omds_ctx* ctx, int mode, float eps) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
-    REQUIRE(mode >= -1 && mode <= 1 && eps == eps, OMDS_ERR_INVALID_ARG, "omds_set_screening: mode in {-1, 0, 1}, eps not NaN");
+    REQUIRE(mode >= -1 && mode <= 2 && eps == eps, OMDS_ERR_INVALID_ARG, "omds_set_screening: mode in {-1, 0, 1, 2}, eps not NaN");
     ctx->screen_mode = mode;
     if (eps > 0.f) {            // the caller's bound instead of a calibration (the run-time checks still widen it when they must)
         ctx->screen_eps = eps; ctx->screen_eps_fixed = true; ctx->screen_cal = true;

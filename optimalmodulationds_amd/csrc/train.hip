@@ -575,8 +575,8 @@ __global__ void k_encode(const float* __restrict__ x, int B, int d, float* __res
     const int j = (int)(i - r * d);
     const float v = x[i];
     H0[r * 3 * d + j] = v;
-    H0[r * 3 * d + d + j] = sinf(v);
-    H0[r * 3 * d + 2 * d + j] = cosf(v);
+    H0[r * 3 * d + d + j] = omds_sinf(v);
+    H0[r * 3 * d + 2 * d + j] = omds_cosf(v);
 }
 
 // G = 2 (pred - y) / count  (the gradient of F.mse_loss(..., reduction='mean')); per-block partial sums of (pred - y)^2 in double

@@ -300,12 +300,12 @@ def test_ragged_and_large_shapes(N, H, k, O):
 
 
 def test_example_drivers_run():
-    """examples/: the reference's two driver loops (Franka planner, planar 2-DoF stand-alone) on the facade."""
+    """examples/: the reference's driver loops (Franka planner, planar 2-DoF and planar 7-DoF stand-alone) on the facade."""
     import importlib.util
     import os
     from helpers import ROOT
     mods = {}
-    for name in ("franka_planner_loop", "standalone_planar2d"):
+    for name in ("franka_planner_loop", "standalone_planar2d", "standalone_planar7d"):
         spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "examples", name + ".py"))
         mods[name] = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mods[name])
@@ -314,6 +314,13 @@ def test_example_drivers_run():
     mppi2, n_iter = mods["standalone_planar2d"].main(max_iter=60, quiet=True)
     d0 = float(torch.norm(torch.tensor([-3.14, 0.0]) - torch.tensor([3.14, 0.0])))
     assert float(torch.norm(mppi2.q_cur - torch.tensor([3.14, 0.0]))) < d0        # it moves towards the goal
+    # standalonePlanar7d.py:96-166 with its own defaults (20 rollouts x 10 steps, dt_sim = 0.02): 60 iterations move q[0] from pi/2 towards -pi/2
+    mppi7, n7 = mods["standalone_planar7d"].main(max_iter=60, quiet=True)
+    q_f7 = torch.zeros(7); q_f7[0] = -torch.pi / 2
+    assert n7 == 60 and torch.isfinite(mppi7.q_cur).all() and float(torch.norm(mppi7.q_cur - q_f7)) < float(torch.pi) - 0.5
+    # ... and at BASELINE configs[1]'s shape (1024 rollouts x 32 steps, 8 obstacles) for a few iterations
+    mppi7b, _ = mods["standalone_planar7d"].main(max_iter=3, n_traj=1024, dt_h=32, n_extra_obs=4, quiet=True)
+    assert mppi7b.all_traj.shape == (1024, 32, 7) and torch.isfinite(mppi7b.q_cur).all()
 
 
 def test_planner_payload_round_trip_into_the_integrator():

@@ -1,6 +1,6 @@
 """Full-size parity, re-derived by the ORACLE (never by the device itself), on the three shapes the bench credits:
 
-  * Franka shelf 4096 x 32, K = 10, the library's default (f16-screened) step  -- BASELINE configs[2]'s size, ReLU weights;
+  * Franka shelf 4096 x 32, K = 10, the opt-in f16-screened step (omds_set_screening(ctx, 2, 0)) -- BASELINE configs[2]'s size, ReLU weights;
   * Franka shelf 1024 x 32, K = 10, the all-fp32 step (omds_set_screening(ctx, 0, 0)) -- bench.py's headline `value`;
   * Franka shelf 4096 x 32 with the 256x3 tanh network (tests/golden/weights/franka_tanh) -- configs[2] as BASELINE.json words it.
 
@@ -26,7 +26,7 @@ def _err(a, b, scale=None):
     return float(e.max()), float(e.mean())
 
 
-@pytest.mark.parametrize("kind,N,S,screen", [("franka", 4096, 1024, -1), ("franka", 1024, 1024, 0), ("franka_tanh", 4096, 512, -1)])
+@pytest.mark.parametrize("kind,N,S,screen", [("franka", 4096, 1024, 2), ("franka", 1024, 1024, 0), ("franka_tanh", 4096, 512, 2)])
 def test_fullsize_rollout_rederived_by_the_oracle(kind, N, S, screen):
     from optimalmodulationds_amd import scenes
     from optimalmodulationds_amd.cost import FRANKA_Q_MAX, FRANKA_Q_MIN
@@ -43,8 +43,7 @@ def test_fullsize_rollout_rederived_by_the_oracle(kind, N, S, screen):
     eng.push_params()
     eng.set_ds(qf)
     eng.set_cost(dh, qmin, qmax)
-    if screen == 0:
-        eng.set_screening(0, 0.0)          # the all-fp32 step: bench.py's `value`
+    eng.set_screening(screen, 0.0)         # 0: the all-fp32 step (the library's default, bench.py's `value`); 2: the opt-in screened step
     rng = np.random.RandomState(7)
     s = (np.arange(K) + 0.5) / K
     mu_c = (q0 + s[:, None] * (qf - q0) + 0.15 * rng.standard_normal((K, 7))).astype(np.float32)
@@ -61,7 +60,7 @@ def test_fullsize_rollout_rederived_by_the_oracle(kind, N, S, screen):
     if screen == 0:
         assert not st_scr["active"], st_scr
     else:
-        assert st_scr["active"] and st_scr["fallbacks"] == 0, st_scr      # the default path at this size is the screened step
+        assert st_scr["active"] and st_scr["fallbacks"] == 0, st_scr      # mode 2 screens at this size
     step_name = "all-fp32 step" if screen == 0 else "screened step"
 
     t0 = time.time()

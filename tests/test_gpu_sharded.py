@@ -24,6 +24,7 @@ def _setup(N, H, k=5, K=6, seed=3, scene="shelf"):
 
     def make(n_traj):
         e = Engine(7, n_traj, H, k, max_obs=512)
+        e.set_screening(2)      # the opt-in screened step where it pays (the library's default is the all-fp32 step)
         e.set_mlp(m.W, m.b)
         e.set_obstacles(obs)
         e.params.dt, e.params.dst_thr, e.params.ignored_links = 0.5, 0.01, 0b111

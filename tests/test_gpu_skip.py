@@ -69,7 +69,7 @@ def test_skip_network_rollouts_all_step_variants_agree():
     m = orc.Mlp.from_npz(weights_path("franka_skip"))
     obs, q0, qf = scenes.shelf_scene(), scenes.FRANKA_Q0, scenes.FRANKA_QF
     outs = []
-    for flags, mode in ((0, 0), (L.FLAG_UNFUSED_STEP, 0), (0, 1), (0, -1)):
+    for flags, mode in ((0, 0), (L.FLAG_UNFUSED_STEP, 0), (0, 1), (0, 2)):
         e = Engine(7, 1024, 4, 5, max_obs=512, flags=flags)
         e.set_mlp(m.W, m.b, act=m.act, skip_after=m.skip_after)
         e.set_obstacles(obs)

@@ -82,10 +82,10 @@ def test_training_at_the_shipped_network_size_against_torch_cpu(act):
         opt.zero_grad()
         got = tr.step(lr=2e-4)
         # the loss BEFORE any update is the forward pass alone: 1e-5.  From the second update on, the trained ReLU weights' rounding-level
-        # gradients (below) have moved some weights by +-lr in opposite directions in the two runs, and the loss follows: 1e-4
-        # (seen 2.4e-5 at the third epoch with the 256-wide layers on gemm256's summation order, 0.9e-5 with the general kernel's)
+        # gradients (below) have moved some weights by +-lr in opposite directions in the two runs, and the loss follows: 2e-5 (every
+        # product of the trainer sums in ascending k like torch's sgemm: seen 0.9e-5 over 30 epochs; the printed `worst` is the record)
         worst = max(worst, abs(got - loss.item()) / loss.item())
-        assert abs(got - loss.item()) <= (1e-5 if (e < 2 or act == "tanh") else 1e-4) * loss.item(), (e, got, loss.item())
+        assert abs(got - loss.item()) <= (1e-5 if (e < 2 or act == "tanh") else 2e-5) * loss.item(), (e, got, loss.item())
         if e + 1 in (5, 30):
             # Trained weights carry units whose gradient is at rounding level (near-dead ReLUs); Adam's first steps are
             # lr * g / |g| whatever |g| is, so two fp32 evaluations move such a weight by +-lr in different directions.
