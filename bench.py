@@ -249,7 +249,7 @@ def measure(args, L, workload, steps, warmup, time_fetch=False, prof=True, reps=
     N = int(rollouts) if rollouts else w["N"]
     H, n = w["H"], q0.shape[0]
     K = args.kernels if kernels is None else int(kernels)
-    eng = Engine(n, N, H, w["k"], max_obs=max(64, obs.shape[0]), device=L.local_rank)
+    eng = Engine(n, N, H, w["k"], max_obs=max(64, obs.shape[0]), device=L.local_rank, flags=(8 if getattr(args, "dense_pass1", False) else 0))
     eng.set_mlp(W, b, act=w.get("act", "relu"))
     eng.set_obstacles(obs)
     eng.set_screening(screening)
@@ -417,8 +417,9 @@ def measure(args, L, workload, steps, warmup, time_fetch=False, prof=True, reps=
             eng.get_rollouts()
         fetch_ms = (time.perf_counter() - tf) / 5 * 1e3
     scr = eng.screen_stats()
+    skip = eng.pass1_skip_stats()
     eng.close()
-    return dict(els=els, scr=scr, k_trace=k_trace, dh=dh, qmin=qmin, qmax=qmax, w=w, W=W, b=b, obs=obs, q0=q0, qf=qf, N=N, H=H, K=K,
+    return dict(els=els, scr=scr, skip=skip, k_trace=k_trace, dh=dh, qmin=qmin, qmax=qmax, w=w, W=W, b=b, obs=obs, q0=q0, qf=qf, N=N, H=H, K=K,
                 p1_ms=p1_ms, p1_launches=p1_launches, p1_rows=p1_rows, p1_flops=p1_flops, p1_kernel=p1_kernel, fetch_ms=fetch_ms,
                 steps=steps)
 
@@ -449,10 +450,21 @@ def roofline(args, rr, workload, fp32):
     f_alg = 2 * sum(int(x.shape[0]) * int(x.shape[1]) for x in W)
     if kern == "k_pass1":      # layer 1 over the encoded inputs padded to K = 32, hidden layers as they are, the last layer padded to 16 columns
         f_iss = 2 * 32 * int(W[0].shape[0]) + 2 * sum(int(x.shape[0]) * int(x.shape[1]) for x in W[1:-1]) + 2 * int(W[-1].shape[1]) * 16
+        basis = (f"analytic: {f_iss} FLOP of MFMA per pair (layer 1 as a K = 32 product over the 3(n+3) encoded inputs -- the reference's single "
+                 f"chain does not split into two precomputed halves --, hidden layers, last layer padded to 16 columns) against {f_alg} algorithmic")
+        skip = rr.get("skip") or {}
+        if skip.get("active") and len(skip.get("chunks", [])) == len(W) - 1:
+            # the exact zero-skip (omds_pass1_skip_stats): level l's consumer multiplies chunks[l] k-chunks of 8 (the last layer: of 16)
+            # instead of 32 (16); a surprised tile multiplies in full (counted, negligible here)
+            ch = skip["chunks"]
+            f_iss = 2 * 32 * int(W[0].shape[0]) + 2 * sum(8 * ch[l] * int(W[l + 1].shape[0]) for l in range(len(W) - 2)) + 2 * 16 * ch[-1] * 16
+            basis = (f"analytic: {f_iss} FLOP of MFMA per pair executed -- layer 1 as a K = 32 product, then the EXACT ZERO-SKIP: the products over the hidden levels stop "
+                     f"after {ch[:-1]} of 32 k-chunks and the last layer after {ch[-1]} of 16 (units that fire for no input are not multiplied: same bits, "
+                     f"include/omds.h omds_pass1_skip_stats; {skip.get('surprises', 0)} tile-levels of this run were multiplied in full) -- against {f_alg} algorithmic: "
+                     f"`frac` credits the dense network's work and can exceed 1, `frac_issued` is what the matrix pipe executed")
+            out["zero_skip"] = {"chunks": ch, "surprised_tile_levels": skip.get("surprises", 0)}
         out["frac_issued"] = out["frac"] * f_iss / f_alg
-        out["frac_issued_basis"] = (f"analytic: {f_iss} FLOP of MFMA per pair (layer 1 as a K = 32 product over the 3(n+3) encoded inputs -- the reference's single "
-                                    f"chain does not split into two precomputed halves --, hidden layers, last layer padded to 16 columns) against {f_alg} algorithmic"
-                                    + (f"; SQ_INSTS_MFMA of the committed pass: {insts:.0f} per launch" if insts else ""))
+        out["frac_issued_basis"] = basis + (f"; SQ_INSTS_MFMA of the committed pass: {insts:.0f} per launch" if insts else "")
     elif kern in FLOP_PER_MFMA and insts and avg_ms > 0:
         out["frac_issued"] = insts * FLOP_PER_MFMA[kern] / (avg_ms * 1e-3) / 1e12 / peak
         out["mfma_insts_per_launch"] = insts
@@ -491,6 +503,7 @@ def main():
                          "is reported beside it unless --no-secondary")
     ap.add_argument("--screening", type=int, default=None, choices=(-1, 0, 1, 2),
                     help="older spelling of --path: 0 = fp32, 2 (or -1) = screened where it pays, 1 = screening forced on")
+    ap.add_argument("--dense-pass1", action="store_true", help="OMDS_FLAG_DENSE_PASS1: k_pass1 without its exact zero-skip (A/B runs; same bits)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other path and the workloads / sweeps reported under 'also'")
     ap.add_argument("--allow-host-collectives", action="store_true",

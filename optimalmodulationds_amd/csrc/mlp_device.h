@@ -107,6 +107,55 @@ __device__ __forceinline__ void gemm256(const float* __restrict__ Hw, const floa
 #undef OMDS_INTERLEAVE
 }
 
+// The same product over the first `nch` k-chunks only (wave-uniform, 2 .. 32) -- the exact zero-skip of
+// pass1_tile<.., SPARSE>.  A ROLLED loop over pairs of chunks: the fully unrolled form with a guard per pair made hipcc copy the
+// accumulators at every merge point (VALU instructions per launch 49 M -> 94 M, tools/sparse_ab.sh); here the accumulators are
+// loop-carried in place, the LDS row pointer and the scalar weight offset advance once per pair, and the body keeps the pinned
+// load / MFMA interleave of gemm256.
+template <int MR, int NR>
+__device__ __forceinline__ void gemm256_rt(const float* __restrict__ Hw, const float4* __restrict__ Wp, int cb0,
+                                           int lane, f32x16 (&acc)[MR][NR], int nch) {
+    const float* arow = Hw + (lane & 31) * LDH + 4 * (lane >> 5);
+    const float4* wbase = Wp + (size_t)__builtin_amdgcn_readfirstlane(cb0) * (32 * 64);
+    const __amdgpu_buffer_rsrc_t wp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wbase), 0, NR * 32 * 64 * 16, 0x00020000);
+    const int wv = lane * 16;
+    float4 a0[MR], a1[MR], w0[NR], w1[NR];
+    auto load_at = [&](const float* ar, int soff, float4 (&a)[MR], float4 (&w)[NR]) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const omds_f4 v = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(wp, wv + j * (32 * 64 * 16), soff, 0));
+            w[j] = make_float4(v.x, v.y, v.z, v.w);
+        }
+#pragma unroll
+        for (int i = 0; i < MR; ++i) a[i] = *reinterpret_cast<const float4*>(ar + i * 32 * LDH);
+    };
+    load_at(arow, 0, a0, w0);
+    const int last = (__builtin_amdgcn_readfirstlane(nch) & ~1) * (64 * 16);   // byte offset behind the last PAIR of chunks
+#define OMDS_INTERLEAVE_RT()                                                          \
+    _Pragma("unroll") for (int q_ = 0; q_ < NR; ++q_) {                               \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                              \
+        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);                             \
+    }                                                                                 \
+    _Pragma("unroll") for (int q_ = 0; q_ < MR; ++q_) {                               \
+        __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);                              \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
+    }                                                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x8, 4 * MR * NR - NR - 2 * MR, 0);          \
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int soff = 0; soff < last; soff += 2 * 64 * 16) {
+        load_at(arow + 8, soff + 64 * 16, a1, w1);
+        mfma_chunk<MR, NR>(a0, w0, acc);
+        OMDS_INTERLEAVE_RT()
+        arow += 16;
+        load_at(arow, (soff + 2 * 64 * 16) & (32 * 64 * 16 - 1), a0, w0);   // behind the last pair: chunk 0 or a chunk that is not multiplied (harmless)
+        mfma_chunk<MR, NR>(a1, w1, acc);
+        OMDS_INTERLEAVE_RT()
+    }
+    if (nch & 1) mfma_chunk<MR, NR>(a0, w0, acc);   // an odd count: the last chunk is the one the final pair prefetched
+#undef OMDS_INTERLEAVE_RT
+}
+
 // C/D layout of the 32x32 MFMA: lane l, register r -> row (r&3) + 8(r>>2) + 4(l>>5), col l&31.
 __device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
@@ -393,7 +442,10 @@ struct OmdsDivisor {
 // pass-2 distance, arg-min link, ReLU masks -- for EVERY pair, indexed by the pair (ex->dr / amin / mask [row]): the forward of
 // the k rows a rollout ends up selecting has been computed here anyway, so the tail selects from Dmin and runs the backward only.
 // The arithmetic of a row is the same in all forms and independent of the other rows of the tile: bit-identical results.
-template <int MT, int MR, int NR, int ACT, int MODE = 0>
+// SPARSE (MODE 0, ReLU, 32- and 64-row tiles): the exact zero-skip described at MlpDev::sparse -- every level's tile is stored
+// [A | B] (MlpDev::sp_pos), the product over it stops after MlpDev::sp_nch chunks with the pack in that order (WfP / WlP); a tile in
+// which a unit beyond the multiplied chunks fires stores the level again in natural order and multiplies it in full.  Same bits.
+template <int MT, int MR, int NR, int ACT, int MODE = 0, bool SPARSE = false>
 __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const float* __restrict__ Fq,
                                            const float* __restrict__ Fp, const float* __restrict__ radius, int O,
                                            long long total_rows, uint32_t ignored, float* __restrict__ Dmin,
@@ -402,6 +454,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                                            const ExactOut* ex = nullptr) {
     constexpr bool LIST = MODE == 1 || MODE == 3 || MODE == 4 || MODE == 5, EMIT = MODE == 1 || MODE == 2 || MODE == 6, DERIV = MODE == 5;
     constexpr bool EMITY = EMIT || DERIV;   // pass 2's distance and arg-min link per row (ex->dr, ex->amin)
+    static_assert(!SPARSE || (MODE == 0 && MT != 16 && ACT == OMDS_ACT_RELU), "the zero-skip is written for k_pass1's own tiles");
     static_assert(!DERIV || MT == 16, "the derivative hand-over is written for the 16-row tiles of k_exact");
     using G = Geo<MT, MR, NR>;
     float* Hs = smem;                                           // [MT][LDH]
@@ -440,6 +493,13 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
     float bcur[NBIAS];   // bias of the layer about to be multiplied, fetched one layer ahead (layer 1's: in flight across the gather)
 #pragma unroll
     for (int j = 0; j < NBIAS; ++j) bcur[j] = m.b1[bias_col(j)];
+    [[maybe_unused]] int* spflag = reinterpret_cast<int*>(rowRad + MT);   // SPARSE: [nhid] a unit beyond the multiplied chunks fired at this level
+    [[maybe_unused]] uint32_t pcur[NBIAS];   // SPARSE: where this thread's column(s) sit in the level about to be produced (MlpDev::sp_pos)
+    if constexpr (SPARSE) {
+        if (tid <= OMDS_MAX_HIDDEN) spflag[tid] = 0;
+#pragma unroll
+        for (int j = 0; j < NBIAS; ++j) pcur[j] = m.sp_pos[bias_col(j)];
+    }
 
     // ---- the tile's encoded inputs: row r = pair (t, o) gets Fq[t] | Fp[o] (each table is zero in the other's slots) at positions
     //      0..31.  A wave fills two rows per step, one per lane half; the row bookkeeping (rollout t, obstacle o, bounds) is
@@ -531,6 +591,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
     // ---- layer 1 (l = -1, K = 32 over the encoded inputs) and the hidden -> hidden layers, each the reference's product: the
     //      accumulators start at ZERO, the k order is ascending (omds_kpos), the bias is added in the epilogue ----------------
     const float* Hw = Hs + (wm * MR * 32) * LDH;
+    [[maybe_unused]] int last_natural = 1;   // SPARSE: how the last hidden level ended up in the tile
     if constexpr (MT == 16) {
         const int scol0 = wave * 32 + omds_kpos(lane & 15);   // position of column wave*32 + 16 j + (lane & 15): + 16 j
         for (int l = -1; l < m.nhh; ++l) {
@@ -568,7 +629,8 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
             if ((m.skip_mask >> (l + 1)) & 1u) inject(l + 1);
             OMDS_TL(2 + (l < 0 ? 0 : l));
         }
-    } else
+    } else {
+    [[maybe_unused]] int natural = 1;   // SPARSE: the level in the tile is stored in natural order (level -1, the inputs: always)
     for (int l = -1; l < m.nhh; ++l) {
         f32x16 acc[MR][NR];
 #pragma unroll
@@ -578,26 +640,42 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         float bnow[NR];
+        [[maybe_unused]] uint32_t pnow[NR];
 #pragma unroll
         for (int j = 0; j < NR; ++j) bnow[j] = bcur[j];
+        if constexpr (SPARSE) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) pnow[j] = pcur[j];
+        }
         if (l + 1 < m.nhh) {
 #pragma unroll
             for (int j = 0; j < NR; ++j) bcur[j] = m.bh[(l + 1) * OMDS_WIDTH + (cb0 + j) * 32 + (lane & 31)];
         }
+        if constexpr (SPARSE) {   // positions of the NEXT level (level l + 2 exists while l + 1 < nhh)
+            if (l + 1 < m.nhh) {
+#pragma unroll
+                for (int j = 0; j < NR; ++j) pcur[j] = m.sp_pos[(l + 2) * OMDS_WIDTH + (cb0 + j) * 32 + (lane & 31)];
+            }
+        }
         if (l < 0) gemm_k32<MR, NR>(Hw, m.W1f, cb0, lane, acc);
+        else if (SPARSE && !natural) gemm256_rt<MR, NR>(Hw, m.WfP + (size_t)l * (OMDS_NCB * 32 * 64), cb0, lane, acc, m.sp_nch[l]);
         else gemm256<MR, NR>(Hw, m.Wf + (size_t)l * (OMDS_NCB * 32 * 64), cb0, lane, acc);
         __syncthreads();  // every wave has finished reading the tile
         if (l == 0) OMDS_TL(6);
         // one lane-dependent base address per column block; everything else of (row, col) is a compile-time offset, so the
         // 16 * MR stores of a block use immediate offsets (hipcc otherwise builds a VGPR address per row: VALU = matrix-pipe time)
+        [[maybe_unused]] float zmax = 0.f;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-            float* hb = Hs + (wm * MR * 32 + 4 * (lane >> 5)) * LDH + (cb0 + j) * 32 + omds_kpos(lane & 31);
+            const int pos = SPARSE ? (int)(pnow[j] & 0x7fffu) : (cb0 + j) * 32 + omds_kpos(lane & 31);
+            float* hb = Hs + (wm * MR * 32 + 4 * (lane >> 5)) * LDH + pos;
+            [[maybe_unused]] float zm = 0.f;
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float z = acc[i][j][r] + bnow[j];
+                    if constexpr (SPARSE) { acc[i][j][r] = z; zm = fmaxf(zm, z); }
                     hb[(i * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = actf(z, ACT);
                     if constexpr (EMIT) {   // lanes 0-31 hold row (r&3) + 8(r>>2) of this 32-column block, lanes 32-63 that row + 4
                         const unsigned long long bal = __ballot(z > 0.f);
@@ -608,16 +686,39 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                         }
                     }
                 }
+            if constexpr (SPARSE) { if (pnow[j] >> 15) zmax = fmaxf(zmax, zm); }   // a column of B
+        }
+        if constexpr (SPARSE) {
+            if (zmax > 0.f) spflag[l + 1] = 1;   // a unit presumed dead fired in this tile: the next product may not stop early
         }
         __syncthreads();
+        if constexpr (SPARSE) {
+            natural = __builtin_amdgcn_readfirstlane(spflag[l + 1]);
+            if (natural) {   // rare: the level once more, in natural order (the values are still in the accumulators), for the natural packs
+                if (tid == 0) atomicAdd(m.sp_surprises, 1u);
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    float* hb = Hs + (wm * MR * 32 + 4 * (lane >> 5)) * LDH + (cb0 + j) * 32 + omds_kpos(lane & 31);
+#pragma unroll
+                    for (int i = 0; i < MR; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) hb[(i * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = actf(acc[i][j][r], ACT);
+                }
+                __syncthreads();
+            }
+        }
         if ((m.skip_mask >> (l + 1)) & 1u) inject(l + 1);
         OMDS_TL(2 + (l < 0 ? 0 : l));
+    }
+    if constexpr (SPARSE) last_natural = natural;
     }
 
     // ---- last layer (256 -> C, padded to 16) on v_mfma_f32_16x16x4_f32, 16 rows per wave.  Kept short on purpose
     //      (buffer loads with constant offsets, DPP min over the 16 link lanes, one 16-byte store per 4 rows): like
     //      the layer-1 build it mostly runs starved next to the other resident workgroup's GEMM ----------------
-    const __amdgpu_buffer_rsrc_t wlr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(m.Wl), 0, 16 * 64 * 16, 0x00020000);
+    const float4* wl_pack = (SPARSE && !last_natural) ? m.WlP : m.Wl;
+    const int nchl = (SPARSE && !last_natural) ? (int)m.sp_nch[m.nhh] : 16;   // chunks of 16 positions multiplied
+    const __amdgpu_buffer_rsrc_t wlr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wl_pack), 0, 16 * 64 * 16, 0x00020000);
     for (int rb = __builtin_amdgcn_readfirstlane(wave); rb < MT / 16; rb += G::NW) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* arow = Hs + (rb * 16 + (lane & 15)) * LDH + pa16(lane);   // the k sequence of gemm16 (ascending k through omds_kpos)
@@ -642,6 +743,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
         }
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
+            if (!SPARSE || c < nchl) {
             const float4 a = load_a16(arow, c);
             const omds_f4 w = wq[c % LPD];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
@@ -650,6 +752,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
             if (c + LPD < 16) wq[c % LPD] = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(wlr, lane * 16, (c + LPD) * 64 * 16, 0));
             __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #ifdef OMDS_TIMELINE
         asm volatile("s_nop 0" ::"v"(acc[0]) : "memory");

@@ -389,6 +389,13 @@ class Engine:
                     sweep_every=sw_every.value, sweeps=sw_n.value, sweep_max_err=sw_err.value)
 
     # ---- measurement --------------------------------------------------------------------------
+    def pass1_skip_stats(self):
+        """omds_pass1_skip_stats: dict(active, chunks [per hidden level], surprises)."""
+        act, sur = C.c_int32(), C.c_int64()
+        ch = np.zeros(9, np.int32)
+        self._ck(self.lib.omds_pass1_skip_stats(self.h, C.byref(act), L.iptr(ch), 9, C.byref(sur)))
+        return dict(active=bool(act.value), chunks=[int(c) for c in ch if c > 0], surprises=int(sur.value))
+
     def sync(self):
         """Waits for everything enqueued on the context's stream (omds_sync)."""
         self._ck(self.lib.omds_sync(self.h))
