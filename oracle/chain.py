@@ -18,7 +18,7 @@ F32 = np.float32
 def build(force=False):
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
         tmp = _SO + f".{os.getpid()}.tmp"
-        subprocess.run(["gcc", "-O2", "-mavx2", "-mfma", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", _SRC, "-o", tmp, "-lm"],
+        subprocess.run(["gcc", "-O3", "-mavx2", "-mfma", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", _SRC, "-o", tmp, "-lm"],
                        check=True)
         os.replace(tmp, _SO)
     return _SO

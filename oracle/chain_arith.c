@@ -10,9 +10,12 @@
  *   - torch.sin / torch.cos are MKL VML's vmsSin / vmsCos (HA mode), a closed implementation; the nearest PUBLISHED algorithm is
  *     SLEEF's 1.0-ULP xsinf_u1 / xcosf_u1 (98.0 % / 97.0 % of 1e8 inputs bit-identical to torch's, one ulp otherwise; a correctly
  *     rounded sine agrees on 95 %), restated here in its FMA form for |x| < 125                -> omds_orc_sin / omds_orc_cos
- * Built by oracle/chain.py (and __graft_entry__.build()):  gcc -O2 -mavx2 -mfma -ffp-contract=off -fopenmp -shared -fPIC
+ * Built by oracle/chain.py (and __graft_entry__.build()):  gcc -O3 -mavx2 -mfma -ffp-contract=off -fopenmp -shared -fPIC
  * (-ffp-contract=off: only the fmaf calls written below fuse). */
 #include <math.h>
+/* a FIXED small team, and only for big batches: the GPU boxes have 128+ cores shared with other jobs, where a default-sized OpenMP team
+ * spins for longer than these loops run (tests/test_gpu_parity.py went from 150 s to 600 s on a busy box) */
+#define OMDS_ORC_THREADS 8
 #include <stdlib.h>
 #include <string.h>
 
@@ -21,7 +24,7 @@ void omds_orc_linear(const float* x, const float* W, const float* b, float* y, l
     float* Wt = (float*)malloc((size_t)K * N * sizeof(float));   /* [K][N]: the chain of column n reads Wt[k][n] */
     for (int n = 0; n < N; ++n)
         for (int k = 0; k < K; ++k) Wt[(size_t)k * N + n] = W[(size_t)n * K + k];
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(OMDS_ORC_THREADS) if (M >= 1024)
     for (long m = 0; m < M; ++m) {
         float* acc = y + (size_t)m * N;
         for (int n = 0; n < N; ++n) acc[n] = 0.0f;
@@ -38,7 +41,7 @@ void omds_orc_linear(const float* x, const float* W, const float* b, float* y, l
 
 /* out[m][n] = sum over k ascending (one fmaf chain from 0) of g[m][k] W[k][n];  W [K][N] row-major (torch: g @ W) */
 void omds_orc_matmul(const float* g, const float* W, float* out, long M, int K, int N) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(OMDS_ORC_THREADS) if (M >= 1024)
     for (long m = 0; m < M; ++m) {
         float* acc = out + (size_t)m * N;
         for (int n = 0; n < N; ++n) acc[n] = 0.0f;
