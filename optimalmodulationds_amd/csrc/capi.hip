@@ -1562,16 +1562,17 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
             omds_tail_sel_supported(n, a.k) && (long long)N * ctx->n_obs <= 24576) {
             const long long pairs = (long long)N * ctx->cfg.max_obs;
             const int nhid = ctx->mlp.nhh + 1;
-            if (pairs > ctx->all_cap || nhid > ctx->all_nhid) {
+            if ((pairs > ctx->all_cap || nhid > ctx->all_nhid) && !(ctx->all_failed_pairs == pairs && ctx->all_failed_nhid == nhid)) {
                 for (void** o : {(void**)&ctx->d_allDr, (void**)&ctx->d_allMin, (void**)&ctx->d_allMask}) { if (*o) (void)hipFree(*o); *o = nullptr; }
                 ctx->all_cap = 0; ctx->all_nhid = 0;
                 const size_t mask_bytes = (size_t)pairs * nhid * 32;
                 if (mask_bytes <= ((size_t)8 << 30) && hipMalloc(&ctx->d_allDr, (size_t)pairs * 4) == hipSuccess &&
                     hipMalloc(&ctx->d_allMin, (size_t)pairs * 4) == hipSuccess && hipMalloc(&ctx->d_allMask, mask_bytes) == hipSuccess) {
                     ctx->all_cap = pairs; ctx->all_nhid = nhid;
-                } else {
+                } else {   // remembered: the same request is not retried at every propagate (hipMalloc / hipFree synchronise the device)
                     (void)hipGetLastError();
                     for (void** o : {(void**)&ctx->d_allDr, (void**)&ctx->d_allMin, (void**)&ctx->d_allMask}) { if (*o) (void)hipFree(*o); *o = nullptr; }
+                    ctx->all_failed_pairs = pairs; ctx->all_failed_nhid = nhid;
                 }
             }
             if (ctx->all_cap >= pairs && ctx->all_nhid >= nhid) {

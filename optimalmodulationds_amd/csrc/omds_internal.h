@@ -198,6 +198,7 @@ struct omds_ctx {
     // the all-fp32 step without a second forward (pass1_tile mode 6): per PAIR what k_exact leaves per candidate
     float* d_allDr = nullptr; int* d_allMin = nullptr; uint32_t* d_allMask = nullptr;   // [all_cap], [all_cap], [all_cap][all_nhid][8]
     long long all_cap = 0; int all_nhid = 0;
+    long long all_failed_pairs = -1; int all_failed_nhid = -1;   // the last request these three could not be allocated for (not retried until it changes)
     float* d_exDeriv = nullptr;  // tanh networks: [hidden layers][ex_cap][256] activation derivatives of the list entries (allocated by omds_set_mlp)
     int* d_sctotal = nullptr;    // [H+2]: candidate rows listed per horizon step; [H+1]: audit entries recorded in this propagate
     int* d_audit_rows = nullptr; // [audit_cap] audit sample of a propagate: pair rows into d_FqAll's row space, their screening values
