@@ -186,9 +186,12 @@ class MPPI:
             c = self._fetch()
             self.all_traj, self.closest_dist_all, self.kernel_val_all = c["all_traj"], c["closest_dist_all"], c["kernel_val_all"]
             self.dot_products, self.kernel_activations, self.qdot, self.normal_dirs = c["dot_products"], c["kernel_activations"], c["qdot"], c["normal"]
-            # torch counts in-place writes: a caller who edits a returned tensor gets the host path of check_traj_for_kernels
+            # torch counts in-place writes: a caller who edits a returned tensor WITH TORCH OPERATIONS gets the host path of
+            # check_traj_for_kernels.  (A write through a numpy view of the tensor -- t.numpy()[...] = x, np.asarray(t) -- shares its memory
+            # without bumping t._version and is NOT seen: pass an edited copy instead.)
             self._versions = {id(t): t._version for t in c.values()}
         else:
+            self._versions = {}
             lz = lambda key, shape: LazyRollout(self, key, shape, self._generation)
             self.all_traj = lz("all_traj", (N, H, n))
             self.closest_dist_all = lz("closest_dist_all", (N, H))
