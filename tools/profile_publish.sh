@@ -2,7 +2,7 @@
 # Copies the summaries tools/profile_refresh.sh left under gpurun_out/prof_<round>/ (scratch, merged back by gpurun) into profiles/
 # under their committed names.  Run here, after the gpurun call:  bash tools/profile_publish.sh r04
 set -eu
-R=${1:-r05}
+R=${1:-r06}
 S=gpurun_out/prof_$R
 D=profiles
 cp "$S/bench.json" "$D/${R}_bench_franka_shelf_1024x32.json"

@@ -2,7 +2,7 @@
 # Regenerates the rocprofv3 summaries committed under profiles/ (run on the GPU box through gpurun from the repo root).
 # Every rocprofv3 call has python3 directly after "--"; counters are collected in their own passes.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 OUT=$PWD/gpurun_out/prof_$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
