@@ -379,7 +379,7 @@ OMDS_API int omds_screen_order_stats(omds_ctx* ctx, int64_t* reorders, int32_t* 
 /* The EXACT ZERO-SKIP of the fp32 pass 1 (k_pass1; ReLU networks without skip concatenations).  A hidden unit whose activation is
  * exactly zero in every row of a 64-row tile adds fmaf(0, w, acc) = acc to every chain of the next layer, so not multiplying it
  * changes no bit.  omds_set_mlp finds the units that fire for NO input of a fixed synthetic sample (8192 inputs: joints uniform in
- * [-pi, pi], points in a +-1.5 / +-8 box; a third of the shipped Franka network's units), k_pass1 keeps each level's tile with
+ * [-pi, pi], points in a +-1.5 / +-8 box; a quarter of the shipped Franka network's hidden units), k_pass1 keeps each level's tile with
  * those units behind the others and stops every product after the chunks that can be non-zero; a tile in which one of them fires
  * after all (a "surprise") notices it and multiplies that level in full, in natural order.  The result is the reference's chain
  * bit for bit either way (tests/test_gpu_sparse.py; OMDS_FLAG_DENSE_PASS1 switches the skip off).
