@@ -453,16 +453,17 @@ def roofline(args, rr, workload, fp32):
         basis = (f"analytic: {f_iss} FLOP of MFMA per pair (layer 1 as a K = 32 product over the 3(n+3) encoded inputs -- the reference's single "
                  f"chain does not split into two precomputed halves --, hidden layers, last layer padded to 16 columns) against {f_alg} algorithmic")
         skip = rr.get("skip") or {}
-        if skip.get("active") and len(skip.get("chunks", [])) == len(W) - 1:
-            # the exact zero-skip (omds_pass1_skip_stats): level l's consumer multiplies chunks[l] k-chunks of 8 (the last layer: of 16)
-            # instead of 32 (16); a surprised tile multiplies in full (counted, negligible here)
-            ch = skip["chunks"]
+        if skip.get("active") and skip.get("tiles", 0) > 0 and len(skip.get("chunks", [])) >= len(W) - 1:
+            # the exact zero-skip (omds_pass1_skip_stats): every tile stores a hidden level compacted to the units that fire in it and
+            # the level's consumer multiplies ceil(T / 8) k-chunks (the last layer: ceil(T / 16)) instead of 32 (16)
+            ch, un = skip["chunks"][:len(W) - 1], skip["units"][:len(W) - 1]
             f_iss = 2 * 32 * int(W[0].shape[0]) + 2 * sum(8 * ch[l] * int(W[l + 1].shape[0]) for l in range(len(W) - 2)) + 2 * 16 * ch[-1] * 16
-            basis = (f"analytic: {f_iss} FLOP of MFMA per pair executed -- layer 1 as a K = 32 product, then the EXACT ZERO-SKIP: the products over the hidden levels stop "
-                     f"after {ch[:-1]} of 32 k-chunks and the last layer after {ch[-1]} of 16 (units that fire for no input are not multiplied: same bits, "
-                     f"include/omds.h omds_pass1_skip_stats; {skip.get('surprises', 0)} tile-levels of this run were multiplied in full) -- against {f_alg} algorithmic: "
-                     f"`frac` credits the dense network's work and can exceed 1, `frac_issued` is what the matrix pipe executed")
-            out["zero_skip"] = {"chunks": ch, "surprised_tile_levels": skip.get("surprises", 0)}
+            basis = (f"analytic: {f_iss:.0f} FLOP of MFMA per pair executed -- layer 1 as a K = 32 product, then the EXACT ZERO-SKIP: a tile keeps only the hidden "
+                     f"units that fire in it ({', '.join(f'{u:.0f}' for u in un)} of 256 per level on average) and their consumers multiply "
+                     f"{', '.join(f'{c:.1f}' for c in ch[:-1])} of 32 k-chunks and {ch[-1]:.1f} of 16 in the last layer (fmaf(0, w, acc) = acc: same bits, include/omds.h "
+                     f"omds_pass1_skip_stats) -- against {f_alg} algorithmic: `frac` credits the dense network's work and exceeds 1, `frac_issued` is what "
+                     f"the matrix pipe executed")
+            out["zero_skip"] = {"mean_units_per_tile": [round(u, 1) for u in un], "mean_chunks": [round(c, 2) for c in ch], "tiles": skip["tiles"]}
         out["frac_issued"] = out["frac"] * f_iss / f_alg
         out["frac_issued_basis"] = basis + (f"; SQ_INSTS_MFMA of the committed pass: {insts:.0f} per launch" if insts else "")
     elif kern in FLOP_PER_MFMA and insts and avg_ms > 0:

@@ -64,8 +64,8 @@ typedef struct {
 /* the all-fp32 step keeps its tail with a forward of its own (k_tail) instead of taking pass 2's forward from pass 1 (k_pass1 in
  * its emitting mode + k_tail_sel: same bits, one forward less); for A/B runs and the tests that compare the two            */
 #define OMDS_FLAG_TAIL_FORWARD 4
-/* k_pass1 multiplies every k-chunk of every layer instead of stopping behind the hidden units that can fire (the exact zero-skip
- * of ReLU networks: same bits either way); for A/B runs and the tests that compare the two                                      */
+/* k_pass1 multiplies every k-chunk of every layer instead of compacting every tile to the hidden units that fire in it (the exact
+ * zero-skip of ReLU networks: same bits either way); for A/B runs and the tests that compare the two                              */
 #define OMDS_FLAG_DENSE_PASS1 8
 
 /* The constants the reference hard-codes inside propagate() (MPPI.py:117-217,277) and
@@ -377,15 +377,16 @@ OMDS_API int omds_screen_fallback_stats(omds_ctx* ctx, int64_t* by_error, int64_
  * sampled row at the last reorder.                                                                                          */
 OMDS_API int omds_screen_order_stats(omds_ctx* ctx, int64_t* reorders, int32_t* never_fired, int n_levels);
 /* The EXACT ZERO-SKIP of the fp32 pass 1 (k_pass1; ReLU networks without skip concatenations).  A hidden unit whose activation is
- * exactly zero in every row of a 64-row tile adds fmaf(0, w, acc) = acc to every chain of the next layer, so not multiplying it
- * changes no bit.  omds_set_mlp finds the units that fire for NO input of a fixed synthetic sample (8192 inputs: joints uniform in
- * [-pi, pi], points in a +-1.5 / +-8 box; a quarter of the shipped Franka network's hidden units), k_pass1 keeps each level's tile with
- * those units behind the others and stops every product after the chunks that can be non-zero; a tile in which one of them fires
- * after all (a "surprise") notices it and multiplies that level in full, in natural order.  The result is the reference's chain
- * bit for bit either way (tests/test_gpu_sparse.py; OMDS_FLAG_DENSE_PASS1 switches the skip off).
- * active: 1 when the installed network qualifies and has units to skip; chunks[L], L = 0 .. n_levels-1: k-chunks of 8 (the last
- * hidden level: of 16) multiplied over level L (dense: 32 / 16); surprises: (tile, level)s multiplied in full since omds_set_mlp. */
-OMDS_API int omds_pass1_skip_stats(omds_ctx* ctx, int32_t* active, int32_t* chunks, int n_levels, int64_t* surprises);
+ * exactly zero in every row of a 64-row tile adds fmaf(0, w, acc) = acc to every chain of the next layer, so leaving it out changes
+ * no bit -- as long as the units that ARE multiplied keep their ascending order.  k_pass1 therefore stores every hidden level of a
+ * tile COMPACTED to the units that fire in that tile (rank order = unit order) and multiplies only those, fetching the weights by
+ * unit; on the Franka shelf task 164 / 195 / 146 / 130 of the 256 units of the four levels fire in a tile.  Nothing is presumed
+ * about which units fire: the result is the reference's chain bit for bit for every input (tests/test_gpu_sparse.py;
+ * OMDS_FLAG_DENSE_PASS1 switches the compaction off).
+ * active: 1 when the installed network qualifies; mean_units[L] / mean_chunks[L], L = 0 .. n_levels-1: firing units per tile of hidden
+ * level L and k-chunks multiplied over it (of 8 positions; the last hidden level: of 16), averaged over the `tiles` tiles since
+ * omds_set_mlp (NULL = skip).                                                                                                      */
+OMDS_API int omds_pass1_skip_stats(omds_ctx* ctx, int32_t* active, double* mean_units, double* mean_chunks, int n_levels, int64_t* tiles);
 /* (The two test hooks that damage the screening inputs / force a tile shape are NOT part of this library: they are declared in
  * include/omds_test.h and exported by libomds_hip_test.so only.)                                                           */
 /* Diagnostic: the fp16 screening network alone on q [B,n] -> mindist [B,O] (the values the candidate selection sees). */

@@ -38,7 +38,7 @@ class OmdsParams(C.Structure):
 
 FLAG_UNFUSED_STEP = 1
 FLAG_TAIL_FORWARD = 4      # the fp32 step's tail keeps its own forward (omds.h: OMDS_FLAG_TAIL_FORWARD)
-FLAG_DENSE_PASS1 = 8       # k_pass1 multiplies every k-chunk (omds.h: OMDS_FLAG_DENSE_PASS1; same bits as the zero-skip)
+FLAG_DENSE_PASS1 = 8       # k_pass1 multiplies every k-chunk (omds.h: OMDS_FLAG_DENSE_PASS1; same bits as the per-tile compaction)
 FLAG_TWO_KERNEL_STEP = 2   # keep few-obstacle scenes on k_pass1 + k_tail (omds.h: OMDS_FLAG_TWO_KERNEL_STEP)   # omds_config.flags
 # omds_params.variant / cost_terms bits (include/omds.h)
 VARIANT_KVAL_TIMES_ACT = 1
@@ -102,7 +102,7 @@ SIGNATURES = {
     "omds_screen_audit_stats": (C.c_int, [C.c_void_p, I32P, C.POINTER(C.c_double), F32P, I32P, C.POINTER(C.c_int64)]),
     "omds_screen_fallback_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "omds_screen_order_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), I32P, C.c_int]),
-    "omds_pass1_skip_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), I32P, C.c_int, C.POINTER(C.c_int64)]),
+    "omds_pass1_skip_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int64)]),
     "omds_set_screening_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "omds_screen_sweep_hist": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int, C.c_int]),
     "omds_screen_sweep_stats": (C.c_int, [C.c_void_p, I32P, C.POINTER(C.c_int64), F32P]),

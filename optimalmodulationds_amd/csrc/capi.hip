@@ -3,8 +3,6 @@
 // order, enqueueing the per-horizon-step kernel sequence on the context stream, layout
 // conversions for host copies, and the final O(K*n) policy update arithmetic.
 #include <algorithm>
-#include <map>
-#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -302,11 +300,8 @@ struct MlpPacks {
     float out_div = 1.f;
     uint32_t skip_mask = 0;
     uint8_t skip_col[OMDS_MAX_HIDDEN + 1] = {0};
-    std::vector<float4> wf, wb, wf16, wb16, wb4, wl, w1b, w1b16, w1f, w1f16, wfp, wlp;
-    std::vector<uint16_t> sp_pos;
-    uint8_t sp_nch[OMDS_MAX_HIDDEN + 1] = {0};
-    bool sparse = false;
-    std::vector<float> bh, bl, wlraw, whraw, w1t, b1, sbias;
+    std::vector<float4> wf, wb, wf16, wb16, wb4, wl, w1b, w1b16, w1f, w1f16;
+    std::vector<float> bh, bl, wlraw, whraw, w1t, b1, sbias, wht, wlt;
     std::vector<uint16_t> wh;
     double f_fwd = 0.0, f_bwd = 0.0;
     // what build_screen_pack needs to build wh / sbias again in another unit order (ReLU / tanh networks the screening kernel takes)
@@ -559,116 +554,14 @@ static int build_mlp_packs(int n, int n_linear, const int32_t* in_dims, const in
         pk.out_dims.assign(out_dims, out_dims + n_linear);
         build_screen_pack(pk, nullptr);
     }
-    // ---- exact zero-skip of k_pass1 (MlpDev::sparse): which hidden units can fire at all?  A fixed synthetic sample (joints uniform in
-    //      [-pi, pi], points uniform in a +-1.5 m box or a +-8 box: every scene the reference ships), the network in plain fp32 on the
-    //      host; units that fire for none of its rows go behind the others in the [A | B] tile order of their level.  The choice can
-    //      only cost speed, never a bit: a firing unit of B is noticed by the tile that holds it (pass1_tile, SPARSE).
-    pk.sparse = false;
-    pk.sp_pos.assign((size_t)(nhh + 1) * Wd, 0);
-    pk.wfp = pk.wf;
-    pk.wlp = pk.wl;
-    for (int L = 0; L <= nhh; ++L) {
-        pk.sp_nch[L] = L < nhh ? 32 : 16;
-        for (int u = 0; u < Wd; ++u) pk.sp_pos[(size_t)L * Wd + u] = (uint16_t)omds_kpos(u);
-    }
-    if (act == OMDS_ACT_RELU && skip_mask == 0 && nhh >= 1) {
-        // (cached per process by a hash of the padded weights: tests and benches install the same few networks many times)
-        static std::mutex cache_mu;
-        static std::map<uint64_t, std::vector<std::vector<char>>> cache;
-        uint64_t hkey = 1469598103934665603ull;
-        auto mix = [&](const void* ptr, size_t bytes) { const unsigned char* c = static_cast<const unsigned char*>(ptr); for (size_t i = 0; i < bytes; ++i) { hkey ^= c[i]; hkey *= 1099511628211ull; } };
-        for (int L = 0; L <= nhh; ++L) { mix(W[L], Wpad[L].size() * 4); mix(b[L], bpad[L].size() * 4); }
-        mix(&d, sizeof(d)); mix(&n, sizeof(n));
-        std::vector<std::vector<char>> fired;
-        {
-            std::lock_guard<std::mutex> g(cache_mu);
-            auto it = cache.find(hkey);
-            if (it != cache.end()) fired = it->second;
-        }
-        if (fired.empty()) {
-            const int S = 8192;
-            std::vector<float> h0((size_t)S * F), ha((size_t)S * Wd), hb((size_t)S * Wd), Wt((size_t)Wd * Wd);
-            uint64_t rs = 0x9E3779B97F4A7C15ull;
-            auto uni = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (float)((rs >> 40) * (1.0 / 16777216.0)); };   // xorshift64, [0, 1)
-            for (int r = 0; r < S; ++r) {
-                const float box = (r & 1) ? 8.0f : 1.5f;
-                for (int j = 0; j < d; ++j) {
-                    const float x = j < n ? (2.f * uni() - 1.f) * 3.14159265f : (2.f * uni() - 1.f) * box;
-                    h0[(size_t)r * F + j] = x; h0[(size_t)r * F + d + j] = std::sin(x); h0[(size_t)r * F + 2 * d + j] = std::cos(x);
-                }
-            }
-            fired.assign(nhh + 1, std::vector<char>(Wd, 0));
-            const float* hin = h0.data();
-            int kin = F;
-            float* hout = ha.data();
-            for (int L = 0; L <= nhh; ++L) {
-                for (int u = 0; u < Wd; ++u)          // transposed: the inner loop below runs over the units (vectorises without reassociation)
-                    for (int kk = 0; kk < kin; ++kk) Wt[(size_t)kk * Wd + u] = W[L][(size_t)u * kin + kk];
-                for (int r = 0; r < S; ++r) {
-                    const float* x = hin + (size_t)r * kin;
-                    float* y = hout + (size_t)r * Wd;
-                    for (int u = 0; u < Wd; ++u) y[u] = b[L][u];
-                    for (int kk = 0; kk < kin; ++kk) {
-                        const float xv = x[kk];
-                        if (xv == 0.f) continue;
-                        const float* w = &Wt[(size_t)kk * Wd];
-                        for (int u = 0; u < Wd; ++u) y[u] += xv * w[u];
-                    }
-                    for (int u = 0; u < Wd; ++u) {
-                        if (y[u] > 0.f) fired[L][u] = 1; else y[u] = 0.f;
-                    }
-                }
-                hin = hout; kin = Wd;
-                hout = hout == ha.data() ? hb.data() : ha.data();
-            }
-            std::lock_guard<std::mutex> g(cache_mu);
-            cache[hkey] = fired;
-        }
-        std::vector<std::vector<int>> order(nhh + 1, std::vector<int>(Wd));
-        bool any_saving = false;
-        for (int L = 0; L <= nhh; ++L) {
-            int nA = 0, p = 0;
-            for (int u = 0; u < Wd; ++u) if (fired[L][u]) { order[L][p++] = u; ++nA; }
-            for (int u = 0; u < Wd; ++u) if (!fired[L][u]) order[L][p++] = u;
-            int nch;   // chunks the consumer multiplies: of 8 positions; the last layer: of 16
-            if (L < nhh) { nch = std::max(2, std::min((nA + 7) / 8, 32)); }
-            else { nch = std::max(1, std::min((nA + 15) / 16, 16)); }
-            pk.sp_nch[L] = (uint8_t)nch;
-            const int covered = L < nhh ? 8 * nch : 16 * nch;
-            any_saving = any_saving || covered < Wd;
-            // EVERY unit of B is watched, also the few that fill A's last chunk: multiplied or not, a firing unit of B sits behind
-            // the units of A in the chain instead of between them
-            for (int pp = 0; pp < Wd; ++pp)
-                pk.sp_pos[(size_t)L * Wd + order[L][pp]] = (uint16_t)(omds_kpos(pp) | (pp >= nA ? 0x8000 : 0));
-        }
-        if (any_saving) {
-            pk.sparse = true;
-            for (int l = 0; l < nhh; ++l) {   // hidden->hidden layer l consumes level l
-                const float* Wl_ = W[l + 1];
-                for (int cb = 0; cb < OMDS_NCB; ++cb)
-                    for (int c = 0; c < 32; ++c)
-                        for (int lane = 0; lane < 64; ++lane) {
-                            const int j = 32 * cb + (lane & 31), s0 = 8 * c + 4 * (lane >> 5);
-                            float v[4];
-                            for (int mm = 0; mm < 4; ++mm) v[mm] = Wl_[(size_t)j * Wd + order[l][omds_kat(s0 + mm)]];
-                            pk.wfp[(((size_t)l * OMDS_NCB + cb) * 32 + c) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
-                        }
-            }
-            for (int c = 0; c < 16; ++c)      // the last layer consumes level nhh
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int j = lane & 15;
-                    float v[4] = {0, 0, 0, 0};
-                    if (j < C)
-                        for (int mm = 0; mm < 4; ++mm) v[mm] = WL[(size_t)j * Wd + order[nhh][k16(c, lane >> 4, mm)]];
-                    pk.wlp[c * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
-                }
-        } else {
-            for (int L = 0; L <= nhh; ++L) {
-                pk.sp_nch[L] = L < nhh ? 32 : 16;
-                for (int u = 0; u < Wd; ++u) pk.sp_pos[(size_t)L * Wd + u] = (uint16_t)omds_kpos(u);
-            }
-        }
-    }
+    // transposed copies for the per-tile compaction (pass1_tile_dyn): row k = the weights leaving unit k
+    pk.wht.assign((size_t)std::max(nhh, 1) * Wd * Wd, 0.f);
+    for (int l = 0; l < nhh; ++l)
+        for (int j = 0; j < Wd; ++j)
+            for (int kk = 0; kk < Wd; ++kk) pk.wht[((size_t)l * Wd + kk) * Wd + j] = W[l + 1][(size_t)j * Wd + kk];
+    pk.wlt.assign((size_t)Wd * 16, 0.f);
+    for (int j = 0; j < C; ++j)
+        for (int kk = 0; kk < Wd; ++kk) pk.wlt[(size_t)kk * 16 + j] = WL[(size_t)j * Wd + kk];
     pk.f_fwd = 0.0;
     for (int i = 0; i < n_linear; ++i) pk.f_fwd += 2.0 * in_dims[i] * out_dims[i];   // algorithmic: un-padded
     pk.f_bwd = pk.f_fwd - 2.0 * in_dims[n_linear - 1] * out_dims[n_linear - 1];   // no weight-gradient, no last-layer GEMM
@@ -850,17 +743,16 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
     if ((rc = upload(ctx, pk.w1b, &m.W1b))) return rc;
     if ((rc = upload(ctx, pk.w1f, &m.W1f))) return rc;
     if ((rc = upload(ctx, pk.w1f16, &m.W1f16))) return rc;
-    if ((rc = upload(ctx, pk.wfp, &m.WfP))) return rc;
-    if ((rc = upload(ctx, pk.wlp, &m.WlP))) return rc;
-    if ((rc = upload(ctx, pk.sp_pos, &m.sp_pos))) return rc;
-    std::memcpy(m.sp_nch, pk.sp_nch, sizeof(m.sp_nch));
-    m.sparse = (pk.sparse && !(ctx->cfg.flags & OMDS_FLAG_DENSE_PASS1)) ? 1 : 0;
+    if ((rc = upload(ctx, pk.wht, &m.WhT))) return rc;
+    if ((rc = upload(ctx, pk.wlt, &m.WlT))) return rc;
     {
-        std::vector<unsigned> zero(4, 0u);
-        const unsigned* dz = nullptr;
+        std::vector<unsigned long long> zero(2 * (OMDS_MAX_HIDDEN + 1) + 2, 0ull);
+        const unsigned long long* dz = nullptr;
         if ((rc = upload(ctx, zero, &dz))) return rc;
-        m.sp_surprises = const_cast<unsigned*>(dz);
+        m.skip_stats = const_cast<unsigned long long*>(dz);
     }
+    // the exact zero-skip of k_pass1 (per-tile compaction): every ReLU network without skip concatenations
+    m.compact = (act == OMDS_ACT_RELU && skip_mask == 0 && pk.nhh >= 1 && !(ctx->cfg.flags & OMDS_FLAG_DENSE_PASS1)) ? 1 : 0;
 #ifdef OMDS_TIMELINE
     {
         static unsigned long long* tl = nullptr;
@@ -2242,24 +2134,25 @@ int omds_screen_order_stats(omds_ctx* ctx, int64_t* reorders, int32_t* never_fir
         for (int L = 0; L < n_levels; ++L) never_fired[L] = ctx->scr_never_fired[L];
     return OMDS_OK;
 }
-// the exact zero-skip of k_pass1 (omds.h): chunks multiplied per hidden level, tiles that had to multiply a level in full
-int omds_pass1_skip_stats(omds_ctx* ctx, int32_t* active, int32_t* chunks, int n_levels, int64_t* surprises) {
+// the exact zero-skip of k_pass1 (omds.h): firing units and multiplied chunks per tile and hidden level, from the device's counters
+int omds_pass1_skip_stats(omds_ctx* ctx, int32_t* active, double* mean_units, double* mean_chunks, int n_levels, int64_t* tiles) {
     if (!ctx) return OMDS_ERR_INVALID_ARG;
     REQUIRE(ctx->have_mlp, OMDS_ERR_NOT_INITIALISED, "distance network not set (omds_set_mlp)");
     REQUIRE(n_levels >= 0 && n_levels <= OMDS_MAX_HIDDEN + 1, OMDS_ERR_INVALID_ARG, "omds_pass1_skip_stats: 0 <= n_levels <= 9");
-    if (active) *active = ctx->mlp.sparse ? 1 : 0;
-    if (chunks)
-        for (int L = 0; L < n_levels; ++L) chunks[L] = L <= ctx->mlp.nhh && !ctx->wide.on ? (int)ctx->mlp.sp_nch[L] : 0;
-    if (surprises) {
-        *surprises = 0;
-        if (ctx->mlp.sp_surprises) {
-            unsigned v = 0;
-            CK(hipSetDevice(ctx->dev));
-            CK(hipStreamSynchronize(ctx->stream));
-            CK(hipMemcpy(&v, ctx->mlp.sp_surprises, 4, hipMemcpyDeviceToHost));
-            *surprises = (int64_t)v;
-        }
+    const bool on = ctx->mlp.compact && !ctx->wide.on;
+    if (active) *active = on ? 1 : 0;
+    unsigned long long h[2 * (OMDS_MAX_HIDDEN + 1) + 2] = {0};
+    if (on && ctx->mlp.skip_stats) {
+        CK(hipSetDevice(ctx->dev));
+        CK(hipStreamSynchronize(ctx->stream));
+        CK(hipMemcpy(h, ctx->mlp.skip_stats, sizeof(h), hipMemcpyDeviceToHost));
     }
+    const double nt = h[0] ? (double)h[0] : 1.0;
+    for (int L = 0; L < n_levels; ++L) {
+        if (mean_chunks) mean_chunks[L] = on && L <= ctx->mlp.nhh ? (double)h[1 + L] / nt : 0.0;
+        if (mean_units) mean_units[L] = on && L <= ctx->mlp.nhh ? (double)h[1 + (OMDS_MAX_HIDDEN + 1) + L] / nt : 0.0;
+    }
+    if (tiles) *tiles = (int64_t)h[0];
     return OMDS_OK;
 }
 int omds_screen_fallback_stats(omds_ctx* ctx, int64_t* by_error, int64_t* by_slack, int64_t* by_overflow, int64_t* suspensions) {

@@ -107,55 +107,6 @@ __device__ __forceinline__ void gemm256(const float* __restrict__ Hw, const floa
 #undef OMDS_INTERLEAVE
 }
 
-// The same product over the first `nch` k-chunks only (wave-uniform, 2 .. 32) -- the exact zero-skip of
-// pass1_tile<.., SPARSE>.  A ROLLED loop over pairs of chunks: the fully unrolled form with a guard per pair made hipcc copy the
-// accumulators at every merge point (VALU instructions per launch 49 M -> 94 M, tools/sparse_ab.sh); here the accumulators are
-// loop-carried in place, the LDS row pointer and the scalar weight offset advance once per pair, and the body keeps the pinned
-// load / MFMA interleave of gemm256.
-template <int MR, int NR>
-__device__ __forceinline__ void gemm256_rt(const float* __restrict__ Hw, const float4* __restrict__ Wp, int cb0,
-                                           int lane, f32x16 (&acc)[MR][NR], int nch) {
-    const float* arow = Hw + (lane & 31) * LDH + 4 * (lane >> 5);
-    const float4* wbase = Wp + (size_t)__builtin_amdgcn_readfirstlane(cb0) * (32 * 64);
-    const __amdgpu_buffer_rsrc_t wp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wbase), 0, NR * 32 * 64 * 16, 0x00020000);
-    const int wv = lane * 16;
-    float4 a0[MR], a1[MR], w0[NR], w1[NR];
-    auto load_at = [&](const float* ar, int soff, float4 (&a)[MR], float4 (&w)[NR]) {
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            const omds_f4 v = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(wp, wv + j * (32 * 64 * 16), soff, 0));
-            w[j] = make_float4(v.x, v.y, v.z, v.w);
-        }
-#pragma unroll
-        for (int i = 0; i < MR; ++i) a[i] = *reinterpret_cast<const float4*>(ar + i * 32 * LDH);
-    };
-    load_at(arow, 0, a0, w0);
-    const int last = (__builtin_amdgcn_readfirstlane(nch) & ~1) * (64 * 16);   // byte offset behind the last PAIR of chunks
-#define OMDS_INTERLEAVE_RT()                                                          \
-    _Pragma("unroll") for (int q_ = 0; q_ < NR; ++q_) {                               \
-        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                              \
-        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);                             \
-    }                                                                                 \
-    _Pragma("unroll") for (int q_ = 0; q_ < MR; ++q_) {                               \
-        __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);                              \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
-    }                                                                                 \
-    __builtin_amdgcn_sched_group_barrier(0x8, 4 * MR * NR - NR - 2 * MR, 0);          \
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-    for (int soff = 0; soff < last; soff += 2 * 64 * 16) {
-        load_at(arow + 8, soff + 64 * 16, a1, w1);
-        mfma_chunk<MR, NR>(a0, w0, acc);
-        OMDS_INTERLEAVE_RT()
-        arow += 16;
-        load_at(arow, (soff + 2 * 64 * 16) & (32 * 64 * 16 - 1), a0, w0);   // behind the last pair: chunk 0 or a chunk that is not multiplied (harmless)
-        mfma_chunk<MR, NR>(a1, w1, acc);
-        OMDS_INTERLEAVE_RT()
-    }
-    if (nch & 1) mfma_chunk<MR, NR>(a0, w0, acc);   // an odd count: the last chunk is the one the final pair prefetched
-#undef OMDS_INTERLEAVE_RT
-}
-
 // C/D layout of the 32x32 MFMA: lane l, register r -> row (r&3) + 8(r>>2) + 4(l>>5), col l&31.
 __device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
@@ -442,10 +393,7 @@ struct OmdsDivisor {
 // pass-2 distance, arg-min link, ReLU masks -- for EVERY pair, indexed by the pair (ex->dr / amin / mask [row]): the forward of
 // the k rows a rollout ends up selecting has been computed here anyway, so the tail selects from Dmin and runs the backward only.
 // The arithmetic of a row is the same in all forms and independent of the other rows of the tile: bit-identical results.
-// SPARSE (MODE 0, ReLU, 32- and 64-row tiles): the exact zero-skip described at MlpDev::sparse -- every level's tile is stored
-// [A | B] (MlpDev::sp_pos), the product over it stops after MlpDev::sp_nch chunks with the pack in that order (WfP / WlP); a tile in
-// which a unit beyond the multiplied chunks fires stores the level again in natural order and multiplies it in full.  Same bits.
-template <int MT, int MR, int NR, int ACT, int MODE = 0, bool SPARSE = false>
+template <int MT, int MR, int NR, int ACT, int MODE = 0>
 __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const float* __restrict__ Fq,
                                            const float* __restrict__ Fp, const float* __restrict__ radius, int O,
                                            long long total_rows, uint32_t ignored, float* __restrict__ Dmin,
@@ -454,7 +402,6 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                                            const ExactOut* ex = nullptr) {
     constexpr bool LIST = MODE == 1 || MODE == 3 || MODE == 4 || MODE == 5, EMIT = MODE == 1 || MODE == 2 || MODE == 6, DERIV = MODE == 5;
     constexpr bool EMITY = EMIT || DERIV;   // pass 2's distance and arg-min link per row (ex->dr, ex->amin)
-    static_assert(!SPARSE || (MODE == 0 && MT != 16 && ACT == OMDS_ACT_RELU), "the zero-skip is written for k_pass1's own tiles");
     static_assert(!DERIV || MT == 16, "the derivative hand-over is written for the 16-row tiles of k_exact");
     using G = Geo<MT, MR, NR>;
     float* Hs = smem;                                           // [MT][LDH]
@@ -493,13 +440,6 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
     float bcur[NBIAS];   // bias of the layer about to be multiplied, fetched one layer ahead (layer 1's: in flight across the gather)
 #pragma unroll
     for (int j = 0; j < NBIAS; ++j) bcur[j] = m.b1[bias_col(j)];
-    [[maybe_unused]] int* spflag = reinterpret_cast<int*>(rowRad + MT);   // SPARSE: [nhid] a unit beyond the multiplied chunks fired at this level
-    [[maybe_unused]] uint32_t pcur[NBIAS];   // SPARSE: where this thread's column(s) sit in the level about to be produced (MlpDev::sp_pos)
-    if constexpr (SPARSE) {
-        if (tid <= OMDS_MAX_HIDDEN) spflag[tid] = 0;
-#pragma unroll
-        for (int j = 0; j < NBIAS; ++j) pcur[j] = m.sp_pos[bias_col(j)];
-    }
 
     // ---- the tile's encoded inputs: row r = pair (t, o) gets Fq[t] | Fp[o] (each table is zero in the other's slots) at positions
     //      0..31.  A wave fills two rows per step, one per lane half; the row bookkeeping (rollout t, obstacle o, bounds) is
@@ -591,7 +531,6 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
     // ---- layer 1 (l = -1, K = 32 over the encoded inputs) and the hidden -> hidden layers, each the reference's product: the
     //      accumulators start at ZERO, the k order is ascending (omds_kpos), the bias is added in the epilogue ----------------
     const float* Hw = Hs + (wm * MR * 32) * LDH;
-    [[maybe_unused]] int last_natural = 1;   // SPARSE: how the last hidden level ended up in the tile
     if constexpr (MT == 16) {
         const int scol0 = wave * 32 + omds_kpos(lane & 15);   // position of column wave*32 + 16 j + (lane & 15): + 16 j
         for (int l = -1; l < m.nhh; ++l) {
@@ -629,8 +568,7 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
             if ((m.skip_mask >> (l + 1)) & 1u) inject(l + 1);
             OMDS_TL(2 + (l < 0 ? 0 : l));
         }
-    } else {
-    [[maybe_unused]] int natural = 1;   // SPARSE: the level in the tile is stored in natural order (level -1, the inputs: always)
+    } else
     for (int l = -1; l < m.nhh; ++l) {
         f32x16 acc[MR][NR];
 #pragma unroll
@@ -640,42 +578,26 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         float bnow[NR];
-        [[maybe_unused]] uint32_t pnow[NR];
 #pragma unroll
         for (int j = 0; j < NR; ++j) bnow[j] = bcur[j];
-        if constexpr (SPARSE) {
-#pragma unroll
-            for (int j = 0; j < NR; ++j) pnow[j] = pcur[j];
-        }
         if (l + 1 < m.nhh) {
 #pragma unroll
             for (int j = 0; j < NR; ++j) bcur[j] = m.bh[(l + 1) * OMDS_WIDTH + (cb0 + j) * 32 + (lane & 31)];
         }
-        if constexpr (SPARSE) {   // positions of the NEXT level (level l + 2 exists while l + 1 < nhh)
-            if (l + 1 < m.nhh) {
-#pragma unroll
-                for (int j = 0; j < NR; ++j) pcur[j] = m.sp_pos[(l + 2) * OMDS_WIDTH + (cb0 + j) * 32 + (lane & 31)];
-            }
-        }
         if (l < 0) gemm_k32<MR, NR>(Hw, m.W1f, cb0, lane, acc);
-        else if (SPARSE && !natural) gemm256_rt<MR, NR>(Hw, m.WfP + (size_t)l * (OMDS_NCB * 32 * 64), cb0, lane, acc, m.sp_nch[l]);
         else gemm256<MR, NR>(Hw, m.Wf + (size_t)l * (OMDS_NCB * 32 * 64), cb0, lane, acc);
         __syncthreads();  // every wave has finished reading the tile
         if (l == 0) OMDS_TL(6);
         // one lane-dependent base address per column block; everything else of (row, col) is a compile-time offset, so the
         // 16 * MR stores of a block use immediate offsets (hipcc otherwise builds a VGPR address per row: VALU = matrix-pipe time)
-        [[maybe_unused]] float zmax = 0.f;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-            const int pos = SPARSE ? (int)(pnow[j] & 0x7fffu) : (cb0 + j) * 32 + omds_kpos(lane & 31);
-            float* hb = Hs + (wm * MR * 32 + 4 * (lane >> 5)) * LDH + pos;
-            [[maybe_unused]] float zm = 0.f;
+            float* hb = Hs + (wm * MR * 32 + 4 * (lane >> 5)) * LDH + (cb0 + j) * 32 + omds_kpos(lane & 31);
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float z = acc[i][j][r] + bnow[j];
-                    if constexpr (SPARSE) { acc[i][j][r] = z; zm = fmaxf(zm, z); }
                     hb[(i * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = actf(z, ACT);
                     if constexpr (EMIT) {   // lanes 0-31 hold row (r&3) + 8(r>>2) of this 32-column block, lanes 32-63 that row + 4
                         const unsigned long long bal = __ballot(z > 0.f);
@@ -686,39 +608,16 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
                         }
                     }
                 }
-            if constexpr (SPARSE) { if (pnow[j] >> 15) zmax = fmaxf(zmax, zm); }   // a column of B
-        }
-        if constexpr (SPARSE) {
-            if (zmax > 0.f) spflag[l + 1] = 1;   // a unit presumed dead fired in this tile: the next product may not stop early
         }
         __syncthreads();
-        if constexpr (SPARSE) {
-            natural = __builtin_amdgcn_readfirstlane(spflag[l + 1]);
-            if (natural) {   // rare: the level once more, in natural order (the values are still in the accumulators), for the natural packs
-                if (tid == 0) atomicAdd(m.sp_surprises, 1u);
-#pragma unroll
-                for (int j = 0; j < NR; ++j) {
-                    float* hb = Hs + (wm * MR * 32 + 4 * (lane >> 5)) * LDH + (cb0 + j) * 32 + omds_kpos(lane & 31);
-#pragma unroll
-                    for (int i = 0; i < MR; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) hb[(i * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = actf(acc[i][j][r], ACT);
-                }
-                __syncthreads();
-            }
-        }
         if ((m.skip_mask >> (l + 1)) & 1u) inject(l + 1);
         OMDS_TL(2 + (l < 0 ? 0 : l));
-    }
-    if constexpr (SPARSE) last_natural = natural;
     }
 
     // ---- last layer (256 -> C, padded to 16) on v_mfma_f32_16x16x4_f32, 16 rows per wave.  Kept short on purpose
     //      (buffer loads with constant offsets, DPP min over the 16 link lanes, one 16-byte store per 4 rows): like
     //      the layer-1 build it mostly runs starved next to the other resident workgroup's GEMM ----------------
-    const float4* wl_pack = (SPARSE && !last_natural) ? m.WlP : m.Wl;
-    const int nchl = (SPARSE && !last_natural) ? (int)m.sp_nch[m.nhh] : 16;   // chunks of 16 positions multiplied
-    const __amdgpu_buffer_rsrc_t wlr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wl_pack), 0, 16 * 64 * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wlr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(m.Wl), 0, 16 * 64 * 16, 0x00020000);
     for (int rb = __builtin_amdgcn_readfirstlane(wave); rb < MT / 16; rb += G::NW) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* arow = Hs + (rb * 16 + (lane & 15)) * LDH + pa16(lane);   // the k sequence of gemm16 (ascending k through omds_kpos)
@@ -743,7 +642,6 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
         }
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            if (!SPARSE || c < nchl) {
             const float4 a = load_a16(arow, c);
             const omds_f4 w = wq[c % LPD];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
@@ -752,7 +650,6 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
             if (c + LPD < 16) wq[c % LPD] = __builtin_bit_cast(omds_f4, __builtin_amdgcn_raw_buffer_load_b128(wlr, lane * 16, (c + LPD) * 64 * 16, 0));
             __builtin_amdgcn_sched_barrier(0);
-            }
         }
 #ifdef OMDS_TIMELINE
         asm volatile("s_nop 0" ::"v"(acc[0]) : "memory");
@@ -848,6 +745,254 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
     __syncthreads();
     OMDS_TL(5);
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 1 with PER-TILE COMPACTION of the hidden levels (k_pass1's 32- and 64-row tiles, ReLU networks without skips).
+// A hidden unit whose activation is exactly zero in every row of the tile adds fmaf(0, w, acc) = acc to every chain of the next
+// layer: leaving it out changes no bit, whatever the order -- as long as the units that ARE multiplied keep their ascending order.
+// So every level is stored COMPACTED: a wave ballots which of its 32 units fired in the tile, the eight masks meet in LDS at the
+// barrier every layer has anyway, and a unit's position is its rank among the tile's firing units (k-permuted by omds_kpos like
+// every tile); dead columns are not stored at all.  The next product runs over ceil(T / 8) chunks, T = firing units of the tile
+// (164 / 195 / 146 / 130 of 256 on the shelf task), and fetches its weight fragments BY UNIT: W^T rows (one per unit, 1 KB) named by
+// the position -> unit table the epilogue leaves in LDS -- four coalesced 256-byte loads per chunk instead of one 1 KB fragment.
+// Exact for every input: nothing is presumed about which units fire.
+// ------------------------------------------------------------------------------------------------
+constexpr int OMDS_IDS = OMDS_WIDTH + 32;   // entries of the position -> unit table (the pipeline reads up to three chunks ahead)
+
+template <int MR>
+__device__ __forceinline__ void gemm_gather(const float* __restrict__ Hw, const uint32_t* __restrict__ idsS, const float* __restrict__ WT, int cb0,
+                                            int lane, f32x16 (&acc)[MR][1], int nch) {
+    const float* arow = Hw + (lane & 31) * LDH + 4 * (lane >> 5);
+    const uint32_t* irow = idsS + 4 * (lane >> 5);   // this lane half's four positions of a chunk: 8c + 4h .. + 3
+    const __amdgpu_buffer_rsrc_t wt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(WT) + __builtin_amdgcn_readfirstlane(cb0) * 32, 0,
+                                                                        OMDS_WIDTH * OMDS_WIDTH * 4, 0x00020000);
+    const int colb = (lane & 31) * 4;
+    float4 a0[MR], a1[MR];
+    float b0[4], b1[4];
+    uint4 i0, i1;
+    auto loadA = [&](const float* ar, float4 (&a)[MR]) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i) a[i] = *reinterpret_cast<const float4*>(ar + i * 32 * LDH);
+    };
+    auto loadB = [&](const uint4& id, float (&b)[4]) {   // W^T[unit][column]: byte offset unit * 1024 (the table's entry) + column * 4
+        b[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wt, (int)id.x + colb, 0, 0));
+        b[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wt, (int)id.y + colb, 0, 0));
+        b[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wt, (int)id.z + colb, 0, 0));
+        b[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wt, (int)id.w + colb, 0, 0));
+    };
+    auto mfma4 = [&](const float4 (&a)[MR], const float (&b)[4]) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[0], acc[i][0], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[1], acc[i][0], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[2], acc[i][0], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[3], acc[i][0], 0, 0, 0);
+    };
+    // three stages: the table entries of chunk c + 2 (LDS), the operands of chunk c + 1 (LDS, L2), the MFMAs of chunk c
+    i0 = *reinterpret_cast<const uint4*>(irow);
+    i1 = *reinterpret_cast<const uint4*>(irow + 8);
+    loadA(arow, a0);
+    loadB(i0, b0);
+    const int npair = __builtin_amdgcn_readfirstlane(nch) >> 1;
+#pragma unroll 1
+    for (int p = 0; p < npair; ++p) {
+        loadA(arow + 8, a1);
+        loadB(i1, b1);
+        i0 = *reinterpret_cast<const uint4*>(irow + 16);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        loadA(arow + 16, a0);
+        loadB(i0, b0);
+        i1 = *reinterpret_cast<const uint4*>(irow + 24);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        arow += 16;
+        irow += 16;
+    }
+    if (nch & 1) mfma4(a0, b0);   // an odd count: the last chunk is the one the final pair (or the prologue) fetched
+}
+
+template <int MT, int MR>
+__device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, const float* __restrict__ Fq, const float* __restrict__ Fp,
+                                               const float* __restrict__ radius, int O, long long total_rows, uint32_t ignored,
+                                               float* __restrict__ Dmin, const long long row0, const OmdsDivisor odiv) {
+    using G = Geo<MT, MR, 1>;
+    static_assert(G::NW == 8 && G::WM == 1, "eight waves, wave w owns the units 32 w .. 32 w + 31 of every level");
+    constexpr int ACT = OMDS_ACT_RELU;
+    float* Hs = smem;                                              // [MT][LDH]
+    float* rowRad = smem + MT * LDH;                               // [MT]
+    uint32_t* aliveS = reinterpret_cast<uint32_t*>(rowRad + MT);   // [8] which of a wave's 32 units fired in this tile at the current level
+    uint32_t* idsS = aliveS + 8;                                   // [OMDS_IDS] position -> unit * 1024 of the current level
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int col = wv * 32 + (lane & 31);                         // the unit this thread's accumulators hold, at every level
+    float bcur = m.b1[col];
+    if (tid < OMDS_IDS - OMDS_WIDTH) idsS[OMDS_WIDTH + tid] = 0u;  // behind the table: valid offsets for the pipeline's look-ahead
+
+    // ---- the tile's encoded inputs (as pass1_tile, un-listed rows) -------------------------------------------------
+    {
+        constexpr int IT = MT / G::NW;
+        const unsigned row0u = (unsigned)row0;
+        const unsigned t0 = odiv.div(row0u);
+        const int rows_here = (int)((total_rows - row0 < MT) ? (total_rows - row0) : MT);
+        const __amdgpu_buffer_rsrc_t qr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Fq) + (size_t)t0 * OMDS_FROW, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Fp), 0, 0x7fffffff, 0x00020000);
+        const bool hi = lane >= 32;
+        const int f4 = (lane & 31) * 4;
+        int o = (int)(row0u - t0 * (unsigned)O) + wv, dt = 0;
+        while (o >= O) { o -= O; ++dt; }
+        float myrad = 0.f;
+        uint32_t fv[IT / 2];
+#pragma unroll
+        for (int it = 0; it < IT; it += 2) {
+            int offq[2], offp[2];
+            bool ok[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                ok[h] = wv + (it + h) * G::NW < rows_here;
+                float rad = 0.f;
+                offq[h] = 0; offp[h] = 0;
+                if (ok[h]) { offq[h] = dt * (OMDS_FROW * 4); offp[h] = o * (OMDS_FROW * 4); rad = radius[o]; }
+                o += G::NW;
+                while (o >= O) { o -= O; ++dt; }
+                const int rbits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rad));
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(myrad) : "s"(rbits), "n"(it + h));
+            }
+            const uint32_t fq = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(qr, (hi ? offq[1] : offq[0]) + f4, 0, 0);
+            const uint32_t fp = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(pr, (hi ? offp[1] : offp[0]) + f4, 0, 0);
+            fv[it / 2] = (hi ? ok[1] : ok[0]) ? (fq | fp) : 0u;
+        }
+        uint32_t* frow = reinterpret_cast<uint32_t*>(Hs) + (wv + (hi ? G::NW : 0)) * LDH + omds_kpos(lane & 31);
+#pragma unroll
+        for (int it = 0; it < IT; it += 2) frow[it * G::NW * LDH] = fv[it / 2];
+        if (lane < IT) rowRad[wv + lane * G::NW] = myrad;
+    }
+    __syncthreads();
+
+    // ---- layer 1 (l = -1) and the hidden -> hidden layers on the compacted tile -----------------------------------------
+    int T = 0;   // firing units of the level in the tile
+    for (int l = -1; l < m.nhh; ++l) {
+        f32x16 acc[MR][1];
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+        const float bnow = bcur;
+        if (l + 1 < m.nhh) bcur = m.bh[(l + 1) * OMDS_WIDTH + col];
+        if (l < 0) gemm_k32<MR, 1>(Hs, m.W1f, wv, lane, acc);
+        else gemm_gather<MR>(Hs, idsS, m.WhT + (size_t)l * (OMDS_WIDTH * OMDS_WIDTH), wv, lane, acc, (T + 7) >> 3);
+        // which of this wave's units fired in the tile: the column of lane l and of lane l + 32 is the same unit
+        float zm = 0.f;
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][0][r] += bnow; zm = fmaxf(zm, acc[i][0][r]); }
+        const unsigned long long bal = __ballot(zm > 0.f);
+        const uint32_t mine = (uint32_t)bal | (uint32_t)(bal >> 32);
+        if (lane == 0) aliveS[wv] = mine;
+        __syncthreads();  // every wave has finished reading the tile and the table; the eight masks are there
+        const uint4 mlo = *reinterpret_cast<const uint4*>(aliveS), mhi = *reinterpret_cast<const uint4*>(aliveS + 4);
+        const uint32_t mk[8] = {mlo.x, mlo.y, mlo.z, mlo.w, mhi.x, mhi.y, mhi.z, mhi.w};
+        int base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const int cnt = __builtin_popcount(__builtin_amdgcn_readfirstlane(mk[w]));
+            base += w < wv ? cnt : 0;
+            total += cnt;
+        }
+        T = total;
+        if (tid == 0) {   // statistics (omds_pass1_skip_stats): chunks the consumer of this level multiplies, firing units
+            atomicAdd(m.skip_stats + 1 + (l + 1), (unsigned long long)(l + 1 < m.nhh ? (T + 7) >> 3 : (T + 15) >> 4));
+            atomicAdd(m.skip_stats + 1 + (OMDS_MAX_HIDDEN + 1) + (l + 1), (unsigned long long)T);
+            if (l < 0) atomicAdd(m.skip_stats, 1ull);
+        }
+        const bool alive = (mine >> (lane & 31)) & 1u;
+        const int rank = base + __builtin_popcount(mine & ((1u << (lane & 31)) - 1u));
+        if (alive) {
+            const int pos = omds_kpos(rank);
+            float* hb = Hs + (4 * (lane >> 5)) * LDH + pos;
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hb[(i * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = actf(acc[i][0][r], ACT);
+            if (lane < 32) idsS[pos] = (uint32_t)col * (OMDS_WIDTH * 4);
+        }
+        // zero columns up to the next multiple of 16 positions (the chunks of both consumers are whole); their table entries: unit 0
+        const int Tp = (T + 15) & ~15;
+        for (int e = tid; e < (Tp - T) * MT; e += G::NT) {
+            const int pz = T + e / MT, row = e - (e / MT) * MT;
+            Hs[row * LDH + omds_kpos(pz)] = 0.f;
+            if (row == 0) idsS[omds_kpos(pz)] = 0u;
+        }
+        __syncthreads();
+    }
+
+    // ---- last layer (256 -> C, padded to 16) on v_mfma_f32_16x16x4_f32 over the compacted level, weights by unit from WlT ----
+    const __amdgpu_buffer_rsrc_t wlt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(m.WlT), 0, OMDS_WIDTH * 16 * 4, 0x00020000);
+    const int nch16 = (T + 15) >> 4;
+    for (int rb = wv; rb < MT / 16; rb += G::NW) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = Hs + (rb * 16 + (lane & 15)) * LDH + pa16(lane);
+        const uint32_t* ir = idsS + pa16(lane);
+        const int jb = (lane & 15) * 4;
+        const int r4 = rb * 16 + 4 * (lane >> 4);
+        constexpr int LPD = 4;
+        float wq[LPD][4];
+        auto loadW = [&](int c, float (&w)[4]) {   // WlT[unit][link]: byte offset unit * 64 = table entry / 16
+            w[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wlt, (int)(ir[16 * c] >> 4) + jb, 0, 0));
+            w[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wlt, (int)(ir[16 * c + 2] >> 4) + jb, 0, 0));
+            w[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wlt, (int)(ir[16 * c + 8] >> 4) + jb, 0, 0));
+            w[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wlt, (int)(ir[16 * c + 10] >> 4) + jb, 0, 0));
+        };
+#pragma unroll
+        for (int c = 0; c < LPD; ++c) {
+            loadW(c, wq[c]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c < nch16) {
+                const float4 a = load_a16(arow, c);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wq[c % LPD][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wq[c % LPD][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wq[c % LPD][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wq[c % LPD][3], acc, 0, 0, 0);
+                if (c + LPD < 16) loadW(c + LPD, wq[c % LPD]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const int j = lane & 15;
+        const float bj = m.bl[j];
+        const bool pad = j >= m.C, ign = (ignored >> j) & 1u;
+        const float4 rr = *reinterpret_cast<const float4*>(rowRad + r4);
+        const float rad[4] = {rr.x, rr.y, rr.z, rr.w};
+        float y[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            float v = (acc[reg] + bj) / m.out_div - rad[reg];
+            v = pad ? __builtin_inff() : (ign ? 1e6f : v);
+            v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false)));
+            v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false)));
+            v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false)));
+            v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false)));
+            y[reg] = v;
+        }
+        if (j == 0) {
+            const long long g = row0 + r4;
+            if (g + 3 < total_rows) {
+                *reinterpret_cast<float4*>(Dmin + g) = make_float4(y[0], y[1], y[2], y[3]);
+            } else {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    if (g + reg < total_rows) Dmin[g + reg] = y[reg];
+            }
+        }
+    }
 }
 
 // k smallest entries of row[0..O) in ascending order (ties by lower index), one wave per row.

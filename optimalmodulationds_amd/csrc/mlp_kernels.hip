@@ -79,20 +79,20 @@ __global__ __launch_bounds__(256) void k_obstacle_features(MlpDev m, const float
     }
 }
 
-template <int MT, int MR, int NR, int ACT, bool SPARSE = false>
+template <int MT, int MR, int NR, int ACT>
 __global__ __launch_bounds__((Geo<MT, MR, NR>::NT)) void k_pass1(MlpDev m, const float* __restrict__ Fq,
                                                                const float* __restrict__ Fp,
                                                                const float* __restrict__ radius, int O,
                                                                long long total_rows, uint32_t ignored,
                                                                float* __restrict__ Dmin, OmdsDivisor odiv) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    pass1_tile<MT, MR, NR, ACT, 0, SPARSE>(m, smem, Fq, Fp, radius, O, total_rows, ignored, Dmin, (long long)blockIdx.x * MT, odiv);
+    pass1_tile<MT, MR, NR, ACT>(m, smem, Fq, Fp, radius, O, total_rows, ignored, Dmin, (long long)blockIdx.x * MT, odiv);
 }
 
 // Mixed-granularity launch: the first n_big workgroups take 64-row tiles, the rest cover the remaining rows
 // in 32-row tiles.  Workgroups are dispatched in index order, so the kernel ends on small tiles and the
 // drain phase (slots idling while the last tiles finish) shrinks with the tile size.
-template <int ACT, bool SPARSE = false>
+template <int ACT>
 __global__ __launch_bounds__(512) void k_pass1_mixed(const float* __restrict__ Fq, const float* __restrict__ Fp,
                                                      const float* __restrict__ radius, float* __restrict__ Dmin,
                                                      long long total_rows, int O, uint32_t ignored, int n_big,
@@ -102,11 +102,22 @@ __global__ __launch_bounds__(512) void k_pass1_mixed(const float* __restrict__ F
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     if (b < n_big) {
-        pass1_tile<64, 2, 1, ACT, 0, SPARSE>(m, smem, Fq, Fp, radius, O, total_rows, ignored, Dmin, (long long)b * 64, odiv);
+        pass1_tile<64, 2, 1, ACT>(m, smem, Fq, Fp, radius, O, total_rows, ignored, Dmin, (long long)b * 64, odiv);
     } else {
-        pass1_tile<32, 1, 1, ACT, 0, SPARSE>(m, smem, Fq, Fp, radius, O, total_rows, ignored, Dmin,
-                                             (long long)n_big * 64 + (long long)(b - n_big) * 32, odiv);
+        pass1_tile<32, 1, 1, ACT>(m, smem, Fq, Fp, radius, O, total_rows, ignored, Dmin,
+                                  (long long)n_big * 64 + (long long)(b - n_big) * 32, odiv);
     }
+}
+
+// k_pass1 on per-tile compacted levels (pass1_tile_dyn): the same launch shape as k_pass1_mixed
+__global__ __launch_bounds__(512) void k_pass1_dyn(const float* __restrict__ Fq, const float* __restrict__ Fp,
+                                                   const float* __restrict__ radius, float* __restrict__ Dmin,
+                                                   long long total_rows, int O, uint32_t ignored, int n_big,
+                                                   OmdsDivisor odiv, MlpDev m) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    if (b < n_big) pass1_tile_dyn<64, 2>(m, smem, Fq, Fp, radius, O, total_rows, ignored, Dmin, (long long)b * 64, odiv);
+    else pass1_tile_dyn<32, 1>(m, smem, Fq, Fp, radius, O, total_rows, ignored, Dmin, (long long)n_big * 64 + (long long)(b - n_big) * 32, odiv);
 }
 
 // The same two kernels in pass1_tile's MODE 6 (kernels of their own: the tuned mode-0 kernels keep their argument lists and code):
@@ -215,43 +226,37 @@ void omds_launch_obstacle_features(hipStream_t s, const MlpDev& m, const float* 
     hipLaunchKernelGGL(k_obstacle_features, dim3((O + 63) / 64), dim3(256), 0, s, m, xyzr, O, Fp, radius, reinterpret_cast<_Float16*>(FpH), ldF);
 }
 
-constexpr size_t P1_SPARSE_LDS = 64;   // pass1_tile<.., SPARSE>: the per-level surprise flags behind rowRad
-
-template <int MT, int MR, int NR, int ACT, bool SPARSE = false>
+template <int MT, int MR, int NR, int ACT>
 static void launch_pass1_a(hipStream_t s, const MlpDev& m, const float* Fq, const float* Fp, const float* radius,
                            int O, long long total, uint32_t ignored, float* Dmin) {
     using G = Geo<MT, MR, NR>;
-    const size_t lds = (size_t)MT * LDH * 4 + (size_t)MT * 4 + (SPARSE ? P1_SPARSE_LDS : 0);
+    const size_t lds = (size_t)MT * LDH * 4 + (size_t)MT * 4;
     static std::atomic<uint64_t> configured{0};
     if (omds_first_use_on_device(configured)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<MT, MR, NR, ACT, SPARSE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<MT, MR, NR, ACT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     const long long tiles = (total + MT - 1) / MT;
-    hipLaunchKernelGGL((k_pass1<MT, MR, NR, ACT, SPARSE>), dim3((unsigned)tiles), dim3(G::NT), lds, s, m, Fq, Fp, radius, O,
+    hipLaunchKernelGGL((k_pass1<MT, MR, NR, ACT>), dim3((unsigned)tiles), dim3(G::NT), lds, s, m, Fq, Fp, radius, O,
                        total, ignored, Dmin, OmdsDivisor::make((unsigned)O));
 }
 
 template <int MT, int MR, int NR>
 static void launch_pass1_t(hipStream_t s, const MlpDev& m, const float* Fq, const float* Fp, const float* radius,
                            int O, long long total, uint32_t ignored, float* Dmin) {
-    if (m.act == OMDS_ACT_RELU) {
-        if constexpr (MT != 16) {
-            if (m.sparse) { launch_pass1_a<MT, MR, NR, OMDS_ACT_RELU, true>(s, m, Fq, Fp, radius, O, total, ignored, Dmin); return; }
-        }
-        launch_pass1_a<MT, MR, NR, OMDS_ACT_RELU>(s, m, Fq, Fp, radius, O, total, ignored, Dmin);
-    } else launch_pass1_a<MT, MR, NR, OMDS_ACT_TANH>(s, m, Fq, Fp, radius, O, total, ignored, Dmin);
+    if (m.act == OMDS_ACT_RELU) launch_pass1_a<MT, MR, NR, OMDS_ACT_RELU>(s, m, Fq, Fp, radius, O, total, ignored, Dmin);
+    else launch_pass1_a<MT, MR, NR, OMDS_ACT_TANH>(s, m, Fq, Fp, radius, O, total, ignored, Dmin);
 }
 
 // Tile choice: 64-row tiles (8 waves, each 64 rows x 32 columns, two workgroups per CU) once there are
 // enough tiles to fill 256 CUs; 32-row tiles for small batches (planar configs, dist_grad calls).
-template <int ACT, bool SPARSE = false>
+template <int ACT>
 static void launch_pass1_mixed(hipStream_t s, const MlpDev& m, const float* Fq, const float* Fp, const float* radius,
                                int O, long long total, uint32_t ignored, float* Dmin, int small_rounds) {
-    const size_t lds = (size_t)64 * LDH * 4 + 64 * 4 + (SPARSE ? P1_SPARSE_LDS : 0);
+    const size_t lds = (size_t)64 * LDH * 4 + 64 * 4;
     static std::atomic<uint64_t> configured{0};
     if (omds_first_use_on_device(configured)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1_mixed<ACT, SPARSE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1_mixed<ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     // keep `small_rounds` x 512 x 64 rows (in units of resident 64-row workgroups) for the 32-row tail tiles
     long long tiles64 = total / 64;
@@ -259,7 +264,7 @@ static void launch_pass1_mixed(hipStream_t s, const MlpDev& m, const float* Fq, 
     long long n_big = tiles64 > keep ? tiles64 - keep : 0;
     const long long rest = total - n_big * 64;
     const long long n_small = (rest + 31) / 32;
-    hipLaunchKernelGGL((k_pass1_mixed<ACT, SPARSE>), dim3((unsigned)(n_big + n_small)), dim3(512), lds, s, Fq, Fp, radius, Dmin,
+    hipLaunchKernelGGL((k_pass1_mixed<ACT>), dim3((unsigned)(n_big + n_small)), dim3(512), lds, s, Fq, Fp, radius, Dmin,
                        total, O, ignored, (int)n_big, OmdsDivisor::make((unsigned)O), m);
 }
 
@@ -275,9 +280,20 @@ void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Fq, const fl
     // tiny batches (<= 128 32-row tiles: integrator tick, planar toy shapes): 16-row tiles on the 16x16x4 MFMA halve the
     // chain of dependent GEMMs that is the whole latency of such a launch
     if (v == 0) v = (total >= 64LL * 1024) ? 11 : ((total >= 64LL * 512) ? 3 : (total <= 32LL * 128 ? 6 : 5));
+    if (m.compact && v != 6) {   // per-tile compaction: 64-row tiles, the last round (or everything, for small batches) in 32-row tiles
+        const size_t lds = (size_t)64 * LDH * 4 + 64 * 4 + 32 + (size_t)OMDS_IDS * 4;
+        static std::atomic<uint64_t> configured{0};
+        if (omds_first_use_on_device(configured))
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1_dyn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const long long tiles64 = total / 64, keep = v >= 10 ? (long long)(v - 10) * 512 / 2 : (v == 5 ? tiles64 : 0);
+        const long long n_big = tiles64 > keep ? tiles64 - keep : 0;
+        const long long n_small = (total - n_big * 64 + 31) / 32;
+        hipLaunchKernelGGL(k_pass1_dyn, dim3((unsigned)(n_big + n_small)), dim3(512), lds, s, Fq, Fp, radius, Dmin, total, O, ignored, (int)n_big,
+                           OmdsDivisor::make((unsigned)O), m);
+        return;
+    }
     if (v >= 10) {   // 10 + r: mixed tiles, the last r "rounds" of 512 workgroups use 32-row tiles
-        if (m.act == OMDS_ACT_RELU && m.sparse) launch_pass1_mixed<OMDS_ACT_RELU, true>(s, m, Fq, Fp, radius, O, total, ignored, Dmin, v - 10);
-        else if (m.act == OMDS_ACT_RELU) launch_pass1_mixed<OMDS_ACT_RELU>(s, m, Fq, Fp, radius, O, total, ignored, Dmin, v - 10);
+        if (m.act == OMDS_ACT_RELU) launch_pass1_mixed<OMDS_ACT_RELU>(s, m, Fq, Fp, radius, O, total, ignored, Dmin, v - 10);
         else launch_pass1_mixed<OMDS_ACT_TANH>(s, m, Fq, Fp, radius, O, total, ignored, Dmin, v - 10);
         return;
     }

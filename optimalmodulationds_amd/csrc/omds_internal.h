@@ -56,21 +56,14 @@ struct MlpDev {
     const float* b1;     // [256]
     const float4* W1f;   // [8 colblk][4 kchunk][64 lane] first layer, forward pack over the 3d encoded inputs (padded to K = 32)
     const float4* W1f16; // [16 colblk16][2 kchunk][64 lane] the same for the 16-row tiles
-    // EXACT ZERO-SKIP of k_pass1 (ReLU networks without skips).  A unit whose activation is exactly zero in every
-    // row of a tile adds fmaf(0, w, acc) = acc to every chain of the next layer: not multiplying it changes no bit, whatever the
-    // order.  omds_set_mlp sorts the units of every hidden level into A (fired for some input of a synthetic sample) and B
-    // (fired for none), and the SPARSE form of pass1_tile stores a level's tile as [A ascending | B ascending] (each k-permuted by
-    // omds_kpos) so that the next product can stop after A's chunks -- the chain over A in ascending order IS the reference's
-    // chain when all of B is zero.  A tile in which a unit of B fires (a "surprise", counted in *sp_surprises) is stored again
-    // in natural order and multiplied in full with the natural packs.
-    const float4* WfP;   // [nhh][8 colblk][32 kchunk][64 lane]: Wf with position s of layer l's input = unit sp_order[l][omds_kat(s)]
-    const float4* WlP;   // [16 kchunk][64 lane]: Wl likewise on level nhh
-    const uint16_t* sp_pos;   // [nhh + 1][256]: position of unit u in the [A | B] tile of its level (omds_kpos applied), bit 15 = u is in B
-                              // (a firing unit of B is a surprise: it would sit behind A in the chain instead of between its units)
-    unsigned* sp_surprises;   // device counter of surprised (tile, level)s since omds_set_mlp (statistics)
-    uint8_t sp_nch[OMDS_MAX_HIDDEN + 1];   // k-chunks of 8 multiplied over level l (level nhh: chunks of 16 of the last layer)
-    uint8_t sparse;      // 0: the network does not qualify (tanh, skips) or every unit may fire
     const float4* W1b;   // [32 kchunk][64 lane] first layer, backward pack (cols = 3d features, padded to 32)
+    // EXACT ZERO-SKIP of k_pass1 by per-tile compaction (pass1_tile_dyn, mlp_device.h; ReLU networks without skips)
+    const float* WhT;    // [nhh][256 unit][256 column] hidden->hidden weights transposed (a W^T row = the weights leaving one unit): the
+                         // compacted products fetch their fragments by unit
+    const float* WlT;    // [256 unit][16] last layer likewise (channels padded to 16)
+    unsigned long long* skip_stats;   // device counters since omds_set_mlp: [0] tiles, [1 + L] sum over tiles of the chunks multiplied over
+                                      // level L (of 8 positions; the last hidden level: of 16), [10 + L] sum of the firing units
+    uint8_t compact;     // 1: k_pass1 runs pass1_tile_dyn (0: the network does not qualify, or OMDS_FLAG_DENSE_PASS1)
     // the same three packs in v_mfma_f32_16x16x4 fragment order, for the 16-row pass-2 tiles of small batches:
     // lane l of chunk c holds 4 consecutive k = 16c + 4(l>>4) .. +3 of column 16*cb + (l&15)
     const float4* Wf16;  // [nhh][16 colblk16][16 kchunk][64 lane]

@@ -390,11 +390,12 @@ class Engine:
 
     # ---- measurement --------------------------------------------------------------------------
     def pass1_skip_stats(self):
-        """omds_pass1_skip_stats: dict(active, chunks [per hidden level], surprises)."""
-        act, sur = C.c_int32(), C.c_int64()
-        ch = np.zeros(9, np.int32)
-        self._ck(self.lib.omds_pass1_skip_stats(self.h, C.byref(act), L.iptr(ch), 9, C.byref(sur)))
-        return dict(active=bool(act.value), chunks=[int(c) for c in ch if c > 0], surprises=int(sur.value))
+        """omds_pass1_skip_stats: dict(active, units, chunks [mean per tile and hidden level since set_mlp], tiles)."""
+        act, tiles = C.c_int32(), C.c_int64()
+        un, ch = (C.c_double * 9)(), (C.c_double * 9)()
+        self._ck(self.lib.omds_pass1_skip_stats(self.h, C.byref(act), un, ch, 9, C.byref(tiles)))
+        nl = getattr(self, "n_hidden_levels", 9)
+        return dict(active=bool(act.value), units=[float(u) for u in un][:nl], chunks=[float(c) for c in ch][:nl], tiles=int(tiles.value))
 
     def sync(self):
         """Waits for everything enqueued on the context's stream (omds_sync)."""
