@@ -817,6 +817,10 @@ __device__ __forceinline__ void gemm_gather(const float* __restrict__ Hw, const 
     if (nch & 1) mfma4(a0, b0);   // an odd count: the last chunk is the one the final pair (or the prologue) fetched
 }
 
+#ifndef OMDS_DYN_PRIO_EPI
+#define OMDS_DYN_PRIO_EPI 3
+#endif
+#define OMDS_DYN_PRIO(p) __builtin_amdgcn_s_setprio(p)
 template <int MT, int MR>
 __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, const float* __restrict__ Fq, const float* __restrict__ Fp,
                                                const float* __restrict__ radius, int O, long long total_rows, uint32_t ignored,
@@ -832,7 +836,13 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int col = wv * 32 + (lane & 31);                         // the unit this thread's accumulators hold, at every level
     float bcur = m.b1[col];
+    OMDS_DYN_PRIO(OMDS_DYN_PRIO_EPI);   // outside its products a wave's VALU / LDS work competes with the co-resident workgroup's MFMA stream for issue
     if (tid < OMDS_IDS - OMDS_WIDTH) idsS[OMDS_WIDTH + tid] = 0u;  // behind the table: valid offsets for the pipeline's look-ahead
+    OMDS_TL(0);
+#ifdef OMDS_TIMELINE
+    if (m.tl && threadIdx.x == 0)   // HW_ID and XCC_ID: which CU this workgroup landed on
+        m.tl[(size_t)blockIdx.x * 16 + 15] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+#endif
 
     // ---- the tile's encoded inputs (as pass1_tile, un-listed rows) -------------------------------------------------
     {
@@ -873,6 +883,7 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
         if (lane < IT) rowRad[wv + lane * G::NW] = myrad;
     }
     __syncthreads();
+    OMDS_TL(1);
 
     // ---- layer 1 (l = -1) and the hidden -> hidden layers on the compacted tile -----------------------------------------
     int T = 0;   // firing units of the level in the tile
@@ -884,8 +895,11 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
             for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
         const float bnow = bcur;
         if (l + 1 < m.nhh) bcur = m.bh[(l + 1) * OMDS_WIDTH + col];
+        OMDS_DYN_PRIO(0);
         if (l < 0) gemm_k32<MR, 1>(Hs, m.W1f, wv, lane, acc);
         else gemm_gather<MR>(Hs, idsS, m.WhT + (size_t)l * (OMDS_WIDTH * OMDS_WIDTH), wv, lane, acc, (T + 7) >> 3);
+        OMDS_DYN_PRIO(OMDS_DYN_PRIO_EPI);
+        OMDS_TL(2 + 2 * (l + 1));   // this wave's share of the product done (diagnostic build)
         // which of this wave's units fired in the tile: the column of lane l and of lane l + 32 is the same unit
         float zm = 0.f;
 #pragma unroll
@@ -930,6 +944,7 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
             if (row == 0) idsS[omds_kpos(pz)] = 0u;
         }
         __syncthreads();
+        OMDS_TL(3 + 2 * (l + 1));
     }
 
     // ---- last layer (256 -> C, padded to 16) on v_mfma_f32_16x16x4_f32 over the compacted level, weights by unit from WlT ----
@@ -993,6 +1008,10 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
             }
         }
     }
+#ifdef OMDS_TIMELINE
+    __syncthreads();
+    OMDS_TL(10);
+#endif
 }
 
 // k smallest entries of row[0..O) in ascending order (ties by lower index), one wave per row.
