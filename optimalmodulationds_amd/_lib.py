@@ -133,6 +133,7 @@ SIGNATURES = {
 TEST_HOOK_SIGNATURES = {
     "omds_screen_debug_corrupt": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float]),
     "omds_debug_force_tile_rows": (C.c_int, [C.c_int, C.c_int]),
+    "omds_debug_trainer_general_gemm": (C.c_int, [C.c_int]),
     "omds_test_pack_mlp": (C.c_int, [C.c_int, C.c_int, I32P, I32P, C.POINTER(F32P), C.POINTER(F32P), C.c_int, C.c_float, C.c_int, I32P,
                                      C.POINTER(C.c_uint64), C.POINTER(C.c_int64)]),
 }

@@ -1543,7 +1543,7 @@ static int enqueue_rollouts(omds_ctx* ctx, StepArgs& a, bool tail, bool screen) 
                                  ctx->d_dscr, ctx->n_obs, a, 0, N, ctx->d_FqH, N, fq_next, ctx->d_range, ctx->screen_eps, ctx->d_scerr + 1);
             else if (emit)   // top-k over the rollout's row of Dmin, masks of the k selected pairs, backward, blend, modulation, Euler step
                 omds_launch_tail_sel(ctx->stream, ctx->mlp, ctx->d_Fp, ctx->d_radius, ctx->d_obs, ctx->d_Fq, ctx->n_obs, a,
-                                     nullptr, nullptr, ex_all, nullptr, 0, 0.f, ctx->d_scerr + 1);
+                                     nullptr, nullptr, ex_all, nullptr, 0, 0.f, nullptr);   // (no window, no slack to count: viol = NULL)
             else
                 omds_launch_tail(ctx->stream, ctx->mlp, ctx->d_Fp, ctx->d_radius, ctx->d_obs, ctx->d_Dmin, ctx->d_Fq,
                                  ctx->d_dscr, ctx->n_obs, a, 0, N);

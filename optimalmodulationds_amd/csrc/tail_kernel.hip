@@ -179,7 +179,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
         const bool dense = a.rowlist == nullptr;
         const int base = dense ? t * O : a.range[4 * t], cnt = dense ? O : a.range[4 * t + 1];
         const float tau = dense ? __builtin_inff() : __builtin_bit_cast(float, a.range[4 * t + 2]);
-        if (lane == 0 && cnt < k) atomicAdd(a.viol, 1u);
+        if (lane == 0 && cnt < k && a.viol) atomicAdd(a.viol, 1u);
         if (cnt <= 64) {
             // the usual case, a few candidates: one per lane, and its rank under (D, obstacle) by comparing with every other
             // candidate's (value, obstacle) broadcast from its lane -- cnt scalar steps instead of k wave-wide reductions
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
             }
             // slack guard: every row that was not listed has a screening value above tau; with an error of at most e_bound its
             // exact value exceeds tau - e_bound, so it stays out of the k smallest as long as tau - D*_k >= e_bound
-            if (have && rank == k - 1 && !(tau - x >= a.e_bound)) atomicAdd(a.viol, 1u);
+            if (have && rank == k - 1 && a.viol && !(tau - x >= a.e_bound)) atomicAdd(a.viol, 1u);   // (dense mode: tau = inf, viol = NULL)
             if (have && rank < k) {
                 const int r = rl * k + rank;
                 sm.rowT[r] = t;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
                 sel[r] = be;
             }
         }
-        if (lane == 0 && !(tau - pv >= a.e_bound)) atomicAdd(a.viol, 1u);   // pv = the exact k-th smallest
+        if (lane == 0 && a.viol && !(tau - pv >= a.e_bound)) atomicAdd(a.viol, 1u);   // pv = the exact k-th smallest
     }
     __syncthreads();
     OMDS_TL_STAMP(2);

@@ -695,6 +695,15 @@ static void launch_gemm(hipStream_t s, const float* A, int lda, const float* Bm,
 // The tall fast path: A row-major [M x 256], 128 < N <= 256.  W is the layer's [out x in] matrix;
 // trans = 0: B(k, n) = W[n][k] (forward, N = out, K = in); trans = 1: B(k, n) = W[k][n] (input gradient, N = in, K = out).
 static bool tall_shape(int N, int K) { return N > 128 && N <= 256 && K == 256; }
+#ifdef OMDS_TEST_HOOKS
+// Test hook (include/omds_test.h, libomds_hip_test.so only): every product of the trainer on the general kernel k_gemm, so that a test
+// can hold the special-shape kernels (k_gemm_tall, k_gemm_thin*, k_wgrad_thin) to its bits.  Process-wide.
+static std::atomic<int> g_trainer_general{0};
+extern "C" OMDS_API int omds_debug_trainer_general_gemm(int on) { g_trainer_general.store(on ? 1 : 0); return OMDS_OK; }
+#define OMDS_TRAINER_GENERAL() (g_trainer_general.load() != 0)
+#else
+#define OMDS_TRAINER_GENERAL() false
+#endif
 // pack = the caller's 256 KB fragment buffer (one per trainer: a launch re-packs it on the trainer's own stream -- the weights change
 // every step -- so two trainers on one device never share it)
 template <int EPI>
@@ -703,7 +712,7 @@ static int launch_gemm_tall(hipStream_t s, float4* pack, const float* A, int lda
     static std::atomic<uint64_t> configured{0};    // per device: function attributes belong to the device the kernel is loaded on
     static const int dbg = OMDS_EXP_ENV("OMDS_TALL_DBG", 0);   // experiment builds: 1 no A traffic, 2 no C traffic, 4 no mask traffic, 8 the general kernel instead
     const int lds = 2 * TALL_BUF;
-    if (dbg & 8) return 1;
+    if ((dbg & 8) || OMDS_TRAINER_GENERAL()) return 1;
     if (!pack || lda != 256 || K != 256 || (reinterpret_cast<size_t>(A) & 15)) return 1;   // the general kernel takes it
     if (omds_first_use_on_device(configured)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tall<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -716,7 +725,7 @@ static int launch_gemm_tall(hipStream_t s, float4* pack, const float* A, int lda
     return 0;
 }
 
-static bool thin_off() { static const int dbg = OMDS_EXP_ENV("OMDS_TALL_DBG", 0); return (dbg & 16) != 0; }   // experiment builds: bit 16 = the general kernel everywhere
+static bool thin_off() { static const int dbg = OMDS_EXP_ENV("OMDS_TALL_DBG", 0); return (dbg & 16) != 0 || OMDS_TRAINER_GENERAL(); }   // experiment builds: bit 16 = the general kernel everywhere
 template <int EPI>
 static bool launch_gemm_thin(hipStream_t s, const float* A, int lda, const float* W, int ldw, int trans, float* C, int ldc, int M, int N, int K,
                              const float* aux, int act) {

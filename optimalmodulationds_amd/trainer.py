@@ -13,8 +13,8 @@ from . import _lib as L
 class SdfTrainer:
     """``dims`` = [3 * (raw inputs), hidden ..., out_channels]; weights ``W[i]`` are [out, in] like torch ``nn.Linear``."""
 
-    def __init__(self, dims, act="relu", device=0):
-        self.lib = L.load()
+    def __init__(self, dims, act="relu", device=0, lib=None):
+        self.lib = lib if lib is not None else L.load()
         self.dims = [int(v) for v in dims]
         self.nl = len(self.dims) - 1
         self.act = act

@@ -43,7 +43,7 @@ def test_test_hooks_live_in_the_test_library_only(lib):
     (only OMDS_SCREEN, OMDS_ROCTX, OMDS_RCCL_LIB appear among its strings)."""
     from optimalmodulationds_amd import _lib
     hooks = _declared("omds_test.h")
-    assert hooks == sorted(_lib.TEST_HOOK_SIGNATURES) and len(hooks) == 3
+    assert hooks == sorted(_lib.TEST_HOOK_SIGNATURES) and len(hooks) == 4
     raw, raw_test = C.CDLL(_lib.LIB_PATH), C.CDLL(_lib.TEST_LIB_PATH)
     for nme in hooks:
         assert not hasattr(raw, nme), f"{nme} is a test hook and must not be exported by the product library"

@@ -168,3 +168,34 @@ def test_small_batches_take_pass_2s_forward_from_pass_1_and_keep_their_bits(N, H
             assert np.array_equal(a[key], b[key]), key
     assert np.array_equal(outs[0][2], outs[1][2])
     assert np.isfinite(outs[0][0]["all_traj"]).all()
+
+
+def test_dense_tail_sel_edge_cases():
+    """the emitting pass 1 + k_tail_sel on rows where every pass-1 value ties (ALL links ignored: 1e6 everywhere, the
+    selection falls back to the obstacle index) -- the same bits as the context that keeps k_tail, finite, and no counter touched (the
+    dense mode has no window: its `viol` pointer is NULL); fewer obstacles than n_closest never reach a kernel (MPPI.py:245-247 would
+    index past the sorted columns): omds_set_obstacles refuses them."""
+    from optimalmodulationds_amd import scenes, _lib
+    from optimalmodulationds_amd._lib import OmdsError
+    from optimalmodulationds_amd.engine import Engine
+    m = orc.Mlp.from_npz(weights_path("franka"))
+    obs = scenes.shelf_scene()
+    q = (scenes.FRANKA_Q0 + 0.3 * np.random.RandomState(0).standard_normal((40, 7))).astype(np.float32)
+    outs = []
+    for flags in (0, _lib.FLAG_TAIL_FORWARD):
+        e = Engine(7, 40, 3, 5, max_obs=296, flags=flags)
+        e.set_mlp(m.W, m.b)
+        e.set_obstacles(obs)
+        e.set_screening(0)
+        e.params.dt, e.params.dst_thr, e.params.ignored_links = 0.5, 0.01, 0x1ff
+        e.push_params()
+        e.set_ds(scenes.FRANKA_QF)
+        e.set_policy_samples(np.zeros((40, 0, 7), np.float32), np.zeros((40, 0), np.float32), np.zeros((40, 0, 7), np.float32))
+        e.propagate(q)
+        outs.append(e.get_rollouts())
+        with pytest.raises(OmdsError, match="fewer obstacles than n_closest"):
+            e.set_obstacles(obs[:3])
+        e.close()
+    assert np.isfinite(outs[0]["all_traj"]).all()
+    for key in outs[0]:
+        assert np.array_equal(outs[0][key], outs[1][key], equal_nan=True), key

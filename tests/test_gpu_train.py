@@ -196,3 +196,34 @@ def test_validation_split_and_optimizer_state_round_trip():
     assert not np.array_equal(fresh.get_weights()[0][0], np.zeros(1)) and fresh.optimizer_state_dict()["state"][0]["step"] == 1.0
     for t in (a, b_, ref, fresh):
         t.close()
+
+
+@pytest.mark.parametrize("act,B", [("relu", 20011), ("tanh", 4099)])
+def test_special_shape_kernels_are_the_general_kernel_bit_for_bit(act, B):
+    """k_gemm_tall (persistent, LDS-DMA rows, parked outputs), k_gemm_thin*, k_wgrad_thin against the general k_gemm -- six
+    training steps from the same start on a batch that is NOT a multiple of the 64-row tile, weights and Adam state array-equal.  The
+    test library's hook (include/omds_test.h: omds_debug_trainer_general_gemm) puts every product on the general kernel; every kernel
+    sums in ascending k from zero, so a difference would be a bug (a race on the parked outputs, a wrong k permutation), not rounding."""
+    from optimalmodulationds_amd import _lib as L
+    from optimalmodulationds_amd.trainer import SdfTrainer
+    lib = L.load_test_hooks()
+    m = orc.Mlp.from_npz(weights_path("franka"))
+    rng = np.random.RandomState(4)
+    x = rng.uniform(-2.0, 2.0, (B, 10)).astype(np.float32)
+    y = (orc.mlp_forward(m, x) + 5.0 * rng.standard_normal((B, 9))).astype(np.float32)
+    outs = []
+    for general in (1, 0):
+        assert lib.omds_debug_trainer_general_gemm(general) == 0
+        tr = SdfTrainer([30, 256, 256, 256, 256, 9], act, lib=lib)
+        tr.set_weights(m.W, m.b)
+        tr.set_data(x, y)
+        losses = [tr.step(lr=2e-4) for _ in range(6)]
+        W, b = tr.get_weights()
+        st = tr.optimizer_state_dict()["state"]
+        outs.append((losses, W, b, [st[i]["exp_avg"].numpy().copy() for i in st], [st[i]["exp_avg_sq"].numpy().copy() for i in st]))
+        tr.close() if hasattr(tr, "close") else None
+    lib.omds_debug_trainer_general_gemm(0)
+    (l0, W0, b0, m0, v0), (l1, W1, b1, m1, v1) = outs
+    assert l0 == l1, (l0, l1)
+    for a, c in zip(W0 + b0 + m0 + v0, W1 + b1 + m1 + v1):
+        assert np.array_equal(a, c)
