@@ -901,11 +901,15 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
         OMDS_DYN_PRIO(OMDS_DYN_PRIO_EPI);
         OMDS_TL(2 + 2 * (l + 1));   // this wave's share of the product done (diagnostic build)
         // which of this wave's units fired in the tile: the column of lane l and of lane l + 32 is the same unit
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][0][r] += bnow;
         float zm = 0.f;
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][0][r] += bnow; zm = fmaxf(zm, acc[i][0][r]); }
+            for (int r = 0; r < 16; r += 2) zm = __builtin_fmaxf(zm, __builtin_fmaxf(acc[i][0][r], acc[i][0][r + 1]));   // (v_max3_f32)
         const unsigned long long bal = __ballot(zm > 0.f);
         const uint32_t mine = (uint32_t)bal | (uint32_t)(bal >> 32);
         if (lane == 0) aliveS[wv] = mine;
