@@ -758,23 +758,43 @@ __device__ __forceinline__ void pass1_tile(const MlpDev& m, float* smem, const f
 // the position -> unit table the epilogue leaves in LDS -- four coalesced 256-byte loads per chunk instead of one 1 KB fragment.
 // Exact for every input: nothing is presumed about which units fire.
 // ------------------------------------------------------------------------------------------------
-constexpr int OMDS_IDS = OMDS_WIDTH + 32;   // entries of the position -> unit table (the pipeline reads up to three chunks ahead)
+// an LDS location as its 32-bit byte address, and a 16-byte read from one (ds_read_b128 with an immediate offset)
+// (the host pass of the compiler parses device functions too: it has no LDS address space to cast into)
+__device__ __forceinline__ uint32_t omds_lds_addr(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)p;
+#else
+    return 0u;
+#endif
+}
+__device__ __forceinline__ float4 omds_lds_f4(uint32_t a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const omds_f4 v = *(const __attribute__((address_space(3))) omds_f4*)a;
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+}
+constexpr int OMDS_IDS = OMDS_WIDTH + 64;   // entries of the position -> unit table (the pipelines read up to four 16-position chunks ahead)
 
 template <int MR>
 __device__ __forceinline__ void gemm_gather(const float* __restrict__ Hw, const uint32_t* __restrict__ idsS, const float* __restrict__ WT, int cb0,
                                             int lane, f32x16 (&acc)[MR][1], int nch) {
-    const float* arow = Hw + (lane & 31) * LDH + 4 * (lane >> 5);
-    const uint32_t* irow = idsS + 4 * (lane >> 5);   // this lane half's four positions of a chunk: 8c + 4h .. + 3
+    // LDS byte addresses, as integers: the two running addresses stay two registers with immediate offsets (derived from one another
+    // by the optimiser they cost three additions per chunk)
+    uint32_t arow = omds_lds_addr(Hw + (lane & 31) * LDH + 4 * (lane >> 5));
+    uint32_t irow = omds_lds_addr(idsS + 4 * (lane >> 5));   // this lane half's four positions of a chunk: 8c + 4h .. + 3
     const __amdgpu_buffer_rsrc_t wt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(WT) + __builtin_amdgcn_readfirstlane(cb0) * 32, 0,
                                                                         OMDS_WIDTH * OMDS_WIDTH * 4, 0x00020000);
     const int colb = (lane & 31) * 4;
     float4 a0[MR], a1[MR];
     float b0[4], b1[4];
     uint4 i0, i1;
-    auto loadA = [&](const float* ar, float4 (&a)[MR]) {
+    auto loadA = [&](uint32_t ar, float4 (&a)[MR]) {
 #pragma unroll
-        for (int i = 0; i < MR; ++i) a[i] = *reinterpret_cast<const float4*>(ar + i * 32 * LDH);
+        for (int i = 0; i < MR; ++i) a[i] = omds_lds_f4(ar + i * 32 * LDH * 4);
     };
+    auto loadI = [&](uint32_t ir) { return __builtin_bit_cast(uint4, omds_lds_f4(ir)); };
     auto loadB = [&](const uint4& id, float (&b)[4]) {   // W^T[unit][column]: byte offset unit * 1024 (the table's entry) + column * 4
         b[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wt, (int)id.x + colb, 0, 0));
         b[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wt, (int)id.y + colb, 0, 0));
@@ -791,30 +811,59 @@ __device__ __forceinline__ void gemm_gather(const float* __restrict__ Hw, const 
 #pragma unroll
         for (int i = 0; i < MR; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[3], acc[i][0], 0, 0, 0);
     };
-    // three stages: the table entries of chunk c + 2 (LDS), the operands of chunk c + 1 (LDS, L2), the MFMAs of chunk c
-    i0 = *reinterpret_cast<const uint4*>(irow);
-    i1 = *reinterpret_cast<const uint4*>(irow + 8);
+    auto mfma4_first = [&](const float4 (&a)[MR], const float (&b)[4]) {   // the chain starts here: C = 0 is the instruction's literal, no accumulator is cleared
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MR; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[0], zero, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[1], acc[i][0], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[2], acc[i][0], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[3], acc[i][0], 0, 0, 0);
+    };
+    // three stages: the table entries of chunk c + 2 (LDS), the operands of chunk c + 1 (LDS, L2), the MFMAs of chunk c.
+    // Every VALU instruction of this kernel costs its ~3.3 issue cycles on top of the MFMAs' (EXPERIMENTS R6.11): chunk 0 is peeled so
+    // that no accumulator is cleared.
+    const int n = __builtin_amdgcn_readfirstlane(nch);
+    if (n == 0) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+        return;
+    }
+    i0 = loadI(irow);
+    i1 = loadI(irow + 32);
     loadA(arow, a0);
     loadB(i0, b0);
-    const int npair = __builtin_amdgcn_readfirstlane(nch) >> 1;
+    loadA(arow + 32, a1);
+    loadB(i1, b1);
+    i0 = loadI(irow + 64);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma4_first(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    // now (a1, b1) is chunk 1, i0 the table entries of chunk 2
+    const int npair = (n - 1) >> 1;
 #pragma unroll 1
     for (int p = 0; p < npair; ++p) {
-        loadA(arow + 8, a1);
-        loadB(i1, b1);
-        i0 = *reinterpret_cast<const uint4*>(irow + 16);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma4(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        loadA(arow + 16, a0);
+        loadA(arow + 64, a0);
         loadB(i0, b0);
-        i1 = *reinterpret_cast<const uint4*>(irow + 24);
+        i1 = loadI(irow + 96);
         __builtin_amdgcn_sched_barrier(0);
         mfma4(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
-        arow += 16;
-        irow += 16;
+        loadA(arow + 96, a1);
+        loadB(i1, b1);
+        i0 = loadI(irow + 128);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        arow += 64;
+        irow += 64;
+        asm volatile("" : "+v"(arow), "+v"(irow));
     }
-    if (nch & 1) mfma4(a0, b0);   // an odd count: the last chunk is the one the final pair (or the prologue) fetched
+    if ((n - 1) & 1) mfma4(a1, b1);   // an even count: the last chunk is the one the final pair (or the prologue) fetched
 }
 
 #ifndef OMDS_DYN_PRIO_EPI
@@ -827,7 +876,6 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
                                                float* __restrict__ Dmin, const long long row0, const OmdsDivisor odiv) {
     using G = Geo<MT, MR, 1>;
     static_assert(G::NW == 8 && G::WM == 1, "eight waves, wave w owns the units 32 w .. 32 w + 31 of every level");
-    constexpr int ACT = OMDS_ACT_RELU;
     float* Hs = smem;                                              // [MT][LDH]
     float* rowRad = smem + MT * LDH;                               // [MT]
     uint32_t* aliveS = reinterpret_cast<uint32_t*>(rowRad + MT);   // [8] which of a wave's 32 units fired in this tile at the current level
@@ -856,7 +904,12 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
         const int f4 = (lane & 31) * 4;
         int o = (int)(row0u - t0 * (unsigned)O) + wv, dt = 0;
         while (o >= O) { o -= O; ++dt; }
+        // the radius of row wv + 8 j by lane j: one vector load (a scalar load per row is a chain of IT L2 round trips in front of the tile)
         float myrad = 0.f;
+        if (lane < IT && wv + lane * G::NW < rows_here) {
+            const unsigned g = row0u + (unsigned)(wv + lane * G::NW);
+            myrad = radius[g - odiv.div(g) * (unsigned)O];
+        }
         uint32_t fv[IT / 2];
 #pragma unroll
         for (int it = 0; it < IT; it += 2) {
@@ -865,13 +918,10 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 ok[h] = wv + (it + h) * G::NW < rows_here;
-                float rad = 0.f;
-                offq[h] = 0; offp[h] = 0;
-                if (ok[h]) { offq[h] = dt * (OMDS_FROW * 4); offp[h] = o * (OMDS_FROW * 4); rad = radius[o]; }
+                offq[h] = ok[h] ? dt * (OMDS_FROW * 4) : 0;
+                offp[h] = ok[h] ? o * (OMDS_FROW * 4) : 0;
                 o += G::NW;
                 while (o >= O) { o -= O; ++dt; }
-                const int rbits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rad));
-                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(myrad) : "s"(rbits), "n"(it + h));
             }
             const uint32_t fq = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(qr, (hi ? offq[1] : offq[0]) + f4, 0, 0);
             const uint32_t fp = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(pr, (hi ? offp[1] : offp[0]) + f4, 0, 0);
@@ -889,27 +939,40 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
     int T = 0;   // firing units of the level in the tile
     for (int l = -1; l < m.nhh; ++l) {
         f32x16 acc[MR][1];
-#pragma unroll
-        for (int i = 0; i < MR; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
         const float bnow = bcur;
         if (l + 1 < m.nhh) bcur = m.bh[(l + 1) * OMDS_WIDTH + col];
         OMDS_DYN_PRIO(0);
-        if (l < 0) gemm_k32<MR, 1>(Hs, m.W1f, wv, lane, acc);
-        else gemm_gather<MR>(Hs, idsS, m.WhT + (size_t)l * (OMDS_WIDTH * OMDS_WIDTH), wv, lane, acc, (T + 7) >> 3);
+        if (l < 0) {
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+            gemm_k32<MR, 1>(Hs, m.W1f, wv, lane, acc);
+        } else gemm_gather<MR>(Hs, idsS, m.WhT + (size_t)l * (OMDS_WIDTH * OMDS_WIDTH), wv, lane, acc, (T + 7) >> 3);
         OMDS_DYN_PRIO(OMDS_DYN_PRIO_EPI);
         OMDS_TL(2 + 2 * (l + 1));   // this wave's share of the product done (diagnostic build)
-        // which of this wave's units fired in the tile: the column of lane l and of lane l + 32 is the same unit
+#ifdef OMDS_DYN_JUNK   // experiment: OMDS_DYN_JUNK independent VALU instructions per wave and level -- what does one cost next to the partner's MFMAs?
+        {
+            int junk = lane;
+#pragma unroll
+            for (int i = 0; i < OMDS_DYN_JUNK; ++i) asm volatile("v_add_u32 %0, %0, 1" : "+v"(junk));
+            if (junk == 0x7fffffff) aliveS[0] = 0u;
+        }
+#endif
+        // bias (last, as the reference adds it), ReLU, and which of this wave's units fired in the tile (the column of lane l and of
+        // lane l + 32 is the same unit).  v_max_f32 / v_max3_f32 written out: fmaxf() would canonicalise every operand first
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][0][r] += bnow;
+            for (int r = 0; r < 16; ++r) {
+                const float z = acc[i][0][r] + bnow;
+                asm("v_max_f32_e32 %0, 0, %1" : "=v"(acc[i][0][r]) : "v"(z));
+            }
         float zm = 0.f;
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) zm = __builtin_fmaxf(zm, __builtin_fmaxf(acc[i][0][r], acc[i][0][r + 1]));   // (v_max3_f32)
+            for (int r = 0; r < 16; r += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(zm) : "v"(zm), "v"(acc[i][0][r]), "v"(acc[i][0][r + 1]));
         const unsigned long long bal = __ballot(zm > 0.f);
         const uint32_t mine = (uint32_t)bal | (uint32_t)(bal >> 32);
         if (lane == 0) aliveS[wv] = mine;
@@ -937,15 +1000,19 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hb[(i * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = actf(acc[i][0][r], ACT);
+                for (int r = 0; r < 16; ++r) hb[(i * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = acc[i][0][r];
             if (lane < 32) idsS[pos] = (uint32_t)col * (OMDS_WIDTH * 4);
         }
         // zero columns up to the next multiple of 16 positions (the chunks of both consumers are whole); their table entries: unit 0
         const int Tp = (T + 15) & ~15;
-        for (int e = tid; e < (Tp - T) * MT; e += G::NT) {
-            const int pz = T + e / MT, row = e - (e / MT) * MT;
-            Hs[row * LDH + omds_kpos(pz)] = 0.f;
-            if (row == 0) idsS[omds_kpos(pz)] = 0u;
+        constexpr int CPP = G::NT / MT;   // columns one pass of the workgroup clears (8 or 16 of at most 15)
+#pragma unroll
+        for (int it = 0; it < (15 + CPP - 1) / CPP; ++it) {
+            const int pz = T + tid / MT + it * CPP;
+            if (pz < Tp) {
+                Hs[(tid % MT) * LDH + omds_kpos(pz)] = 0.f;
+                if (tid % MT == 0) idsS[omds_kpos(pz)] = 0u;
+            }
         }
         __syncthreads();
         OMDS_TL(3 + 2 * (l + 1));
@@ -962,29 +1029,39 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
         const int r4 = rb * 16 + 4 * (lane >> 4);
         constexpr int LPD = 4;
         float wq[LPD][4];
-        auto loadW = [&](int c, float (&w)[4]) {   // WlT[unit][link]: byte offset unit * 64 = table entry / 16
-            w[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wlt, (int)(ir[16 * c] >> 4) + jb, 0, 0));
-            w[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wlt, (int)(ir[16 * c + 2] >> 4) + jb, 0, 0));
-            w[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wlt, (int)(ir[16 * c + 8] >> 4) + jb, 0, 0));
-            w[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wlt, (int)(ir[16 * c + 10] >> 4) + jb, 0, 0));
+        auto loadW = [&](const uint32_t* ic, float (&w)[4]) {   // WlT[unit][link]: byte offset unit * 64 = table entry / 16
+            w[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wlt, (int)(ic[0] >> 4) + jb, 0, 0));
+            w[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wlt, (int)(ic[2] >> 4) + jb, 0, 0));
+            w[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wlt, (int)(ic[8] >> 4) + jb, 0, 0));
+            w[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wlt, (int)(ic[10] >> 4) + jb, 0, 0));
         };
+        auto mfma4 = [&](const float* ac, const float (&w)[4]) {
+            const float4 a = load_a16(ac, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[3], acc, 0, 0, 0);
+        };
+        // the weights run LPD chunks ahead of the chain, in a ROLLED loop of LPD chunks per trip (a guard per chunk in an unrolled
+        // loop made every chunk wait for the newest fetch); the fetches behind the level read the table's look-ahead entries
 #pragma unroll
-        for (int c = 0; c < LPD; ++c) {
-            loadW(c, wq[c]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int c = 0; c < LPD; ++c) loadW(ir + 16 * c, wq[c]);
+        __builtin_amdgcn_sched_barrier(0);
+        int c = 0;
+#pragma unroll 1
+        for (; c + LPD <= nch16; c += LPD) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            if (c < nch16) {
-                const float4 a = load_a16(arow, c);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wq[c % LPD][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wq[c % LPD][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wq[c % LPD][2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wq[c % LPD][3], acc, 0, 0, 0);
-                if (c + LPD < 16) loadW(c + LPD, wq[c % LPD]);
+            for (int q = 0; q < LPD; ++q) {
+                mfma4(arow + 16 * q, wq[q]);
+                loadW(ir + 16 * (LPD + q), wq[q]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            arow += 16 * LPD;
+            ir += 16 * LPD;
         }
+#pragma unroll
+        for (int q = 0; q < LPD - 1; ++q)
+            if (c + q < nch16) mfma4(arow + 16 * q, wq[q]);
         const int j = lane & 15;
         const float bj = m.bl[j];
         const bool pad = j >= m.C, ign = (ignored >> j) & 1u;

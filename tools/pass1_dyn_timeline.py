@@ -73,4 +73,14 @@ for s_ in np.unique(slot):
     cov[0] += us[idx, 10].max() - last
     span_tot += us[idx, 10].max() - us[idx, 0].min()
 print("share of each CU's busy span with 0 / 1 / 2 workgroups inside a product: " + " / ".join(f"{100 * c / span_tot:.1f} %" for c in cov))
+res = np.zeros(3); launch_span = us[:, 10].max() - us[:, 0].min(); ncu = len(np.unique(slot))
+for s_ in np.unique(slot):   # resident workgroups (between a workgroup's first and last stamp) per CU over the LAUNCH span
+    idx = np.where(slot == s_)[0]
+    ev = sorted([(us[i, 0], +1) for i in idx] + [(us[i, 10], -1) for i in idx])
+    cur = 0; last = us[:, 0].min()
+    for (tt, d) in ev:
+        res[min(cur, 2)] += tt - last
+        cur += d; last = tt
+    res[0] += us[:, 10].max() - last
+print("share of the launch span with 0 / 1 / 2 workgroups resident on a CU: " + " / ".join(f"{100 * c / (launch_span * ncu):.1f} %" for c in res))
 print(f"mean CU busy span {span_tot / len(np.unique(slot)):.1f} us of launch span {us[:, 10].max():.1f} us")
