@@ -823,7 +823,7 @@ __device__ __forceinline__ void gemm_gather(const float* __restrict__ Hw, const 
         for (int i = 0; i < MR; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[3], acc[i][0], 0, 0, 0);
     };
     // three stages: the table entries of chunk c + 2 (LDS), the operands of chunk c + 1 (LDS, L2), the MFMAs of chunk c.
-    // Every VALU instruction of this kernel costs its ~3.3 issue cycles on top of the MFMAs' (EXPERIMENTS R6.11): chunk 0 is peeled so
+    // Every VALU instruction of this kernel costs its ~3.3 issue cycles on top of the MFMAs' (EXPERIMENTS.md R6.11): chunk 0 is peeled so
     // that no accumulator is cleared.
     const int n = __builtin_amdgcn_readfirstlane(nch);
     if (n == 0) {
@@ -951,14 +951,6 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
         } else gemm_gather<MR>(Hs, idsS, m.WhT + (size_t)l * (OMDS_WIDTH * OMDS_WIDTH), wv, lane, acc, (T + 7) >> 3);
         OMDS_DYN_PRIO(OMDS_DYN_PRIO_EPI);
         OMDS_TL(2 + 2 * (l + 1));   // this wave's share of the product done (diagnostic build)
-#ifdef OMDS_DYN_JUNK   // experiment: OMDS_DYN_JUNK independent VALU instructions per wave and level -- what does one cost next to the partner's MFMAs?
-        {
-            int junk = lane;
-#pragma unroll
-            for (int i = 0; i < OMDS_DYN_JUNK; ++i) asm volatile("v_add_u32 %0, %0, 1" : "+v"(junk));
-            if (junk == 0x7fffffff) aliveS[0] = 0u;
-        }
-#endif
         // bias (last, as the reference adds it), ReLU, and which of this wave's units fired in the tile (the column of lane l and of
         // lane l + 32 is the same unit).  v_max_f32 / v_max3_f32 written out: fmaxf() would canonicalise every operand first
 #pragma unroll

@@ -120,14 +120,6 @@ __global__ __launch_bounds__(512) void k_pass1_dyn(const float* __restrict__ Fq,
     else pass1_tile_dyn<32, 1>(m, smem, Fq, Fp, radius, O, total_rows, ignored, Dmin, (long long)n_big * 64 + (long long)(b - n_big) * 32, odiv);
 }
 
-// EXPERIMENT (OMDS_PASS1_VARIANT=7): 32-row tiles only, LDS for 32 rows and <= 64 registers: four workgroups per CU instead of two
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_pass1_dyn32(const float* __restrict__ Fq, const float* __restrict__ Fp,
-                                                   const float* __restrict__ radius, float* __restrict__ Dmin,
-                                                   long long total_rows, int O, uint32_t ignored, OmdsDivisor odiv, MlpDev m) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    pass1_tile_dyn<32, 1>(m, smem, Fq, Fp, radius, O, total_rows, ignored, Dmin, (long long)blockIdx.x * 32, odiv);
-}
-
 // The same two kernels in pass1_tile's MODE 6 (kernels of their own: the tuned mode-0 kernels keep their argument lists and code):
 // beside Dmin every pair's pass-2 distance, arg-min link and ReLU masks go to `ex`, indexed by the pair.
 template <int MT, int MR, int NR, int ACT>
@@ -294,12 +286,6 @@ void omds_launch_pass1(hipStream_t s, const MlpDev& m, const float* Fq, const fl
         static std::atomic<uint64_t> configured{0};
         if (omds_first_use_on_device(configured))
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1_dyn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (v == 7) {
-            const size_t lds32 = (size_t)32 * LDH * 4 + 32 * 4 + 32 + (size_t)OMDS_IDS * 4;
-            hipLaunchKernelGGL(k_pass1_dyn32, dim3((unsigned)((total + 31) / 32)), dim3(512), lds32, s, Fq, Fp, radius, Dmin, total, O, ignored,
-                               OmdsDivisor::make((unsigned)O), m);
-            return;
-        }
         const long long tiles64 = total / 64, keep = v >= 10 ? (long long)(v - 10) * 512 / 2 : (v == 5 ? tiles64 : 0);
         const long long n_big = tiles64 > keep ? tiles64 - keep : 0;
         const long long n_small = (total - n_big * 64 + 31) / 32;
