@@ -9,7 +9,6 @@ export TMPDIR=/tmp
 # the library's default (screened) step unless a line says --path fp32; bench.py's own default primary is the all-fp32 step
 B="bench.py --steps 5 --warmup 1 --reps 1 --no-cpu-baseline --no-secondary --path screened"
 P="bench.py --steps 2 --warmup 1 --reps 1 --no-cpu-baseline --no-secondary --path screened"
-python3 bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
 finddb() { find "$1" -name '*_results.db' | head -1; }
 # the all-fp32 step (omds_set_screening(0)): the precision-matched figure of the bench line (roofline.fp32_only), k_pass1 + k_tail
 rocprofv3 --kernel-trace --stats -d "$OUT/kt_fp32" -- python3 $B --path fp32 > "$OUT/kt_fp32.log" 2>&1
@@ -70,5 +69,8 @@ for wl, tag in (("franka_shelf_1024x32", ""), ("franka_shelf_1024x32_fp32", "_fp
 json.dump(res, open(out + "/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
+# the committed bench line once more, now beside THIS run's counters (roofline.traffic / SQ_INSTS_MFMA are read from profiles/pmc_traffic.json)
+cp "$OUT/pmc_traffic.json" profiles/pmc_traffic.json
+python3 bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
 python3 -m pytest tests/test_gpu_fullsize_parity.py -q -s > "$OUT/parity_fullsize.txt" 2>&1
 ls -la "$OUT"
