@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
             }
 }
 
-// ---- the tall GEMMs of a 256-wide layer: C [M x N] = A [M x K] . B with M = the batch and 128 < N, K <= 256 ----------------------------
+// ---- the tall GEMMs of a 256-wide layer: C [M x N] = A [M x K] . B with M = the batch, K = 256 and 128 < N <= 256 ------------------------
 // (forward H . W^T and input gradient G . W of the hidden layers: 2/3 of an epoch's FLOPs).  The general kernel above stages both
 // operands through LDS 16 k at a time, two barriers per step: 0.62 of the fp32 MFMA peak.  Here a workgroup owns 64 rows and ALL
 // columns: its A tile [64 x 256] sits in LDS for the whole product (row stride 260: conflict-free 16-byte fragment reads), the
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(128) void k_gemm_thin_out(const float* __restrict__
 // The thin weight gradients (the first layer's dW [256 x 3 d], the last layer's dW [C x 256]): one of the two matrices of dW = G^T . H is at most 32
 // wide.  The contraction runs over the batch in the SAME chunks as the general kernel's split (blockIdx.y = chunk z), every (z, wide column, thin
 // column) sum is one fmaf chain over the chunk's rows in ascending order from zero -- the general kernel's partials bit for bit, summed by the same
-// k_sum_partials -- but the wide matrix streams through once, coalesced, 16 rows in flight per lane, instead of through MFMA tiles that are 90 %
+// k_sum_partials -- but the wide matrix streams through once, coalesced, WG_BATCH = 32 rows in flight per lane, instead of through MFMA tiles that are 90 %
 // padding.  thin_is_n: the thin matrix indexes dW's columns (first layer: Y = H, X = G), else its rows (last layer: Y = G, X = H).
 constexpr int WG_TMAX = 32, WG_YROWS = 256, WG_BATCH = 32;
 // (256 chunks x 256 columns are 1024 waves, one per SIMD: nothing hides a wave's own load latency but the wave itself -- the next batch of 32 rows
@@ -690,9 +690,8 @@ static void launch_gemm(hipStream_t s, const float* A, int lda, const float* Bm,
     hipLaunchKernelGGL((k_gemm<TA, TB, EPI>), grid, dim3(256), 0, s, A, lda, Bm, ldb, C, ldc, M, N, K, kchunk, cstride, aux, act);
 }
 
-// The tall fast path: A row-major [M x K], one output tile row per 64 rows, 128 < N, K <= 256.  W is the layer's [out x in] matrix;
-// trans = 0: B(k, n) = W[n][k] (forward, N = out, K = in); trans = 1: B(k, n) = W[k][n] (input gradient, N = in, K = out).
-// The tall fast path: A row-major [M x 256], 128 < N <= 256.  W is the layer's [out x in] matrix;
+// The tall fast path: A row-major [M x 256] (K == lda == 256, 16-byte aligned), one output tile row per 64 rows, 128 < N <= 256.  W is the
+// layer's [out x in] matrix;
 // trans = 0: B(k, n) = W[n][k] (forward, N = out, K = in); trans = 1: B(k, n) = W[k][n] (input gradient, N = in, K = out).
 static bool tall_shape(int N, int K) { return N > 128 && N <= 256 && K == 256; }
 #ifdef OMDS_TEST_HOOKS
