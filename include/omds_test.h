@@ -19,8 +19,8 @@ extern "C" {
  * touched.                                                                                                               */
 OMDS_API int omds_screen_debug_corrupt(omds_ctx* ctx, int what, int index, float value);
 /* Process-wide: the tile shape of the step's tail kernels instead of the launcher's own choice -- tail_sel_rows in {0, 4, 16, 32}
- * for the screened step (4 = the backward on 4-row groups; ReLU networks without skip concatenations), tail_rows in {0, 16, 32}
- * for the unscreened one; 0 = the launcher chooses again.  Every shape computes the same bits per row: the tests run them against
+ * for the screened step (4 = the backward on 4-row groups; ReLU networks without skip concatenations), tail_rows in {0, 4, 16, 32}
+ * for the unscreened one (4 = forward and backward on 4-row groups); 0 = the launcher chooses again.  Every shape computes the same bits per row: the tests run them against
  * each other.                                                                                                             */
 OMDS_API int omds_debug_force_tile_rows(int tail_sel_rows, int tail_rows);
 /* Process-wide: every product of the trainer (omds_trainer_step / _eval) on the general GEMM kernel instead of the special-shape

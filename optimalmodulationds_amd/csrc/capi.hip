@@ -300,7 +300,7 @@ struct MlpPacks {
     float out_div = 1.f;
     uint32_t skip_mask = 0;
     uint8_t skip_col[OMDS_MAX_HIDDEN + 1] = {0};
-    std::vector<float4> wf, wb, wf16, wb16, wb4, wl, w1b, w1b16, w1f, w1f16;
+    std::vector<float4> wf, wb, wf16, wb16, wb4, wf4, wl, w1b, w1b16, w1f, w1f16;
     std::vector<float> bh, bl, wlraw, whraw, w1t, b1, sbias, wht, wlt;
     std::vector<uint16_t> wh;
     double f_fwd = 0.0, f_bwd = 0.0;
@@ -466,8 +466,10 @@ static int build_mlp_packs(int n, int n_linear, const int32_t* in_dims, const in
     }
     // backward pack for the 4-row-group GEMM (v_mfma_f32_4x4x1, mlp_device.h gemm4): the gradient at a layer's inputs is
     // sum_k G[row][k] W[k][j] (W [out = k][in = j]); lane l of column block cb holds W[4 kq .. 4 kq + 3][64 cb + l]
-    std::vector<float4>& wb4 = pk.wb4;
+    // (and the forward pack of the same GEMM, pass2_body_g4: sum_k H[row][k] W[j][k], lane l of block cb holds W[64 cb + l][k0 .. k3])
+    std::vector<float4>&wb4 = pk.wb4, &wf4 = pk.wf4;
     wb4.assign((size_t)std::max(nhh, 1) * 4 * 64 * 64, make_float4(0, 0, 0, 0));
+    wf4.assign(wb4.size(), make_float4(0, 0, 0, 0));
     for (int l = 0; l < nhh; ++l) {
         const float* Wl = W[l + 1];
         for (int cb = 0; cb < 4; ++cb)
@@ -477,6 +479,8 @@ static int build_mlp_packs(int n, int n_linear, const int32_t* in_dims, const in
                     const int k0 = omds_kat(s0), k1 = omds_kat(s0 + 1), k2 = omds_kat(s0 + 2), k3 = omds_kat(s0 + 3);
                     wb4[(((size_t)l * 4 + cb) * 64 + kq) * 64 + lane] =
                         make_float4(Wl[(size_t)k0 * Wd + j], Wl[(size_t)k1 * Wd + j], Wl[(size_t)k2 * Wd + j], Wl[(size_t)k3 * Wd + j]);
+                    wf4[(((size_t)l * 4 + cb) * 64 + kq) * 64 + lane] =
+                        make_float4(Wl[(size_t)j * Wd + k0], Wl[(size_t)j * Wd + k1], Wl[(size_t)j * Wd + k2], Wl[(size_t)j * Wd + k3]);
                 }
     }
     // last layer: 16x16x4 B-fragments, channels padded to 16
@@ -730,6 +734,7 @@ int omds_set_mlp_ex(omds_ctx* ctx, int n_linear, const int32_t* in_dims, const i
     if ((rc = upload(ctx, pk.wf16, &m.Wf16))) return rc;
     if ((rc = upload(ctx, pk.wb16, &m.Wb16))) return rc;
     if ((rc = upload(ctx, pk.wb4, &m.Wb4))) return rc;
+    if ((rc = upload(ctx, pk.wf4, &m.Wf4))) return rc;
     if ((rc = upload(ctx, pk.w1b16, &m.W1b16))) return rc;
     if ((rc = upload(ctx, pk.wf, &m.Wf))) return rc;
     if ((rc = upload(ctx, pk.wb, &m.Wb))) return rc;
@@ -792,7 +797,7 @@ int omds_test_pack_mlp(int n_dof, int n_linear, const int32_t* in_dims, const in
         total += (int64_t)nb;
     };
     mix(pk.wh.data(), pk.wh.size() * 2); mix(pk.sbias.data(), pk.sbias.size() * 4);
-    mix(pk.wf16.data(), pk.wf16.size() * 16); mix(pk.wb16.data(), pk.wb16.size() * 16); mix(pk.wb4.data(), pk.wb4.size() * 16);
+    mix(pk.wf16.data(), pk.wf16.size() * 16); mix(pk.wb16.data(), pk.wb16.size() * 16); mix(pk.wb4.data(), pk.wb4.size() * 16); mix(pk.wf4.data(), pk.wf4.size() * 16);
     mix(pk.w1b16.data(), pk.w1b16.size() * 16); mix(pk.wf.data(), pk.wf.size() * 16); mix(pk.wb.data(), pk.wb.size() * 16);
     mix(pk.bh.data(), pk.bh.size() * 4); mix(pk.wl.data(), pk.wl.size() * 16); mix(pk.bl.data(), pk.bl.size() * 4);
     mix(pk.wlraw.data(), pk.wlraw.size() * 4); mix(pk.whraw.data(), pk.whraw.size() * 4); mix(pk.w1t.data(), pk.w1t.size() * 4);
@@ -2180,7 +2185,7 @@ int omds_screen_audit_stats(omds_ctx* ctx, int32_t* one_in, double* audit_rows_p
 // screening value moves; what = 1: shifts obstacle `index` by `value` along x in the SCREENING input table only (undone by
 // the next omds_set_obstacles) -- the fp16 network sees that one sphere elsewhere, so only the audit rows can notice.
 int omds_debug_force_tile_rows(int tail_sel_rows, int tail_rows) {
-    if (!((tail_sel_rows == 0 || tail_sel_rows == 4 || tail_sel_rows == 16 || tail_sel_rows == 32) && (tail_rows == 0 || tail_rows == 16 || tail_rows == 32)))
+    if (!((tail_sel_rows == 0 || tail_sel_rows == 4 || tail_sel_rows == 16 || tail_sel_rows == 32) && (tail_rows == 0 || tail_rows == 4 || tail_rows == 16 || tail_rows == 32)))
         return OMDS_ERR_INVALID_ARG;
     omds_force_tile_rows(tail_sel_rows, tail_rows);
     return OMDS_OK;

@@ -1527,3 +1527,127 @@ __device__ __forceinline__ void pass2_backward_hidden_g4(const MlpDev& m, const 
     }
     OMDS_TL_STAMP(8);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Pass 2 -- forward AND backward -- on 4-ROW GROUPS, for the all-fp32 tail of large batches (k_tail<ND, ACT, 4>): a workgroup
+// owns 4 NG = 20 network rows (four rollouts at k = 5), so that 1024 rollouts are 256 workgroups, one per CU, each multiplying
+// five groups of 4 rows per hidden layer where the 32-row tile of 171 workgroups multiplies 32 (11 264 against 16 384 matrix-
+// pipe cycles per SIMD and layer, forward and backward).  ReLU networks without skip concatenations.
+//   layer 1 (K = 32): the 32-row product of pass2_body on all eight waves (rows >= 4 NG are padding);
+//   hidden layers: gemm4 on waves 0-3 (columns 64 w .. +63), forward weights MlpDev::Wf4 through the ring across the layers;
+//     the epilogue (bias last, ReLU) leaves the level in the tile and its masks as sm.maskG4[(l + 1) * 256 + column], bit e =
+//     row e -- the layout pass2_backward_hidden_g4 reads; level 0's word is read back from the tile (h > 0 <=> z > 0);
+//   last layer, arg-min link, distance: as pass2_body; then pass2_backward_hidden_g4 + p2_backward_first<32>.
+// The same fmaf chains in the same k order as pass2_body<ACT, 32 | 16>: the same bits per row (tests/test_gpu_screen.py runs the
+// shapes against each other).
+// ------------------------------------------------------------------------------------------------
+template <int NG>
+__device__ __forceinline__ void pass2_body_g4(const MlpDev& m, P2Smem& sm, const float* __restrict__ Fq, const float* __restrict__ Fp,
+                                              const float* __restrict__ radius, const float* __restrict__ xyzr, int R0, int total_rows,
+                                              const float* __restrict__ qT, int ldq, float* gradx, float* drow, int dbase, int dbg = 0) {
+    using G = P2Geo<32>;
+    float* Hs = sm.Hs;
+    int* rowT = sm.rowT;
+    int* rowO = sm.rowO;
+    int* rowMin = sm.rowMin;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave & 3, col4 = 64 * cw + lane, pcol = omds_kpos(col4);
+    const bool mine = wave < 4;
+    sm.maskG4 = reinterpret_cast<uint32_t*>(sm.maskL);   // (nhh + 1) * 256 words <= the (nhh + 1) * 512 halfwords of maskL
+    constexpr int PD = 8;
+    W4Ring<PD> ring;
+    if (mine) {   // the first chunks of the first hidden product are on their way during the gather and layer 1
+        ring.bind(m.Wf4, m.nhh, cw, lane);
+        ring.fill(0);
+    }
+    const float b1v = m.b1[G::col(0, wave, lane)];
+    float bnext = mine ? m.bh[col4] : 0.f;
+    // ---- the rows' encoded inputs at positions 0..31: Fq[t] | Fp[o] (padding rows: zero), as pass2_body --------------------
+    for (int e = tid; e < 32 * 32; e += P2_NT) {
+        const int r = e >> 5, f = e & 31, t = rowT[r];
+        uint32_t v = 0u;
+        if (t >= 0) v = __builtin_bit_cast(uint32_t, Fq[(size_t)t * OMDS_FROW + f]) | __builtin_bit_cast(uint32_t, Fp[(size_t)rowO[r] * OMDS_FROW + f]);
+        reinterpret_cast<uint32_t*>(Hs)[r * LDH + omds_kpos(f)] = v;
+    }
+    __syncthreads();
+    // ---- layer 1 on the 32-row tile ---------------------------------------------------------------------------------------
+    {
+        float acc[G::NV];
+        p2_gemm<32>(Hs, m, -1, false, wave, lane, acc);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < G::NV; ++r) Hs[G::row(r, lane) * LDH + G::pos(r, wave, lane)] = actf(acc[r] + b1v, OMDS_ACT_RELU);
+    }
+    __syncthreads();
+    if (mine) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int e = 0; e < 4 * NG; ++e) bits |= (Hs[e * LDH + pcol] > 0.f ? 1u : 0u) << e;
+        sm.maskG4[col4] = bits;
+    }
+    // ---- hidden -> hidden layers on 4-row groups --------------------------------------------------------------------------
+    for (int l = 0; l < m.nhh; ++l) {
+        f32x4 acc[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float bv = bnext;
+        if (mine && l + 1 < m.nhh) bnext = m.bh[(l + 1) * OMDS_WIDTH + col4];
+        if (mine) gemm4<NG, PD>(Hs, ring, l, l + 1 < m.nhh ? l + 1 : -1, lane, acc);
+        __syncthreads();   // every wave has finished reading the tile
+        if (mine) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int e = 0; e < 4 * NG; ++e) {
+                const float z = acc[e >> 2][e & 3] + bv;
+                bits |= (z > 0.f ? 1u : 0u) << e;
+                Hs[e * LDH + pcol] = actf(z, OMDS_ACT_RELU);
+            }
+            sm.maskG4[(l + 1) * 256 + col4] = bits;
+        }
+        __syncthreads();
+    }
+    if (dbg == 11) return;
+    // ---- last layer, arg-min over ALL raw outputs (robot_sdf.py:155), distance of that link: as pass2_body ------------------
+    if (wave < 2) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = Hs + (wave * 16 + (lane & 15)) * LDH + pa16(lane);
+        const int j = lane & 15;
+        const float bj = m.bl[j];
+        {
+            float4 wl[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) wl[c] = m.Wl[c * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const float4 a = load_a16(arow, c);
+                const float4 w = wl[c];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int r = wave * 16 + 4 * (lane >> 4) + reg;
+            const int R = R0 + r;
+            const float y = acc[reg] + bj;
+            float bv = (j < m.C) ? y : __builtin_inff();
+            int bi = j;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const float ov = __shfl_xor(bv, off);
+                const int oi = __shfl_xor(bi, off);
+                if ((ov < bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (j == 0) {
+                rowMin[r] = bi;
+                if (R < total_rows) drow[dbase + r] = bv / m.out_div - radius[rowO[r]];
+            }
+        }
+    }
+    __syncthreads();
+    if (dbg == 12) return;
+    pass2_backward_hidden_g4<NG>(m, sm);
+    p2_backward_first<32>(m, sm, xyzr, R0, total_rows, qT, ldq, gradx, dbase, dbg);
+}

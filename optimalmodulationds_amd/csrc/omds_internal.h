@@ -70,6 +70,7 @@ struct MlpDev {
     const float4* Wb16;  // same shape, transposed
     const float4* W1b16; // [16 kchunk][2 colblk16][64 lane]
     const float4* Wb4;   // [nhh][4 colblk64][64 kq][64 lane] backward pack for the 4-row-group GEMM (gemm4): lane l = W[4kq .. +3][64cb + l]
+    const float4* Wf4;   // same shape, forward: lane l = W[64cb + l][positions 4kq .. +3] (pass2_body_g4: the all-fp32 tail on 4-row groups)
     int nhh;             // number of hidden->hidden layers (= hidden layers - 1)
     int C;               // output channels (links)
     int d;               // raw inputs: n_dof + 3 (obstacle x, y, z), or n_dof + 2 for the toy networks (x, y)
@@ -448,7 +449,7 @@ void omds_launch_modulate(hipStream_t s, const StepArgs& a);
 // fused per-step tail (tail_kernel.hip): top-k + pass 2 + blend + modulation + next-step layer-1 half
 bool omds_tail_supported(int n_dof, int k);
 int omds_tail_scratch_rows(int N, int k);
-int omds_tail_rows(int N, int k);            // pass-2 tile height (16 | 32) for a batch of N rollouts with k closest obstacles   // rows of the tanh-derivative scratch the tail may touch (either tile height)
+int omds_tail_rows(int N, int k, bool g4_ok = false);   // pass-2 tile height (16 | 32; 4 = 4-row groups, only with g4_ok) for N rollouts with k closest obstacles   // rows of the tanh-derivative scratch the tail may touch (either tile height)
 // FqOut: where the next step's encoded joint inputs go (nullptr: in place).  guard_range / e_bound / viol: screened tanh step --
 // Dmin holds exact values on the candidates and screening values elsewhere; the tail counts the rollouts whose k-th smallest
 // value is not e_bound below k_select's tau (range[4 t + 2]) into *viol

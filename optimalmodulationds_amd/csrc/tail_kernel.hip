@@ -55,7 +55,10 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
     float* feat = dr + 32;                                      // [32][3*ND]: q_next, sin, cos
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.st.N, k = a.st.k, O = a.O;
-    const int RW = ROWS / k;                  // rollouts per workgroup
+    // ROWS = 4: forward and backward on 4-row groups (pass2_body_g4): 4 G4_NG = 20 network rows per workgroup
+    static_assert(ACT == OMDS_ACT_RELU || ROWS != 4, "the 4-row-group pass 2 works on ReLU masks");
+    constexpr int G4_NG = 5, TROWS = ROWS == 4 ? 4 * G4_NG : ROWS;
+    const int RW = TROWS / k;                 // rollouts per workgroup
     const int t_base = a.t_begin + blockIdx.x * RW;
     const int t_end = a.t_end;
 
@@ -79,8 +82,11 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
 
     // ---- forward + backward on the selected rows; gradients and distances stay in LDS ------------
     const float* qT = a.st.trajT + (size_t)(a.st.step - 1) * ND * N;
-    pass2_body<ACT, ROWS>(m, sm, a.Fq, a.Fp, a.radius, a.xyzr, t_base * k, N * k, qT, N, gx, dr, 0, nullptr, nullptr,
-                                 a.dscr, (size_t)a.n_slots * ROWS * OMDS_WIDTH, (a.slot0 + (int)blockIdx.x) * ROWS, OMDS_DBG(a.dbg_stop));
+    if constexpr (ROWS == 4)
+        pass2_body_g4<G4_NG>(m, sm, a.Fq, a.Fp, a.radius, a.xyzr, t_base * k, N * k, qT, N, gx, dr, 0, OMDS_DBG(a.dbg_stop));
+    else
+        pass2_body<ACT, ROWS>(m, sm, a.Fq, a.Fp, a.radius, a.xyzr, t_base * k, N * k, qT, N, gx, dr, 0, nullptr, nullptr,
+                              a.dscr, (size_t)a.n_slots * ROWS * OMDS_WIDTH, (a.slot0 + (int)blockIdx.x) * ROWS, OMDS_DBG(a.dbg_stop));
     __syncthreads();
     if (OMDS_DBG(a.dbg_stop) == 2) return;
 
@@ -446,25 +452,37 @@ static void launch_tail_a(hipStream_t s, const TailArgs& a) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<ND, ACT, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)tail_lds_bytes(OMDS_MAX_HIDDEN + 1));
     }
-    const int RW = ROWS / a.st.k;
+    const int RW = (ROWS == 4 ? 20 : ROWS) / a.st.k;
     hipLaunchKernelGGL((k_tail<ND, ACT, ROWS>), dim3((a.t_end - a.t_begin + RW - 1) / RW), dim3(P2_NT), tail_lds_bytes(a.m.nhh + 1), s, a);
 }
 
 template <int ND, int ROWS>
 static void launch_tail_t(hipStream_t s, const TailArgs& a) {
     if (a.m.act == OMDS_ACT_RELU) launch_tail_a<ND, OMDS_ACT_RELU, ROWS>(s, a);
-    else launch_tail_a<ND, OMDS_ACT_TANH, ROWS>(s, a);
+    else if constexpr (ROWS != 4) launch_tail_a<ND, OMDS_ACT_TANH, ROWS>(s, a);
 }
 
 bool omds_tail_supported(int n_dof, int k) { return (n_dof == 7 || n_dof == 2) && k >= 1 && k <= P2_MT; }
 
-// 16-row tiles when 32-row tiles would leave most CUs without a workgroup (OMDS_TAIL_ROWS=16|32 forces one)
-int omds_tail_rows(int N, int k) {
+// 16-row tiles when 32-row tiles would leave most CUs without a workgroup (OMDS_TAIL_ROWS=4|16|32 forces one); g4_ok (ReLU network
+// without skip concatenations): 4-row groups, 20 rows per workgroup (k_tail<ND, ACT, 4>), where the busiest CU multiplies less that
+// way -- matrix-pipe cycles per hidden layer of the CU with the most workgroups, 5 groups x 2048 x 1.1 against 16 384 per 32-row tile
+// (the rule of tail_sel_rows).  N = 1024, k = 5: 256 workgroups, one per CU, against 171 tiles of 32 rows.
+int omds_tail_rows(int N, int k, bool g4_ok) {
     const int forced = OMDS_FORCED_ROWS(g_force_tail_rows, "OMDS_TAIL_ROWS");
     if (k > 16) return 32;
+    if (forced == 4 && g4_ok && k <= 20) return 4;
     if (forced == 16 || forced == 32) return forced;
     const int RW32 = 32 / k;
-    return (N + RW32 - 1) / RW32 <= 128 ? 16 : 32;
+    const long long wg32 = (N + RW32 - 1) / RW32;
+    if (wg32 <= 128) return 16;
+    if (forced == 0 && g4_ok && k <= 10) {
+        const int ncu = omds_cu_count(), RW4 = 20 / k;
+        const long long wg4 = (N + RW4 - 1) / RW4;
+        const long long cost32 = ((wg32 + ncu - 1) / ncu) * 16384, cost4 = ((wg4 + ncu - 1) / ncu) * (5 * 2048 * 11 / 10);
+        if (cost4 < cost32) return 4;
+    }
+    return 32;
 }
 
 int omds_tail_scratch_rows(int N, int k) {
@@ -480,8 +498,8 @@ void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Fp, const flo
     TailArgs a;
     a.FqH = reinterpret_cast<_Float16*>(FqH);
     a.ldF = ldF;
-    const int rows = omds_tail_rows(st.N, st.k);
-    const int RW = rows / st.k;
+    const int rows = omds_tail_rows(st.N, st.k, m.act == OMDS_ACT_RELU && m.skip_mask == 0 && m.nhh >= 1);
+    const int RW = (rows == 4 ? 20 : rows) / st.k;
     a.t_begin = t_begin; a.t_end = t_end;          // t_begin must be a multiple of RW
     a.slot0 = t_begin / RW;
     a.n_slots = (st.N + RW - 1) / RW;
@@ -489,7 +507,10 @@ void omds_launch_tail(hipStream_t s, const MlpDev& m, const float* Fp, const flo
     a.dbg_stop = stop;
     a.rowlist = nullptr; a.range = guard_range; a.ex = ExactOut{}; a.e_bound = e_bound; a.viol = viol;
     a.m = m; a.Fp = Fp; a.radius = radius; a.xyzr = xyzr; a.Dmin = Dmin; a.Fq = Fq; a.FqOut = FqOut ? FqOut : Fq; a.dscr = dscr; a.O = O; a.st = st;
-    if (rows == 16) {
+    if (rows == 4) {
+        if (st.n == 7) launch_tail_t<7, 4>(s, a);
+        else launch_tail_t<2, 4>(s, a);
+    } else if (rows == 16) {
         if (st.n == 7) launch_tail_t<7, 16>(s, a);
         else launch_tail_t<2, 16>(s, a);
     } else {

@@ -335,8 +335,8 @@ def test_screened_planar_networks_are_bit_identical(kind, n, k):
 @pytest.mark.parametrize("kind,n,k,N", [("planar2", 2, 1, 512), ("planar2", 2, 2, 512), ("planar2", 2, 5, 300), ("planar7", 7, 3, 512),
                                          ("franka", 7, 5, 1024), ("franka", 7, 4, 250)])
 def test_every_tile_shape_computes_the_same_bits(kind, n, k, N):
-    """The tail kernels choose a tile shape from the batch (32-row, 16-row, and for the screened step the backward on 4-row
-    groups); the choice must not show in the results.  Forces each shape in turn (omds_debug_force_tile_rows) for the screened
+    """The tail kernels choose a tile shape from the batch (32-row, 16-row, 4-row groups: the backward of the screened step, forward and
+    backward of the unscreened one); the choice must not show in the results.  Forces each shape in turn (omds_debug_force_tile_rows) for the screened
     and the unscreened step and compares every rollout tensor bit for bit -- the 2-DoF tail with the 4-row groups is the
     case in which a cross-statement multiply-add contraction once differed between two instantiations of the same source."""
     from optimalmodulationds_amd import scenes
@@ -383,7 +383,7 @@ def test_every_tile_shape_computes_the_same_bits(kind, n, k, N):
             e.close()
 
     ref, _ = run(0, 0, 32)
-    variants = [("unscreened 16-row", 0, 0, 16), ("screened 32-row", 1, 32, 0), ("screened 16-row", 1, 16, 0), ("screened 4-row groups", 1, 4, 0)]
+    variants = [("unscreened 16-row", 0, 0, 16), ("unscreened 4-row groups", 0, 0, 4), ("screened 32-row", 1, 32, 0), ("screened 16-row", 1, 16, 0), ("screened 4-row groups", 1, 4, 0)]
     for name, mode, sel_rows, tail_rows in variants:
         if sel_rows == 16 and k > 16:
             continue
