@@ -1541,8 +1541,33 @@ __device__ __forceinline__ void pass2_backward_hidden_g4(const MlpDev& m, const 
 // The same fmaf chains in the same k order as pass2_body<ACT, 32 | 16>: the same bits per row (tests/test_gpu_screen.py runs the
 // shapes against each other).
 // ------------------------------------------------------------------------------------------------
+// What pass2_body_g4 needs that does not depend on WHICH obstacles the rows are: requested before the caller's top-k, so that the
+// kernel's first dependent round trips (a fetch from another XCD's writes takes microseconds) run side by side instead of in a row
+struct P2G4Pre {
+    W4Ring<8> ring;      // waves 0-3: the first chunks of the first hidden product
+    float b1v, bnext;    // biases of layer 1 (this thread's column of the 32-row product) and of the first hidden product
+    uint32_t q[2];       // the rollout halves of this thread's two encoded-input elements: rows (tid >> 5) and 16 + (tid >> 5), feature tid & 31
+};
+// t_of_row(r) = the rollout of tile row r, or -1 (what the top-k will write to sm.rowT[r])
+template <typename TOfRow>
+__device__ __forceinline__ void pass2_g4_prefetch(const MlpDev& m, const float* __restrict__ Fq, TOfRow t_of_row, P2G4Pre& pre) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave & 3, col4 = 64 * cw + lane;
+    if (wave < 4) {
+        pre.ring.bind(m.Wf4, m.nhh, cw, lane);
+        pre.ring.fill(0);
+    }
+    pre.b1v = m.b1[P2Geo<32>::col(0, wave, lane)];
+    pre.bnext = wave < 4 ? m.bh[col4] : 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int t = t_of_row((tid >> 5) + 16 * h);
+        pre.q[h] = t >= 0 ? __builtin_bit_cast(uint32_t, Fq[(size_t)t * OMDS_FROW + (tid & 31)]) : 0u;
+    }
+}
+
 template <int NG>
-__device__ __forceinline__ void pass2_body_g4(const MlpDev& m, P2Smem& sm, const float* __restrict__ Fq, const float* __restrict__ Fp,
+__device__ __forceinline__ void pass2_body_g4(const MlpDev& m, P2Smem& sm, P2G4Pre& pre, const float* __restrict__ Fp,
                                               const float* __restrict__ radius, const float* __restrict__ xyzr, int R0, int total_rows,
                                               const float* __restrict__ qT, int ldq, float* gradx, float* drow, int dbase, int dbg = 0) {
     using G = P2Geo<32>;
@@ -1555,21 +1580,25 @@ __device__ __forceinline__ void pass2_body_g4(const MlpDev& m, P2Smem& sm, const
     const bool mine = wave < 4;
     sm.maskG4 = reinterpret_cast<uint32_t*>(sm.maskL);   // (nhh + 1) * 256 words <= the (nhh + 1) * 512 halfwords of maskL
     constexpr int PD = 8;
-    W4Ring<PD> ring;
-    if (mine) {   // the first chunks of the first hidden product are on their way during the gather and layer 1
-        ring.bind(m.Wf4, m.nhh, cw, lane);
-        ring.fill(0);
-    }
-    const float b1v = m.b1[G::col(0, wave, lane)];
-    float bnext = mine ? m.bh[col4] : 0.f;
-    // ---- the rows' encoded inputs at positions 0..31: Fq[t] | Fp[o] (padding rows: zero), as pass2_body --------------------
-    for (int e = tid; e < 32 * 32; e += P2_NT) {
-        const int r = e >> 5, f = e & 31, t = rowT[r];
-        uint32_t v = 0u;
-        if (t >= 0) v = __builtin_bit_cast(uint32_t, Fq[(size_t)t * OMDS_FROW + f]) | __builtin_bit_cast(uint32_t, Fp[(size_t)rowO[r] * OMDS_FROW + f]);
-        reinterpret_cast<uint32_t*>(Hs)[r * LDH + omds_kpos(f)] = v;
+    W4Ring<PD>& ring = pre.ring;
+    const float b1v = pre.b1v;
+    float bnext = pre.bnext;
+    // ---- the rows' encoded inputs at positions 0..31: Fq[t] | Fp[o] (padding rows: zero), as pass2_body; the rollout half is
+    //      already here, the two obstacle halves are one round trip -----------------------------------------------------------
+    {
+        uint32_t pv[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = (tid >> 5) + 16 * h;
+            pv[h] = rowT[r] >= 0 ? __builtin_bit_cast(uint32_t, Fp[(size_t)rowO[r] * OMDS_FROW + (tid & 31)]) : 0u;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            reinterpret_cast<uint32_t*>(Hs)[((tid >> 5) + 16 * h) * LDH + omds_kpos(tid & 31)] = rowT[(tid >> 5) + 16 * h] >= 0 ? (pre.q[h] | pv[h]) : 0u;
     }
     __syncthreads();
+    OMDS_TL_STAMP(3);
+    if (dbg == 16) return;
     // ---- layer 1 on the 32-row tile ---------------------------------------------------------------------------------------
     {
         float acc[G::NV];
@@ -1579,6 +1608,8 @@ __device__ __forceinline__ void pass2_body_g4(const MlpDev& m, P2Smem& sm, const
         for (int r = 0; r < G::NV; ++r) Hs[G::row(r, lane) * LDH + G::pos(r, wave, lane)] = actf(acc[r] + b1v, OMDS_ACT_RELU);
     }
     __syncthreads();
+    OMDS_TL_STAMP(17);
+    if (dbg == 10) return;
     if (mine) {
         uint32_t bits = 0;
 #pragma unroll
@@ -1606,6 +1637,7 @@ __device__ __forceinline__ void pass2_body_g4(const MlpDev& m, P2Smem& sm, const
         }
         __syncthreads();
     }
+    OMDS_TL_STAMP(18);
     if (dbg == 11) return;
     // ---- last layer, arg-min over ALL raw outputs (robot_sdf.py:155), distance of that link: as pass2_body ------------------
     if (wave < 2) {
@@ -1649,5 +1681,6 @@ __device__ __forceinline__ void pass2_body_g4(const MlpDev& m, P2Smem& sm, const
     __syncthreads();
     if (dbg == 12) return;
     pass2_backward_hidden_g4<NG>(m, sm);
+    if (dbg == 14) return;
     p2_backward_first<32>(m, sm, xyzr, R0, total_rows, qT, ldq, gradx, dbase, dbg);
 }

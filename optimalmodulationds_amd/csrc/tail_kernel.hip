@@ -62,6 +62,11 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
     const int t_base = a.t_begin + blockIdx.x * RW;
     const int t_end = a.t_end;
 
+    OMDS_TL_STAMP(0);
+    OMDS_TL_STAMP(1);
+    P2G4Pre pre;   // (ROWS = 4) everything of pass 2 that does not wait for the top-k is requested in front of it
+    if constexpr (ROWS == 4)
+        pass2_g4_prefetch(m, a.Fq, [&](int r) { const int rl = r / k; return (rl < RW && t_base + rl < t_end) ? t_base + rl : -1; }, pre);
     // ---- top-k of each rollout's min-distance row (ascending, ties by lower obstacle index) -------
     if (tid < P2_MT) { sm.rowT[tid] = -1; sm.rowO[tid] = 0; }
     __syncthreads();
@@ -78,16 +83,18 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
         });
     }
     __syncthreads();
+    OMDS_TL_STAMP(2);
     if (OMDS_DBG(a.dbg_stop) == 1) return;
 
     // ---- forward + backward on the selected rows; gradients and distances stay in LDS ------------
     const float* qT = a.st.trajT + (size_t)(a.st.step - 1) * ND * N;
     if constexpr (ROWS == 4)
-        pass2_body_g4<G4_NG>(m, sm, a.Fq, a.Fp, a.radius, a.xyzr, t_base * k, N * k, qT, N, gx, dr, 0, OMDS_DBG(a.dbg_stop));
+        pass2_body_g4<G4_NG>(m, sm, pre, a.Fp, a.radius, a.xyzr, t_base * k, N * k, qT, N, gx, dr, 0, OMDS_DBG(a.dbg_stop));
     else
         pass2_body<ACT, ROWS>(m, sm, a.Fq, a.Fp, a.radius, a.xyzr, t_base * k, N * k, qT, N, gx, dr, 0, nullptr, nullptr,
                               a.dscr, (size_t)a.n_slots * ROWS * OMDS_WIDTH, (a.slot0 + (int)blockIdx.x) * ROWS, OMDS_DBG(a.dbg_stop));
     __syncthreads();
+    OMDS_TL_STAMP(9);
     if (OMDS_DBG(a.dbg_stop) == 2) return;
 
     // ---- modulation / policy / Euler step: 16 lanes per rollout -------------------------------------
@@ -121,6 +128,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
             }
         }
     }
+    OMDS_TL_STAMP(10);
     if (a.st.step >= a.st.H || OMDS_DBG(a.dbg_stop) == 3) return;   // last step: nothing is integrated, no next network evaluation
     __syncthreads();
 
@@ -132,10 +140,15 @@ __global__ __launch_bounds__(P2_NT) void k_tail(TailArgs a) {
             if (t < t_end) a.FqOut[(size_t)t * OMDS_FROW + part * d + (cc - part * ND)] = feat[e];
         }
     }
+    OMDS_TL_STAMP(11);
+    OMDS_TL_STAMP(19);
 }
 
 
 static size_t tail_lds_bytes(int nhid);
+#ifdef OMDS_TAIL_TL
+__global__ void k_tail_tl_dump(int nb);
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Screened step: k_screen -> k_select -> k_exact -> k_tail_sel.  k_exact has evaluated every candidate row in fp32 with
@@ -353,7 +366,7 @@ __global__ __launch_bounds__(P2_NT) void k_tail_sel(TailArgs a) {
 __global__ void k_tail_tl_dump(int nb) {
     for (int b = 0; b < nb && b < 1024; ++b) {
         printf("TL %d", b);
-        for (int i = 0; i < 17; ++i) printf(" %llu", g_tail_tl[b][i]);   // 12..16: inside modulate_core
+        for (int i = 0; i < 19; ++i) printf(" %llu", g_tail_tl[b][i]);   // 12..16: inside modulate_core, 17..18: pass2_body_g4
         printf(" %llu\n", g_tail_tl[b][19]);
     }
 }
@@ -454,6 +467,13 @@ static void launch_tail_a(hipStream_t s, const TailArgs& a) {
     }
     const int RW = (ROWS == 4 ? 20 : ROWS) / a.st.k;
     hipLaunchKernelGGL((k_tail<ND, ACT, ROWS>), dim3((a.t_end - a.t_begin + RW - 1) / RW), dim3(P2_NT), tail_lds_bytes(a.m.nhh + 1), s, a);
+#ifdef OMDS_TAIL_TL
+    {
+        static int seen = 0;
+        static const int want = OMDS_EXP_ENV("OMDS_TAIL_TL_STEP", -1);
+        if (a.st.step == want && ++seen == 3) hipLaunchKernelGGL(k_tail_tl_dump, dim3(1), dim3(1), 0, s, (a.t_end - a.t_begin + RW - 1) / RW);
+    }
+#endif
 }
 
 template <int ND, int ROWS>

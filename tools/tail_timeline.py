@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase timeline of k_tail_sel from the diagnostic build (-DOMDS_TAIL_TL): reads the 'TL ...' lines the dump kernel printed
+"""Phase timeline of k_tail_sel (and of k_tail on 4-row groups: --path fp32) from the diagnostic build (-DOMDS_TAIL_TL): reads the 'TL ...' lines the dump kernel printed
 (stdin or a file) and reports, over the workgroups of one launch, when each phase boundary is reached after the first
 workgroup's entry (median / max, microseconds at the measured shader clock) and the clock itself.
 
@@ -36,5 +36,11 @@ if len(rows[0]) >= 19:
         d = [(r[i] - r[2]) / (ghz * 1e3) for r in rows if r[i]]
         if d:
             print("%-28s %10.2f %10.2f" % (nm, statistics.median(d), max(d)))
+if len(rows[0]) >= 21 and rows[0][18]:   # k_tail on 4-row groups (pass2_body_g4 stamps 3, 17, 18): its own phase list
+    print("-- k_tail<.., 4>: phase boundary, median / max us after the workgroup's own entry")
+    for i, nm in ((3, "top-k done"), (4, "inputs gathered"), (18, "layer 1 done"), (19, "hidden forward done"), (5, "last layer + seed done"),
+                  (9, "hidden backward done"), (10, "backward done"), (11, "modulation done"), (12, "next inputs written")):
+        d = [(r[i] - r[2]) / (ghz * 1e3) for r in rows if r[i]]
+        print("%-28s %10.2f %10.2f" % (nm, statistics.median(d), max(d)))
 late = sorted(rows, key=lambda r: r[1])
 print("entry of the 257th workgroup: %.2f us after the first" % ((late[256][1] - t0) / 100.0) if len(late) > 256 else "at most 256 workgroups")
