@@ -485,9 +485,11 @@ static void launch_tail_t(hipStream_t s, const TailArgs& a) {
 bool omds_tail_supported(int n_dof, int k) { return (n_dof == 7 || n_dof == 2) && k >= 1 && k <= P2_MT; }
 
 // 16-row tiles when 32-row tiles would leave most CUs without a workgroup (OMDS_TAIL_ROWS=4|16|32 forces one); g4_ok (ReLU network
-// without skip concatenations): 4-row groups, 20 rows per workgroup (k_tail<ND, ACT, 4>), where the busiest CU multiplies less that
-// way -- matrix-pipe cycles per hidden layer of the CU with the most workgroups, 5 groups x 2048 x 1.1 against 16 384 per 32-row tile
-// (the rule of tail_sel_rows).  N = 1024, k = 5: 256 workgroups, one per CU, against 171 tiles of 32 rows.
+// without skip concatenations): 4-row groups, 20 rows per workgroup (k_tail<ND, ACT, 4>), while its workgroups fit the CUs in ONE
+// round -- 5 groups x 2048 x 1.1 matrix-pipe cycles per hidden layer against 16 384 per 32-row tile.  N = 1024, k = 5: 256 workgroups,
+// one per CU, against 171 tiles of 32 rows (71.6 -> 58.4 us).  Beyond one round the 32-row tile wins: the 4-row-group kernel holds
+// the weight ring in 64 registers (134 in all: one workgroup per CU, nothing fills its top-k / modulation phases) and multiplies on
+// four of its eight waves -- N = 4096: 233 against 200 us, N = 8192: 460 against 358 (tools/tail_rows_ab.sh).
 int omds_tail_rows(int N, int k, bool g4_ok) {
     const int forced = OMDS_FORCED_ROWS(g_force_tail_rows, "OMDS_TAIL_ROWS");
     if (k > 16) return 32;
@@ -499,8 +501,7 @@ int omds_tail_rows(int N, int k, bool g4_ok) {
     if (forced == 0 && g4_ok && k <= 10) {
         const int ncu = omds_cu_count(), RW4 = 20 / k;
         const long long wg4 = (N + RW4 - 1) / RW4;
-        const long long cost32 = ((wg32 + ncu - 1) / ncu) * 16384, cost4 = ((wg4 + ncu - 1) / ncu) * (5 * 2048 * 11 / 10);
-        if (cost4 < cost32) return 4;
+        if (wg4 <= ncu) return 4;
     }
     return 32;
 }
