@@ -1089,34 +1089,73 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
 
 // k smallest entries of row[0..O) in ascending order (ties by lower index), one wave per row.
 // emit(j, index) is called by lane 0.  Rows of up to 512 entries are held in registers.
+// In-register rows: every entry becomes ONE 64-bit key, (order-preserving image of the value) << 32 | index, so that "smaller value,
+// then lower index" is an unsigned comparison, "after the previous pick" is key > previous key, and a round is a local minimum over
+// the lane's keys + a wave minimum on DPP row operations (quad xor 1 / 2, half-row and row mirror, row broadcasts 15 / 31: no LDS
+// crossbar in the chain) -- a third of the cycles of the (value, index) butterfly of ds_bpermutes it replaces.  -0 counts as +0
+// (they compare equal, the index decides); a NaN is never picked (its key is the "nothing" key); rows with fewer than k pickable
+// entries repeat index 0, as before.
+__device__ __forceinline__ unsigned long long omds_dpp_min_u64(unsigned long long v, unsigned long long o) { return o < v ? o : v; }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long omds_dpp_step_min_u64(unsigned long long v) {
+    const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+    return omds_dpp_min_u64(v, ((unsigned long long)ohi << 32) | olo);
+}
+// the minimum over the wave, in every lane's copy of lane 63 (returned as a uniform value)
+__device__ __forceinline__ unsigned long long omds_wave_min_u64(unsigned long long v) {
+    v = omds_dpp_step_min_u64<0xB1, 0xF>(v);    // quad_perm [1, 0, 3, 2]
+    v = omds_dpp_step_min_u64<0x4E, 0xF>(v);    // quad_perm [2, 3, 0, 1]
+    v = omds_dpp_step_min_u64<0x141, 0xF>(v);   // row_half_mirror
+    v = omds_dpp_step_min_u64<0x140, 0xF>(v);   // row_mirror: every lane of a 16-lane row holds the row's minimum
+    v = omds_dpp_step_min_u64<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+    v = omds_dpp_step_min_u64<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's minimum
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
 template <typename Emit>
 __device__ __forceinline__ void topk_row(const float* __restrict__ row, int O, int k, int lane, Emit emit) {
     constexpr int NV = 8;
-    float v[NV];
-    const bool in_regs = O <= 64 * NV;
-    if (in_regs) {
+    constexpr unsigned long long NONE = ~0ull;
+    if (O <= 64 * NV) {
+        unsigned long long key[NV];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) { const int o = lane + 64 * i; v[i] = (o < O) ? row[o] : __builtin_nanf(""); }
+        for (int i = 0; i < NV; ++i) {
+            const int o = lane + 64 * i;
+            key[i] = NONE;
+            if (o < O) {
+                const float x = row[o] + 0.f;   // -0 -> +0
+                const unsigned u = __builtin_bit_cast(unsigned, x);
+                const unsigned ord = u ^ ((unsigned)((int)u >> 31) | 0x80000000u);   // x < y  <=>  ord(x) < ord(y)
+                if (x == x) key[i] = ((unsigned long long)ord << 32) | (unsigned)o;
+            }
+        }
+        unsigned long long prev = 0ull;
+        bool first = true;
+        for (int j = 0; j < k; ++j) {
+            unsigned long long best = NONE;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const bool after = first || key[i] > prev;
+                best = (after && key[i] < best) ? key[i] : best;
+            }
+            best = omds_wave_min_u64(best);
+            if (lane == 0) emit(j, best == NONE ? 0 : (int)(unsigned)best);
+            prev = best;
+            first = false;
+        }
+        return;
     }
     float pv = -__builtin_inff();
     int pi = -1;
     for (int j = 0; j < k; ++j) {
         float bv = __builtin_inff();
         int bi = 0x7fffffff;
-        if (in_regs) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int o = lane + 64 * i;
-                const float x = v[i];                      // NaN (padding) fails every comparison
-                const bool after = (x > pv) || (x == pv && o > pi);
-                if (after && ((x < bv) || (x == bv && o < bi))) { bv = x; bi = o; }
-            }
-        } else {
-            for (int o = lane; o < O; o += 64) {
-                const float x = row[o];
-                const bool after = (x > pv) || (x == pv && o > pi);
-                if (after && ((x < bv) || (x == bv && o < bi))) { bv = x; bi = o; }
-            }
+        for (int o = lane; o < O; o += 64) {
+            const float x = row[o];
+            const bool after = (x > pv) || (x == pv && o > pi);
+            if (after && ((x < bv) || (x == bv && o < bi))) { bv = x; bi = o; }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
