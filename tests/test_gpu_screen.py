@@ -333,7 +333,7 @@ def test_screened_planar_networks_are_bit_identical(kind, n, k):
 
 
 @pytest.mark.parametrize("kind,n,k,N", [("planar2", 2, 1, 512), ("planar2", 2, 2, 512), ("planar2", 2, 5, 300), ("planar7", 7, 3, 512),
-                                         ("franka", 7, 5, 1024), ("franka", 7, 4, 250)])
+                                         ("franka", 7, 5, 1024), ("franka", 7, 4, 250), ("franka_dup", 7, 7, 600), ("franka_dup", 7, 10, 333)])
 def test_every_tile_shape_computes_the_same_bits(kind, n, k, N):
     """The tail kernels choose a tile shape from the batch (32-row, 16-row, 4-row groups: the backward of the screened step, forward and
     backward of the unscreened one); the choice must not show in the results.  Forces each shape in turn (omds_debug_force_tile_rows) for the screened
@@ -341,10 +341,14 @@ def test_every_tile_shape_computes_the_same_bits(kind, n, k, N):
     case in which a cross-statement multiply-add contraction once differed between two instantiations of the same source."""
     from optimalmodulationds_amd import scenes
     from optimalmodulationds_amd.engine import Engine
+    dup = kind == "franka_dup"   # every 4th obstacle twice: exactly equal distances, the top-k's tie rule (lower index) in every shape
+    kind = "franka" if dup else kind
     m = orc.Mlp.from_npz(weights_path(kind))
     rng = np.random.RandomState(5)
     if kind == "franka":
         obs, q0, qf = scenes.shelf_scene(), scenes.FRANKA_Q0, scenes.FRANKA_QF
+        if dup:
+            obs = np.concatenate([obs, obs[::4]]).astype(np.float32)
         dt, thr, ign = 0.5, 0.01, 0b111
     else:
         reach = 6.5 if n == 2 else 7.5
