@@ -779,7 +779,7 @@ constexpr int OMDS_IDS = OMDS_WIDTH + 64;   // entries of the position -> unit t
 
 template <int MR>
 __device__ __forceinline__ void gemm_gather(const float* __restrict__ Hw, const uint32_t* __restrict__ idsS, const float* __restrict__ WT, int cb0,
-                                            int lane, f32x16 (&acc)[MR][1], int nch) {
+                                            int lane, f32x16 (&acc)[MR][1], int nch, unsigned long long* tl_first = nullptr) {
     // LDS byte addresses, as integers: the two running addresses stay two registers with immediate offsets (derived from one another
     // by the optimiser they cost three additions per chunk)
     uint32_t arow = omds_lds_addr(Hw + (lane & 31) * LDH + 4 * (lane >> 5));
@@ -841,6 +841,9 @@ __device__ __forceinline__ void gemm_gather(const float* __restrict__ Hw, const 
     loadB(i1, b1);
     i0 = loadI(irow + 64);
     __builtin_amdgcn_sched_barrier(0);
+#ifdef OMDS_TIMELINE   // diagnostic build: when this product's first operands are here (tl_first: thread 0's slot)
+    if (tl_first) { OMDS_TL_WAIT("vmcnt(4) lgkmcnt(1)"); *tl_first = wall_clock64(); }
+#endif
     mfma4_first(a0, b0);
     __builtin_amdgcn_sched_barrier(0);
     // now (a1, b1) is chunk 1, i0 the table entries of chunk 2
@@ -948,7 +951,13 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
             gemm_k32<MR, 1>(Hs, m.W1f, wv, lane, acc);
-        } else gemm_gather<MR>(Hs, idsS, m.WhT + (size_t)l * (OMDS_WIDTH * OMDS_WIDTH), wv, lane, acc, (T + 7) >> 3);
+        }
+#ifdef OMDS_TIMELINE
+        else gemm_gather<MR>(Hs, idsS, m.WhT + (size_t)l * (OMDS_WIDTH * OMDS_WIDTH), wv, lane, acc, (T + 7) >> 3,
+                             (m.tl && threadIdx.x == 0 && l < 3) ? m.tl + (size_t)blockIdx.x * 16 + 11 + l : nullptr);
+#else
+        else gemm_gather<MR>(Hs, idsS, m.WhT + (size_t)l * (OMDS_WIDTH * OMDS_WIDTH), wv, lane, acc, (T + 7) >> 3);
+#endif
         OMDS_DYN_PRIO(OMDS_DYN_PRIO_EPI);
         OMDS_TL(2 + 2 * (l + 1));   // this wave's share of the product done (diagnostic build)
         // bias (last, as the reference adds it), ReLU, and which of this wave's units fired in the tile (the column of lane l and of

@@ -37,7 +37,7 @@ fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 assert fn(eng.h, buf.ctypes.data, nwg) == 0
 print(eng.pass1_skip_stats())
 eng.close()
-t = buf[:, :11].astype(np.int64)
+t = buf[:, :15].astype(np.int64)
 hw = buf[:, 15]
 us = (t - t[:, 0].min()) / 100.0
 xcc = (hw >> np.uint64(32)).astype(np.int64) & 0xF
@@ -53,6 +53,10 @@ for name, sel in (("64-row", big), ("32-row", ~big)):
     for k in range(4):
         ph.append((f"product {k}", u[:, 2 + 2 * k] - (u[:, 1] if k == 0 else u[:, 1 + 2 * k])))
         ph.append((f"store level {k}", u[:, 3 + 2 * k] - u[:, 2 + 2 * k]))
+    for k in range(1, 4):
+        ok = t[sel][:, 10 + k] > 0
+        if ok.any():
+            ph.append((f"  product {k}: operands of chunk 0 here", (us[sel][ok][:, 10 + k] - u[ok][:, 1 + 2 * k])))
     ph.append(("last layer", u[:, 10] - u[:, 9]))
     ph.append(("whole tile", u[:, 10] - u[:, 0]))
     for kname, v in ph:
