@@ -869,6 +869,9 @@ __device__ __forceinline__ void gemm_gather(const float* __restrict__ Hw, const 
     if ((n - 1) & 1) mfma4(a1, b1);   // an even count: the last chunk is the one the final pair (or the prologue) fetched
 }
 
+#ifndef OMDS_DYN_PRIO_PROD
+#define OMDS_DYN_PRIO_PROD 0
+#endif
 #ifndef OMDS_DYN_PRIO_EPI
 #define OMDS_DYN_PRIO_EPI 3
 #endif
@@ -944,7 +947,7 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
         f32x16 acc[MR][1];
         const float bnow = bcur;
         if (l + 1 < m.nhh) bcur = m.bh[(l + 1) * OMDS_WIDTH + col];
-        OMDS_DYN_PRIO(0);
+        OMDS_DYN_PRIO(OMDS_DYN_PRIO_PROD);
         if (l < 0) {
 #pragma unroll
             for (int i = 0; i < MR; ++i)
