@@ -355,10 +355,17 @@ struct Geo<16, 1, 1> {
 // ------------------------------------------------------------------------------------------------
 // Diagnostic build (make timeline): workgroup phase timestamps, read by tools/pass1_timeline.py.  Compiles to nothing otherwise.
 #ifdef OMDS_TIMELINE
+#ifdef OMDS_TIMELINE_E   // per-WAVE stamps around one level's product and epilogue instead (tools/pass1_dyn_epilogue.py): [workgroup][wave][8]
+#define OMDS_TL(i) do { } while (0)
+#define OMDS_TLE(l, s) do { if (m.tl && (l) == OMDS_TIMELINE_E && (threadIdx.x & 63) == 0) m.tl[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (s)] = wall_clock64(); } while (0)
+#else
 #define OMDS_TL(i) do { if (m.tl && threadIdx.x == 0) m.tl[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#define OMDS_TLE(l, s) do { } while (0)
+#endif
 #define OMDS_TL_WAIT(what) asm volatile("s_waitcnt " what ::: "memory")
 #else
 #define OMDS_TL(i) do { } while (0)
+#define OMDS_TLE(l, s) do { } while (0)
 #define OMDS_TL_WAIT(what) do { } while (0)
 #endif
 
@@ -947,6 +954,7 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
         f32x16 acc[MR][1];
         const float bnow = bcur;
         if (l + 1 < m.nhh) bcur = m.bh[(l + 1) * OMDS_WIDTH + col];
+        OMDS_TLE(l, 0);
         OMDS_DYN_PRIO(OMDS_DYN_PRIO_PROD);
         if (l < 0) {
 #pragma unroll
@@ -963,6 +971,7 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
 #endif
         OMDS_DYN_PRIO(OMDS_DYN_PRIO_EPI);
         OMDS_TL(2 + 2 * (l + 1));   // this wave's share of the product done (diagnostic build)
+        OMDS_TLE(l, 1);
         // bias (last, as the reference adds it), ReLU, and which of this wave's units fired in the tile (the column of lane l and of
         // lane l + 32 is the same unit).  v_max_f32 / v_max3_f32 written out: fmaxf() would canonicalise every operand first
 #pragma unroll
@@ -980,7 +989,9 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
         const unsigned long long bal = __ballot(zm > 0.f);
         const uint32_t mine = (uint32_t)bal | (uint32_t)(bal >> 32);
         if (lane == 0) aliveS[wv] = mine;
+        OMDS_TLE(l, 2);
         __syncthreads();  // every wave has finished reading the tile and the table; the eight masks are there
+        OMDS_TLE(l, 3);
         const uint4 mlo = *reinterpret_cast<const uint4*>(aliveS), mhi = *reinterpret_cast<const uint4*>(aliveS + 4);
         const uint32_t mk[8] = {mlo.x, mlo.y, mlo.z, mlo.w, mhi.x, mhi.y, mhi.z, mhi.w};
         int base = 0, total = 0;
@@ -1018,7 +1029,9 @@ __device__ __forceinline__ void pass1_tile_dyn(const MlpDev& m, float* smem, con
                 if (tid % MT == 0) idsS[omds_kpos(pz)] = 0u;
             }
         }
+        OMDS_TLE(l, 4);
         __syncthreads();
+        OMDS_TLE(l, 5);
         OMDS_TL(3 + 2 * (l + 1));
     }
 
