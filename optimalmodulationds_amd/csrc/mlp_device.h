@@ -830,8 +830,7 @@ __device__ __forceinline__ void gemm_gather(const float* __restrict__ Hw, const 
         for (int i = 0; i < MR; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[3], acc[i][0], 0, 0, 0);
     };
     // three stages: the table entries of chunk c + 2 (LDS), the operands of chunk c + 1 (LDS, L2), the MFMAs of chunk c.
-    // Every VALU instruction of this kernel costs its ~3.3 issue cycles on top of the MFMAs' (EXPERIMENTS.md R6.11): chunk 0 is peeled so
-    // that no accumulator is cleared.
+    // Chunk 0 is peeled so that no accumulator is cleared (a VALU instruction beside the MFMAs is not free: EXPERIMENTS.md R6.11, R6.13).
     const int n = __builtin_amdgcn_readfirstlane(nch);
     if (n == 0) {
 #pragma unroll
