@@ -1259,6 +1259,67 @@ template <int ROWS>
 __device__ __forceinline__ void p2_backward_first(const MlpDev& m, const P2Smem& sm, const float* __restrict__ xyzr, int R0,
                                                   int total_rows, const float* __restrict__ qT, int ldq, float* gradx, int dbase, int dbg = 0);
 
+// The last layer of pass 2 on the tile in LDS (v_mfma_f32_16x16x4, waves 0 .. ROWS / 16 - 1), the arg-min over ALL raw outputs
+// (robot_sdf.py:155) and the distance of that link: sm.rowMin[r], drow[dbase + r]; optionally the raw outputs, the arg-min per global
+// row, and the pass-1 value of each row (d1row: min over the un-ignored links of y / out_div - radius, MPPI.py:236-242).  seed_col >= 0:
+// that output column instead of the arg-min one.  Shared by pass2_body and pass2_body_g4 (32 rows there, 20 of them real).
+template <int ROWS>
+__device__ __forceinline__ void p2_last_layer(const MlpDev& m, const float* Hs, int* rowMin, const int* rowO, const float* __restrict__ radius,
+                                              int R0, int total_rows, float* drow, int dbase, float* __restrict__ yraw,
+                                              int32_t* __restrict__ minidx, float* d1row, uint32_t ignored, int seed_col) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave < ROWS / 16) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = Hs + (wave * 16 + (lane & 15)) * LDH + pa16(lane);
+        const int j = lane & 15;
+        const float bj = m.bl[j];
+        // all 16 weight fragments in flight at once: the MFMA chain below is latency-bound otherwise
+        {
+            float4 wl[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) wl[c] = m.Wl[c * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const float4 a = load_a16(arow, c);
+                const float4 w = wl[c];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int r = wave * 16 + 4 * (lane >> 4) + reg;
+            const int R = R0 + r;
+            const float y = acc[reg] + bj;
+            if (yraw != nullptr && R < total_rows) yraw[(size_t)R * OMDS_CPAD + j] = (j < m.C) ? y : 0.f;
+            float bv = (j < m.C && (seed_col < 0 || j == seed_col)) ? y : __builtin_inff();
+            int bi = j;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const float ov = __shfl_xor(bv, off);
+                const int oi = __shfl_xor(bi, off);
+                if ((ov < bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (d1row != nullptr) {
+                float v = y / m.out_div - radius[rowO[r]];
+                v = (j >= m.C) ? __builtin_inff() : (((ignored >> j) & 1u) ? 1e6f : v);
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) v = fminf(v, __shfl_xor(v, off));
+                if (j == 0) d1row[r] = v;
+            }
+            if (j == 0) {
+                rowMin[r] = bi;
+                if (R < total_rows) {
+                    drow[dbase + r] = bv / m.out_div - radius[rowO[r]];
+                    if (minidx != nullptr) minidx[R] = bi;
+                }
+            }
+        }
+    }
+}
+
 // Body of pass 2 for the ROWS rows described by sm.rowT / sm.rowO (already in LDS, barrier done by the
 // caller).  R0 = global index of row 0 (tanh scratch, yraw, minidx); outputs go to
 // gradx[(dbase + row) * d + j] and drow[dbase + row] (global memory or LDS).
@@ -1342,56 +1403,7 @@ __device__ __forceinline__ void pass2_body(const MlpDev& m, const P2Smem& sm, co
 
     if (dbg == 11) return;
     // ---- last layer, arg-min over ALL raw outputs (robot_sdf.py:155), distance of that link -------
-    if (wave < ROWS / 16) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* arow = Hs + (wave * 16 + (lane & 15)) * LDH + pa16(lane);
-        const int j = lane & 15;
-        const float bj = m.bl[j];
-        // all 16 weight fragments in flight at once: the MFMA chain below is latency-bound otherwise
-        {
-            float4 wl[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) wl[c] = m.Wl[c * 64 + lane];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const float4 a = load_a16(arow, c);
-                const float4 w = wl[c];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int r = wave * 16 + 4 * (lane >> 4) + reg;
-            const int R = R0 + r;
-            const float y = acc[reg] + bj;
-            if (yraw != nullptr && R < total_rows) yraw[(size_t)R * OMDS_CPAD + j] = (j < m.C) ? y : 0.f;
-            float bv = (j < m.C && (seed_col < 0 || j == seed_col)) ? y : __builtin_inff();
-            int bi = j;
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                const float ov = __shfl_xor(bv, off);
-                const int oi = __shfl_xor(bi, off);
-                if ((ov < bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
-            if (d1row != nullptr) {
-                float v = y / m.out_div - radius[rowO[r]];
-                v = (j >= m.C) ? __builtin_inff() : (((ignored >> j) & 1u) ? 1e6f : v);
-#pragma unroll
-                for (int off = 1; off < 16; off <<= 1) v = fminf(v, __shfl_xor(v, off));
-                if (j == 0) d1row[r] = v;
-            }
-            if (j == 0) {
-                rowMin[r] = bi;
-                if (R < total_rows) {
-                    drow[dbase + r] = bv / m.out_div - radius[rowO[r]];
-                    if (minidx != nullptr) minidx[R] = bi;
-                }
-            }
-        }
-    }
+    p2_last_layer<ROWS>(m, Hs, rowMin, rowO, radius, R0, total_rows, drow, dbase, yraw, minidx, d1row, ignored, seed_col);
     __syncthreads();
     if (dbg == 12) return;
     pass2_backward<ACT, ROWS>(m, sm, xyzr, R0, total_rows, qT, ldq, gradx, dbase, dscr, dlayer, S0, dbg);
@@ -1702,45 +1714,8 @@ __device__ __forceinline__ void pass2_body_g4(const MlpDev& m, P2Smem& sm, P2G4P
     }
     OMDS_TL_STAMP(18);
     if (dbg == 11) return;
-    // ---- last layer, arg-min over ALL raw outputs (robot_sdf.py:155), distance of that link: as pass2_body ------------------
-    if (wave < 2) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* arow = Hs + (wave * 16 + (lane & 15)) * LDH + pa16(lane);
-        const int j = lane & 15;
-        const float bj = m.bl[j];
-        {
-            float4 wl[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) wl[c] = m.Wl[c * 64 + lane];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const float4 a = load_a16(arow, c);
-                const float4 w = wl[c];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int r = wave * 16 + 4 * (lane >> 4) + reg;
-            const int R = R0 + r;
-            const float y = acc[reg] + bj;
-            float bv = (j < m.C) ? y : __builtin_inff();
-            int bi = j;
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                const float ov = __shfl_xor(bv, off);
-                const int oi = __shfl_xor(bi, off);
-                if ((ov < bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
-            if (j == 0) {
-                rowMin[r] = bi;
-                if (R < total_rows) drow[dbase + r] = bv / m.out_div - radius[rowO[r]];
-            }
-        }
-    }
+    // ---- last layer, arg-min over ALL raw outputs (robot_sdf.py:155), distance of that link: pass2_body's ---------------------
+    p2_last_layer<32>(m, Hs, rowMin, rowO, radius, R0, total_rows, drow, dbase, nullptr, nullptr, nullptr, 0u, -1);
     __syncthreads();
     if (dbg == 12) return;
     pass2_backward_hidden_g4<NG>(m, sm);
